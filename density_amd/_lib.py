@@ -1,0 +1,69 @@
+"""Loads libdensity_hip.so (the HIP product library) and declares its C ABI (include/density_hip.h).
+
+There is no fallback: if the library is missing this raises, and if no gfx950 device is usable every call returns
+its error value (0 / error code) with density_hip_last_error() explaining why.
+"""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libdensity_hip.so")
+
+ALGO_IDS = {"chameleon": 0, "cheetah": 1, "lion": 2}
+ALGO_NAMES = {v: k for k, v in ALGO_IDS.items()}
+DEFAULT_CHUNK = 1 << 20
+
+OK, ERR_ARGUMENT, ERR_CAPACITY, ERR_FORMAT, ERR_RUNTIME, ERR_UNSUPPORTED = range(6)
+
+
+class Header(ctypes.Structure):
+    """density_hip_header_t"""
+    _fields_ = [("magic", ctypes.c_uint32), ("algo", ctypes.c_uint8), ("version", ctypes.c_uint8), ("reserved", ctypes.c_uint16),
+                ("chunk_size", ctypes.c_uint32), ("n_chunks", ctypes.c_uint32), ("total_len", ctypes.c_uint64),
+                ("container_len", ctypes.c_uint64)]
+
+
+_lib = None
+
+# every symbol include/density_hip.h declares: name -> (restype, argtypes)
+_SZ, _VP, _I = ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int
+SYMBOLS = {}
+for _a in ("chameleon", "cheetah", "lion"):
+    SYMBOLS[f"{_a}_encode"] = (_SZ, [_VP, _SZ, _VP, _SZ])
+    SYMBOLS[f"{_a}_decode"] = (_SZ, [_VP, _SZ, _VP, _SZ])
+    SYMBOLS[f"{_a}_safe_encode_buffer_size"] = (_SZ, [_SZ])
+SYMBOLS.update({
+    "density_hip_container_bound": (_SZ, [_I, _SZ, _SZ]),
+    "density_hip_encode": (_SZ, [_I, _VP, _SZ, _VP, _SZ, _SZ]),
+    "density_hip_decode": (_SZ, [_VP, _SZ, _VP, _SZ]),
+    "density_hip_decoded_size": (_SZ, [_VP, _SZ]),
+    "density_hip_encode_workspace_size": (_SZ, [_I, _SZ, _SZ]),
+    "density_hip_decode_workspace_size": (_SZ, [ctypes.c_uint32]),
+    "density_hip_encode_device": (_I, [_I, _VP, _SZ, _VP, _SZ, _SZ, _VP, _SZ, _VP, ctypes.POINTER(Header)]),
+    "density_hip_decode_device": (_I, [_VP, _SZ, ctypes.POINTER(Header), _VP, _SZ, _VP, _SZ, _VP, ctypes.POINTER(_SZ)]),
+    "density_hip_stream_encode_device": (_I, [_I, _VP, _SZ, _VP, _SZ, _VP, ctypes.POINTER(_SZ)]),
+    "density_hip_stream_decode_device": (_I, [_I, _VP, _SZ, _VP, _SZ, _VP, ctypes.POINTER(_SZ)]),
+    "density_hip_set_profiling": (None, [_I]),
+    "density_hip_last_timings": (_I, [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_char_p), _I]),
+    "density_hip_selftest": (_I, []),
+    "density_hip_last_error": (ctypes.c_char_p, []),
+    "density_hip_version": (ctypes.c_char_p, []),
+})
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -m density_amd.build` "
+                               "(there is no CPU fallback in the product path)")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def last_error():
+    return lib().density_hip_last_error().decode()

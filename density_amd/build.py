@@ -1,0 +1,36 @@
+"""Builds libdensity_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libdensity_hip.so")
+SOURCES = ["api.hip", "chameleon.hip", "container.hip"]
+HEADERS = ["common.hpp", "kernels.hpp", os.path.join("..", "..", "include", "density_hip.h")]
+
+
+def _hipcc():
+    return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return LIB
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-value",
+           "-o", LIB] + [os.path.join(CSRC, f) for f in SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=CSRC)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

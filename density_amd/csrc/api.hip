@@ -1,0 +1,490 @@
+// api.hip — the C ABI of libdensity_hip.so (include/density_hip.h): per-device context, workspace management,
+// host-pointer staging, container assembly.  No CPU codec lives here: every byte is produced by the gfx950 kernels,
+// and every entry point fails (returns 0 / an error code) when no usable HIP device is present.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/density_hip.h"
+#include "kernels.hpp"
+
+namespace {
+
+using namespace density;
+
+constexpr int kMaxDevices = 16;
+constexpr size_t kAlign = 256;
+constexpr size_t kMaxChunk = 1u << 30;   // u32 size table: a chunk stream must stay below 4 GiB
+
+thread_local std::string g_last_error;
+int g_profiling = 0;
+
+void set_error(const char* what, hipError_t e = hipSuccess) {
+    g_last_error = what;
+    if (e != hipSuccess) { g_last_error += ": "; g_last_error += hipGetErrorString(e); }
+}
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// codec/codec.rs:18-21 with the geometry of chameleon.rs:138-146, cheetah.rs:188-196, lion.rs:317-325
+inline size_t block_bytes(int algo) { return algo == DENSITY_HIP_CHAMELEON ? 256 : algo == DENSITY_HIP_CHEETAH ? 128 : 64; }
+inline size_t sig_bytes(int algo) { return algo == DENSITY_HIP_LION ? 6 : 8; }
+inline size_t safe_size(int algo, size_t n) {
+    const size_t b = block_bytes(algo), s = sig_bytes(algo);
+    return n + (n / b) * s + ((n % b) ? s : 0);
+}
+inline bool valid_algo(int algo) { return algo >= DENSITY_HIP_CHAMELEON && algo <= DENSITY_HIP_LION; }
+inline size_t normalise_chunk(size_t chunk) { return chunk == 0 ? (size_t)DENSITY_HIP_DEFAULT_CHUNK : chunk; }
+inline bool valid_chunk(size_t chunk) { return chunk >= 256 && chunk % 256 == 0 && chunk <= kMaxChunk; }
+inline size_t chunk_count(size_t n, size_t chunk) { return (n + chunk - 1) / chunk; }
+inline size_t payload_base(size_t n_chunks) { return align_up(sizeof(density_hip_header_t) + 4 * n_chunks, 16); }
+inline size_t slot_stride(int algo, size_t chunk) { return align_up(safe_size(algo, chunk), kAlign); }
+
+struct Buffer {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+        const size_t want = align_up(n + n / 8, 1 << 20);
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { p = nullptr; return e; }
+        cap = want;
+        return hipSuccess;
+    }
+};
+
+struct DeviceCtx {
+    std::mutex mu;
+    bool ready = false, selftest_ok = false;
+    hipStream_t stream = nullptr;
+    Buffer work, stage_in, stage_out;
+    // profiling: event marks accumulated since the last density_hip_last_timings() (name == nullptr opens a call)
+    std::vector<hipEvent_t> events;
+    std::vector<const char*> names;
+    size_t n_marks = 0;
+};
+constexpr size_t kMaxMarks = 8192;
+
+DeviceCtx g_ctx[kMaxDevices];
+
+// Returns the context of the current device with its internal stream created and the LDS self-test passed.
+DeviceCtx* acquire_ctx() {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess || dev < 0 || dev >= kMaxDevices) { set_error("no HIP device available", e); return nullptr; }
+    DeviceCtx* c = &g_ctx[dev];
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!c->ready) {
+        hipDeviceProp_t prop;
+        e = hipGetDeviceProperties(&prop, dev);
+        if (e != hipSuccess) { set_error("hipGetDeviceProperties", e); return nullptr; }
+        if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) { set_error("device is not gfx950 (MI355X); this library has no other code path"); return nullptr; }
+        e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { set_error("hipStreamCreate", e); return nullptr; }
+        // kernels rely on ascending-lane service order of same-address LDS accesses: verify on this device
+        uint32_t* d_fail = nullptr;
+        uint32_t h_fail = 1;
+        e = hipMalloc((void**)&d_fail, sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMemsetAsync(d_fail, 0, sizeof(uint32_t), c->stream);
+        if (e == hipSuccess) e = launch_selftest(d_fail, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(&h_fail, d_fail, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (d_fail) (void)hipFree(d_fail);
+        if (e != hipSuccess) { set_error("LDS self-test launch", e); return nullptr; }
+        c->selftest_ok = (h_fail == 0);
+        c->ready = true;
+    }
+    if (!c->selftest_ok) { set_error("LDS write-order self-test failed on this device; refusing to run"); return nullptr; }
+    return c;
+}
+
+struct Profiler {
+    DeviceCtx* c;
+    hipStream_t s;
+    bool on;
+    Profiler(DeviceCtx* ctx, hipStream_t stream) : c(ctx), s(stream), on(g_profiling != 0) { mark(nullptr); }
+    void mark(const char* name) {
+        if (!on) return;
+        if (c->n_marks >= kMaxMarks) { on = false; return; }
+        if (c->n_marks >= c->events.size()) {
+            hipEvent_t ev;
+            if (hipEventCreate(&ev) != hipSuccess) { on = false; return; }
+            c->events.push_back(ev);
+            c->names.push_back(nullptr);
+        }
+        c->names[c->n_marks] = name;
+        (void)hipEventRecord(c->events[c->n_marks++], s);
+    }
+};
+
+struct EncodePlan {
+    size_t chunk, n_chunks, stride, off_err, off_sizes, off_offsets, off_slots, total;
+};
+EncodePlan plan_encode(int algo, size_t n, size_t chunk) {
+    EncodePlan p{};
+    p.chunk = chunk;
+    p.n_chunks = chunk_count(n, chunk);
+    p.stride = slot_stride(algo, chunk);
+    p.off_err = 0;
+    p.off_sizes = kAlign;
+    p.off_offsets = p.off_sizes + align_up(8 * p.n_chunks, kAlign);
+    p.off_slots = p.off_offsets + align_up(8 * (p.n_chunks + 1), kAlign);
+    p.total = p.off_slots + (p.n_chunks > 1 ? p.n_chunks * p.stride : 0);   // one chunk encodes straight into the container
+    return p;
+}
+struct DecodePlan {
+    size_t off_err, off_sizes, off_offsets, off_produced, total;
+};
+DecodePlan plan_decode(size_t n_chunks) {
+    DecodePlan p{};
+    p.off_err = 0;
+    p.off_sizes = kAlign;
+    p.off_offsets = p.off_sizes + align_up(8 * n_chunks, kAlign);
+    p.off_produced = p.off_offsets + align_up(8 * (n_chunks + 1), kAlign);
+    p.total = p.off_produced + align_up(8 * (n_chunks ? n_chunks : 1), kAlign);
+    return p;
+}
+
+size_t container_bound(int algo, size_t n, size_t chunk) {
+    const size_t nc = chunk_count(n, chunk);
+    size_t bound = payload_base(nc);
+    if (nc) bound += (nc - 1) * align_up(safe_size(algo, chunk), 16) + safe_size(algo, n - (nc - 1) * chunk);
+    return bound;
+}
+
+int check_header(const density_hip_header_t& h, size_t container_size) {
+    if (h.magic != DENSITY_HIP_MAGIC || h.version != 1 || !valid_algo(h.algo)) return DENSITY_HIP_ERR_FORMAT;
+    if (!valid_chunk(h.chunk_size)) return DENSITY_HIP_ERR_FORMAT;
+    if (h.n_chunks != chunk_count(h.total_len, h.chunk_size)) return DENSITY_HIP_ERR_FORMAT;
+    if (h.container_len > container_size || h.container_len < payload_base(h.n_chunks)) return DENSITY_HIP_ERR_FORMAT;
+    return DENSITY_HIP_OK;
+}
+
+// ---- device-side drivers (ctx already acquired; `ws` points at a workspace of sufficient size) ----
+
+int run_encode_container(DeviceCtx* c, int algo, const uint8_t* d_in, size_t n, uint8_t* d_out, size_t cap, size_t chunk,
+                         uint8_t* ws, hipStream_t s, density_hip_header_t* header_out) {
+    if (algo != DENSITY_HIP_CHAMELEON) { set_error("this build runs Chameleon on the device; Cheetah/Lion kernels are not built in"); return DENSITY_HIP_ERR_UNSUPPORTED; }
+    const EncodePlan p = plan_encode(algo, n, chunk);
+    if (p.n_chunks > 0xffffffffull) { set_error("too many chunks"); return DENSITY_HIP_ERR_ARGUMENT; }
+    if (cap < container_bound(algo, n, chunk)) { set_error("output capacity below density_hip_container_bound()"); return DENSITY_HIP_ERR_CAPACITY; }
+    uint32_t* d_err = reinterpret_cast<uint32_t*>(ws + p.off_err);
+    uint64_t* d_sizes = reinterpret_cast<uint64_t*>(ws + p.off_sizes);
+    uint64_t* d_offsets = reinterpret_cast<uint64_t*>(ws + p.off_offsets);
+    uint8_t* d_slots = ws + p.off_slots;
+    density_hip_header_t hdr{};
+    hdr.magic = DENSITY_HIP_MAGIC; hdr.algo = (uint8_t)algo; hdr.version = 1; hdr.reserved = 0;
+    hdr.chunk_size = (uint32_t)chunk; hdr.n_chunks = (uint32_t)p.n_chunks; hdr.total_len = n; hdr.container_len = 0;
+
+    Profiler prof(c, s);
+    hipError_t e = hipMemsetAsync(d_err, 0, sizeof(uint32_t), s);
+    if (e != hipSuccess) { set_error("hipMemsetAsync", e); return DENSITY_HIP_ERR_RUNTIME; }
+    if (p.n_chunks == 1) {
+        // single chunk: its stream goes straight to its final place, no stitch pass
+        e = launch_chameleon_encode(d_in, n, chunk, 1, d_out + payload_base(1), 0, d_sizes, s);
+        prof.mark("chameleon_encode_chunks");
+        if (e == hipSuccess) e = launch_layout_encode(d_sizes, 1, hdr, d_out, cap, d_offsets, d_err, s);
+        prof.mark("layout_encode");
+    } else {
+        e = launch_chameleon_encode(d_in, n, chunk, (uint32_t)p.n_chunks, d_slots, p.stride, d_sizes, s);
+        prof.mark("chameleon_encode_chunks");
+        if (e == hipSuccess) e = launch_layout_encode(d_sizes, (uint32_t)p.n_chunks, hdr, d_out, cap, d_offsets, d_err, s);
+        prof.mark("layout_encode");
+        if (e == hipSuccess) e = launch_compact(d_slots, p.stride, d_sizes, d_offsets, (uint32_t)p.n_chunks, d_out, d_err, s);
+        prof.mark("compact");
+    }
+    if (e != hipSuccess) { set_error("kernel launch (encode)", e); return DENSITY_HIP_ERR_RUNTIME; }
+    if (header_out) {
+        uint32_t h_err = 0;
+        e = hipMemcpyAsync(header_out, d_out, sizeof(*header_out), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(&h_err, d_err, sizeof(h_err), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) { set_error("encode (device)", e); return DENSITY_HIP_ERR_RUNTIME; }
+        if (h_err) { set_error("container does not fit the output capacity"); return DENSITY_HIP_ERR_CAPACITY; }
+    }
+    return DENSITY_HIP_OK;
+}
+
+int run_decode_container(DeviceCtx* c, const uint8_t* d_in, size_t container_size, const density_hip_header_t& h, uint8_t* d_out,
+                         size_t cap, uint8_t* ws, hipStream_t s, size_t* decoded_out) {
+    if (h.algo != DENSITY_HIP_CHAMELEON) { set_error("this build runs Chameleon on the device; Cheetah/Lion kernels are not built in"); return DENSITY_HIP_ERR_UNSUPPORTED; }
+    if (cap < h.total_len) { set_error("output capacity below the container's total_len"); return DENSITY_HIP_ERR_CAPACITY; }
+    const DecodePlan p = plan_decode(h.n_chunks);
+    uint32_t* d_err = reinterpret_cast<uint32_t*>(ws + p.off_err);
+    uint64_t* d_sizes = reinterpret_cast<uint64_t*>(ws + p.off_sizes);
+    uint64_t* d_offsets = reinterpret_cast<uint64_t*>(ws + p.off_offsets);
+    uint64_t* d_produced = reinterpret_cast<uint64_t*>(ws + p.off_produced);
+    Profiler prof(c, s);
+    hipError_t e = hipMemsetAsync(d_err, 0, sizeof(uint32_t), s);
+    if (e == hipSuccess) e = launch_layout_decode(d_in, container_size, h.n_chunks, d_sizes, d_offsets, d_err, s);
+    prof.mark("layout_decode");
+    if (e == hipSuccess) e = launch_chameleon_decode(d_in, d_offsets, d_sizes, h.n_chunks, d_out, h.chunk_size, h.total_len, true, d_produced, d_err, s);
+    prof.mark("chameleon_decode_chunks");
+    if (e != hipSuccess) { set_error("kernel launch (decode)", e); return DENSITY_HIP_ERR_RUNTIME; }
+    if (decoded_out) {
+        uint32_t h_err = 0;
+        e = hipMemcpyAsync(&h_err, d_err, sizeof(h_err), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) { set_error("decode (device)", e); return DENSITY_HIP_ERR_RUNTIME; }
+        if (h_err) { set_error("malformed or truncated container payload"); *decoded_out = 0; return DENSITY_HIP_ERR_FORMAT; }
+        *decoded_out = h.total_len;
+    }
+    return DENSITY_HIP_OK;
+}
+
+int run_stream_encode(DeviceCtx* c, int algo, const uint8_t* d_in, size_t n, uint8_t* d_out, size_t cap, uint8_t* ws, hipStream_t s,
+                      size_t* size_out) {
+    if (algo != DENSITY_HIP_CHAMELEON) { set_error("this build runs Chameleon on the device; Cheetah/Lion kernels are not built in"); return DENSITY_HIP_ERR_UNSUPPORTED; }
+    if (cap < safe_size(algo, n)) { set_error("output capacity below safe_encode_buffer_size()"); return DENSITY_HIP_ERR_CAPACITY; }
+    uint64_t* d_sizes = reinterpret_cast<uint64_t*>(ws + kAlign);
+    *size_out = 0;
+    if (n == 0) return DENSITY_HIP_OK;
+    Profiler prof(c, s);
+    hipError_t e = launch_chameleon_encode(d_in, n, n, 1, d_out, 0, d_sizes, s);
+    prof.mark("chameleon_encode_chunks");
+    uint64_t h_size = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&h_size, d_sizes, sizeof(h_size), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { set_error("stream encode", e); return DENSITY_HIP_ERR_RUNTIME; }
+    *size_out = (size_t)h_size;
+    return DENSITY_HIP_OK;
+}
+
+int run_stream_decode(DeviceCtx* c, int algo, const uint8_t* d_in, size_t n, uint8_t* d_out, size_t cap, uint8_t* ws, hipStream_t s,
+                      size_t* size_out) {
+    if (algo != DENSITY_HIP_CHAMELEON) { set_error("this build runs Chameleon on the device; Cheetah/Lion kernels are not built in"); return DENSITY_HIP_ERR_UNSUPPORTED; }
+    *size_out = 0;
+    if (n == 0) return DENSITY_HIP_OK;
+    const DecodePlan p = plan_decode(1);
+    uint32_t* d_err = reinterpret_cast<uint32_t*>(ws + p.off_err);
+    uint64_t* d_sizes = reinterpret_cast<uint64_t*>(ws + p.off_sizes);
+    uint64_t* d_offsets = reinterpret_cast<uint64_t*>(ws + p.off_offsets);
+    uint64_t* d_produced = reinterpret_cast<uint64_t*>(ws + p.off_produced);
+    const uint64_t h_size = n, h_off = 0;
+    Profiler prof(c, s);
+    hipError_t e = hipMemsetAsync(d_err, 0, sizeof(uint32_t), s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_sizes, &h_size, 8, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_offsets, &h_off, 8, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);   // h_size/h_off live on this stack frame
+    if (e == hipSuccess) e = launch_chameleon_decode(d_in, d_offsets, d_sizes, 1, d_out, cap, cap, false, d_produced, d_err, s);
+    prof.mark("chameleon_decode_chunks");
+    uint64_t h_prod = 0;
+    uint32_t h_err = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&h_prod, d_produced, 8, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(&h_err, d_err, 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { set_error("stream decode", e); return DENSITY_HIP_ERR_RUNTIME; }
+    if (h_err) { set_error("truncated stream or output too small"); return DENSITY_HIP_ERR_FORMAT; }
+    *size_out = (size_t)h_prod;
+    return DENSITY_HIP_OK;
+}
+
+// ---- host-pointer front ends ----
+
+size_t host_stream_codec(int algo, bool encode, const uint8_t* in, size_t n, uint8_t* out, size_t cap) {
+    g_last_error.clear();
+    if (!in || !out || !valid_algo(algo)) { set_error("null pointer or bad algorithm"); return 0; }
+    if (n == 0) return 0;
+    DeviceCtx* c = acquire_ctx();
+    if (!c) return 0;
+    std::lock_guard<std::mutex> lk(c->mu);
+    const size_t dev_cap = encode ? safe_size(algo, n) : cap;
+    hipError_t e = c->stage_in.ensure(n);
+    if (e == hipSuccess) e = c->stage_out.ensure(dev_cap ? dev_cap : 1);
+    if (e == hipSuccess) e = c->work.ensure(plan_decode(1).total + kAlign);
+    if (e == hipSuccess) e = hipMemcpyAsync(c->stage_in.p, in, n, hipMemcpyHostToDevice, c->stream);
+    if (e != hipSuccess) { set_error("staging (H2D)", e); return 0; }
+    size_t produced = 0;
+    const int rc = encode ? run_stream_encode(c, algo, (const uint8_t*)c->stage_in.p, n, (uint8_t*)c->stage_out.p, dev_cap, (uint8_t*)c->work.p, c->stream, &produced)
+                          : run_stream_decode(c, algo, (const uint8_t*)c->stage_in.p, n, (uint8_t*)c->stage_out.p, dev_cap, (uint8_t*)c->work.p, c->stream, &produced);
+    if (rc != DENSITY_HIP_OK) return 0;
+    if (produced > cap) { set_error("output buffer too small"); return 0; }   // reference: slice-index panic (write_buffer.rs:19)
+    if (produced) {
+        e = hipMemcpy(out, c->stage_out.p, produced, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { set_error("staging (D2H)", e); return 0; }
+    }
+    return produced;
+}
+
+}  // namespace
+
+extern "C" {
+
+// ---- section 1: the reference's nine symbols ----
+size_t chameleon_encode(const uint8_t* input, size_t input_size, uint8_t* output, size_t output_size) { return host_stream_codec(DENSITY_HIP_CHAMELEON, true, input, input_size, output, output_size); }
+size_t chameleon_decode(const uint8_t* input, size_t input_size, uint8_t* output, size_t output_size) { return host_stream_codec(DENSITY_HIP_CHAMELEON, false, input, input_size, output, output_size); }
+size_t chameleon_safe_encode_buffer_size(size_t size) { return safe_size(DENSITY_HIP_CHAMELEON, size); }
+size_t cheetah_encode(const uint8_t* input, size_t input_size, uint8_t* output, size_t output_size) { return host_stream_codec(DENSITY_HIP_CHEETAH, true, input, input_size, output, output_size); }
+size_t cheetah_decode(const uint8_t* input, size_t input_size, uint8_t* output, size_t output_size) { return host_stream_codec(DENSITY_HIP_CHEETAH, false, input, input_size, output, output_size); }
+size_t cheetah_safe_encode_buffer_size(size_t size) { return safe_size(DENSITY_HIP_CHEETAH, size); }
+size_t lion_encode(const uint8_t* input, size_t input_size, uint8_t* output, size_t output_size) { return host_stream_codec(DENSITY_HIP_LION, true, input, input_size, output, output_size); }
+size_t lion_decode(const uint8_t* input, size_t input_size, uint8_t* output, size_t output_size) { return host_stream_codec(DENSITY_HIP_LION, false, input, input_size, output, output_size); }
+size_t lion_safe_encode_buffer_size(size_t size) { return safe_size(DENSITY_HIP_LION, size); }
+
+// ---- section 2: container + device API ----
+size_t density_hip_container_bound(int algo, size_t input_size, size_t chunk_size) {
+    chunk_size = normalise_chunk(chunk_size);
+    if (!valid_algo(algo) || !valid_chunk(chunk_size)) return 0;
+    return container_bound(algo, input_size, chunk_size);
+}
+
+size_t density_hip_encode_workspace_size(int algo, size_t input_size, size_t chunk_size) {
+    chunk_size = normalise_chunk(chunk_size);
+    if (!valid_algo(algo) || !valid_chunk(chunk_size)) return 0;
+    return plan_encode(algo, input_size, chunk_size).total;
+}
+
+size_t density_hip_decode_workspace_size(uint32_t n_chunks) { return plan_decode(n_chunks).total; }
+
+int density_hip_encode_device(int algo, const void* d_input, size_t input_size, void* d_output, size_t output_capacity,
+                              size_t chunk_size, void* d_workspace, size_t workspace_size, void* stream,
+                              density_hip_header_t* header_out) {
+    g_last_error.clear();
+    chunk_size = normalise_chunk(chunk_size);
+    if (!valid_algo(algo) || !valid_chunk(chunk_size) || (!d_input && input_size) || !d_output) { set_error("bad argument"); return DENSITY_HIP_ERR_ARGUMENT; }
+    DeviceCtx* c = acquire_ctx();
+    if (!c) return DENSITY_HIP_ERR_RUNTIME;
+    std::lock_guard<std::mutex> lk(c->mu);
+    const size_t need = plan_encode(algo, input_size, chunk_size).total;
+    uint8_t* ws = (uint8_t*)d_workspace;
+    if (ws) { if (workspace_size < need) { set_error("workspace too small"); return DENSITY_HIP_ERR_CAPACITY; } }
+    else { hipError_t e = c->work.ensure(need); if (e != hipSuccess) { set_error("workspace allocation", e); return DENSITY_HIP_ERR_RUNTIME; } ws = (uint8_t*)c->work.p; }
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    return run_encode_container(c, algo, (const uint8_t*)d_input, input_size, (uint8_t*)d_output, output_capacity, chunk_size, ws, s, header_out);
+}
+
+int density_hip_decode_device(const void* d_container, size_t container_size, const density_hip_header_t* header, void* d_output,
+                              size_t output_capacity, void* d_workspace, size_t workspace_size, void* stream, size_t* decoded_size_out) {
+    g_last_error.clear();
+    if (!d_container || container_size < sizeof(density_hip_header_t) || (!d_output && output_capacity)) { set_error("bad argument"); return DENSITY_HIP_ERR_ARGUMENT; }
+    DeviceCtx* c = acquire_ctx();
+    if (!c) return DENSITY_HIP_ERR_RUNTIME;
+    std::lock_guard<std::mutex> lk(c->mu);
+    density_hip_header_t h;
+    if (header) h = *header;
+    else {
+        hipError_t e = hipMemcpy(&h, d_container, sizeof(h), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { set_error("header read-back", e); return DENSITY_HIP_ERR_RUNTIME; }
+    }
+    if (check_header(h, container_size) != DENSITY_HIP_OK) { set_error("bad container header"); return DENSITY_HIP_ERR_FORMAT; }
+    const size_t need = plan_decode(h.n_chunks).total;
+    uint8_t* ws = (uint8_t*)d_workspace;
+    if (ws) { if (workspace_size < need) { set_error("workspace too small"); return DENSITY_HIP_ERR_CAPACITY; } }
+    else { hipError_t e = c->work.ensure(need); if (e != hipSuccess) { set_error("workspace allocation", e); return DENSITY_HIP_ERR_RUNTIME; } ws = (uint8_t*)c->work.p; }
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    return run_decode_container(c, (const uint8_t*)d_container, container_size, h, (uint8_t*)d_output, output_capacity, ws, s, decoded_size_out);
+}
+
+int density_hip_stream_encode_device(int algo, const void* d_input, size_t input_size, void* d_output, size_t output_capacity,
+                                     void* stream, size_t* size_out) {
+    g_last_error.clear();
+    if (!valid_algo(algo) || !size_out || (!d_input && input_size) || (!d_output && output_capacity)) { set_error("bad argument"); return DENSITY_HIP_ERR_ARGUMENT; }
+    DeviceCtx* c = acquire_ctx();
+    if (!c) return DENSITY_HIP_ERR_RUNTIME;
+    std::lock_guard<std::mutex> lk(c->mu);
+    hipError_t e = c->work.ensure(plan_decode(1).total + kAlign);
+    if (e != hipSuccess) { set_error("workspace allocation", e); return DENSITY_HIP_ERR_RUNTIME; }
+    return run_stream_encode(c, algo, (const uint8_t*)d_input, input_size, (uint8_t*)d_output, output_capacity, (uint8_t*)c->work.p,
+                             stream ? (hipStream_t)stream : c->stream, size_out);
+}
+
+int density_hip_stream_decode_device(int algo, const void* d_input, size_t input_size, void* d_output, size_t output_capacity,
+                                     void* stream, size_t* size_out) {
+    g_last_error.clear();
+    if (!valid_algo(algo) || !size_out || (!d_input && input_size) || (!d_output && output_capacity)) { set_error("bad argument"); return DENSITY_HIP_ERR_ARGUMENT; }
+    DeviceCtx* c = acquire_ctx();
+    if (!c) return DENSITY_HIP_ERR_RUNTIME;
+    std::lock_guard<std::mutex> lk(c->mu);
+    hipError_t e = c->work.ensure(plan_decode(1).total + kAlign);
+    if (e != hipSuccess) { set_error("workspace allocation", e); return DENSITY_HIP_ERR_RUNTIME; }
+    return run_stream_decode(c, algo, (const uint8_t*)d_input, input_size, (uint8_t*)d_output, output_capacity, (uint8_t*)c->work.p,
+                             stream ? (hipStream_t)stream : c->stream, size_out);
+}
+
+size_t density_hip_encode(int algo, const uint8_t* input, size_t input_size, uint8_t* output, size_t output_size, size_t chunk_size) {
+    g_last_error.clear();
+    chunk_size = normalise_chunk(chunk_size);
+    if (!valid_algo(algo) || !valid_chunk(chunk_size) || (!input && input_size) || !output) { set_error("bad argument"); return 0; }
+    DeviceCtx* c = acquire_ctx();
+    if (!c) return 0;
+    std::lock_guard<std::mutex> lk(c->mu);
+    const size_t bound = container_bound(algo, input_size, chunk_size);
+    hipError_t e = c->stage_in.ensure(input_size ? input_size : 1);
+    if (e == hipSuccess) e = c->stage_out.ensure(bound);
+    if (e == hipSuccess) e = c->work.ensure(plan_encode(algo, input_size, chunk_size).total);
+    if (e == hipSuccess && input_size) e = hipMemcpyAsync(c->stage_in.p, input, input_size, hipMemcpyHostToDevice, c->stream);
+    if (e != hipSuccess) { set_error("staging (H2D)", e); return 0; }
+    density_hip_header_t h;
+    if (run_encode_container(c, algo, (const uint8_t*)c->stage_in.p, input_size, (uint8_t*)c->stage_out.p, bound, chunk_size, (uint8_t*)c->work.p, c->stream, &h) != DENSITY_HIP_OK) return 0;
+    if (h.container_len > output_size) { set_error("output buffer too small"); return 0; }
+    e = hipMemcpy(output, c->stage_out.p, h.container_len, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { set_error("staging (D2H)", e); return 0; }
+    return (size_t)h.container_len;
+}
+
+size_t density_hip_decoded_size(const uint8_t* container, size_t container_size) {
+    if (!container || container_size < sizeof(density_hip_header_t)) return 0;
+    density_hip_header_t h;
+    std::memcpy(&h, container, sizeof(h));
+    return check_header(h, container_size) == DENSITY_HIP_OK ? (size_t)h.total_len : 0;
+}
+
+size_t density_hip_decode(const uint8_t* container, size_t container_size, uint8_t* output, size_t output_size) {
+    g_last_error.clear();
+    if (!container || container_size < sizeof(density_hip_header_t) || (!output && output_size)) { set_error("bad argument"); return 0; }
+    density_hip_header_t h;
+    std::memcpy(&h, container, sizeof(h));
+    if (check_header(h, container_size) != DENSITY_HIP_OK) { set_error("bad container header"); return 0; }
+    if (h.total_len > output_size) { set_error("output buffer too small"); return 0; }
+    if (h.total_len == 0) return 0;
+    DeviceCtx* c = acquire_ctx();
+    if (!c) return 0;
+    std::lock_guard<std::mutex> lk(c->mu);
+    hipError_t e = c->stage_in.ensure(h.container_len);
+    if (e == hipSuccess) e = c->stage_out.ensure(h.total_len);
+    if (e == hipSuccess) e = c->work.ensure(plan_decode(h.n_chunks).total);
+    if (e == hipSuccess) e = hipMemcpyAsync(c->stage_in.p, container, h.container_len, hipMemcpyHostToDevice, c->stream);
+    if (e != hipSuccess) { set_error("staging (H2D)", e); return 0; }
+    size_t produced = 0;
+    if (run_decode_container(c, (const uint8_t*)c->stage_in.p, h.container_len, h, (uint8_t*)c->stage_out.p, h.total_len, (uint8_t*)c->work.p, c->stream, &produced) != DENSITY_HIP_OK) return 0;
+    e = hipMemcpy(output, c->stage_out.p, produced, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { set_error("staging (D2H)", e); return 0; }
+    return produced;
+}
+
+void density_hip_set_profiling(int enabled) { g_profiling = enabled; }
+
+int density_hip_last_timings(float* milliseconds, const char** names, int capacity) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return 0;
+    DeviceCtx* c = &g_ctx[dev];
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->n_marks < 2) { c->n_marks = 0; return 0; }
+    if (hipEventSynchronize(c->events[c->n_marks - 1]) != hipSuccess) { c->n_marks = 0; return 0; }
+    int n = 0;
+    for (size_t i = 1; i < c->n_marks && n < capacity; ++i) {
+        if (!c->names[i]) continue;                       // start-of-call mark
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, c->events[i - 1], c->events[i]);
+        if (milliseconds) milliseconds[n] = ms;
+        if (names) names[n] = c->names[i];
+        ++n;
+    }
+    c->n_marks = 0;
+    return n;
+}
+
+int density_hip_selftest(void) {
+    g_last_error.clear();
+    return acquire_ctx() ? 0 : 1;
+}
+
+const char* density_hip_last_error(void) { return g_last_error.c_str(); }
+const char* density_hip_version(void) { return "density_hip 0.1 (gfx950; reference: density-rs 0.16.6)"; }
+
+}  // extern "C"

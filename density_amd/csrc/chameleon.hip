@@ -1,0 +1,323 @@
+// chameleon.hip — Chameleon encode/decode kernels for gfx950 (MI355X).
+//
+// One 64-lane wavefront owns one chunk (= one independent reference stream) and walks it block by block:
+// a Chameleon block is 64 quads with 1 flag bit each (chameleon.rs:138-146), so one block == one wavefront pass,
+// the 64-bit signature == __ballot(hit) (first quad in bit 0, io/write_signature.rs:14-17) and a lane's output
+// offset inside the record is a pair of mbcnt's.
+//
+// Dictionary.  The reference keeps 64 Ki x u32 = 256 KiB per stream (chameleon.rs:30-43); that does not fit the
+// 160 KiB LDS of a CU.  Because the multiplier 0x9D6EF916 is 2 x odd, the product P = quad * M (mod 2^32) is even and
+// (P, quad >> 31) determines the quad; with the slot index h = P >> 16 known, the 16-bit entry
+//        e = (P & 0xfffe) | (quad >> 31)
+// identifies the quad exactly.  The table is therefore 64 Ki x u16 = 128 KiB of LDS, exact, not a lossy fingerprint.
+// All 2^16 entry values are legal for every slot, so "slot never written" (the reference's zero-initialised word:
+// it matches only the zero quad, and only in slot 0) needs a 17th state: a never-written slot is stored as 0, and the
+// only entry it aliases, e == 0 in a slot h != 0, is disambiguated by a 64 Ki-bit "this slot was written with e == 0"
+// map (8 KiB) that is touched only when such a quad actually occurs (never in text: it needs two zero low bytes).
+//
+// Sequential semantics inside a block.  Lane i must observe the dictionary writes of lanes j < i of the same block.
+// gfx950 LDS services the lanes of one ds instruction in ascending lane order (probes/lds_order.hip; re-checked by
+// density_hip_selftest at start-up), so:  old = table[h];  table[h] = lane;  w = table[h];  table[h] = e;
+// issued back to back gives every lane the pre-block value `old`, tells it the last lane `w` sharing its slot, and
+// leaves the table in the state the sequential reference would (last writer wins).  Lanes whose slot is shared
+// (w != lane somewhere in the group) take the value of the nearest earlier lane of the group instead of `old`;
+// groups are enumerated with wave-level ballots.
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace density {
+
+extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+
+namespace {
+
+constexpr uint32_t kTableBytes = 65536u * 2u;   // 64 Ki x u16 entries
+constexpr uint32_t kZmapBytes = 65536u / 8u;    // 1 bit per slot
+constexpr uint32_t kLdsBytes = kTableBytes + kZmapBytes;
+constexpr uint32_t kBlock = 256;                // chameleon.rs:140
+constexpr uint32_t kSig = 8;                    // chameleon.rs:146
+
+__device__ __forceinline__ void lds_clear(uint32_t lane) {
+    uint4* p = reinterpret_cast<uint4*>(smem);
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    for (uint32_t i = lane; i < kLdsBytes / 16; i += 64) p[i] = z;
+    __syncthreads();
+}
+
+// the four-instruction dictionary step described in the file header; the caller masks inactive lanes with exec
+__device__ __forceinline__ void dict_step(uint32_t addr, uint32_t lane, uint32_t e, uint32_t& old, uint32_t& w) {
+    asm volatile(
+        "ds_read_u16 %0, %2\n\t"
+        "ds_write_b16 %2, %3\n\t"
+        "ds_read_u16 %1, %2\n\t"
+        "ds_write_b16 %2, %4\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(old), "=&v"(w)
+        : "v"(addr), "v"(lane), "v"(e)
+        : "memory");
+}
+__device__ __forceinline__ void dict_probe(uint32_t addr, uint32_t lane, uint32_t& old, uint32_t& w) {
+    asm volatile(
+        "ds_read_u16 %0, %2\n\t"
+        "ds_write_b16 %2, %3\n\t"
+        "ds_read_u16 %1, %2\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(old), "=&v"(w)
+        : "v"(addr), "v"(lane)
+        : "memory");
+}
+__device__ __forceinline__ void dict_store(uint32_t addr, uint32_t v) {
+    asm volatile("ds_write_b16 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ uint32_t zmap_test_and_set(uint32_t zbase, uint32_t h) {
+    uint32_t r;
+    asm volatile("ds_or_rtn_b32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r) : "v"(zbase + (h >> 5) * 4u), "v"(1u << (h & 31u)) : "memory");
+    return (r >> (h & 31u)) & 1u;
+}
+__device__ __forceinline__ uint32_t zmap_test(uint32_t zbase, uint32_t h) {
+    uint32_t r;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r) : "v"(zbase + (h >> 5) * 4u) : "memory");
+    return (r >> (h & 31u)) & 1u;
+}
+__device__ __forceinline__ void zmap_set(uint32_t zbase, uint32_t h) {
+    asm volatile("ds_or_b32 %0, %1" ::"v"(zbase + (h >> 5) * 4u), "v"(1u << (h & 31u)) : "memory");
+}
+
+// For every lane that shares its slot with other lanes of this block: the entry written by the nearest earlier lane
+// of its group that is in `writers` (encode: every lane writes; decode: only PLAIN lanes do).
+__device__ __forceinline__ void resolve_groups(bool active, uint32_t lane, uint32_t w, uint32_t e, uint64_t writers,
+                                               bool& has_pred, uint32_t& pred_e) {
+    has_pred = false;
+    pred_e = 0;
+    uint64_t todo = ballot64(active && w != lane);      // every multi-lane group has >= 1 lane in here
+    const uint64_t lt = (1ull << lane) - 1ull;
+    while (todo) {
+        const int leader = __builtin_ctzll(todo);
+        const uint32_t wsel = (uint32_t)__builtin_amdgcn_readlane((int)w, leader);
+        const bool mine = active && (w == wsel);
+        const uint64_t members = ballot64(mine);
+        const uint64_t below = members & writers & lt;
+        const uint32_t src = below ? (63u - (uint32_t)__builtin_clzll(below)) : lane;
+        const uint32_t pe = bperm(src, e);
+        if (mine && below) { has_pred = true; pred_e = pe; }
+        todo &= ~members;
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------
+// encode: Codec::encode + encode_block (codec/codec.rs:34-80) with Chameleon::encode_quad (chameleon.rs:88-100)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void chameleon_encode_chunks(const uint8_t* __restrict__ in, uint64_t total,
+                                                              uint64_t chunk_bytes, uint8_t* __restrict__ out,
+                                                              uint64_t out_stride, uint64_t* __restrict__ sizes) {
+    const uint32_t lane = threadIdx.x;
+    const uint64_t chunk = blockIdx.x;
+    const uint8_t* src = in + chunk * chunk_bytes;
+    const uint64_t len = (total - chunk * chunk_bytes) < chunk_bytes ? (total - chunk * chunk_bytes) : chunk_bytes;
+    uint8_t* dst = out + chunk * out_stride;
+    const uint64_t nblk = (len + kBlock - 1) / kBlock;
+
+    lds_clear(lane);
+    const uint32_t tbl = lds_addr(smem);
+    const uint32_t zmap = tbl + kTableBytes;
+
+    Guard guard;
+    uint64_t opos = 0;
+
+    constexpr int PF = 4;   // blocks of input kept in flight per lane
+    uint32_t qbuf[PF];
+    auto load_quad = [&](uint64_t b) -> uint32_t {
+        const uint64_t off = b * kBlock + 4u * lane;
+        return (off + 4 <= len) ? ld32u(src + off) : 0u;
+    };
+#pragma unroll
+    for (int u = 0; u < PF; ++u) qbuf[u] = load_quad(u);
+
+    for (uint64_t b0 = 0; b0 < nblk; b0 += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const uint64_t b = b0 + u;
+            if (b >= nblk) break;
+            const uint32_t q = qbuf[u];
+            qbuf[u] = load_quad(b + PF);
+
+            const uint64_t boff = b * kBlock;
+            const uint32_t blen = (len - boff) < kBlock ? (uint32_t)(len - boff) : kBlock;
+            const uint32_t nq = blen >> 2, tail = blen & 3u;
+            const bool active = lane < nq;
+            uint8_t* rec = dst + opos;
+
+            if (guard.block_is_copy()) {                       // codec.rs:35-37: raw block, dictionary untouched
+                if (active) st32u(rec + 4u * lane, q);
+                if (lane < tail) rec[4u * nq + lane] = src[boff + 4u * nq + lane];
+                opos += blen;
+                guard.decay();
+                continue;
+            }
+
+            const uint32_t P = q * kHashMul;
+            const uint32_t h = P >> 16;
+            const uint32_t e = (P & 0xfffeu) | (q >> 31);
+            uint32_t old = 0, w = lane;
+            if (active) dict_step(tbl + 2u * h, lane, e, old, w);
+
+            bool has_pred;
+            uint32_t pred_e;
+            resolve_groups(active, lane, w, e, ~0ull, has_pred, pred_e);
+
+            // e == 0 outside slot 0 aliases "never written": consult / update the zero-entry map (rare)
+            const bool susp = active && e == 0 && h != 0;
+            uint32_t zbit = 1;
+            if (ballot64(susp)) {
+                if (susp) zbit = zmap_test_and_set(zmap, h);
+            }
+            const bool hit = active && (has_pred ? (pred_e == e) : (old == e && (!susp || zbit)));
+
+            const uint64_t sig = ballot64(hit);                // chameleon.rs:96: MAP flag = 1, PLAIN = 0
+            const uint32_t nhit = (uint32_t)__builtin_popcountll(sig);
+            const uint32_t off = kSig + 4u * lane - 2u * mbcnt64(sig);
+            if (lane == 0) { st32u(rec, (uint32_t)sig); st32u(rec + 4, (uint32_t)(sig >> 32)); }   // codec.rs:24-26
+            if (active) {
+                if (hit) st16u(rec + off, h); else st32u(rec + off, q);
+            }
+            const uint32_t items_end = kSig + 4u * nq - 2u * nhit;
+            if (lane < tail) rec[items_end + lane] = src[boff + 4u * nq + lane];                   // codec.rs:58-61
+            const uint32_t rec_len = items_end + tail;
+            guard.update(rec_len >= kBlock);                   // codec.rs:68
+            opos += rec_len;
+        }
+    }
+    if (lane == 0) sizes[chunk] = opos;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// decode: Codec::decode (codec/codec.rs:82-126) with Chameleon::decode_unit / decode_partial_unit
+// (chameleon.rs:56-68,105-135).  The fast loop and the tail loop of the reference differ only in bounds checks; one
+// vectorised stop test per record reproduces both (a record that is followed by >= 264 bytes can never trip it).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void chameleon_decode_chunks(const uint8_t* __restrict__ in,
+                                                              const uint64_t* __restrict__ offsets,
+                                                              const uint64_t* __restrict__ sizes,
+                                                              uint8_t* __restrict__ out, uint64_t out_stride,
+                                                              uint64_t out_total, uint32_t exact,
+                                                              uint64_t* __restrict__ produced,
+                                                              uint32_t* __restrict__ err) {
+    const uint32_t lane = threadIdx.x;
+    const uint64_t chunk = blockIdx.x;
+    const uint8_t* src = in + offsets[chunk];
+    const uint64_t elen = sizes[chunk];
+    uint8_t* dst = out + chunk * out_stride;
+    // bytes this chunk may produce: its slice of the output
+    const uint64_t room_all = out_total - chunk * out_stride;
+    const uint64_t cap = room_all < out_stride ? room_all : out_stride;
+
+    lds_clear(lane);
+    const uint32_t tbl = lds_addr(smem);
+    const uint32_t zmap = tbl + kTableBytes;
+
+    Guard guard;
+    uint64_t ipos = 0, opos = 0;
+    bool bad = false;
+
+    while (ipos < elen) {
+        const uint64_t rem = elen - ipos;
+        const uint8_t* rec = src + ipos;
+        uint8_t* o = dst + opos;
+        if (guard.block_is_copy()) {                              // codec.rs:89-91,103-110
+            const uint32_t take = rem > kBlock ? kBlock : (uint32_t)rem;
+            if (opos + take > cap) { bad = true; break; }
+            if (lane < (take >> 2)) st32u(o + 4u * lane, ld32u(rec + 4u * lane));
+            if (lane < (take & 3u)) o[(take & ~3u) + lane] = rec[(take & ~3u) + lane];
+            ipos += take;
+            opos += take;
+            if (rem <= kBlock) break;                             // codec.rs:107-109: no decay after the last raw block
+            guard.decay();
+            continue;
+        }
+        if (rem < kSig) { bad = true; break; }                    // reference: read_u64_le panics (read_buffer.rs:22)
+        const uint64_t sig = (uint64_t)ld32u(rec) | ((uint64_t)ld32u(rec + 4) << 32);
+        const bool hit = (sig >> lane) & 1ull;
+        const uint32_t off = kSig + 4u * lane - 2u * mbcnt64(sig);
+        const uint32_t rem32 = rem > 4096 ? 4096u : (uint32_t)rem;
+        const int32_t left = (int32_t)rem32 - (int32_t)off;
+        // chameleon.rs:121-126: PLAIN with < 4 bytes left ends the stream (copying 1..3 raw bytes); a MAP item with
+        // < 2 bytes left is a truncated stream (reference panics)
+        const bool stop = hit ? (left < 2) : (left < 4);
+        const uint64_t stopm = ballot64(stop);
+        const uint32_t kstop = stopm ? (uint32_t)__builtin_ctzll(stopm) : 64u;
+        if (kstop < 64 && ((sig >> kstop) & 1ull)) { bad = true; break; }
+        const bool active = lane < kstop;
+        const uint32_t tailb = kstop < 64 ? (uint32_t)((int32_t)rem32 - __builtin_amdgcn_readlane((int)off, (int)kstop)) : 0u;
+        if (opos + 4ull * kstop + tailb > cap) { bad = true; break; }
+
+        uint32_t q = 0, h = 0, e = 0;
+        if (active) {
+            if (hit) { h = ld16u(rec + off); }
+            else { q = ld32u(rec + off); const uint32_t P = q * kHashMul; h = P >> 16; e = (P & 0xfffeu) | (q >> 31); }
+        }
+        uint32_t old = 0, w = lane;
+        if (active) dict_probe(tbl + 2u * h, lane, old, w);
+        const uint64_t plain = ballot64(active && !hit);
+        bool has_pred;
+        uint32_t pred_e;
+        resolve_groups(active, lane, w, e, plain, has_pred, pred_e);
+        const uint32_t eff = has_pred ? pred_e : old;             // what the slot holds when this lane's turn comes
+
+        bool empty = false;                                       // MAP on a never-written slot yields the zero quad
+        const bool hsusp = active && hit && !has_pred && old == 0 && h != 0;
+        const bool psusp = active && !hit && e == 0 && h != 0;
+        if (ballot64(hsusp || psusp)) {
+            if (hsusp) empty = !zmap_test(zmap, h);
+            if (psusp) zmap_set(zmap, h);
+        }
+        if (active) {
+            if (hit) {                                            // chameleon.rs:64-68: quad = chunk_map[hash]
+                const uint32_t Pfull = (h << 16) | (eff & 0xfffeu);
+                q = empty ? 0u : ((((Pfull >> 1) * kHalfMulInv) & 0x7fffffffu) | ((eff & 1u) << 31));
+            }
+            dict_store(tbl + 2u * h, hit ? eff : e);              // chameleon.rs:56-61: PLAIN stores, MAP leaves as is
+            st32u(o + 4u * lane, q);
+        }
+        if (kstop < 64) {                                         // end of data inside this record
+            if (lane < tailb) o[4u * kstop + lane] = rec[__builtin_amdgcn_readlane((int)off, (int)kstop) + lane];
+            opos += 4ull * kstop + tailb;
+            ipos = elen;
+            break;
+        }
+        const uint32_t rec_len = kSig + kBlock - 2u * (uint32_t)__builtin_popcountll(sig);
+        guard.update(rec_len >= kBlock);                          // codec.rs:98,122
+        ipos += rec_len;
+        opos += kBlock;
+    }
+    if (exact && !bad && opos != cap) bad = true;
+    if (lane == 0) {
+        produced[chunk] = opos;
+        if (bad) atomicOr(err, 1u);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host launchers
+// ---------------------------------------------------------------------------------------------------------------
+hipError_t launch_chameleon_encode(const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks,
+                                   uint8_t* d_out, uint64_t out_stride, uint64_t* d_sizes, hipStream_t stream) {
+    hipError_t e = hipFuncSetAttribute((const void*)chameleon_encode_chunks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
+    if (e != hipSuccess) return e;
+    if (n_chunks == 0) return hipSuccess;
+    hipLaunchKernelGGL(chameleon_encode_chunks, dim3(n_chunks), dim3(64), kLdsBytes, stream, d_in, total, chunk_bytes, d_out, out_stride, d_sizes);
+    return hipGetLastError();
+}
+
+hipError_t launch_chameleon_decode(const uint8_t* d_in, const uint64_t* d_offsets, const uint64_t* d_sizes,
+                                   uint32_t n_chunks, uint8_t* d_out, uint64_t out_stride, uint64_t out_total,
+                                   bool exact, uint64_t* d_produced, uint32_t* d_err, hipStream_t stream) {
+    hipError_t e = hipFuncSetAttribute((const void*)chameleon_decode_chunks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
+    if (e != hipSuccess) return e;
+    if (n_chunks == 0) return hipSuccess;
+    hipLaunchKernelGGL(chameleon_decode_chunks, dim3(n_chunks), dim3(64), kLdsBytes, stream, d_in, d_offsets, d_sizes, d_out, out_stride, out_total, exact ? 1u : 0u, d_produced, d_err);
+    return hipGetLastError();
+}
+
+}  // namespace density

@@ -1,0 +1,150 @@
+/*
+ * density_hip.h — C ABI of libdensity_hip.so, the MI355X (gfx950) implementation of density's
+ * 4-byte-word dictionary-hash encode/decode hot path.
+ *
+ * Section 1 is the drop-in boundary: the nine `extern "C"` symbols the reference crate (density-rs 0.16.6)
+ * itself exports, with identical names, signatures and return convention.  A reference-side FFI (Rust
+ * `extern "C"` block, cgo, ctypes ...) binds exactly these; see INTEGRATION.md.
+ *
+ * Section 2 is additive: the chunked container that makes the path data-parallel (each chunk is an independent
+ * reference stream), device-pointer + stream variants, and profiling hooks.  Nothing in section 2 changes the
+ * meaning of section 1.
+ *
+ * All citations are file:line in the reference tree (src/...).
+ */
+#ifndef DENSITY_HIP_H
+#define DENSITY_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------------------------------
+ * 1. Reference-compatible symbols (host pointers, single reference-format stream, bit-exact with the crate).
+ *
+ *    Return value: bytes written; 0 on any failure (the reference maps Err to 0 via unwrap_or(0) and otherwise
+ *    panics on a short buffer or truncated input; this library returns 0 instead and never writes past
+ *    output_size).  An empty input also returns 0, as in the reference.
+ *    `output_size` must be >= {algo}_safe_encode_buffer_size(input_size) for encode and >= the original length
+ *    for decode (the stream does not carry its decoded length; codec/codec.rs:72-80).
+ *
+ *    These calls stage through device memory (H2D, kernels, D2H) on a per-device internal stream and are
+ *    thread-safe.  One reference stream is one sequential dependency chain, so this entry point runs a single
+ *    work-group; the data-parallel path is the container API of section 2.
+ * ---------------------------------------------------------------------------------------------------------- */
+
+/* algorithms/chameleon/chameleon.rs:70-73 */
+size_t chameleon_encode(const uint8_t* input, size_t input_size, uint8_t* output, size_t output_size);
+/* algorithms/chameleon/chameleon.rs:75-78 */
+size_t chameleon_decode(const uint8_t* input, size_t input_size, uint8_t* output, size_t output_size);
+/* algorithms/chameleon/chameleon.rs:80-83 -> codec/codec.rs:18-21 */
+size_t chameleon_safe_encode_buffer_size(size_t size);
+
+/* algorithms/cheetah/cheetah.rs:105-108 */
+size_t cheetah_encode(const uint8_t* input, size_t input_size, uint8_t* output, size_t output_size);
+/* algorithms/cheetah/cheetah.rs:110-113 */
+size_t cheetah_decode(const uint8_t* input, size_t input_size, uint8_t* output, size_t output_size);
+/* algorithms/cheetah/cheetah.rs:115-118 */
+size_t cheetah_safe_encode_buffer_size(size_t size);
+
+/* algorithms/lion/lion.rs:193-196 */
+size_t lion_encode(const uint8_t* input, size_t input_size, uint8_t* output, size_t output_size);
+/* algorithms/lion/lion.rs:198-201 */
+size_t lion_decode(const uint8_t* input, size_t input_size, uint8_t* output, size_t output_size);
+/* algorithms/lion/lion.rs:203-206 */
+size_t lion_safe_encode_buffer_size(size_t size);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * 2. Additive extensions (not in the reference).
+ * ---------------------------------------------------------------------------------------------------------- */
+
+enum { DENSITY_HIP_CHAMELEON = 0, DENSITY_HIP_CHEETAH = 1, DENSITY_HIP_LION = 2 };
+
+enum {
+    DENSITY_HIP_OK = 0,
+    DENSITY_HIP_ERR_ARGUMENT = 1,     /* bad algo / chunk size / null pointer */
+    DENSITY_HIP_ERR_CAPACITY = 2,     /* output or workspace too small */
+    DENSITY_HIP_ERR_FORMAT = 3,       /* container header or payload malformed / truncated */
+    DENSITY_HIP_ERR_RUNTIME = 4,      /* HIP runtime error, no gfx950 device, failed self-test */
+    DENSITY_HIP_ERR_UNSUPPORTED = 5   /* algorithm not available on the device path in this build */
+};
+
+/*
+ * Chunked container ("DHC1").  The input is cut into chunks of `chunk_size` bytes (a multiple of 256, i.e. of
+ * every algorithm's block size); chunk i is encoded as an independent reference stream — fresh zero tables and a
+ * fresh ProtectionState, exactly what {Algo}::encode(&input[i*C..]) returns (chameleon.rs:45-48) — so chunks
+ * encode and decode in parallel.  Layout (little-endian):
+ *     [0,32)                 density_hip_header_t
+ *     [32, 32+4*n_chunks)    u32 encoded size of each chunk payload
+ *     payload i starts at the next 16-byte boundary after payload i-1 (payload 0 after the size table)
+ * With one chunk (chunk_size >= total_len) the single payload IS the reference stream of the whole input.
+ */
+#define DENSITY_HIP_MAGIC 0x31434844u /* "DHC1" */
+#define DENSITY_HIP_DEFAULT_CHUNK (1u << 20)
+
+typedef struct density_hip_header {
+    uint32_t magic;          /* DENSITY_HIP_MAGIC */
+    uint8_t  algo;           /* DENSITY_HIP_CHAMELEON ... */
+    uint8_t  version;        /* 1 */
+    uint16_t reserved;       /* 0 */
+    uint32_t chunk_size;     /* bytes of input per chunk, multiple of 256 */
+    uint32_t n_chunks;       /* ceil(total_len / chunk_size) */
+    uint64_t total_len;      /* decoded length in bytes */
+    uint64_t container_len;  /* total container length in bytes (header + table + padded payloads) */
+} density_hip_header_t;
+
+/* Upper bound of the container size for `input_size` bytes (0 if the arguments are invalid). chunk_size 0 means
+ * DENSITY_HIP_DEFAULT_CHUNK. */
+size_t density_hip_container_bound(int algo, size_t input_size, size_t chunk_size);
+
+/* Host-pointer container codec (H2D, kernels, D2H). Return bytes written, 0 on failure. */
+size_t density_hip_encode(int algo, const uint8_t* input, size_t input_size, uint8_t* output, size_t output_size,
+                          size_t chunk_size);
+size_t density_hip_decode(const uint8_t* container, size_t container_size, uint8_t* output, size_t output_size);
+/* Reads total_len from a host-resident container header (0 if malformed). */
+size_t density_hip_decoded_size(const uint8_t* container, size_t container_size);
+
+/* Device-resident container codec: pointers are device pointers on the current HIP device, `stream` is a
+ * hipStream_t (NULL = the library's internal stream).  Work is enqueued on `stream`.
+ *   - workspace: pass a device buffer of at least density_hip_{encode,decode}_workspace_size() bytes, or NULL to
+ *     use the library's per-device cached workspace (then calls on different streams must not overlap).
+ *   - header_out / decoded_size_out: optional HOST pointers; when non-NULL the call synchronises `stream` and
+ *     fills them (and then also reports kernel-detected format errors).  When NULL the call is fully asynchronous.
+ * Returns DENSITY_HIP_OK or an error code. */
+size_t density_hip_encode_workspace_size(int algo, size_t input_size, size_t chunk_size);
+size_t density_hip_decode_workspace_size(uint32_t n_chunks);
+int density_hip_encode_device(int algo, const void* d_input, size_t input_size, void* d_output, size_t output_capacity,
+                              size_t chunk_size, void* d_workspace, size_t workspace_size, void* stream,
+                              density_hip_header_t* header_out);
+/* `header` may be NULL: it is then read back from the device (one small synchronous copy). */
+int density_hip_decode_device(const void* d_container, size_t container_size, const density_hip_header_t* header,
+                              void* d_output, size_t output_capacity, void* d_workspace, size_t workspace_size,
+                              void* stream, size_t* decoded_size_out);
+
+/* Device-resident single reference stream (the format of section 1, device pointers).  `size_out` is a HOST
+ * pointer and must be non-NULL: the call synchronises `stream`. */
+int density_hip_stream_encode_device(int algo, const void* d_input, size_t input_size, void* d_output,
+                                     size_t output_capacity, void* stream, size_t* size_out);
+int density_hip_stream_decode_device(int algo, const void* d_input, size_t input_size, void* d_output,
+                                     size_t output_capacity, void* stream, size_t* size_out);
+
+/* Profiling: when enabled, the device entry points bracket each kernel with HIP events on the launch stream.
+ * density_hip_last_timings() synchronises the last event and returns the duration of every kernel launched on the
+ * current device since the previous density_hip_last_timings() call (at most 8192 marks are kept), in launch order;
+ * names[i] points to a static string.  Returns the number of entries written (<= capacity). */
+void density_hip_set_profiling(int enabled);
+int density_hip_last_timings(float* milliseconds, const char** names, int capacity);
+
+/* Runs the LDS write-order self-test the kernels rely on (also run lazily before first use). 0 = pass. */
+int density_hip_selftest(void);
+/* Thread-local description of the last failure in this thread ("" if none). */
+const char* density_hip_last_error(void);
+const char* density_hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DENSITY_HIP_H */

@@ -84,3 +84,43 @@ def mixed(n, seed=5):
         left -= k
         kinds += 1
     return np.concatenate(parts)[:n].copy()
+
+
+def low_zero_quads(n_quads, seed=4):
+    """Quads whose 16-bit dictionary entry packs to 0 outside slot 0 (low 15 bits and top bit clear, e.g. the bytes
+    00 00 xx yy / 00 80 xx yy with yy < 0x80): the one value that aliases a never-written slot in the GPU table
+    (density_amd/csrc/chameleon.hip header).  Mixed with zero quads and ordinary values, with repeats."""
+    rng = np.random.default_rng(seed)
+    pool = (rng.integers(0, 1 << 16, size=48, dtype=np.uint64) << np.uint64(15)).astype(np.uint64)
+    pool = np.concatenate([pool, np.zeros(4, np.uint64), rng.integers(0, 1 << 32, size=12, dtype=np.uint64)])
+    q = pool[rng.integers(0, pool.size, size=n_quads)]
+    return q.astype("<u4").view(np.uint8).copy()
+
+
+def binaryish(n, seed=6):
+    """Little-endian 32-bit records with small values and zero padding: lots of 00 00 xx 00 style quads."""
+    rng = np.random.default_rng(seed)
+    vals = rng.choice(np.array([0, 1, 2, 65536, 32768, 98304, 0x10000 * 7, 0x8000 * 5, 255, 256], dtype=np.uint32), size=n // 4 + 1)
+    noise = rng.integers(0, 1 << 32, size=n // 4 + 1, dtype=np.uint64).astype(np.uint32)
+    pick = rng.random(n // 4 + 1) < 0.1
+    return np.where(pick, noise, vals).astype("<u4").view(np.uint8)[:n].copy()
+
+
+def by_kind(kind, n, seed=1):
+    if kind == "prose":
+        return prose(n, seed)
+    if kind == "random":
+        return random_bytes(n, seed)
+    if kind == "zeros":
+        return np.zeros(n, dtype=np.uint8)
+    if kind == "mixed":
+        return mixed(n, seed)
+    if kind == "samehash":
+        return same_hash_quads(n // 4 + 1, seed)[:n].copy()
+    if kind == "lowzero":
+        return low_zero_quads(n // 4 + 1, seed)[:n].copy()
+    if kind == "binaryish":
+        return binaryish(n, seed)
+    if kind == "rep":
+        return rep_text(n, period=100_003, seed=seed)
+    raise ValueError(kind)

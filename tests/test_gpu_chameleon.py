@@ -1,0 +1,175 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP Chameleon path, called through the C ABI, against the
+CPU oracle on the same inputs — bit-exact (integer/byte work, no tolerance)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import datagen
+from density_amd import Chameleon, DecodeError, EncodeError, container
+from oracle import pyoracle
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+KAT = json.load(open(os.path.join(HERE, "golden", "kat.json")))
+ALGO = "chameleon"
+
+
+def gpu_encode(data):
+    data = np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+    out = np.zeros(max(Chameleon.safe_encode_buffer_size(data.size), 1), dtype=np.uint8)
+    n = Chameleon.encode(data, out)
+    return out[:n].tobytes()
+
+
+def gpu_decode(enc, n):
+    enc = np.frombuffer(bytes(enc), dtype=np.uint8)
+    out = np.zeros(max(n, 1), dtype=np.uint8)
+    m = Chameleon.decode(enc, out)
+    return out[:m].tobytes()
+
+
+def test_reference_golden_vector_on_gpu():
+    """src/lib.rs:22-42: exact 73 bytes, output buffer of len(input) bytes like the reference test, then decode."""
+    data = bytes.fromhex(KAT["reference_input_hex"])
+    out = bytearray(len(data))
+    n = Chameleon.encode(data, out)
+    assert bytes(out[:n]) == bytes.fromhex(KAT["reference"][ALGO])
+    back = bytearray(len(data))
+    m = Chameleon.decode(bytes(out[:n]), back)
+    assert bytes(back[:m]) == data
+
+
+def test_committed_kat_fixtures_on_gpu():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_kat", os.path.join(HERE, "golden", "make_kat.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for name, data in mod.derived_inputs().items():
+        row = KAT["derived"][name][ALGO]
+        enc = gpu_encode(data) if data else b""
+        assert (len(enc), hashlib.sha256(enc).hexdigest()) == (row["len"], row["sha256"]), name
+        assert gpu_decode(enc, len(data)) == data if data else True
+
+
+EDGE_SIZES = sorted(set(list(range(1, 41)) + [63, 64, 65, 127, 128, 129, 251, 252, 253, 254, 255, 256, 257, 258, 259, 260, 263, 264, 265,
+                                              271, 272, 273, 511, 512, 513, 519, 520, 521, 767, 768, 769, 4093, 4094, 4095, 4096, 4097, 4098, 4099]))
+
+
+@pytest.mark.parametrize("kind", ["prose", "random", "zeros", "mixed", "samehash", "lowzero"])
+def test_stream_parity_edge_sizes(kind):
+    big = {"prose": datagen.prose(5000, 21), "random": datagen.random_bytes(5000, 22), "zeros": np.zeros(5000, np.uint8),
+           "mixed": datagen.mixed(5000, 23), "samehash": datagen.same_hash_quads(1250, 24),
+           "lowzero": datagen.low_zero_quads(1250, 25)}[kind]
+    for n in EDGE_SIZES:
+        data = big[:n].copy()
+        want = pyoracle.encode(ALGO, data)
+        got = gpu_encode(data)
+        assert got == want, (kind, n)
+        assert gpu_decode(want, n) == data.tobytes(), (kind, n)
+
+
+@pytest.mark.parametrize("kind,n", [("prose", 1_000_003), ("random", 300_001), ("zeros", 262_144 + 2), ("mixed", 2_000_000),
+                                    ("samehash", 400_000), ("lowzero", 500_002), ("binaryish", 700_001), ("rep", 1_500_000)])
+def test_stream_parity_large(kind, n):
+    """Whole-stream (single chunk) parity at sizes the oracle finishes in well under a second: exercises multi-block
+    dictionary carry, copy mode entering/leaving (random, mixed), the all-one-slot hazard and the zero-entry map."""
+    data = datagen.by_kind(kind, n, seed=77)
+    want, st = pyoracle.encode_stats(ALGO, data)
+    got = gpu_encode(data)
+    assert len(got) == len(want)
+    assert got == want
+    if kind in ("random", "mixed"):
+        assert st["copy_blocks"] > 0
+    assert gpu_decode(want, n) == data.tobytes()
+
+
+@pytest.mark.parametrize("chunk", [256, 512, 4096, 65536, 1 << 20])
+@pytest.mark.parametrize("kind", ["prose", "mixed"])
+def test_container_chunks_match_oracle(kind, chunk):
+    n = 3 * (1 << 20) + 12345 if chunk >= 65536 else 40 * chunk + 77
+    data = datagen.by_kind(kind, n, seed=chunk)
+    cont = np.zeros(container.container_bound(ALGO, n, chunk), dtype=np.uint8)
+    cn = container.encode(ALGO, data, cont, chunk)
+    hdr, payloads = container.chunk_payloads(cont[:cn])
+    assert (hdr.total_len, hdr.chunk_size, hdr.n_chunks, hdr.container_len) == (n, chunk, -(-n // chunk), cn)
+    for i, p in enumerate(payloads):
+        assert p == pyoracle.encode(ALGO, data[i * chunk:(i + 1) * chunk]), (kind, chunk, i)
+    back = np.zeros(n, dtype=np.uint8)
+    assert container.decode(cont[:cn], back) == n
+    assert np.array_equal(back, data)
+
+
+def test_gpu_decodes_cpu_built_container():
+    """A container assembled on the CPU from oracle streams (what a CPU producer would write) decodes on the GPU."""
+    chunk, n = 8192, 100_000
+    data = datagen.mixed(n, seed=5)
+    streams = [pyoracle.encode(ALGO, data[i:i + chunk]) for i in range(0, n, chunk)]
+    nc = len(streams)
+    body = bytearray()
+    base = (32 + 4 * nc + 15) // 16 * 16
+    for s in streams:
+        body += s
+        body += bytes(-len(body) % 16)
+    body = body[:len(body) - (-len(streams[-1]) % 16)] if streams else body
+    import struct
+    total = base + len(body)
+    head = struct.pack("<IBBHIIQQ", 0x31434844, 0, 1, 0, chunk, nc, n, total)
+    table = b"".join(struct.pack("<I", len(s)) for s in streams)
+    raw = head + table + bytes(base - 32 - 4 * nc) + bytes(body)
+    back = np.zeros(n, dtype=np.uint8)
+    assert container.decode(raw, back) == n
+    assert np.array_equal(back, data)
+
+
+def test_errors_are_reported_not_crashes():
+    data = datagen.prose(3000, 41)
+    enc = pyoracle.encode(ALGO, data)
+    out = np.zeros(3000, dtype=np.uint8)
+    # truncated stream whose last record ends on a MAP item with < 2 bytes -> reference panics, we raise
+    bad = 0
+    for cut in (1, 2, 3, 5, 7, 9, 100):
+        try:
+            m = Chameleon.decode(enc[:-cut], out)
+            assert out[:m].tobytes() != data.tobytes()
+        except DecodeError:
+            bad += 1
+    assert bad >= 1
+    with pytest.raises(DecodeError):
+        Chameleon.decode(enc, np.zeros(100, dtype=np.uint8))          # output too small
+    with pytest.raises(EncodeError):
+        Chameleon.encode(datagen.random_bytes(3000, 1), np.zeros(100, dtype=np.uint8))
+    # corrupted container header
+    cont = np.zeros(container.container_bound(ALGO, 3000, 1024), dtype=np.uint8)
+    cn = container.encode(ALGO, data, cont, 1024)
+    broken = cont[:cn].copy()
+    broken[0] ^= 0xFF
+    with pytest.raises(DecodeError):
+        container.decode(broken, out)
+    short = cont[:cn - 40].copy()
+    with pytest.raises(DecodeError):
+        container.decode(short, out)
+
+
+def test_full_size_properties_device_resident():
+    """256 MiB device-resident container round trip (BASELINE config-2 shape at a quarter of the size): decode(encode(x))
+    == x bit for bit, header arithmetic, and a sample of chunk streams equal to the oracle."""
+    import torch
+    n, chunk = 1 << 28, 1 << 20
+    host = datagen.rep_text(n)
+    x = torch.from_numpy(host).cuda()
+    cap = container.container_bound(ALGO, n, chunk)
+    cont = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    back = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    hdr = container.encode_device(ALGO, x.data_ptr(), n, cont.data_ptr(), cap, chunk, stream=s)
+    assert hdr.n_chunks == n // chunk and hdr.total_len == n
+    got = container.decode_device(cont.data_ptr(), hdr.container_len, back.data_ptr(), n, header=hdr, stream=s)
+    assert got == n
+    assert torch.equal(back, x)
+    raw = cont[:hdr.container_len].cpu().numpy()
+    _, payloads = container.chunk_payloads(raw)
+    for i in (0, 1, 117, hdr.n_chunks - 1):
+        assert payloads[i] == pyoracle.encode(ALGO, host[i * chunk:(i + 1) * chunk]), i
