@@ -1,0 +1,213 @@
+#!/usr/bin/env python
+"""bench.py — Chameleon encode+decode round trip on device-resident buffers (BASELINE.json metric).
+
+One "step" = one container encode followed by one container decode of this rank's synthetic buffer (inputs already
+resident in HBM).  `value` = uncompressed bytes processed by ALL ranks / wall time of the K timed steps, in MB/s
+(= N / (t_enc + t_dec), the round-trip throughput of SURVEY.md §8d, matching divan's BytesCount of the uncompressed
+slice in both directions, benches/density.rs:29,48).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--size BYTES] [--chunk BYTES]
+
+N > 1 is launched by the driver through torch.distributed.run (one rank per GPU, RCCL); the path shards by chunks with
+no data-path collective, so scaling is weak: every rank encodes/decodes its own buffer.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+
+
+def cpu_baseline(host, chunk, sample_bytes, reps=3):
+    """Times the CPU oracle (C restatement of the Rust reference, single thread like the reference's bench) on a bounded
+    sample of the same workload.  Checker/baseline only — never part of the measured GPU path."""
+    from oracle import pyoracle
+    n = min(sample_bytes, host.size)
+    src = np.ascontiguousarray(host[:n])
+    cap = pyoracle.safe_encode_buffer_size("chameleon", n)
+    enc = np.empty(cap, dtype=np.uint8)
+    dec = np.empty(n, dtype=np.uint8)
+    best_e = best_d = 1e30
+    esize = 0
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        esize = pyoracle.encode_into("chameleon", src.ctypes.data, n, enc.ctypes.data, cap)
+        t1 = time.perf_counter()
+        got = pyoracle.decode_into("chameleon", enc.ctypes.data, esize, dec.ctypes.data, n)
+        t2 = time.perf_counter()
+        assert got == n
+        best_e, best_d = min(best_e, t1 - t0), min(best_d, t2 - t1)
+    assert np.array_equal(dec, src)
+    out = {"value": round(n / (best_e + best_d) / 1e6, 1), "unit": "MB/s", "cores": 1, "kind": "port",
+           "sample": f"first {n >> 20} MiB of the rank-0 buffer, whole-stream Chameleon encode+decode, best of {reps}, "
+                     f"C restatement of density-rs 0.16.6 (oracle/density_oracle.c), 1 thread",
+           "encode_MBps": round(n / best_e / 1e6, 1), "decode_MBps": round(n / best_d / 1e6, 1),
+           "ratio_whole_stream": round(n / esize, 4)}
+    # all host cores, one chunk per task (ctypes releases the GIL): what a chunked CPU build of the same container does
+    try:
+        from concurrent.futures import ThreadPoolExecutor
+        ncpu = os.cpu_count() or 1
+        nchunks = (n + chunk - 1) // chunk
+        ccap = pyoracle.safe_encode_buffer_size("chameleon", chunk)
+        encs = np.empty((nchunks, ccap), dtype=np.uint8)
+        sizes = [0] * nchunks
+
+        def enc_task(i):
+            ln = min(chunk, n - i * chunk)
+            sizes[i] = pyoracle.encode_into("chameleon", src.ctypes.data + i * chunk, ln, encs[i].ctypes.data, ccap)
+
+        def dec_task(i):
+            ln = min(chunk, n - i * chunk)
+            pyoracle.decode_into("chameleon", encs[i].ctypes.data, sizes[i], dec.ctypes.data + i * chunk, ln)
+
+        with ThreadPoolExecutor(ncpu) as ex:
+            list(ex.map(enc_task, range(nchunks)))     # warm
+            t0 = time.perf_counter(); list(ex.map(enc_task, range(nchunks))); t1 = time.perf_counter()
+            list(ex.map(dec_task, range(nchunks))); t2 = time.perf_counter()
+        assert np.array_equal(dec, src)
+        out["all_cores"] = {"value": round(n / (t2 - t0) / 1e6, 1), "unit": "MB/s", "cores": ncpu,
+                            "ratio_chunked": round(n / sum(sizes), 4), "chunk": chunk}
+    except Exception as ex:  # pragma: no cover
+        out["all_cores"] = {"error": str(ex)}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--size", type=int, default=1 << 30, help="bytes per GPU (default 1 GiB = BASELINE config 2)")
+    ap.add_argument("--chunk", type=int, default=1 << 20)
+    ap.add_argument("--cpu-sample", type=int, default=256 << 20)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--variant", type=int, default=0, help="0 = default kernels, 1 = simple one-wavefront kernels")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import datagen
+    from density_amd import container
+    from oracle import pyoracle
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    if world != args.gpus and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+
+    n, chunk = args.size, args.chunk
+    container.set_kernel_variant(args.variant)
+    # config 2 / 5 of BASELINE.json: rep-text, per-shard seed = seed + rank
+    host = datagen.rep_text(n, seed=0x9E3779B97F4A7C15 + rank)
+    x = torch.from_numpy(host).cuda()
+    cap = container.container_bound("chameleon", n, chunk)
+    cont = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    back = torch.empty(n, dtype=torch.uint8, device="cuda")
+    ws_size = max(int(density_ws(container, n, chunk)), 1)
+    ws = torch.empty(ws_size, dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream()
+    s = stream.cuda_stream
+
+    # correctness before any timing: decode(encode(x)) == x, and a sample of chunk streams equals the oracle's
+    hdr = container.encode_device("chameleon", x.data_ptr(), n, cont.data_ptr(), cap, chunk, stream=s, workspace=(ws.data_ptr(), ws_size))
+    got = container.decode_device(cont.data_ptr(), hdr.container_len, back.data_ptr(), n, header=hdr, stream=s, workspace=(ws.data_ptr(), ws_size))
+    assert got == n and torch.equal(back, x), "round trip mismatch"
+    raw = cont[:hdr.container_len].cpu().numpy()
+    _, payloads = container.chunk_payloads(raw)
+    for i in sorted(set([0, hdr.n_chunks // 3, hdr.n_chunks - 1])):
+        assert payloads[i] == pyoracle.encode("chameleon", host[i * chunk:(i + 1) * chunk]), f"chunk {i} differs from the oracle"
+    E = int(hdr.container_len)
+    del raw, payloads
+
+    def step():
+        container.encode_device("chameleon", x.data_ptr(), n, cont.data_ptr(), cap, chunk, stream=s, workspace=(ws.data_ptr(), ws_size), want_header=False)
+        container.decode_device(cont.data_ptr(), E, back.data_ptr(), n, header=hdr, stream=s, workspace=(ws.data_ptr(), ws_size), sync=False)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    container.set_profiling(True)      # HIP events around every kernel, on the launch stream, inside the timed region
+    container.last_timings()           # drain
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    timings = container.last_timings()
+    container.set_profiling(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert torch.equal(back, x), "round trip mismatch after timed steps"
+
+    if rank == 0:
+        per = {}
+        for name, ms in timings:
+            per.setdefault(name, []).append(ms)
+        avg = {k: sum(v) / len(v) for k, v in per.items()}
+        # algorithmic bytes per launch: encode reads N writes E, decode reads E writes N; the stitch pass
+        # (layout + compact) moves no algorithmic bytes — it is overhead that lowers the whole-path fraction.
+        alg = {"chameleon_encode_chunks": n + E, "chameleon_decode_chunks": n + E}
+        dom = max(alg, key=lambda k: avg.get(k, 0.0))
+        ach = alg[dom] / (avg[dom] * 1e-3) / 1e9 if avg.get(dom) else 0.0
+        ms_step = dt / args.steps * 1e3
+        t_enc = sum(avg.get(k, 0.0) for k in ("chameleon_encode_chunks", "layout_encode", "compact"))
+        t_dec = sum(avg.get(k, 0.0) for k in ("layout_decode", "chameleon_decode_chunks"))
+        result = {
+            "metric": "MB/s encode+decode (round-trip) per GPU + compression ratio, dickens/enwik8",
+            "value": round(world * n * args.steps / dt / 1e6, 1),
+            "unit": "MB/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32", "data": "synthetic",
+            "config": {"workload": f"chameleon rep-text {n >> 20} MiB per GPU (BASELINE config 2: 1 GiB synthetic repeating text, "
+                                   f"period 1000003 B), device-resident container encode+decode, chunk {chunk >> 10} KiB",
+                       "algorithm": "chameleon", "bytes_per_gpu": n, "chunk_bytes": chunk, "n_chunks": int(hdr.n_chunks),
+                       "parallelism": f"chunk-sharded x{world}, no data-path collective"},
+            "compression_ratio": round(n / E, 4),
+            "encoded_bytes": E,
+            "encode_ms": round(t_enc, 4), "decode_ms": round(t_dec, 4),
+            "kernel_ms": {k: round(v, 4) for k, v in avg.items()},
+            "whole_path_hbm_frac": round((2.0 * (n + E)) / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                         "algorithmic_bytes_per_launch": alg[dom]},
+        }
+        if not args.no_cpu:
+            result["cpu_baseline"] = cpu_baseline(host, chunk, args.cpu_sample)
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def density_ws(container, n, chunk):
+    from density_amd import _lib
+    return max(_lib.lib().density_hip_encode_workspace_size(0, n, chunk), _lib.lib().density_hip_decode_workspace_size((n + chunk - 1) // chunk))
+
+
+if __name__ == "__main__":
+    main()

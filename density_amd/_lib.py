@@ -44,6 +44,7 @@ SYMBOLS.update({
     "density_hip_stream_encode_device": (_I, [_I, _VP, _SZ, _VP, _SZ, _VP, ctypes.POINTER(_SZ)]),
     "density_hip_stream_decode_device": (_I, [_I, _VP, _SZ, _VP, _SZ, _VP, ctypes.POINTER(_SZ)]),
     "density_hip_set_profiling": (None, [_I]),
+    "density_hip_set_kernel_variant": (None, [_I]),
     "density_hip_last_timings": (_I, [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_char_p), _I]),
     "density_hip_selftest": (_I, []),
     "density_hip_last_error": (ctypes.c_char_p, []),

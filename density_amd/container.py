@@ -88,6 +88,11 @@ def stream_decode_device(algo, d_in, n, d_out, cap, stream=0):
     return size.value
 
 
+def set_kernel_variant(variant):
+    """0 = default (pipelined) kernels, 1 = simple one-wavefront kernels (test hook)."""
+    _lib.lib().density_hip_set_kernel_variant(int(variant))
+
+
 def set_profiling(on):
     _lib.lib().density_hip_set_profiling(1 if on else 0)
 

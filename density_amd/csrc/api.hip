@@ -458,6 +458,7 @@ size_t density_hip_decode(const uint8_t* container, size_t container_size, uint8
 }
 
 void density_hip_set_profiling(int enabled) { g_profiling = enabled; }
+void density_hip_set_kernel_variant(int variant) { density::g_force_simple = (variant == 1); }
 
 int density_hip_last_timings(float* milliseconds, const char** names, int capacity) {
     int dev = -1;

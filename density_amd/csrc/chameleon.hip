@@ -22,6 +22,8 @@
 // leaves the table in the state the sequential reference would (last writer wins).  Lanes whose slot is shared
 // (w != lane somewhere in the group) take the value of the nearest earlier lane of the group instead of `old`;
 // groups are enumerated with wave-level ballots.
+#include <cstdlib>
+
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -69,6 +71,17 @@ __device__ __forceinline__ void dict_probe(uint32_t addr, uint32_t lane, uint32_
 __device__ __forceinline__ void dict_store(uint32_t addr, uint32_t v) {
     asm volatile("ds_write_b16 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
+// Ordered exchange: every lane swaps its 16-bit entry into its slot and gets back what the slot held at ITS turn.  gfx950
+// services the lanes of one LDS atomic in ascending lane order, so one instruction performs 64 sequential dictionary
+// steps (chameleon.rs:88-100) including every same-slot dependency inside the block.  Two entries share a dword, hence
+// the masked form ds_mskor_rtn_b32: mem = (mem & ~mask) | val.  Issue only; pair with lds_wait_keep / lds_wait_all.
+__device__ __forceinline__ void dict_xchg_issue(uint32_t dword_addr, uint32_t mask, uint32_t val, uint32_t& ret) {
+    asm volatile("ds_mskor_rtn_b32 %0, %1, %2, %3" : "=v"(ret) : "v"(dword_addr), "v"(mask), "v"(val) : "memory");
+}
+// wait until at most N LDS operations younger than the one producing `r` are outstanding (LDS returns in order)
+template <int N>
+__device__ __forceinline__ void lds_wait_keep(uint32_t& r) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(r) : "n"(N) : "memory"); }
+__device__ __forceinline__ void lds_wait_all() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ uint32_t zmap_test_and_set(uint32_t zbase, uint32_t h) {
     uint32_t r;
     asm volatile("ds_or_rtn_b32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r) : "v"(zbase + (h >> 5) * 4u), "v"(1u << (h & 31u)) : "memory");
@@ -193,6 +206,263 @@ __global__ __launch_bounds__(64) void chameleon_encode_chunks(const uint8_t* __r
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Pipelined encoder: one work-group (4 waves) per chunk.
+//
+//   wave 0  "dictionary wave": the only wave that touches the table, so the in-order LDS pipeline gives the sequential
+//           dictionary semantics for free.  It also issues the global->LDS DMA (global_load_lds_dwordx4, 1 KiB = 4
+//           blocks per instruction) that stages the chunk through a ring in LDS two rounds ahead, runs the copy-mode FSM,
+//           and publishes one 16-byte result per block: {signature, output offset, mode}.
+//   waves 1-3 "emit waves": one round behind, they turn (signature, quads) into the record bytes: a pair of mbcnt's per
+//           lane, then 2-/4-byte stores straight to global memory.
+//
+// A round is kRound blocks; rounds are separated by one s_barrier.  Buffers: input ring of 4 rounds (DMA at t-2, hashed at
+// t, emitted at t+1), result ring of 2 rounds.  Only whole 256-byte blocks go through the pipeline; a ragged last block
+// (codec.rs:51-63) is finished by the dictionary wave with the scalar-path code of chameleon_encode_chunks.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr uint32_t kRound = 8;                               // blocks per round
+constexpr uint32_t kRoundBytes = kRound * kBlock;            // 2 KiB
+constexpr uint32_t kInRing = 4, kResRing = 2;
+constexpr uint32_t kInBase = kLdsBytes;                      // 139264, 16-byte aligned
+constexpr uint32_t kResBase = kInBase + kInRing * kRoundBytes;
+constexpr uint32_t kLdsBytesPipe = kResBase + kResRing * kRound * 16u;
+constexpr uint32_t kEmitWaves = 3;
+static_assert(kLdsBytesPipe <= 160u * 1024u, "LDS budget");
+static_assert(kRound % 4 == 0, "one DMA instruction moves 4 blocks");
+
+constexpr uint64_t kModeCopy = 1ull << 63;
+
+// one LDS-DMA instruction: lane l copies 16 bytes from its global pointer to lds_dst + 16*l (lds_dst wave-uniform)
+__device__ __forceinline__ void dma_1k(const uint8_t* gsrc, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_dst)
+        : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// all of this wave's LDS traffic retired, then the work-group barrier; no vmcnt: stores and DMA stay in flight
+__device__ __forceinline__ void round_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+}  // namespace
+
+__global__ __launch_bounds__(256) void chameleon_encode_chunks_pipe(const uint8_t* __restrict__ in, uint64_t total,
+                                                                    uint64_t chunk_bytes, uint8_t* __restrict__ out,
+                                                                    uint64_t out_stride, uint64_t* __restrict__ sizes, uint32_t dbg) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint64_t chunk = blockIdx.x;
+    const uint8_t* src = in + chunk * chunk_bytes;
+    const uint64_t len = (total - chunk * chunk_bytes) < chunk_bytes ? (total - chunk * chunk_bytes) : chunk_bytes;
+    uint8_t* dst = out + chunk * out_stride;
+    const uint64_t nfull = len / kBlock;                       // whole blocks: these go through the pipeline
+    const uint64_t nrounds = (nfull + kRound - 1) / kRound;
+
+    {   // clear table + zero-entry map (all 256 threads)
+        uint4* p = reinterpret_cast<uint4*>(smem);
+        const uint4 z = make_uint4(0, 0, 0, 0);
+        for (uint32_t i = threadIdx.x; i < kLdsBytes / 16; i += 256) p[i] = z;
+    }
+    const uint32_t lds0 = lds_addr(smem);
+    const uint32_t tbl = lds0, zmap = lds0 + kTableBytes;
+    round_barrier();
+
+    Guard guard;
+    uint64_t opos = 0;
+
+    // DMA of round r into ring slot r % 4 (dictionary wave only). Lanes past the last whole block stay idle.
+    auto issue_round = [&](uint64_t r) {
+        if (r >= nrounds) return;
+        const uint64_t base = r * kRoundBytes;
+#pragma unroll
+        for (uint32_t j = 0; j < kRound / 4; ++j) {
+            const uint64_t off = base + j * 1024u + 16u * lane;
+            if (off + 16 <= nfull * kBlock) dma_1k(src + off, lds0 + kInBase + (uint32_t)(r % kInRing) * kRoundBytes + j * 1024u);
+        }
+    };
+
+    if (wave == 0) { issue_round(0); issue_round(1); }
+
+    for (uint64_t t = 0; t <= nrounds; ++t) {
+        if (wave == 0) {
+            // ---------------- dictionary wave: round t ----------------
+            if (t < nrounds) {
+                issue_round(t + 2);
+                // Round t must have landed; rounds t+1 and t+2 may stay in flight.  vmcnt retires in order, and every round
+                // before the last issues exactly kRound/4 DMA instructions, so the count is exact away from the chunk's end.
+                if (t + 3 < nrounds && !(dbg & 1u)) wait_vm<2 * (kRound / 4)>(); else wait_vm<0>();
+                const uint32_t qbase = kInBase + (uint32_t)(t % kInRing) * kRoundBytes;
+                const uint32_t rbase = kResBase + (uint32_t)(t % kResRing) * kRound * 16u;
+                const uint64_t b0 = t * kRound;
+                const uint32_t nb = (nfull - b0) < kRound ? (uint32_t)(nfull - b0) : kRound;
+                auto publish = [&](uint32_t k, uint64_t sig, uint64_t word1) {
+                    if (lane == 0) *reinterpret_cast<uint4*>(smem + rbase + 16u * k) = make_uint4((uint32_t)sig, (uint32_t)(sig >> 32), (uint32_t)word1, (uint32_t)(word1 >> 32));
+                };
+                // everything after the dictionary answer `old` (the entry the slot held when this lane's turn came)
+                auto finish_coded = [&](uint32_t k, uint32_t q, uint32_t old) {
+                    const uint32_t P = q * kHashMul;
+                    const uint32_t h = P >> 16;
+                    const uint32_t e = (P & 0xfffeu) | (q >> 31);
+                    const bool susp = e == 0 && h != 0;
+                    uint32_t zbit = 1;
+                    if (ballot64(susp)) {
+                        if (susp) zbit = zmap_test_and_set(zmap, h);
+                    }
+                    const uint64_t sig = ballot64(old == e && (!susp || zbit));
+                    const uint32_t rec_len = kSig + kBlock - 2u * (uint32_t)__builtin_popcountll(sig);
+                    publish(k, sig, opos);
+                    guard.update(rec_len >= kBlock);              // codec.rs:68
+                    opos += rec_len;
+                };
+                uint32_t k = 0;
+                bool pending_copy = false;                        // guard already advanced for block k and said "copy"
+                if (nb == kRound && guard.penalty == 0) {
+                    // Speculative batch: the ordered LDS exchange for all kRound blocks is issued back to back assuming none
+                    // of them is a raw-copy block (the FSM can only say otherwise after two incompressible blocks in a row).
+                    uint32_t q[kRound], ret[kRound], sh[kRound];
+#pragma unroll
+                    for (uint32_t j = 0; j < kRound; ++j) q[j] = *reinterpret_cast<const uint32_t*>(smem + qbase + kBlock * j + 4u * lane);
+                    // all quads in registers before the first exchange is issued, so no compiler-inserted lgkmcnt wait (which
+                    // cannot see the asm exchanges and would drain them) lands between the exchanges
+                    static_assert(kRound == 8, "operand list below");
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7]) :: "memory");
+#pragma unroll
+                    for (uint32_t j = 0; j < kRound; ++j) {
+                        const uint32_t P = q[j] * kHashMul;
+                        sh[j] = (P >> 12) & 16u;
+                        dict_xchg_issue(tbl + ((P >> 15) & 0x1fffcu), 0xffffu << sh[j], ((P & 0xfffeu) | (q[j] >> 31)) << sh[j], ret[j]);
+                    }
+                    bool ok = true;
+                    uint32_t kfail = kRound;
+#pragma unroll
+                    for (uint32_t j = 0; j < kRound; ++j) {
+                        if (ok) {
+                            if (guard.block_is_copy()) { ok = false; kfail = j; }
+                            else {
+                                // in-order LDS returns: exchanges j+1.. and the j result stores already issued may stay in flight
+                                lds_wait_keep<kRound - 1>(ret[j]);
+                                finish_coded(j, q[j], (ret[j] >> sh[j]) & 0xffffu);
+                            }
+                        }
+                    }
+                    k = kfail;
+                    if (!ok) {
+                        // Mis-speculation: blocks kfail.. are (or follow) raw-copy blocks but already went through the table.
+                        // Undo them newest first; inside a block the lowest lane of a slot holds the pre-block entry, so the
+                        // lanes write back in descending order.
+                        lds_wait_all();
+#pragma unroll
+                        for (int j = (int)kRound - 1; j >= 0; --j) {
+                            if ((uint32_t)j >= kfail) {
+                                const uint32_t P = q[j] * kHashMul;
+                                const uint32_t a16 = tbl + 2u * (P >> 16);
+                                const uint32_t prev = (ret[j] >> sh[j]) & 0xffffu;
+#pragma nounroll
+                                for (int l = 63; l >= 0; --l) {
+                                    if (lane == (uint32_t)l) dict_store(a16, prev);
+                                }
+                            }
+                        }
+                        lds_wait_all();
+                        pending_copy = true;
+                    }
+                }
+                for (; k < nb; ++k) {                             // in-order path: copy runs, the blocks after a mis-speculation, short rounds
+                    const bool cp = pending_copy ? true : guard.block_is_copy();
+                    pending_copy = false;
+                    if (cp) {                                     // codec.rs:35-37
+                        publish(k, 0, opos | kModeCopy);
+                        opos += kBlock;
+                        guard.decay();
+                        continue;
+                    }
+                    const uint32_t q = *reinterpret_cast<const uint32_t*>(smem + qbase + kBlock * k + 4u * lane);
+                    const uint32_t P = q * kHashMul;
+                    const uint32_t shk = (P >> 12) & 16u;
+                    uint32_t ret;
+                    dict_xchg_issue(tbl + ((P >> 15) & 0x1fffcu), 0xffffu << shk, ((P & 0xfffeu) | (q >> 31)) << shk, ret);
+                    lds_wait_keep<0>(ret);
+                    finish_coded(k, q, (ret >> shk) & 0xffffu);
+                }
+            }
+        } else if (t >= 1) {
+            // ---------------- emit waves: round t-1 ----------------
+            const uint64_t r = t - 1;
+            const uint32_t qbase = kInBase + (uint32_t)(r % kInRing) * kRoundBytes;
+            const uint32_t rbase = kResBase + (uint32_t)(r % kResRing) * kRound * 16u;
+            const uint64_t b0 = r * kRound;
+            const uint32_t nb = (nfull - b0) < kRound ? (uint32_t)(nfull - b0) : kRound;
+            for (uint32_t k = wave - 1; k < nb; k += kEmitWaves) {
+                const uint4 res = *reinterpret_cast<const uint4*>(smem + rbase + 16u * k);       // same address in all lanes: broadcast
+                const uint32_t q = *reinterpret_cast<const uint32_t*>(smem + qbase + kBlock * k + 4u * lane);
+                const uint64_t word1 = (uint64_t)rfl(res.z) | ((uint64_t)rfl(res.w) << 32);
+                uint8_t* rec = dst + (word1 & ~kModeCopy);
+                if (word1 & kModeCopy) {
+                    st32u(rec + 4u * lane, q);
+                } else {
+                    const uint64_t sig = (uint64_t)rfl(res.x) | ((uint64_t)rfl(res.y) << 32);
+                    const bool hit = (sig >> lane) & 1ull;
+                    const uint32_t off = kSig + 4u * lane - 2u * mbcnt64(sig);
+                    if (lane == 0) { st32u(rec, (uint32_t)sig); st32u(rec + 4, (uint32_t)(sig >> 32)); }
+                    if (hit) st16u(rec + off, (q * kHashMul) >> 16); else st32u(rec + off, q);
+                }
+            }
+        }
+        round_barrier();
+    }
+
+    // ragged last block (and the size word): dictionary wave, scalar-path code
+    if (wave == 0) {
+        const uint64_t boff = nfull * kBlock;
+        const uint32_t blen = (uint32_t)(len - boff);
+        if (blen) {
+            const uint32_t nq = blen >> 2, tail = blen & 3u;
+            const bool active = lane < nq;
+            const uint32_t q = active ? ld32u(src + boff + 4u * lane) : 0u;
+            uint8_t* rec = dst + opos;
+            if (guard.block_is_copy()) {
+                if (active) st32u(rec + 4u * lane, q);
+                if (lane < tail) rec[4u * nq + lane] = src[boff + 4u * nq + lane];
+                opos += blen;
+            } else {
+                const uint32_t P = q * kHashMul;
+                const uint32_t h = P >> 16;
+                const uint32_t e = (P & 0xfffeu) | (q >> 31);
+                uint32_t old = 0, w = lane;
+                if (active) dict_step(tbl + 2u * h, lane, e, old, w);
+                bool has_pred;
+                uint32_t pred_e;
+                resolve_groups(active, lane, w, e, ~0ull, has_pred, pred_e);
+                const bool susp = active && e == 0 && h != 0;
+                uint32_t zbit = 1;
+                if (ballot64(susp)) {
+                    if (susp) zbit = zmap_test_and_set(zmap, h);
+                }
+                const bool hit = active && (has_pred ? (pred_e == e) : (old == e && (!susp || zbit)));
+                const uint64_t sig = ballot64(hit);
+                const uint32_t nhit = (uint32_t)__builtin_popcountll(sig);
+                const uint32_t off = kSig + 4u * lane - 2u * mbcnt64(sig);
+                if (lane == 0) { st32u(rec, (uint32_t)sig); st32u(rec + 4, (uint32_t)(sig >> 32)); }
+                if (active) {
+                    if (hit) st16u(rec + off, h); else st32u(rec + off, q);
+                }
+                const uint32_t items_end = kSig + 4u * nq - 2u * nhit;
+                if (lane < tail) rec[items_end + lane] = src[boff + 4u * nq + lane];
+                opos += items_end + tail;
+            }
+        }
+        if (lane == 0) sizes[chunk] = opos;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // decode: Codec::decode (codec/codec.rs:82-126) with Chameleon::decode_unit / decode_partial_unit
 // (chameleon.rs:56-68,105-135).  The fast loop and the tail loop of the reference differ only in bounds checks; one
 // vectorised stop test per record reproduces both (a record that is followed by >= 264 bytes can never trip it).
@@ -301,12 +571,22 @@ __global__ __launch_bounds__(64) void chameleon_decode_chunks(const uint8_t* __r
 // ---------------------------------------------------------------------------------------------------------------
 // host launchers
 // ---------------------------------------------------------------------------------------------------------------
+bool g_force_simple = false;   // test hook (density_hip_set_kernel_variant): run the one-wave kernels
 hipError_t launch_chameleon_encode(const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks,
                                    uint8_t* d_out, uint64_t out_stride, uint64_t* d_sizes, hipStream_t stream) {
     hipError_t e = hipFuncSetAttribute((const void*)chameleon_encode_chunks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
     if (e != hipSuccess) return e;
     if (n_chunks == 0) return hipSuccess;
-    hipLaunchKernelGGL(chameleon_encode_chunks, dim3(n_chunks), dim3(64), kLdsBytes, stream, d_in, total, chunk_bytes, d_out, out_stride, d_sizes);
+    // the pipelined kernel stages its input with 16-byte LDS-DMA pieces: needs 16-byte aligned chunk bases
+    const bool aligned = ((uintptr_t)d_in % 16 == 0) && (n_chunks == 1 || chunk_bytes % 16 == 0);
+    if (aligned && !g_force_simple) {
+        e = hipFuncSetAttribute((const void*)chameleon_encode_chunks_pipe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytesPipe);
+        if (e != hipSuccess) return e;
+        static const uint32_t dbg = getenv("DENSITY_HIP_DBG") ? (uint32_t)atoi(getenv("DENSITY_HIP_DBG")) : 0u;
+        hipLaunchKernelGGL(chameleon_encode_chunks_pipe, dim3(n_chunks), dim3(256), kLdsBytesPipe, stream, d_in, total, chunk_bytes, d_out, out_stride, d_sizes, dbg);
+    } else {
+        hipLaunchKernelGGL(chameleon_encode_chunks, dim3(n_chunks), dim3(64), kLdsBytes, stream, d_in, total, chunk_bytes, d_out, out_stride, d_sizes);
+    }
     return hipGetLastError();
 }
 

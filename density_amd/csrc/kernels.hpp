@@ -8,6 +8,7 @@
 namespace density {
 
 // ---- chameleon.hip ----
+extern bool g_force_simple;   // density_hip_set_kernel_variant(1)
 // One wavefront per chunk.  Chunk c reads in[c*chunk_bytes ...) and writes its reference stream at
 // out + c*out_stride; sizes[c] receives the stream length.
 hipError_t launch_chameleon_encode(const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks,

@@ -138,6 +138,10 @@ int density_hip_stream_decode_device(int algo, const void* d_input, size_t input
 void density_hip_set_profiling(int enabled);
 int density_hip_last_timings(float* milliseconds, const char** names, int capacity);
 
+/* Test hook: 0 = default kernels (pipelined 4-wave work-groups where the input alignment allows), 1 = force the simple
+ * one-wavefront-per-chunk kernels.  Both produce identical bytes. */
+void density_hip_set_kernel_variant(int variant);
+
 /* Runs the LDS write-order self-test the kernels rely on (also run lazily before first use). 0 = pass. */
 int density_hip_selftest(void);
 /* Thread-local description of the last failure in this thread ("" if none). */

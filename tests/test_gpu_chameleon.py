@@ -17,6 +17,14 @@ KAT = json.load(open(os.path.join(HERE, "golden", "kat.json")))
 ALGO = "chameleon"
 
 
+@pytest.fixture(autouse=True, params=["pipelined", "simple"])
+def kernel_variant(request):
+    """Every test runs against both kernel families: the 4-wave pipelined work-groups and the one-wavefront kernels."""
+    container.set_kernel_variant(1 if request.param == "simple" else 0)
+    yield request.param
+    container.set_kernel_variant(0)
+
+
 def gpu_encode(data):
     data = np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else data
     out = np.zeros(max(Chameleon.safe_encode_buffer_size(data.size), 1), dtype=np.uint8)
