@@ -81,6 +81,18 @@ __device__ __forceinline__ void dict_xchg_issue(uint32_t dword_addr, uint32_t ma
 // wait until at most N LDS operations younger than the one producing `r` are outstanding (LDS returns in order)
 template <int N>
 __device__ __forceinline__ void lds_wait_keep(uint32_t& r) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(r) : "n"(N) : "memory"); }
+__device__ __forceinline__ void lds_wait_keep_n(uint32_t& r, uint32_t n) {   // n is a compile-time constant after unrolling
+    switch (n) {
+        case 0: lds_wait_keep<0>(r); break;
+        case 1: lds_wait_keep<1>(r); break;
+        case 2: lds_wait_keep<2>(r); break;
+        case 3: lds_wait_keep<3>(r); break;
+        case 4: lds_wait_keep<4>(r); break;
+        case 5: lds_wait_keep<5>(r); break;
+        case 6: lds_wait_keep<6>(r); break;
+        default: lds_wait_keep<7>(r); break;
+    }
+}
 __device__ __forceinline__ void lds_wait_all() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ uint32_t zmap_test_and_set(uint32_t zbase, uint32_t h) {
     uint32_t r;
@@ -206,32 +218,38 @@ __global__ __launch_bounds__(64) void chameleon_encode_chunks(const uint8_t* __r
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Pipelined encoder: one work-group (4 waves) per chunk.
+// Pipelined encoder: one work-group (8 waves) per chunk.
 //
 //   wave 0  "dictionary wave": the only wave that touches the table, so the in-order LDS pipeline gives the sequential
 //           dictionary semantics for free.  It also issues the global->LDS DMA (global_load_lds_dwordx4, 1 KiB = 4
 //           blocks per instruction) that stages the chunk through a ring in LDS two rounds ahead, runs the copy-mode FSM,
-//           and publishes one 16-byte result per block: {signature, output offset, mode}.
-//   waves 1-3 "emit waves": one round behind, they turn (signature, quads) into the record bytes: a pair of mbcnt's per
-//           lane, then 2-/4-byte stores straight to global memory.
+//           and publishes one record per round: the 8 signatures, the output offset of the round, the raw-copy mask.
+//   waves 1-7 "emit waves": one round behind, they turn (signature, quads) into record bytes: a prefix sum of the 8
+//           record lengths, a pair of mbcnt's per lane, then 2-/4-byte stores straight to global memory.
 //
-// A round is kRound blocks; rounds are separated by one s_barrier.  Buffers: input ring of 4 rounds (DMA at t-2, hashed at
-// t, emitted at t+1), result ring of 2 rounds.  Only whole 256-byte blocks go through the pipeline; a ragged last block
+// A round is kRound = 8 blocks; rounds are separated by one s_barrier.  Buffers: input ring of kInRing rounds (DMA issued at
+// t-kAhead, hashed at t, emitted at t+1), result ring of 2 rounds.  Only whole 256-byte blocks go through the pipeline; a ragged last block
 // (codec.rs:51-63) is finished by the dictionary wave with the scalar-path code of chameleon_encode_chunks.
+//
+// The dictionary wave is the critical path (one stream = one dependency chain), so its per-block work is pared down to:
+// hash, one ordered LDS exchange, one compare (= the signature), one popcount.  The copy-mode FSM (protection_state.rs) is
+// evaluated per ROUND: in a round without an incompressible block (< 5 hits of 64) it only advances its block counter; the
+// exchanges of a round are issued speculatively "no raw-copy block in this round", and a round in which the FSM does switch
+// to copy mode is rolled back from the first copied block and redone in order.
 // ---------------------------------------------------------------------------------------------------------------
 namespace {
 
 constexpr uint32_t kRound = 8;                               // blocks per round
 constexpr uint32_t kRoundBytes = kRound * kBlock;            // 2 KiB
-constexpr uint32_t kInRing = 4, kResRing = 2;
+constexpr uint32_t kInRing = 6, kResRing = 2;              // input ring: kAhead rounds in flight + hashed + emitted
+constexpr uint32_t kAhead = kInRing - 2;                     // DMA runs this many rounds ahead of the dictionary wave
 constexpr uint32_t kInBase = kLdsBytes;                      // 139264, 16-byte aligned
 constexpr uint32_t kResBase = kInBase + kInRing * kRoundBytes;
-constexpr uint32_t kLdsBytesPipe = kResBase + kResRing * kRound * 16u;
-constexpr uint32_t kEmitWaves = 3;
+constexpr uint32_t kResBytes = 128;                          // dwords 0..15 signatures, 16..17 round offset, 18 copy mask
+constexpr uint32_t kLdsBytesPipe = kResBase + kResRing * kResBytes;
+constexpr uint32_t kPipeWaves = 8, kEmitWaves = kPipeWaves - 1;
 static_assert(kLdsBytesPipe <= 160u * 1024u, "LDS budget");
-static_assert(kRound % 4 == 0, "one DMA instruction moves 4 blocks");
-
-constexpr uint64_t kModeCopy = 1ull << 63;
+static_assert(kRound == 8, "register arrays, asm operand lists and the result record are written for 8 blocks per round");
 
 // one LDS-DMA instruction: lane l copies 16 bytes from its global pointer to lds_dst + 16*l (lds_dst wave-uniform)
 __device__ __forceinline__ void dma_1k(const uint8_t* gsrc, uint32_t lds_dst) {
@@ -251,13 +269,54 @@ __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :
 // all of this wave's LDS traffic retired, then the work-group barrier; no vmcnt: stores and DMA stay in flight
 __device__ __forceinline__ void round_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// vec[L] = value (value wave-uniform).  gfx9 allows one SGPR operand per VALU instruction, so the lane is an immediate.
+template <int L>
+__device__ __forceinline__ uint32_t wlane_c(uint32_t vec, uint32_t value) {
+    asm volatile("s_nop 4\n\tv_writelane_b32 %0, %1, %2\n\ts_nop 1" : "+v"(vec) : "s"(rfl(value)), "n"(L));
+    return vec;
+}
+// lane_sel is a compile-time constant after unrolling (the switch folds away)
+__device__ __forceinline__ uint32_t wlane(uint32_t vec, uint32_t value, uint32_t lane_sel) {
+    switch (lane_sel) {
+        case 0: return wlane_c<0>(vec, value);
+        case 1: return wlane_c<1>(vec, value);
+        case 2: return wlane_c<2>(vec, value);
+        case 3: return wlane_c<3>(vec, value);
+        case 4: return wlane_c<4>(vec, value);
+        case 5: return wlane_c<5>(vec, value);
+        case 6: return wlane_c<6>(vec, value);
+        case 7: return wlane_c<7>(vec, value);
+        case 8: return wlane_c<8>(vec, value);
+        case 9: return wlane_c<9>(vec, value);
+        case 10: return wlane_c<10>(vec, value);
+        case 11: return wlane_c<11>(vec, value);
+        case 12: return wlane_c<12>(vec, value);
+        case 13: return wlane_c<13>(vec, value);
+        case 14: return wlane_c<14>(vec, value);
+        case 15: return wlane_c<15>(vec, value);
+        case 16: return wlane_c<16>(vec, value);
+        case 17: return wlane_c<17>(vec, value);
+        case 18: return wlane_c<18>(vec, value);
+        default: return vec;
+    }
+}
+// run-time lane select (in-order path only)
+__device__ __forceinline__ uint32_t wlane_dyn(uint32_t vec, uint32_t value, uint32_t lane_sel, uint32_t lane) { return lane == lane_sel ? value : vec; }
+__device__ __forceinline__ uint32_t rlane(uint32_t vec, uint32_t lane_sel) { return (uint32_t)__builtin_amdgcn_readlane((int)vec, (int)lane_sel); }
+
+// per-block state of the dictionary wave between issue and finish
+struct Issued {
+    uint32_t q, key, sh, ret;     // key = (P & ~1) | (q >> 31): slot index in the high half, 16-bit entry in the low half
+};
+
 }  // namespace
 
-__global__ __launch_bounds__(256) void chameleon_encode_chunks_pipe(const uint8_t* __restrict__ in, uint64_t total,
-                                                                    uint64_t chunk_bytes, uint8_t* __restrict__ out,
-                                                                    uint64_t out_stride, uint64_t* __restrict__ sizes, uint32_t dbg) {
+__global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(const uint8_t* __restrict__ in, uint64_t total,
+                                                                                uint64_t chunk_bytes, uint8_t* __restrict__ out,
+                                                                                uint64_t out_stride, uint64_t* __restrict__ sizes,
+                                                                                uint32_t dbg) {
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t wave = rfl(threadIdx.x >> 6);
     const uint64_t chunk = blockIdx.x;
     const uint8_t* src = in + chunk * chunk_bytes;
     const uint64_t len = (total - chunk * chunk_bytes) < chunk_bytes ? (total - chunk * chunk_bytes) : chunk_bytes;
@@ -265,10 +324,10 @@ __global__ __launch_bounds__(256) void chameleon_encode_chunks_pipe(const uint8_
     const uint64_t nfull = len / kBlock;                       // whole blocks: these go through the pipeline
     const uint64_t nrounds = (nfull + kRound - 1) / kRound;
 
-    {   // clear table + zero-entry map (all 256 threads)
+    {   // clear table + zero-entry map
         uint4* p = reinterpret_cast<uint4*>(smem);
         const uint4 z = make_uint4(0, 0, 0, 0);
-        for (uint32_t i = threadIdx.x; i < kLdsBytes / 16; i += 256) p[i] = z;
+        for (uint32_t i = threadIdx.x; i < kLdsBytes / 16; i += kPipeWaves * 64) p[i] = z;
     }
     const uint32_t lds0 = lds_addr(smem);
     const uint32_t tbl = lds0, zmap = lds0 + kTableBytes;
@@ -288,130 +347,192 @@ __global__ __launch_bounds__(256) void chameleon_encode_chunks_pipe(const uint8_
         }
     };
 
-    if (wave == 0) { issue_round(0); issue_round(1); }
+    if (wave == 0) {
+#pragma unroll
+        for (uint32_t r = 0; r < kAhead; ++r) issue_round(r);
+    }
 
     for (uint64_t t = 0; t <= nrounds; ++t) {
         if (wave == 0) {
             // ---------------- dictionary wave: round t ----------------
             if (t < nrounds) {
-                issue_round(t + 2);
-                // Round t must have landed; rounds t+1 and t+2 may stay in flight.  vmcnt retires in order, and every round
+                issue_round(t + kAhead);
+                // Round t must have landed; rounds t+1 .. t+kAhead may stay in flight.  vmcnt retires in order, and every round
                 // before the last issues exactly kRound/4 DMA instructions, so the count is exact away from the chunk's end.
-                if (t + 3 < nrounds && !(dbg & 1u)) wait_vm<2 * (kRound / 4)>(); else wait_vm<0>();
+                if (t + kAhead + 1 < nrounds && !(dbg & 1u)) wait_vm<kAhead * (kRound / 4)>(); else wait_vm<0>();
                 const uint32_t qbase = kInBase + (uint32_t)(t % kInRing) * kRoundBytes;
-                const uint32_t rbase = kResBase + (uint32_t)(t % kResRing) * kRound * 16u;
+                const uint32_t rbase = kResBase + (uint32_t)(t % kResRing) * kResBytes;
                 const uint64_t b0 = t * kRound;
                 const uint32_t nb = (nfull - b0) < kRound ? (uint32_t)(nfull - b0) : kRound;
-                auto publish = [&](uint32_t k, uint64_t sig, uint64_t word1) {
-                    if (lane == 0) *reinterpret_cast<uint4*>(smem + rbase + 16u * k) = make_uint4((uint32_t)sig, (uint32_t)(sig >> 32), (uint32_t)word1, (uint32_t)(word1 >> 32));
+
+                uint32_t rec = 0;                                 // lane i holds dword i of the round's result record
+                uint32_t copy_mask = 0;
+                const uint64_t round_opos = opos;
+
+                auto issue = [&](Issued& b) {
+                    const uint32_t P = b.q * kHashMul;
+                    b.key = (P & 0xfffffffeu) | (b.q >> 31);
+                    b.sh = (P >> 12) & 16u;
+                    dict_xchg_issue(tbl + ((P >> 15) & 0x1fffcu), 0xffffu << b.sh, (b.key & 0xffffu) << b.sh, b.ret);
                 };
-                // everything after the dictionary answer `old` (the entry the slot held when this lane's turn came)
-                auto finish_coded = [&](uint32_t k, uint32_t q, uint32_t old) {
-                    const uint32_t P = q * kHashMul;
-                    const uint32_t h = P >> 16;
-                    const uint32_t e = (P & 0xfffeu) | (q >> 31);
+                // signature of a block from the dictionary answers, including the zero-entry disambiguation (rare path)
+                auto signature = [&](const Issued& b) -> uint64_t {
+                    const uint32_t e = b.key & 0xffffu, h = b.key >> 16;
+                    const uint32_t old = (b.ret >> b.sh) & 0xffffu;
                     const bool susp = e == 0 && h != 0;
                     uint32_t zbit = 1;
                     if (ballot64(susp)) {
                         if (susp) zbit = zmap_test_and_set(zmap, h);
                     }
-                    const uint64_t sig = ballot64(old == e && (!susp || zbit));
-                    const uint32_t rec_len = kSig + kBlock - 2u * (uint32_t)__builtin_popcountll(sig);
-                    publish(k, sig, opos);
-                    guard.update(rec_len >= kBlock);              // codec.rs:68
-                    opos += rec_len;
+                    return ballot64(old == e && (!susp || zbit));
                 };
+                // undo a speculatively applied block: the lowest lane of a slot holds the pre-block entry, so the lanes
+                // write their answers back in descending order
+                auto rollback = [&](const Issued& b) {
+                    const uint32_t a16 = tbl + 2u * (b.key >> 16);
+                    const uint32_t prev = (b.ret >> b.sh) & 0xffffu;
+#pragma nounroll
+                    for (int l = 63; l >= 0; --l) {
+                        if (lane == (uint32_t)l) dict_store(a16, prev);
+                    }
+                };
+
                 uint32_t k = 0;
                 bool pending_copy = false;                        // guard already advanced for block k and said "copy"
                 if (nb == kRound && guard.penalty == 0) {
-                    // Speculative batch: the ordered LDS exchange for all kRound blocks is issued back to back assuming none
-                    // of them is a raw-copy block (the FSM can only say otherwise after two incompressible blocks in a row).
-                    uint32_t q[kRound], ret[kRound], sh[kRound];
+                    Issued blk[kRound];
 #pragma unroll
-                    for (uint32_t j = 0; j < kRound; ++j) q[j] = *reinterpret_cast<const uint32_t*>(smem + qbase + kBlock * j + 4u * lane);
+                    for (uint32_t j = 0; j < kRound; ++j) blk[j].q = *reinterpret_cast<const uint32_t*>(smem + qbase + kBlock * j + 4u * lane);
                     // all quads in registers before the first exchange is issued, so no compiler-inserted lgkmcnt wait (which
                     // cannot see the asm exchanges and would drain them) lands between the exchanges
-                    static_assert(kRound == 8, "operand list below");
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7]) :: "memory");
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(blk[0].q), "+v"(blk[1].q), "+v"(blk[2].q), "+v"(blk[3].q), "+v"(blk[4].q), "+v"(blk[5].q), "+v"(blk[6].q), "+v"(blk[7].q) :: "memory");
+                    uint32_t low_min = 0xffffu;
 #pragma unroll
                     for (uint32_t j = 0; j < kRound; ++j) {
-                        const uint32_t P = q[j] * kHashMul;
-                        sh[j] = (P >> 12) & 16u;
-                        dict_xchg_issue(tbl + ((P >> 15) & 0x1fffcu), 0xffffu << sh[j], ((P & 0xfffeu) | (q[j] >> 31)) << sh[j], ret[j]);
+                        issue(blk[j]);
+                        const uint32_t e = blk[j].key & 0xffffu;
+                        low_min = e < low_min ? e : low_min;
                     }
-                    bool ok = true;
-                    uint32_t kfail = kRound;
+                    uint64_t sig[kRound];
+                    uint32_t hits = 0, min_hits = 64;
+                    const bool plain_round = ballot64(low_min == 0) == 0;
+                    if (plain_round) {
+                        // common case: no quad of this round packs to entry 0, a hit is simply "answer == entry"; computing the
+                        // signatures has no side effect, so all eight are taken before the FSM is consulted
 #pragma unroll
-                    for (uint32_t j = 0; j < kRound; ++j) {
-                        if (ok) {
-                            if (guard.block_is_copy()) { ok = false; kfail = j; }
-                            else {
-                                // in-order LDS returns: exchanges j+1.. and the j result stores already issued may stay in flight
-                                lds_wait_keep<kRound - 1>(ret[j]);
-                                finish_coded(j, q[j], (ret[j] >> sh[j]) & 0xffffu);
-                            }
+                        for (uint32_t j = 0; j < kRound; ++j) {
+                            lds_wait_keep_n(blk[j].ret, kRound - 1 - j);          // later exchanges stay in flight
+                            sig[j] = ballot64(((blk[j].ret >> blk[j].sh) & 0xffffu) == (blk[j].key & 0xffffu));
+                            const uint32_t nh = (uint32_t)__builtin_popcountll(sig[j]);
+                            hits += nh;
+                            min_hits = nh < min_hits ? nh : min_hits;
+                            rec = wlane(rec, (uint32_t)sig[j], 2 * j);
+                            rec = wlane(rec, (uint32_t)(sig[j] >> 32), 2 * j + 1);
                         }
-                    }
-                    k = kfail;
-                    if (!ok) {
-                        // Mis-speculation: blocks kfail.. are (or follow) raw-copy blocks but already went through the table.
-                        // Undo them newest first; inside a block the lowest lane of a slot holds the pre-block entry, so the
-                        // lanes write back in descending order.
+                    } else {
                         lds_wait_all();
+                    }
+                    if (plain_round && min_hits > 4 && !guard.prev) {
+                        // no incompressible record (codec.rs:68: 8 + 256 - 2*hits >= 256) in this round: the FSM only counts
+                        // blocks (protection_state.rs:19-27); at most one of 8 consecutive counters is a multiple of 16
+                        const uint32_t to16 = (16u - (guard.counter & 15u)) & 15u;
+                        if (to16 < kRound && guard.start > 1) guard.start >>= 1;
+                        guard.counter += kRound;
+                        opos += kRound * (kSig + kBlock) - 2u * hits;
+                        k = kRound;
+                    } else {
+                        // walk the FSM block by block; stop at the first block it turns into a raw copy.  With zero-entry quads
+                        // in the round the signature itself updates the zero-entry map, so it is taken only for blocks the FSM
+                        // has admitted.
+                        uint64_t o = opos;
 #pragma unroll
-                        for (int j = (int)kRound - 1; j >= 0; --j) {
-                            if ((uint32_t)j >= kfail) {
-                                const uint32_t P = q[j] * kHashMul;
-                                const uint32_t a16 = tbl + 2u * (P >> 16);
-                                const uint32_t prev = (ret[j] >> sh[j]) & 0xffffu;
-#pragma nounroll
-                                for (int l = 63; l >= 0; --l) {
-                                    if (lane == (uint32_t)l) dict_store(a16, prev);
+                        for (uint32_t j = 0; j < kRound; ++j) {
+                            if (k == j) {
+                                if (guard.block_is_copy()) {
+                                    pending_copy = true;
+                                } else {
+                                    if (!plain_round) {
+                                        sig[j] = signature(blk[j]);
+                                        rec = wlane(rec, (uint32_t)sig[j], 2 * j);
+                                        rec = wlane(rec, (uint32_t)(sig[j] >> 32), 2 * j + 1);
+                                    }
+                                    const uint32_t nh = (uint32_t)__builtin_popcountll(sig[j]);
+                                    guard.update(nh <= 4);
+                                    o += kSig + kBlock - 2u * nh;
+                                    k = j + 1;
                                 }
                             }
                         }
-                        lds_wait_all();
-                        pending_copy = true;
+                        opos = o;
+                        if (pending_copy) {
+                            lds_wait_all();
+#pragma unroll
+                            for (int j = (int)kRound - 1; j >= 0; --j) {
+                                if ((uint32_t)j >= k) rollback(blk[j]);
+                            }
+                            lds_wait_all();
+                        }
                     }
                 }
                 for (; k < nb; ++k) {                             // in-order path: copy runs, the blocks after a mis-speculation, short rounds
                     const bool cp = pending_copy ? true : guard.block_is_copy();
                     pending_copy = false;
+                    uint64_t sg = 0;
                     if (cp) {                                     // codec.rs:35-37
-                        publish(k, 0, opos | kModeCopy);
+                        copy_mask |= 1u << k;
                         opos += kBlock;
                         guard.decay();
-                        continue;
+                    } else {
+                        Issued b;
+                        b.q = *reinterpret_cast<const uint32_t*>(smem + qbase + kBlock * k + 4u * lane);
+                        issue(b);
+                        lds_wait_keep_n(b.ret, 0);
+                        sg = signature(b);
+                        const uint32_t nh = (uint32_t)__builtin_popcountll(sg);
+                        guard.update(nh <= 4);                    // codec.rs:68
+                        opos += kSig + kBlock - 2u * nh;
                     }
-                    const uint32_t q = *reinterpret_cast<const uint32_t*>(smem + qbase + kBlock * k + 4u * lane);
-                    const uint32_t P = q * kHashMul;
-                    const uint32_t shk = (P >> 12) & 16u;
-                    uint32_t ret;
-                    dict_xchg_issue(tbl + ((P >> 15) & 0x1fffcu), 0xffffu << shk, ((P & 0xfffeu) | (q >> 31)) << shk, ret);
-                    lds_wait_keep<0>(ret);
-                    finish_coded(k, q, (ret >> shk) & 0xffffu);
+                    rec = wlane_dyn(rec, (uint32_t)sg, 2 * k, lane);
+                    rec = wlane_dyn(rec, (uint32_t)(sg >> 32), 2 * k + 1, lane);
                 }
+                rec = wlane(rec, (uint32_t)round_opos, 16);
+                rec = wlane(rec, (uint32_t)(round_opos >> 32), 17);
+                rec = wlane(rec, copy_mask, 18);
+                if (lane < 19) *reinterpret_cast<uint32_t*>(smem + rbase + 4u * lane) = rec;
             }
-        } else if (t >= 1) {
+        } else if (t >= 1 && !(dbg & 2u)) {
             // ---------------- emit waves: round t-1 ----------------
             const uint64_t r = t - 1;
             const uint32_t qbase = kInBase + (uint32_t)(r % kInRing) * kRoundBytes;
-            const uint32_t rbase = kResBase + (uint32_t)(r % kResRing) * kRound * 16u;
+            const uint32_t rbase = kResBase + (uint32_t)(r % kResRing) * kResBytes;
             const uint64_t b0 = r * kRound;
             const uint32_t nb = (nfull - b0) < kRound ? (uint32_t)(nfull - b0) : kRound;
-            for (uint32_t k = wave - 1; k < nb; k += kEmitWaves) {
-                const uint4 res = *reinterpret_cast<const uint4*>(smem + rbase + 16u * k);       // same address in all lanes: broadcast
-                const uint32_t q = *reinterpret_cast<const uint32_t*>(smem + qbase + kBlock * k + 4u * lane);
-                const uint64_t word1 = (uint64_t)rfl(res.z) | ((uint64_t)rfl(res.w) << 32);
-                uint8_t* rec = dst + (word1 & ~kModeCopy);
-                if (word1 & kModeCopy) {
-                    st32u(rec + 4u * lane, q);
-                } else {
-                    const uint64_t sig = (uint64_t)rfl(res.x) | ((uint64_t)rfl(res.y) << 32);
-                    const bool hit = (sig >> lane) & 1ull;
-                    const uint32_t off = kSig + 4u * lane - 2u * mbcnt64(sig);
-                    if (lane == 0) { st32u(rec, (uint32_t)sig); st32u(rec + 4, (uint32_t)(sig >> 32)); }
-                    if (hit) st16u(rec + off, (q * kHashMul) >> 16); else st32u(rec + off, q);
+            if (wave - 1 < nb) {
+                // lanes 0..7: signature and record length of block `lane`; exclusive prefix over the round
+                const uint32_t sl = lane & 7u;
+                const uint32_t slo = *reinterpret_cast<const uint32_t*>(smem + rbase + 8u * sl);
+                const uint32_t shi = *reinterpret_cast<const uint32_t*>(smem + rbase + 8u * sl + 4);
+                const uint32_t base_lo = *reinterpret_cast<const uint32_t*>(smem + rbase + 64);
+                const uint32_t base_hi = *reinterpret_cast<const uint32_t*>(smem + rbase + 68);
+                const uint32_t cmask = rfl(*reinterpret_cast<const uint32_t*>(smem + rbase + 72));
+                const uint32_t mylen = ((cmask >> sl) & 1u) ? kBlock : (kSig + kBlock - 2u * (uint32_t)(__builtin_popcount(slo) + __builtin_popcount(shi)));
+                for (uint32_t k = wave - 1; k < nb; k += kEmitWaves) {
+                    uint32_t before = 0;
+                    for (uint32_t j = 0; j < k; ++j) before += rlane(mylen, j);
+                    const uint64_t sig = (uint64_t)rlane(slo, k) | ((uint64_t)rlane(shi, k) << 32);
+                    const uint64_t base = (uint64_t)rfl(base_lo) | ((uint64_t)rfl(base_hi) << 32);
+                    uint8_t* recp = dst + base + before;
+                    const uint32_t q = *reinterpret_cast<const uint32_t*>(smem + qbase + kBlock * k + 4u * lane);
+                    if (dbg & 8u) {
+                        asm volatile("" ::"v"(q), "v"(recp));
+                    } else if ((cmask >> k) & 1u) {
+                        st32u(recp + 4u * lane, q);
+                    } else {
+                        const bool hit = (sig >> lane) & 1ull;
+                        const uint32_t off = kSig + 4u * lane - 2u * mbcnt64(sig);
+                        if (lane == 0) { st32u(recp, (uint32_t)sig); st32u(recp + 4, (uint32_t)(sig >> 32)); }
+                        if (hit) st16u(recp + off, (q * kHashMul) >> 16); else st32u(recp + off, q);
+                    }
                 }
             }
         }
@@ -582,8 +703,8 @@ hipError_t launch_chameleon_encode(const uint8_t* d_in, uint64_t total, uint64_t
     if (aligned && !g_force_simple) {
         e = hipFuncSetAttribute((const void*)chameleon_encode_chunks_pipe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytesPipe);
         if (e != hipSuccess) return e;
-        static const uint32_t dbg = getenv("DENSITY_HIP_DBG") ? (uint32_t)atoi(getenv("DENSITY_HIP_DBG")) : 0u;
-        hipLaunchKernelGGL(chameleon_encode_chunks_pipe, dim3(n_chunks), dim3(256), kLdsBytesPipe, stream, d_in, total, chunk_bytes, d_out, out_stride, d_sizes, dbg);
+        const uint32_t dbg = getenv("DENSITY_HIP_DBG") ? (uint32_t)atoi(getenv("DENSITY_HIP_DBG")) : 0u;
+        hipLaunchKernelGGL(chameleon_encode_chunks_pipe, dim3(n_chunks), dim3(kPipeWaves * 64), kLdsBytesPipe, stream, d_in, total, chunk_bytes, d_out, out_stride, d_sizes, dbg);
     } else {
         hipLaunchKernelGGL(chameleon_encode_chunks, dim3(n_chunks), dim3(64), kLdsBytes, stream, d_in, total, chunk_bytes, d_out, out_stride, d_sizes);
     }
