@@ -46,6 +46,12 @@ __device__ __forceinline__ void lds_clear(uint32_t lane) {
     __syncthreads();
 }
 
+// inverse of the entry packing: slot index h and 16-bit entry e -> the quad (see file header)
+__device__ __forceinline__ uint32_t entry_to_quad(uint32_t h, uint32_t e) {
+    const uint32_t Pfull = (h << 16) | (e & 0xfffeu);
+    return (((Pfull >> 1) * kHalfMulInv) & 0x7fffffffu) | ((e & 1u) << 31);
+}
+
 // the four-instruction dictionary step described in the file header; the caller masks inactive lanes with exec
 __device__ __forceinline__ void dict_step(uint32_t addr, uint32_t lane, uint32_t e, uint32_t& old, uint32_t& w) {
     asm volatile(
@@ -588,37 +594,18 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
 // (chameleon.rs:56-68,105-135).  The fast loop and the tail loop of the reference differ only in bounds checks; one
 // vectorised stop test per record reproduces both (a record that is followed by >= 264 bytes can never trip it).
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void chameleon_decode_chunks(const uint8_t* __restrict__ in,
-                                                              const uint64_t* __restrict__ offsets,
-                                                              const uint64_t* __restrict__ sizes,
-                                                              uint8_t* __restrict__ out, uint64_t out_stride,
-                                                              uint64_t out_total, uint32_t exact,
-                                                              uint64_t* __restrict__ produced,
-                                                              uint32_t* __restrict__ err) {
-    const uint32_t lane = threadIdx.x;
-    const uint64_t chunk = blockIdx.x;
-    const uint8_t* src = in + offsets[chunk];
-    const uint64_t elen = sizes[chunk];
-    uint8_t* dst = out + chunk * out_stride;
-    // bytes this chunk may produce: its slice of the output
-    const uint64_t room_all = out_total - chunk * out_stride;
-    const uint64_t cap = room_all < out_stride ? room_all : out_stride;
-
-    lds_clear(lane);
-    const uint32_t tbl = lds_addr(smem);
-    const uint32_t zmap = tbl + kTableBytes;
-
-    Guard guard;
-    uint64_t ipos = 0, opos = 0;
-    bool bad = false;
-
+// In-order record loop shared by the one-wavefront kernel (whole stream) and the pipelined kernel (ragged end of the
+// stream).  Runs on ONE wavefront from the state (ipos, opos, guard) until the input is exhausted; returns false where the
+// reference would panic (truncated stream, output too small).
+__device__ __forceinline__ bool decode_in_order(const uint8_t* __restrict__ src, uint64_t elen, uint8_t* __restrict__ dst, uint64_t cap,
+                                                Guard& guard, uint64_t& ipos, uint64_t& opos, uint32_t tbl, uint32_t zmap, uint32_t lane) {
     while (ipos < elen) {
         const uint64_t rem = elen - ipos;
         const uint8_t* rec = src + ipos;
         uint8_t* o = dst + opos;
         if (guard.block_is_copy()) {                              // codec.rs:89-91,103-110
             const uint32_t take = rem > kBlock ? kBlock : (uint32_t)rem;
-            if (opos + take > cap) { bad = true; break; }
+            if (opos + take > cap) return false;
             if (lane < (take >> 2)) st32u(o + 4u * lane, ld32u(rec + 4u * lane));
             if (lane < (take & 3u)) o[(take & ~3u) + lane] = rec[(take & ~3u) + lane];
             ipos += take;
@@ -627,7 +614,7 @@ __global__ __launch_bounds__(64) void chameleon_decode_chunks(const uint8_t* __r
             guard.decay();
             continue;
         }
-        if (rem < kSig) { bad = true; break; }                    // reference: read_u64_le panics (read_buffer.rs:22)
+        if (rem < kSig) return false;                             // reference: read_u64_le panics (read_buffer.rs:22)
         const uint64_t sig = (uint64_t)ld32u(rec) | ((uint64_t)ld32u(rec + 4) << 32);
         const bool hit = (sig >> lane) & 1ull;
         const uint32_t off = kSig + 4u * lane - 2u * mbcnt64(sig);
@@ -638,10 +625,10 @@ __global__ __launch_bounds__(64) void chameleon_decode_chunks(const uint8_t* __r
         const bool stop = hit ? (left < 2) : (left < 4);
         const uint64_t stopm = ballot64(stop);
         const uint32_t kstop = stopm ? (uint32_t)__builtin_ctzll(stopm) : 64u;
-        if (kstop < 64 && ((sig >> kstop) & 1ull)) { bad = true; break; }
+        if (kstop < 64 && ((sig >> kstop) & 1ull)) return false;
         const bool active = lane < kstop;
         const uint32_t tailb = kstop < 64 ? (uint32_t)((int32_t)rem32 - __builtin_amdgcn_readlane((int)off, (int)kstop)) : 0u;
-        if (opos + 4ull * kstop + tailb > cap) { bad = true; break; }
+        if (opos + 4ull * kstop + tailb > cap) return false;
 
         uint32_t q = 0, h = 0, e = 0;
         if (active) {
@@ -664,10 +651,7 @@ __global__ __launch_bounds__(64) void chameleon_decode_chunks(const uint8_t* __r
             if (psusp) zmap_set(zmap, h);
         }
         if (active) {
-            if (hit) {                                            // chameleon.rs:64-68: quad = chunk_map[hash]
-                const uint32_t Pfull = (h << 16) | (eff & 0xfffeu);
-                q = empty ? 0u : ((((Pfull >> 1) * kHalfMulInv) & 0x7fffffffu) | ((eff & 1u) << 31));
-            }
+            if (hit) q = empty ? 0u : entry_to_quad(h, eff);       // chameleon.rs:64-68: quad = chunk_map[hash]
             dict_store(tbl + 2u * h, hit ? eff : e);              // chameleon.rs:56-61: PLAIN stores, MAP leaves as is
             st32u(o + 4u * lane, q);
         }
@@ -682,10 +666,318 @@ __global__ __launch_bounds__(64) void chameleon_decode_chunks(const uint8_t* __r
         ipos += rec_len;
         opos += kBlock;
     }
+    return true;
+}
+
+__global__ __launch_bounds__(64) void chameleon_decode_chunks(const uint8_t* __restrict__ in,
+                                                              const uint64_t* __restrict__ offsets,
+                                                              const uint64_t* __restrict__ sizes,
+                                                              uint8_t* __restrict__ out, uint64_t out_stride,
+                                                              uint64_t out_total, uint32_t exact,
+                                                              uint64_t* __restrict__ produced,
+                                                              uint32_t* __restrict__ err) {
+    const uint32_t lane = threadIdx.x;
+    const uint64_t chunk = blockIdx.x;
+    const uint8_t* src = in + offsets[chunk];
+    const uint64_t elen = sizes[chunk];
+    uint8_t* dst = out + chunk * out_stride;
+    // bytes this chunk may produce: its slice of the output
+    const uint64_t room_all = out_total - chunk * out_stride;
+    const uint64_t cap = room_all < out_stride ? room_all : out_stride;
+
+    lds_clear(lane);
+    const uint32_t tbl = lds_addr(smem);
+    const uint32_t zmap = tbl + kTableBytes;
+
+    Guard guard;
+    uint64_t ipos = 0, opos = 0;
+    bool bad = !decode_in_order(src, elen, dst, cap, guard, ipos, opos, tbl, zmap, lane);
     if (exact && !bad && opos != cap) bad = true;
     if (lane == 0) {
         produced[chunk] = opos;
         if (bad) atomicOr(err, 1u);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Pipelined decoder: one work-group (8 waves) per chunk, four stages one round (<= 8 records) apart, separated by one
+// s_barrier per step.  At step s:
+//
+//   wave 1   "parser"   round s+2: walks the record chain (signature -> popcount -> next record; the only inherently serial
+//                       part of the format, codec.rs:88-100) in the LDS byte ring, runs the copy-mode FSM, and publishes
+//                       a descriptor {signature, position} per record.  It also issues the global->LDS DMA that keeps the
+//                       ring filled ahead of the parse position.
+//   waves 2-7 "fetch"   round s+1: pull each lane's item out of the ring (2-byte granular), hash PLAIN quads, and stage the
+//                       operands of the dictionary step {slot address, half, write flag, value}.
+//   wave 0   "dictionary wave"   round s: one ordered LDS exchange per record (PLAIN lanes write their entry, MAP lanes
+//                       only read: mask 0), exactly the sequential chameleon.rs:56-68 semantics; stores the answers.
+//   waves 2-7 "emit"    round s-1: entry -> quad (inverse of the hash product), coalesced 256-byte stores.
+//
+// The pipeline handles whole coded records and whole raw blocks that are followed by more data; everything the reference
+// handles with per-unit checks (the ragged end: codec.rs:102-123) is left to decode_in_order on wave 0 once the
+// pipeline has drained, starting from the parser's final (position, FSM) state.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr uint32_t kRingBytes = 8192;                        // compressed-byte ring (power of two)
+constexpr uint32_t kRingTiles = kRingBytes / 1024;
+constexpr uint32_t kDescBytes = 128, kDescRing = 4;          // dwords 0..15 signatures, 16..23 positions, 24 copy mask, 25 count, 26 flags
+constexpr uint32_t kStageRec = 640, kStageRing = 3;          // per record: 64 x {d0, d1} + 64 x u16 answers
+constexpr uint32_t kDRingBase = kLdsBytes;
+constexpr uint32_t kDDescBase = kDRingBase + kRingBytes;
+constexpr uint32_t kDStageBase = kDDescBase + kDescRing * kDescBytes;
+constexpr uint32_t kDHandBase = kDStageBase + kStageRing * kRound * kStageRec;   // parser -> wave 0 hand-over (32 B)
+constexpr uint32_t kLdsBytesDec = kDHandBase + 32;
+static_assert(kLdsBytesDec <= 160u * 1024u, "LDS budget");
+constexpr uint32_t kFlagLast = 1u, kFlagPsusp = 2u;
+constexpr uint32_t kD0Write = 2u, kD0Half = 1u, kD0Empty = 0x80000000u, kD0Addr = 0x1fffcu;
+
+}  // namespace
+
+__global__ __launch_bounds__(kPipeWaves * 64) void chameleon_decode_chunks_pipe(const uint8_t* __restrict__ in,
+                                                                                const uint64_t* __restrict__ offsets,
+                                                                                const uint64_t* __restrict__ sizes,
+                                                                                uint8_t* __restrict__ out, uint64_t out_stride,
+                                                                                uint64_t out_total, uint32_t exact,
+                                                                                uint64_t* __restrict__ produced,
+                                                                                uint32_t* __restrict__ err, uint32_t dbg) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = rfl(threadIdx.x >> 6);
+    const uint64_t chunk = blockIdx.x;
+    const uint8_t* src = in + offsets[chunk];
+    const uint64_t elen64 = sizes[chunk];
+    uint8_t* dst = out + chunk * out_stride;
+    const uint64_t room_all = out_total - chunk * out_stride;
+    const uint64_t cap = room_all < out_stride ? room_all : out_stride;
+    // the pipeline addresses the stream with 32-bit offsets; longer streams (only possible through the single-stream entry
+    // points) are cut off here and finished by the in-order loop
+    const uint32_t elen = elen64 > 0xfff00000ull ? 0xfff00000u : (uint32_t)elen64;
+
+    {   // clear table + zero-entry map + descriptor ring
+        uint4* p = reinterpret_cast<uint4*>(smem);
+        const uint4 z = make_uint4(0, 0, 0, 0);
+        for (uint32_t i = threadIdx.x; i < kLdsBytes / 16; i += kPipeWaves * 64) p[i] = z;
+        for (uint32_t i = threadIdx.x; i < kDescRing * kDescBytes / 16; i += kPipeWaves * 64) reinterpret_cast<uint4*>(smem + kDDescBase)[i] = z;
+    }
+    const uint32_t lds0 = lds_addr(smem);
+    const uint32_t tbl = lds0, zmap = lds0 + kTableBytes;
+    round_barrier();
+
+    // parser state (wave 1)
+    Guard guard;
+    uint32_t ipos = 0, recs = 0;              // parse position; records published so far
+    uint32_t tiles = 0;                       // DMA tiles issued
+    uint32_t keep = 0;                        // start of the round parsed by the previous parse_round call
+    uint32_t idle = 0;                        // consecutive rounds without progress (watchdog)
+    bool parse_done = false;
+    uint32_t last_round = 0xffffffffu;        // every wave learns it from the descriptor flags
+
+    const uint32_t ntiles = (elen + 1023u) / 1024u;
+    auto issue_tiles = [&](uint32_t limit_tile) {             // tiles < min(limit_tile, ntiles)
+        while (tiles < ntiles && tiles < limit_tile) {
+            const uint32_t off = tiles * 1024u + 16u * lane;
+            if (off < elen) dma_1k(src + off, lds0 + kDRingBase + (tiles % kRingTiles) * 1024u);
+            ++tiles;
+        }
+    };
+    auto ring16 = [&](uint32_t pos) -> uint32_t {            // little-endian u16 at stream position pos (even)
+        return *reinterpret_cast<const uint16_t*>(smem + kDRingBase + (pos & (kRingBytes - 1u)));
+    };
+
+    // ---- stage bodies ----
+    auto parse_round = [&](uint32_t r) {                      // wave 1
+        wait_vm<0>();                                         // tiles issued one step ago have had a whole step to land
+        const uint32_t landed = tiles * 1024u < elen ? tiles * 1024u : elen;
+        const uint32_t dbase = kDDescBase + (r % kDescRing) * kDescBytes;
+        const uint32_t round_start = ipos, recs_before = recs;
+        uint32_t rec = 0, copy_mask = 0, n = 0;
+        while (n < kRound && !parse_done) {
+            const uint32_t rem = elen - ipos;
+            if ((uint64_t)recs * kBlock + kBlock > cap) { parse_done = true; break; }   // the in-order loop reports the overflow
+            if (guard.penalty > 0) {                          // raw block; the last one of a stream is left to the in-order loop
+                if (rem <= kBlock) { parse_done = true; break; }                        // codec.rs:104-109
+                if (ipos + kBlock > landed) break;            // not staged yet: short round
+                (void)guard.block_is_copy();
+                guard.decay();
+                copy_mask |= 1u << n;
+                rec = wlane_dyn(rec, ipos, 16 + n, lane);
+                ipos += kBlock;
+            } else {
+                if (rem < kSig) { parse_done = true; break; }
+                if (ipos + kSig > landed) break;
+                const uint32_t part = lane < 4 ? ring16(ipos + 2u * lane) : 0u;
+                const uint32_t slo = rlane(part, 0) | (rlane(part, 1) << 16), shi = rlane(part, 2) | (rlane(part, 3) << 16);
+                const uint32_t len = kSig + kBlock - 2u * (uint32_t)(__builtin_popcount(slo) + __builtin_popcount(shi));
+                if (rem < len) { parse_done = true; break; }  // ragged last record: in-order loop
+                if (ipos + len > landed) break;
+                (void)guard.block_is_copy();
+                guard.update(len >= kBlock);                  // codec.rs:98
+                rec = wlane_dyn(rec, slo, 2 * n, lane);
+                rec = wlane_dyn(rec, shi, 2 * n + 1, lane);
+                rec = wlane_dyn(rec, ipos, 16 + n, lane);
+                ipos += len;
+            }
+            ++n;
+            ++recs;
+        }
+        // watchdog: the ring always has room for the next round, so an empty round means the DMA has not
+        // landed yet; after a few of them give the rest of the stream to the in-order loop rather than spin
+        idle = (n == 0 && !parse_done) ? idle + 1 : 0;
+        if (idle >= 8) parse_done = true;
+        if (parse_done && last_round == 0xffffffffu) last_round = r;
+        rec = wlane_dyn(rec, copy_mask, 24, lane);
+        rec = wlane_dyn(rec, n, 25, lane);
+        rec = wlane_dyn(rec, (last_round == r) ? kFlagLast : 0u, 26, lane);
+        rec = wlane_dyn(rec, recs_before, 27, lane);
+        if (lane < 28) *reinterpret_cast<uint32_t*>(smem + dbase + 4u * lane) = rec;
+        // Refill.  While these tiles land, the fetch waves read the round parsed by the PREVIOUS call (it starts at `keep`),
+        // so tile i may only replace tile i-8 if that one ends at or before `keep`.
+        issue_tiles(keep / 1024u + kRingTiles);
+        keep = round_start;
+    };
+
+    auto fetch_round = [&](uint32_t r) {                      // waves 2..7
+        const uint32_t w = wave - 2;
+        const uint32_t dbase = kDDescBase + (r % kDescRing) * kDescBytes;
+        const uint32_t sbase = kDStageBase + (r % kStageRing) * kRound * kStageRec;
+        const uint32_t n = rfl(*reinterpret_cast<const uint32_t*>(smem + dbase + 100));
+        const uint32_t copy_mask = rfl(*reinterpret_cast<const uint32_t*>(smem + dbase + 96));
+        for (uint32_t k = w; k < n; k += kPipeWaves - 2) {
+            const uint32_t pos = rfl(*reinterpret_cast<const uint32_t*>(smem + dbase + 64 + 4u * k));
+            uint32_t d0, d1;
+            if ((copy_mask >> k) & 1u) {
+                const uint32_t a = pos + 4u * lane;
+                d0 = 0;
+                d1 = ring16(a) | (ring16(a + 2) << 16);
+            } else {
+                const uint64_t sig = (uint64_t)rfl(*reinterpret_cast<const uint32_t*>(smem + dbase + 8u * k)) |
+                                     ((uint64_t)rfl(*reinterpret_cast<const uint32_t*>(smem + dbase + 8u * k + 4)) << 32);
+                const bool hit = (sig >> lane) & 1ull;
+                const uint32_t a = pos + kSig + 4u * lane - 2u * mbcnt64(sig);
+                const uint32_t lo = ring16(a), hi = ring16(a + 2);
+                if (hit) {                                    // MAP: the item is the slot index (chameleon.rs:64-68)
+                    d0 = ((lo >> 1) << 2) | (lo & 1u);
+                    d1 = 0;
+                } else {                                      // PLAIN: hash the quad, stage its entry (chameleon.rs:56-61)
+                    const uint32_t q = lo | (hi << 16);
+                    const uint32_t P = q * kHashMul;
+                    const uint32_t h = P >> 16;
+                    d0 = ((h >> 1) << 2) | (h & 1u) | kD0Write;
+                    d1 = ((P & 0xfffeu) | (q >> 31)) << ((h & 1u) << 4);
+                }
+            }
+            *reinterpret_cast<uint2*>(smem + sbase + k * kStageRec + 8u * lane) = make_uint2(d0, d1);
+        }
+    };
+
+    auto dict_round = [&](uint32_t r) {                       // wave 0
+        const uint32_t dbase = kDDescBase + (r % kDescRing) * kDescBytes;
+        const uint32_t sbase = kDStageBase + (r % kStageRing) * kRound * kStageRec;
+        const uint32_t n = rfl(*reinterpret_cast<const uint32_t*>(smem + dbase + 100));
+        const uint32_t copy_mask = rfl(*reinterpret_cast<const uint32_t*>(smem + dbase + 96));
+        const uint32_t flags = rfl(*reinterpret_cast<const uint32_t*>(smem + dbase + 104));
+        if (flags & kFlagLast) last_round = r;
+        if (n == 0) return;
+        uint32_t d0[kRound], d1[kRound], ret[kRound];
+#pragma unroll
+        for (uint32_t j = 0; j < kRound; ++j) {
+            const uint2 v = *reinterpret_cast<const uint2*>(smem + sbase + j * kStageRec + 8u * lane);
+            d0[j] = v.x; d1[j] = v.y; ret[j] = 0;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d0[0]), "+v"(d0[1]), "+v"(d0[2]), "+v"(d0[3]), "+v"(d0[4]), "+v"(d0[5]), "+v"(d0[6]), "+v"(d0[7]),
+                                              "+v"(d1[0]), "+v"(d1[1]), "+v"(d1[2]), "+v"(d1[3]), "+v"(d1[4]), "+v"(d1[5]), "+v"(d1[6]), "+v"(d1[7]) :: "memory");
+#pragma unroll
+        for (uint32_t j = 0; j < kRound; ++j) {
+            if (j < n && !((copy_mask >> j) & 1u)) {
+                const uint32_t sh = (d0[j] & kD0Half) << 4;
+                const uint32_t mask = (uint32_t)(((int32_t)(d0[j] << 30) >> 31) & 0xffff) << sh;   // write flag -> 0xffff or 0
+                dict_xchg_issue(tbl + (d0[j] & kD0Addr), mask, d1[j], ret[j]);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ret[0]), "+v"(ret[1]), "+v"(ret[2]), "+v"(ret[3]), "+v"(ret[4]), "+v"(ret[5]), "+v"(ret[6]), "+v"(ret[7]) :: "memory");
+#pragma unroll
+        for (uint32_t j = 0; j < kRound; ++j) {
+            if (j < n && !((copy_mask >> j) & 1u)) {
+                const uint32_t sh = (d0[j] & kD0Half) << 4;
+                const uint32_t eff = (ret[j] >> sh) & 0xffffu;
+                const bool write = d0[j] & kD0Write;
+                const bool slot0 = (d0[j] & (kD0Addr | kD0Half)) == 0;
+                // zero-entry disambiguation (rare): a MAP lane that read 0 outside slot 0, or a PLAIN lane that wrote 0 there
+                const bool hs = !write && eff == 0 && !slot0;
+                const bool ps = write && ((d1[j] >> sh) & 0xffffu) == 0 && !slot0;
+                if (ballot64(hs || ps)) {
+                    const uint32_t h = ((d0[j] & kD0Addr) >> 1) | (d0[j] & kD0Half);
+                    if (hs || ps) {
+                        uint32_t zr;                          // ordered like the exchange: MAP lanes read, PLAIN lanes set the bit
+                        asm volatile("ds_or_rtn_b32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(zr) : "v"(zmap + (h >> 5) * 4u), "v"(ps ? (1u << (h & 31u)) : 0u) : "memory");
+                        if (hs && !((zr >> (h & 31u)) & 1u)) *reinterpret_cast<uint32_t*>(smem + sbase + j * kStageRec + 8u * lane) = d0[j] | kD0Empty;
+                    }
+                }
+                *reinterpret_cast<uint16_t*>(smem + sbase + j * kStageRec + 512u + 2u * lane) = (uint16_t)eff;
+            }
+        }
+    };
+
+    auto emit_round = [&](uint32_t r) {                       // waves 2..7
+        const uint32_t w = wave - 2;
+        const uint32_t dbase = kDDescBase + (r % kDescRing) * kDescBytes;
+        const uint32_t sbase = kDStageBase + (r % kStageRing) * kRound * kStageRec;
+        const uint32_t n = rfl(*reinterpret_cast<const uint32_t*>(smem + dbase + 100));
+        const uint32_t copy_mask = rfl(*reinterpret_cast<const uint32_t*>(smem + dbase + 96));
+        const uint32_t flags = rfl(*reinterpret_cast<const uint32_t*>(smem + dbase + 104));
+        const uint32_t first = rfl(*reinterpret_cast<const uint32_t*>(smem + dbase + 108));
+        if (flags & kFlagLast) last_round = r;
+        for (uint32_t k = w; k < n; k += kPipeWaves - 2) {
+            const uint2 v = *reinterpret_cast<const uint2*>(smem + sbase + k * kStageRec + 8u * lane);
+            uint32_t q;
+            if ((copy_mask >> k) & 1u) {
+                q = v.y;
+            } else {
+                const uint32_t eff = *reinterpret_cast<const uint16_t*>(smem + sbase + k * kStageRec + 512u + 2u * lane);
+                const uint32_t sh = (v.x & kD0Half) << 4;
+                const uint32_t e16 = (v.x & kD0Write) ? ((v.y >> sh) & 0xffffu) : eff;
+                const uint32_t h = ((v.x & kD0Addr) >> 1) | (v.x & kD0Half);
+                q = (v.x & kD0Empty) ? 0u : entry_to_quad(h, e16);
+            }
+            *reinterpret_cast<uint32_t*>(dst + (uint64_t)(first + k) * kBlock + 4u * lane) = q;
+        }
+    };
+
+    // ---- prologue: fill the pipeline ----
+    if (wave == 1) { issue_tiles(kRingTiles); parse_round(0); parse_round(1); }
+    round_barrier();
+    if (wave >= 2) fetch_round(0);
+    round_barrier();
+
+    // ---- steady state: step s = parse s+2 | fetch s+1 | dictionary s | emit s-1 ----
+    for (uint32_t s = 0;; ++s) {
+        if (wave == 1) parse_round(s + 2);
+        else if (wave == 0) dict_round(s);
+        else {
+            fetch_round(s + 1);
+            if (s >= 1) emit_round(s - 1);
+        }
+        round_barrier();
+        if (last_round != 0xffffffffu && s >= last_round + 1) break;
+    }
+
+    // hand the parser's final state to wave 0, which finishes the ragged end of the stream in order
+    if (wave == 1 && lane == 0) {
+        uint32_t* hand = reinterpret_cast<uint32_t*>(smem + kDHandBase);
+        hand[0] = ipos; hand[1] = recs; hand[2] = guard.penalty; hand[3] = guard.start; hand[4] = guard.prev; hand[5] = guard.counter;
+    }
+    round_barrier();
+    if (wave == 0) {
+        const uint32_t* hand = reinterpret_cast<const uint32_t*>(smem + kDHandBase);
+        Guard g;
+        uint64_t ip = rfl(hand[0]), op = (uint64_t)rfl(hand[1]) * kBlock;
+        g.penalty = rfl(hand[2]); g.start = rfl(hand[3]); g.prev = rfl(hand[4]); g.counter = rfl(hand[5]);
+        bool bad = !decode_in_order(src, elen64, dst, cap, g, ip, op, tbl, zmap, lane);
+        if (exact && !bad && op != cap) bad = true;
+        if (lane == 0) {
+            produced[chunk] = op;
+            if (bad) atomicOr(err, 1u);
+        }
     }
 }
 
@@ -717,7 +1009,17 @@ hipError_t launch_chameleon_decode(const uint8_t* d_in, const uint64_t* d_offset
     hipError_t e = hipFuncSetAttribute((const void*)chameleon_decode_chunks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
     if (e != hipSuccess) return e;
     if (n_chunks == 0) return hipSuccess;
-    hipLaunchKernelGGL(chameleon_decode_chunks, dim3(n_chunks), dim3(64), kLdsBytes, stream, d_in, d_offsets, d_sizes, d_out, out_stride, out_total, exact ? 1u : 0u, d_produced, d_err);
+    // the pipelined kernel stages the stream with 16-byte LDS-DMA pieces (container payloads are 16-byte aligned) and stores
+    // quads with aligned dwords
+    const bool aligned = ((uintptr_t)d_in % 16 == 0) && ((uintptr_t)d_out % 4 == 0) && (n_chunks == 1 || out_stride % 4 == 0);
+    if (aligned && !g_force_simple) {
+        e = hipFuncSetAttribute((const void*)chameleon_decode_chunks_pipe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytesDec);
+        if (e != hipSuccess) return e;
+        const uint32_t dbg = getenv("DENSITY_HIP_DBG") ? (uint32_t)atoi(getenv("DENSITY_HIP_DBG")) : 0u;
+        hipLaunchKernelGGL(chameleon_decode_chunks_pipe, dim3(n_chunks), dim3(kPipeWaves * 64), kLdsBytesDec, stream, d_in, d_offsets, d_sizes, d_out, out_stride, out_total, exact ? 1u : 0u, d_produced, d_err, dbg);
+    } else {
+        hipLaunchKernelGGL(chameleon_decode_chunks, dim3(n_chunks), dim3(64), kLdsBytes, stream, d_in, d_offsets, d_sizes, d_out, out_stride, out_total, exact ? 1u : 0u, d_produced, d_err);
+    }
     return hipGetLastError();
 }
 
