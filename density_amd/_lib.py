@@ -18,7 +18,7 @@ OK, ERR_ARGUMENT, ERR_CAPACITY, ERR_FORMAT, ERR_RUNTIME, ERR_UNSUPPORTED = range
 
 class Header(ctypes.Structure):
     """density_hip_header_t"""
-    _fields_ = [("magic", ctypes.c_uint32), ("algo", ctypes.c_uint8), ("version", ctypes.c_uint8), ("reserved", ctypes.c_uint16),
+    _fields_ = [("magic", ctypes.c_uint32), ("algo", ctypes.c_uint8), ("version", ctypes.c_uint8), ("flags", ctypes.c_uint16),
                 ("chunk_size", ctypes.c_uint32), ("n_chunks", ctypes.c_uint32), ("total_len", ctypes.c_uint64),
                 ("container_len", ctypes.c_uint64)]
 

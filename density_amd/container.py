@@ -41,12 +41,27 @@ def parse_header(raw32):
     return h
 
 
+FLAG_BLOCK_INDEX = 1
+
+
+def block_index(container):
+    """The container's block index (bytes, one per 256-byte input block) or None."""
+    b = bytes(container)
+    h = parse_header(b)
+    if not (h.flags & FLAG_BLOCK_INDEX):
+        return None
+    base = (32 + 4 * h.n_chunks + 15) // 16 * 16
+    return b[base:base + (h.total_len + 255) // 256]
+
+
 def chunk_payloads(container):
     """Splits a host-resident container into its per-chunk reference streams (for parity checks)."""
     b = bytes(container)
     h = parse_header(b)
     sizes = [int.from_bytes(b[32 + 4 * i:36 + 4 * i], "little") for i in range(h.n_chunks)]
     off = (32 + 4 * h.n_chunks + 15) // 16 * 16
+    if h.flags & FLAG_BLOCK_INDEX:
+        off = (off + (h.total_len + 255) // 256 + 15) // 16 * 16
     out = []
     for s in sizes:
         out.append(b[off:off + s])
@@ -89,7 +104,7 @@ def stream_decode_device(algo, d_in, n, d_out, cap, stream=0):
 
 
 def set_kernel_variant(variant):
-    """0 = default (pipelined) kernels, 1 = simple one-wavefront kernels (test hook)."""
+    """Bit mask (test hook): 1 = simple one-wavefront kernels, 2 = containers without the block index."""
     _lib.lib().density_hip_set_kernel_variant(int(variant))
 
 

@@ -41,7 +41,11 @@ inline bool valid_algo(int algo) { return algo >= DENSITY_HIP_CHAMELEON && algo 
 inline size_t normalise_chunk(size_t chunk) { return chunk == 0 ? (size_t)DENSITY_HIP_DEFAULT_CHUNK : chunk; }
 inline bool valid_chunk(size_t chunk) { return chunk >= 256 && chunk % 256 == 0 && chunk <= kMaxChunk; }
 inline size_t chunk_count(size_t n, size_t chunk) { return (n + chunk - 1) / chunk; }
-inline size_t payload_base(size_t n_chunks) { return align_up(sizeof(density_hip_header_t) + 4 * n_chunks, 16); }
+inline size_t index_base(size_t n_chunks) { return align_up(sizeof(density_hip_header_t) + 4 * n_chunks, 16); }
+inline size_t index_bytes(size_t total_len, bool with_index) { return with_index ? (total_len + 255) / 256 : 0; }
+inline size_t payload_base(size_t n_chunks, size_t total_len, bool with_index) { return align_up(index_base(n_chunks) + index_bytes(total_len, with_index), 16); }
+int g_variant = 0;   // density_hip_set_kernel_variant
+inline bool want_index(int algo) { return algo == DENSITY_HIP_CHAMELEON && !(g_variant & 2); }
 inline size_t slot_stride(int algo, size_t chunk) { return align_up(safe_size(algo, chunk), kAlign); }
 
 struct Buffer {
@@ -152,7 +156,7 @@ DecodePlan plan_decode(size_t n_chunks) {
 
 size_t container_bound(int algo, size_t n, size_t chunk) {
     const size_t nc = chunk_count(n, chunk);
-    size_t bound = payload_base(nc);
+    size_t bound = payload_base(nc, n, true);      // an upper bound for both flavours
     if (nc) bound += (nc - 1) * align_up(safe_size(algo, chunk), 16) + safe_size(algo, n - (nc - 1) * chunk);
     return bound;
 }
@@ -161,7 +165,8 @@ int check_header(const density_hip_header_t& h, size_t container_size) {
     if (h.magic != DENSITY_HIP_MAGIC || h.version != 1 || !valid_algo(h.algo)) return DENSITY_HIP_ERR_FORMAT;
     if (!valid_chunk(h.chunk_size)) return DENSITY_HIP_ERR_FORMAT;
     if (h.n_chunks != chunk_count(h.total_len, h.chunk_size)) return DENSITY_HIP_ERR_FORMAT;
-    if (h.container_len > container_size || h.container_len < payload_base(h.n_chunks)) return DENSITY_HIP_ERR_FORMAT;
+    if (h.flags & ~DENSITY_HIP_FLAG_BLOCK_INDEX) return DENSITY_HIP_ERR_FORMAT;
+    if (h.container_len > container_size || h.container_len < payload_base(h.n_chunks, h.total_len, h.flags & DENSITY_HIP_FLAG_BLOCK_INDEX)) return DENSITY_HIP_ERR_FORMAT;
     return DENSITY_HIP_OK;
 }
 
@@ -178,22 +183,25 @@ int run_encode_container(DeviceCtx* c, int algo, const uint8_t* d_in, size_t n, 
     uint64_t* d_offsets = reinterpret_cast<uint64_t*>(ws + p.off_offsets);
     uint8_t* d_slots = ws + p.off_slots;
     density_hip_header_t hdr{};
-    hdr.magic = DENSITY_HIP_MAGIC; hdr.algo = (uint8_t)algo; hdr.version = 1; hdr.reserved = 0;
+    hdr.magic = DENSITY_HIP_MAGIC; hdr.algo = (uint8_t)algo; hdr.version = 1; hdr.flags = want_index(algo) ? DENSITY_HIP_FLAG_BLOCK_INDEX : 0;
     hdr.chunk_size = (uint32_t)chunk; hdr.n_chunks = (uint32_t)p.n_chunks; hdr.total_len = n; hdr.container_len = 0;
 
+    const bool with_index = hdr.flags & DENSITY_HIP_FLAG_BLOCK_INDEX;
+    const uint64_t pbase = payload_base(p.n_chunks, n, with_index);
+    uint8_t* d_index = with_index ? d_out + index_base(p.n_chunks) : nullptr;
     Profiler prof(c, s);
     hipError_t e = hipMemsetAsync(d_err, 0, sizeof(uint32_t), s);
     if (e != hipSuccess) { set_error("hipMemsetAsync", e); return DENSITY_HIP_ERR_RUNTIME; }
     if (p.n_chunks == 1) {
         // single chunk: its stream goes straight to its final place, no stitch pass
-        e = launch_chameleon_encode(d_in, n, chunk, 1, d_out + payload_base(1), 0, d_sizes, s);
+        e = launch_chameleon_encode(d_in, n, chunk, 1, d_out + pbase, 0, d_sizes, d_index, s);
         prof.mark("chameleon_encode_chunks");
-        if (e == hipSuccess) e = launch_layout_encode(d_sizes, 1, hdr, d_out, cap, d_offsets, d_err, s);
+        if (e == hipSuccess) e = launch_layout_encode(d_sizes, 1, hdr, pbase, d_out, cap, d_offsets, d_err, s);
         prof.mark("layout_encode");
     } else {
-        e = launch_chameleon_encode(d_in, n, chunk, (uint32_t)p.n_chunks, d_slots, p.stride, d_sizes, s);
+        e = launch_chameleon_encode(d_in, n, chunk, (uint32_t)p.n_chunks, d_slots, p.stride, d_sizes, d_index, s);
         prof.mark("chameleon_encode_chunks");
-        if (e == hipSuccess) e = launch_layout_encode(d_sizes, (uint32_t)p.n_chunks, hdr, d_out, cap, d_offsets, d_err, s);
+        if (e == hipSuccess) e = launch_layout_encode(d_sizes, (uint32_t)p.n_chunks, hdr, pbase, d_out, cap, d_offsets, d_err, s);
         prof.mark("layout_encode");
         if (e == hipSuccess) e = launch_compact(d_slots, p.stride, d_sizes, d_offsets, (uint32_t)p.n_chunks, d_out, d_err, s);
         prof.mark("compact");
@@ -221,9 +229,11 @@ int run_decode_container(DeviceCtx* c, const uint8_t* d_in, size_t container_siz
     uint64_t* d_produced = reinterpret_cast<uint64_t*>(ws + p.off_produced);
     Profiler prof(c, s);
     hipError_t e = hipMemsetAsync(d_err, 0, sizeof(uint32_t), s);
-    if (e == hipSuccess) e = launch_layout_decode(d_in, container_size, h.n_chunks, d_sizes, d_offsets, d_err, s);
+    const bool with_index = h.flags & DENSITY_HIP_FLAG_BLOCK_INDEX;
+    const uint8_t* d_index = with_index ? d_in + index_base(h.n_chunks) : nullptr;
+    if (e == hipSuccess) e = launch_layout_decode(d_in, container_size, h.n_chunks, payload_base(h.n_chunks, h.total_len, with_index), d_sizes, d_offsets, d_err, s);
     prof.mark("layout_decode");
-    if (e == hipSuccess) e = launch_chameleon_decode(d_in, d_offsets, d_sizes, h.n_chunks, d_out, h.chunk_size, h.total_len, true, d_produced, d_err, s);
+    if (e == hipSuccess) e = launch_chameleon_decode(d_in, d_offsets, d_sizes, h.n_chunks, d_out, h.chunk_size, h.total_len, true, d_index, d_produced, d_err, s);
     prof.mark("chameleon_decode_chunks");
     if (e != hipSuccess) { set_error("kernel launch (decode)", e); return DENSITY_HIP_ERR_RUNTIME; }
     if (decoded_out) {
@@ -245,7 +255,7 @@ int run_stream_encode(DeviceCtx* c, int algo, const uint8_t* d_in, size_t n, uin
     *size_out = 0;
     if (n == 0) return DENSITY_HIP_OK;
     Profiler prof(c, s);
-    hipError_t e = launch_chameleon_encode(d_in, n, n, 1, d_out, 0, d_sizes, s);
+    hipError_t e = launch_chameleon_encode(d_in, n, n, 1, d_out, 0, d_sizes, nullptr, s);
     prof.mark("chameleon_encode_chunks");
     uint64_t h_size = 0;
     if (e == hipSuccess) e = hipMemcpyAsync(&h_size, d_sizes, sizeof(h_size), hipMemcpyDeviceToHost, s);
@@ -271,7 +281,7 @@ int run_stream_decode(DeviceCtx* c, int algo, const uint8_t* d_in, size_t n, uin
     if (e == hipSuccess) e = hipMemcpyAsync(d_sizes, &h_size, 8, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemcpyAsync(d_offsets, &h_off, 8, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);   // h_size/h_off live on this stack frame
-    if (e == hipSuccess) e = launch_chameleon_decode(d_in, d_offsets, d_sizes, 1, d_out, cap, cap, false, d_produced, d_err, s);
+    if (e == hipSuccess) e = launch_chameleon_decode(d_in, d_offsets, d_sizes, 1, d_out, cap, cap, false, nullptr, d_produced, d_err, s);
     prof.mark("chameleon_decode_chunks");
     uint64_t h_prod = 0;
     uint32_t h_err = 0;
@@ -458,7 +468,7 @@ size_t density_hip_decode(const uint8_t* container, size_t container_size, uint8
 }
 
 void density_hip_set_profiling(int enabled) { g_profiling = enabled; }
-void density_hip_set_kernel_variant(int variant) { density::g_force_simple = (variant == 1); }
+void density_hip_set_kernel_variant(int variant) { g_variant = variant; density::g_force_simple = (variant & 1) != 0; }
 
 int density_hip_last_timings(float* milliseconds, const char** names, int capacity) {
     int dev = -1;

@@ -38,6 +38,7 @@ constexpr uint32_t kZmapBytes = 65536u / 8u;    // 1 bit per slot
 constexpr uint32_t kLdsBytes = kTableBytes + kZmapBytes;
 constexpr uint32_t kBlock = 256;                // chameleon.rs:140
 constexpr uint32_t kSig = 8;                    // chameleon.rs:146
+constexpr uint32_t kIdxCopy = 0x80u, kIdxRagged = 0x7fu;   // block index entry: bit 7 raw copy; low 7 bits MAP count or 0x7f = ragged (include/density_hip.h)
 
 __device__ __forceinline__ void lds_clear(uint32_t lane) {
     uint4* p = reinterpret_cast<uint4*>(smem);
@@ -142,7 +143,8 @@ __device__ __forceinline__ void resolve_groups(bool active, uint32_t lane, uint3
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void chameleon_encode_chunks(const uint8_t* __restrict__ in, uint64_t total,
                                                               uint64_t chunk_bytes, uint8_t* __restrict__ out,
-                                                              uint64_t out_stride, uint64_t* __restrict__ sizes) {
+                                                              uint64_t out_stride, uint64_t* __restrict__ sizes,
+                                                              uint8_t* __restrict__ index) {
     const uint32_t lane = threadIdx.x;
     const uint64_t chunk = blockIdx.x;
     const uint8_t* src = in + chunk * chunk_bytes;
@@ -180,9 +182,11 @@ __global__ __launch_bounds__(64) void chameleon_encode_chunks(const uint8_t* __r
             const bool active = lane < nq;
             uint8_t* rec = dst + opos;
 
+            uint8_t* idx = index ? index + (chunk * chunk_bytes + boff) / kBlock : nullptr;    // block index entry (density_hip.h)
             if (guard.block_is_copy()) {                       // codec.rs:35-37: raw block, dictionary untouched
                 if (active) st32u(rec + 4u * lane, q);
                 if (lane < tail) rec[4u * nq + lane] = src[boff + 4u * nq + lane];
+                if (idx && lane == 0) *idx = (uint8_t)(kIdxCopy | (blen < kBlock ? kIdxRagged : 0u));
                 opos += blen;
                 guard.decay();
                 continue;
@@ -216,6 +220,7 @@ __global__ __launch_bounds__(64) void chameleon_encode_chunks(const uint8_t* __r
             const uint32_t items_end = kSig + 4u * nq - 2u * nhit;
             if (lane < tail) rec[items_end + lane] = src[boff + 4u * nq + lane];                   // codec.rs:58-61
             const uint32_t rec_len = items_end + tail;
+            if (idx && lane == 0) *idx = (uint8_t)(blen < kBlock ? kIdxRagged : nhit);
             guard.update(rec_len >= kBlock);                   // codec.rs:68
             opos += rec_len;
         }
@@ -320,13 +325,14 @@ struct Issued {
 __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(const uint8_t* __restrict__ in, uint64_t total,
                                                                                 uint64_t chunk_bytes, uint8_t* __restrict__ out,
                                                                                 uint64_t out_stride, uint64_t* __restrict__ sizes,
-                                                                                uint32_t dbg) {
+                                                                                uint8_t* __restrict__ index, uint32_t dbg) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = rfl(threadIdx.x >> 6);
     const uint64_t chunk = blockIdx.x;
     const uint8_t* src = in + chunk * chunk_bytes;
     const uint64_t len = (total - chunk * chunk_bytes) < chunk_bytes ? (total - chunk * chunk_bytes) : chunk_bytes;
     uint8_t* dst = out + chunk * out_stride;
+    uint8_t* idx = index ? index + chunk * (chunk_bytes / kBlock) : nullptr;     // this chunk's slice of the block index
     const uint64_t nfull = len / kBlock;                       // whole blocks: these go through the pipeline
     const uint64_t nrounds = (nfull + kRound - 1) / kRound;
 
@@ -521,7 +527,9 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
                 const uint32_t base_lo = *reinterpret_cast<const uint32_t*>(smem + rbase + 64);
                 const uint32_t base_hi = *reinterpret_cast<const uint32_t*>(smem + rbase + 68);
                 const uint32_t cmask = rfl(*reinterpret_cast<const uint32_t*>(smem + rbase + 72));
-                const uint32_t mylen = ((cmask >> sl) & 1u) ? kBlock : (kSig + kBlock - 2u * (uint32_t)(__builtin_popcount(slo) + __builtin_popcount(shi)));
+                const uint32_t myhits = (uint32_t)(__builtin_popcount(slo) + __builtin_popcount(shi));
+                const uint32_t mylen = ((cmask >> sl) & 1u) ? kBlock : (kSig + kBlock - 2u * myhits);
+                if (idx && wave == 1 && lane < nb) idx[b0 + lane] = (uint8_t)(((cmask >> sl) & 1u) ? kIdxCopy : myhits);
                 for (uint32_t k = wave - 1; k < nb; k += kEmitWaves) {
                     uint32_t before = 0;
                     for (uint32_t j = 0; j < k; ++j) before += rlane(mylen, j);
@@ -557,6 +565,7 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
             if (guard.block_is_copy()) {
                 if (active) st32u(rec + 4u * lane, q);
                 if (lane < tail) rec[4u * nq + lane] = src[boff + 4u * nq + lane];
+                if (idx && lane == 0) idx[nfull] = (uint8_t)(kIdxCopy | kIdxRagged);
                 opos += blen;
             } else {
                 const uint32_t P = q * kHashMul;
@@ -582,6 +591,7 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
                 }
                 const uint32_t items_end = kSig + 4u * nq - 2u * nhit;
                 if (lane < tail) rec[items_end + lane] = src[boff + 4u * nq + lane];
+                if (idx && lane == 0) idx[nfull] = (uint8_t)kIdxRagged;
                 opos += items_end + tail;
             }
         }
@@ -721,7 +731,7 @@ namespace {
 
 constexpr uint32_t kRingBytes = 8192;                        // compressed-byte ring (power of two)
 constexpr uint32_t kRingTiles = kRingBytes / 1024;
-constexpr uint32_t kDescBytes = 128, kDescRing = 4;          // dwords 0..15 signatures, 16..23 positions, 24 copy mask, 25 count, 26 flags
+constexpr uint32_t kDescBytes = 128, kDescRing = 4;          // dwords 16..23 record positions, 24 copy mask, 25 count, 26 flags, 27 first ordinal
 constexpr uint32_t kStageRec = 640, kStageRing = 3;          // per record: 64 x {d0, d1} + 64 x u16 answers
 constexpr uint32_t kDRingBase = kLdsBytes;
 constexpr uint32_t kDDescBase = kDRingBase + kRingBytes;
@@ -739,12 +749,14 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_decode_chunks_pipe(
                                                                                 const uint64_t* __restrict__ sizes,
                                                                                 uint8_t* __restrict__ out, uint64_t out_stride,
                                                                                 uint64_t out_total, uint32_t exact,
+                                                                                const uint8_t* __restrict__ index,
                                                                                 uint64_t* __restrict__ produced,
                                                                                 uint32_t* __restrict__ err, uint32_t dbg) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = rfl(threadIdx.x >> 6);
     const uint64_t chunk = blockIdx.x;
     const uint8_t* src = in + offsets[chunk];
+    const uint8_t* idx = index ? index + chunk * (out_stride / kBlock) : nullptr;   // this chunk's slice of the block index
     const uint64_t elen64 = sizes[chunk];
     uint8_t* dst = out + chunk * out_stride;
     const uint64_t room_all = out_total - chunk * out_stride;
@@ -769,7 +781,13 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_decode_chunks_pipe(
     uint32_t tiles = 0;                       // DMA tiles issued
     uint32_t keep = 0;                        // start of the round parsed by the previous parse_round call
     uint32_t idle = 0;                        // consecutive rounds without progress (watchdog)
-    bool parse_done = false;
+    // block index window (wave 1): lane l of idx_cur holds the entry of record idx_base + l, idx_next the 64 entries after those
+    auto load_index = [&](uint32_t first) -> uint32_t {
+        return (idx && (uint64_t)(first + lane) * kBlock < cap) ? (uint32_t)idx[first + lane] : kIdxRagged;
+    };
+    uint32_t idx_base = 0, idx_cur = kIdxRagged, idx_next = kIdxRagged;
+    if (wave == 1) { idx_cur = load_index(0); idx_next = load_index(64); }
+    bool parse_done = false, index_fault = false;
     uint32_t last_round = 0xffffffffu;        // every wave learns it from the descriptor flags
 
     const uint32_t ntiles = (elen + 1023u) / 1024u;
@@ -785,13 +803,86 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_decode_chunks_pipe(
     };
 
     // ---- stage bodies ----
+    // number of MAP flags (set bits) in the 8-byte signature at stream position pos: lanes 0..3 fetch one u16 each
+    auto sig_hits = [&](uint32_t pos) -> uint32_t {
+        const uint32_t part = lane < 4 ? ring16(pos + 2u * lane) : 0u;
+        uint32_t c = (uint32_t)__builtin_popcount(part);
+        c += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c, 0x111, 0xf, 0xf, true);   // row_shr:1
+        c += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c, 0x112, 0xf, 0xf, true);   // row_shr:2
+        return rlane(c, 3);
+    };
+
     auto parse_round = [&](uint32_t r) {                      // wave 1
-        wait_vm<0>();                                         // tiles issued one step ago have had a whole step to land
+        // the record walker reads the stream here, so everything issued so far must have landed; the indexed feeder reads
+        // nothing and waits at the end of the call, only for the tiles the next fetch needs
+        if (!idx) wait_vm<0>();
         const uint32_t landed = tiles * 1024u < elen ? tiles * 1024u : elen;
         const uint32_t dbase = kDDescBase + (r % kDescRing) * kDescBytes;
         const uint32_t round_start = ipos, recs_before = recs;
         uint32_t rec = 0, copy_mask = 0, n = 0;
-        while (n < kRound && !parse_done) {
+        constexpr uint32_t kMaxRound = kRound * (kSig + kBlock);
+        if (idx) {
+            // Indexed container: the block index says where every record starts and which blocks are raw copies, so there is
+            // no record chain to walk, no FSM to run and no stream byte to read here (include/density_hip.h).
+            const uint32_t nblocks_out = (uint32_t)((cap + kBlock - 1) / kBlock);
+            if (recs + kRound > idx_base + 64) {
+                // slide the 64-entry window so that it starts at `recs`: entries still in idx_cur, then the prefetched idx_next
+                const uint32_t shift = recs - idx_base;            // 57..64
+                const uint32_t from_cur = bperm((lane + shift) & 63u, idx_cur), from_next = bperm((lane + shift) & 63u, idx_next);
+                idx_cur = (lane + shift < 64) ? from_cur : from_next;
+                idx_base = recs;
+                idx_next = load_index(idx_base + 64);              // used at the next slide, >= 7 rounds from now
+            }
+            if (!parse_done) {
+                // lanes 0..7 work on this round's eight entries in parallel: record length, exclusive prefix = position, first
+                // entry that ends the pipelined part
+                const uint32_t ent = bperm((lane + recs - idx_base) & 63u, idx_cur);
+                const bool is_copy = (ent & kIdxCopy) != 0;
+                const uint32_t mylen = lane < kRound ? (is_copy ? kBlock : (kSig + kBlock - 2u * (ent & 0x7fu))) : 0u;
+                uint32_t incl = mylen;
+                incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xf, 0xf, true);   // row_shr:1
+                incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xf, 0xf, true);   // row_shr:2
+                incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xf, 0xf, true);   // row_shr:4
+                const uint32_t pos = ipos + incl - mylen;
+                // ragged last block, last block of the chunk, or an index that disagrees with the stream length: the in-order
+                // loop finishes from there, told whether its (single) block is a raw copy
+                const bool stop = lane < kRound && ((ent & 0x7fu) == kIdxRagged || recs + lane >= nblocks_out || elen - pos <= mylen || pos >= elen);
+                const uint32_t stopm = (uint32_t)ballot64(stop);
+                n = stopm ? (uint32_t)__builtin_ctz(stopm) : kRound;
+                copy_mask = (uint32_t)ballot64(is_copy && lane < n);
+                if (lane < n) *reinterpret_cast<uint32_t*>(smem + dbase + 64 + 4u * lane) = pos;
+                if (n < kRound) {
+                    parse_done = true;
+                    guard.penalty = (rlane(ent, n) & kIdxCopy) ? 1u : 0u; guard.start = 1; guard.prev = 0; guard.counter = 1;
+                }
+                ipos = n ? rlane(pos + mylen, n - 1) : ipos;
+                recs += n;
+            }
+        } else if (!parse_done && guard.penalty == 0 && !guard.prev && ipos + kMaxRound <= landed && elen - ipos > kMaxRound &&
+            ((uint64_t)recs + kRound) * kBlock <= cap) {
+            // Fast round: eight coded records are certainly staged, complete and followed by more data, so the per-record work
+            // is just the chain  signature -> popcount -> next position.  The FSM is advanced once per round unless a record
+            // turns out incompressible (< 5 MAP flags: 8 + 256 - 2*hits >= 256, codec.rs:98), in which case the records after
+            // it are dropped again and the careful loop below takes over.
+            uint32_t pos = ipos, inc_at = kRound;
+#pragma unroll
+            for (uint32_t j = 0; j < kRound; ++j) {
+                const uint32_t hits = sig_hits(pos);
+                rec = lane == 16 + j ? pos : rec;
+                if (hits <= 4 && inc_at == kRound) inc_at = j;
+                pos += kSig + kBlock - 2u * hits;
+            }
+            if (inc_at == kRound) {
+                const uint32_t to16 = (16u - (guard.counter & 15u)) & 15u;      // protection_state.rs:19-27, once per round
+                if (to16 < kRound && guard.start > 1) guard.start >>= 1;
+                guard.counter += kRound;
+                ipos = pos;
+                n = kRound;
+                recs += kRound;
+            }
+            // else: nothing committed; reparse the round record by record with the full FSM
+        }
+        while (!idx && n < kRound && !parse_done) {
             const uint32_t rem = elen - ipos;
             if ((uint64_t)recs * kBlock + kBlock > cap) { parse_done = true; break; }   // the in-order loop reports the overflow
             if (guard.penalty > 0) {                          // raw block; the last one of a stream is left to the in-order loop
@@ -805,15 +896,11 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_decode_chunks_pipe(
             } else {
                 if (rem < kSig) { parse_done = true; break; }
                 if (ipos + kSig > landed) break;
-                const uint32_t part = lane < 4 ? ring16(ipos + 2u * lane) : 0u;
-                const uint32_t slo = rlane(part, 0) | (rlane(part, 1) << 16), shi = rlane(part, 2) | (rlane(part, 3) << 16);
-                const uint32_t len = kSig + kBlock - 2u * (uint32_t)(__builtin_popcount(slo) + __builtin_popcount(shi));
+                const uint32_t len = kSig + kBlock - 2u * sig_hits(ipos);
                 if (rem < len) { parse_done = true; break; }  // ragged last record: in-order loop
                 if (ipos + len > landed) break;
                 (void)guard.block_is_copy();
                 guard.update(len >= kBlock);                  // codec.rs:98
-                rec = wlane_dyn(rec, slo, 2 * n, lane);
-                rec = wlane_dyn(rec, shi, 2 * n + 1, lane);
                 rec = wlane_dyn(rec, ipos, 16 + n, lane);
                 ipos += len;
             }
@@ -823,17 +910,33 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_decode_chunks_pipe(
         // watchdog: the ring always has room for the next round, so an empty round means the DMA has not
         // landed yet; after a few of them give the rest of the stream to the in-order loop rather than spin
         idle = (n == 0 && !parse_done) ? idle + 1 : 0;
-        if (idle >= 8) parse_done = true;
+        if (idle >= 8) { parse_done = true; index_fault = idx != nullptr; }   // without the FSM the in-order loop cannot take over mid-stream
         if (parse_done && last_round == 0xffffffffu) last_round = r;
         rec = wlane_dyn(rec, copy_mask, 24, lane);
         rec = wlane_dyn(rec, n, 25, lane);
         rec = wlane_dyn(rec, (last_round == r) ? kFlagLast : 0u, 26, lane);
         rec = wlane_dyn(rec, recs_before, 27, lane);
-        if (lane < 28) *reinterpret_cast<uint32_t*>(smem + dbase + 4u * lane) = rec;
+        if (lane >= (idx ? 24u : 16u) && lane < 28) *reinterpret_cast<uint32_t*>(smem + dbase + 4u * lane) = rec;
         // Refill.  While these tiles land, the fetch waves read the round parsed by the PREVIOUS call (it starts at `keep`),
         // so tile i may only replace tile i-8 if that one ends at or before `keep`.
         issue_tiles(keep / 1024u + kRingTiles);
         keep = round_start;
+        if (idx) {
+            // The fetch waves read this round's bytes [round_start, ipos) during the next step.  Tiles retire in order, so
+            // allow exactly the tiles issued beyond that range to stay in flight (an index load in flight only makes the wait
+            // stricter).  The tile limit above always covers the range (ring 8 KiB >= a round of 2112 bytes + a tile).
+            const uint32_t need = (ipos + 1023u) / 1024u;        // tiles [0, need) must have landed
+            const uint32_t in_flight_ok = tiles > need ? tiles - need : 0u;
+            switch (in_flight_ok) {
+                case 0: wait_vm<0>(); break;
+                case 1: wait_vm<1>(); break;
+                case 2: wait_vm<2>(); break;
+                case 3: wait_vm<3>(); break;
+                case 4: wait_vm<4>(); break;
+                case 5: wait_vm<5>(); break;
+                default: wait_vm<6>(); break;
+            }
+        }
     };
 
     auto fetch_round = [&](uint32_t r) {                      // waves 2..7
@@ -850,8 +953,8 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_decode_chunks_pipe(
                 d0 = 0;
                 d1 = ring16(a) | (ring16(a + 2) << 16);
             } else {
-                const uint64_t sig = (uint64_t)rfl(*reinterpret_cast<const uint32_t*>(smem + dbase + 8u * k)) |
-                                     ((uint64_t)rfl(*reinterpret_cast<const uint32_t*>(smem + dbase + 8u * k + 4)) << 32);
+                const uint32_t part = lane < 4 ? ring16(pos + 2u * lane) : 0u;       // the record's signature (codec.rs:28-31)
+                const uint64_t sig = (uint64_t)(rlane(part, 0) | (rlane(part, 1) << 16)) | ((uint64_t)(rlane(part, 2) | (rlane(part, 3) << 16)) << 32);
                 const bool hit = (sig >> lane) & 1ull;
                 const uint32_t a = pos + kSig + 4u * lane - 2u * mbcnt64(sig);
                 const uint32_t lo = ring16(a), hi = ring16(a + 2);
@@ -952,10 +1055,10 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_decode_chunks_pipe(
     // ---- steady state: step s = parse s+2 | fetch s+1 | dictionary s | emit s-1 ----
     for (uint32_t s = 0;; ++s) {
         if (wave == 1) parse_round(s + 2);
-        else if (wave == 0) dict_round(s);
+        else if (wave == 0) { if (!(dbg & 64u)) dict_round(s); else { const uint32_t fl = rfl(*reinterpret_cast<const uint32_t*>(smem + kDDescBase + (s % kDescRing) * kDescBytes + 104)); if (fl & kFlagLast) last_round = s; } }
         else {
-            fetch_round(s + 1);
-            if (s >= 1) emit_round(s - 1);
+            if (!(dbg & 32u)) fetch_round(s + 1);
+            if (s >= 1) { if (!(dbg & 16u)) emit_round(s - 1); else { const uint32_t fl = rfl(*reinterpret_cast<const uint32_t*>(smem + kDDescBase + ((s - 1) % kDescRing) * kDescBytes + 104)); if (fl & kFlagLast) last_round = s - 1; } }
         }
         round_barrier();
         if (last_round != 0xffffffffu && s >= last_round + 1) break;
@@ -964,7 +1067,7 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_decode_chunks_pipe(
     // hand the parser's final state to wave 0, which finishes the ragged end of the stream in order
     if (wave == 1 && lane == 0) {
         uint32_t* hand = reinterpret_cast<uint32_t*>(smem + kDHandBase);
-        hand[0] = ipos; hand[1] = recs; hand[2] = guard.penalty; hand[3] = guard.start; hand[4] = guard.prev; hand[5] = guard.counter;
+        hand[0] = ipos; hand[1] = recs; hand[2] = guard.penalty; hand[3] = guard.start; hand[4] = guard.prev; hand[5] = guard.counter; hand[6] = index_fault ? 1u : 0u;
     }
     round_barrier();
     if (wave == 0) {
@@ -973,6 +1076,7 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_decode_chunks_pipe(
         uint64_t ip = rfl(hand[0]), op = (uint64_t)rfl(hand[1]) * kBlock;
         g.penalty = rfl(hand[2]); g.start = rfl(hand[3]); g.prev = rfl(hand[4]); g.counter = rfl(hand[5]);
         bool bad = !decode_in_order(src, elen64, dst, cap, g, ip, op, tbl, zmap, lane);
+        if (rfl(hand[6])) bad = true;
         if (exact && !bad && op != cap) bad = true;
         if (lane == 0) {
             produced[chunk] = op;
@@ -986,7 +1090,7 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_decode_chunks_pipe(
 // ---------------------------------------------------------------------------------------------------------------
 bool g_force_simple = false;   // test hook (density_hip_set_kernel_variant): run the one-wave kernels
 hipError_t launch_chameleon_encode(const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks,
-                                   uint8_t* d_out, uint64_t out_stride, uint64_t* d_sizes, hipStream_t stream) {
+                                   uint8_t* d_out, uint64_t out_stride, uint64_t* d_sizes, uint8_t* d_index, hipStream_t stream) {
     hipError_t e = hipFuncSetAttribute((const void*)chameleon_encode_chunks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
     if (e != hipSuccess) return e;
     if (n_chunks == 0) return hipSuccess;
@@ -996,16 +1100,16 @@ hipError_t launch_chameleon_encode(const uint8_t* d_in, uint64_t total, uint64_t
         e = hipFuncSetAttribute((const void*)chameleon_encode_chunks_pipe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytesPipe);
         if (e != hipSuccess) return e;
         const uint32_t dbg = getenv("DENSITY_HIP_DBG") ? (uint32_t)atoi(getenv("DENSITY_HIP_DBG")) : 0u;
-        hipLaunchKernelGGL(chameleon_encode_chunks_pipe, dim3(n_chunks), dim3(kPipeWaves * 64), kLdsBytesPipe, stream, d_in, total, chunk_bytes, d_out, out_stride, d_sizes, dbg);
+        hipLaunchKernelGGL(chameleon_encode_chunks_pipe, dim3(n_chunks), dim3(kPipeWaves * 64), kLdsBytesPipe, stream, d_in, total, chunk_bytes, d_out, out_stride, d_sizes, d_index, dbg);
     } else {
-        hipLaunchKernelGGL(chameleon_encode_chunks, dim3(n_chunks), dim3(64), kLdsBytes, stream, d_in, total, chunk_bytes, d_out, out_stride, d_sizes);
+        hipLaunchKernelGGL(chameleon_encode_chunks, dim3(n_chunks), dim3(64), kLdsBytes, stream, d_in, total, chunk_bytes, d_out, out_stride, d_sizes, d_index);
     }
     return hipGetLastError();
 }
 
 hipError_t launch_chameleon_decode(const uint8_t* d_in, const uint64_t* d_offsets, const uint64_t* d_sizes,
                                    uint32_t n_chunks, uint8_t* d_out, uint64_t out_stride, uint64_t out_total,
-                                   bool exact, uint64_t* d_produced, uint32_t* d_err, hipStream_t stream) {
+                                   bool exact, const uint8_t* d_index, uint64_t* d_produced, uint32_t* d_err, hipStream_t stream) {
     hipError_t e = hipFuncSetAttribute((const void*)chameleon_decode_chunks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
     if (e != hipSuccess) return e;
     if (n_chunks == 0) return hipSuccess;
@@ -1016,7 +1120,7 @@ hipError_t launch_chameleon_decode(const uint8_t* d_in, const uint64_t* d_offset
         e = hipFuncSetAttribute((const void*)chameleon_decode_chunks_pipe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytesDec);
         if (e != hipSuccess) return e;
         const uint32_t dbg = getenv("DENSITY_HIP_DBG") ? (uint32_t)atoi(getenv("DENSITY_HIP_DBG")) : 0u;
-        hipLaunchKernelGGL(chameleon_decode_chunks_pipe, dim3(n_chunks), dim3(kPipeWaves * 64), kLdsBytesDec, stream, d_in, d_offsets, d_sizes, d_out, out_stride, out_total, exact ? 1u : 0u, d_produced, d_err, dbg);
+        hipLaunchKernelGGL(chameleon_decode_chunks_pipe, dim3(n_chunks), dim3(kPipeWaves * 64), kLdsBytesDec, stream, d_in, d_offsets, d_sizes, d_out, out_stride, out_total, exact ? 1u : 0u, d_index, d_produced, d_err, dbg);
     } else {
         hipLaunchKernelGGL(chameleon_decode_chunks, dim3(n_chunks), dim3(64), kLdsBytes, stream, d_in, d_offsets, d_sizes, d_out, out_stride, out_total, exact ? 1u : 0u, d_produced, d_err);
     }

@@ -62,10 +62,9 @@ __device__ __forceinline__ void layout_common(const SizeT* __restrict__ sizes_in
 }
 
 __global__ __launch_bounds__(kScanThreads) void layout_encode_kernel(const uint64_t* __restrict__ sizes, uint32_t n,
-                                                                     density_hip_header_t hdr, uint8_t* __restrict__ container,
+                                                                     density_hip_header_t hdr, uint64_t base, uint8_t* __restrict__ container,
                                                                      uint64_t capacity, uint64_t* __restrict__ offsets,
                                                                      uint64_t* __restrict__ end_scratch, uint32_t* __restrict__ err) {
-    const uint64_t base = align16(kHeaderBytes + 4ull * n);
     if (threadIdx.x == 0) *end_scratch = base;
     __syncthreads();
     layout_common<uint64_t>(sizes, n, base, nullptr, reinterpret_cast<uint32_t*>(container + kHeaderBytes), offsets, end_scratch);
@@ -78,10 +77,9 @@ __global__ __launch_bounds__(kScanThreads) void layout_encode_kernel(const uint6
 }
 
 __global__ __launch_bounds__(kScanThreads) void layout_decode_kernel(const uint8_t* __restrict__ container, uint64_t container_size,
-                                                                     uint32_t n, uint64_t* __restrict__ sizes,
+                                                                     uint32_t n, uint64_t base, uint64_t* __restrict__ sizes,
                                                                      uint64_t* __restrict__ offsets, uint64_t* __restrict__ end_scratch,
                                                                      uint32_t* __restrict__ err) {
-    const uint64_t base = align16(kHeaderBytes + 4ull * n);
     if (threadIdx.x == 0) *end_scratch = base;
     __syncthreads();
     layout_common<uint32_t>(reinterpret_cast<const uint32_t*>(container + kHeaderBytes), n, base, sizes, nullptr, offsets, end_scratch);
@@ -153,17 +151,17 @@ __global__ __launch_bounds__(64) void selftest_kernel(uint32_t* __restrict__ fai
 
 }  // namespace
 
-hipError_t launch_layout_encode(const uint64_t* d_sizes, uint32_t n_chunks, density_hip_header_t hdr, uint8_t* d_container,
+hipError_t launch_layout_encode(const uint64_t* d_sizes, uint32_t n_chunks, density_hip_header_t hdr, uint64_t payload_base, uint8_t* d_container,
                                 uint64_t capacity, uint64_t* d_offsets, uint32_t* d_err, hipStream_t stream) {
     // d_offsets has n_chunks + 1 entries; the extra one is scratch for the end offset
-    hipLaunchKernelGGL(layout_encode_kernel, dim3(1), dim3(kScanThreads), 0, stream, d_sizes, n_chunks, hdr, d_container, capacity,
+    hipLaunchKernelGGL(layout_encode_kernel, dim3(1), dim3(kScanThreads), 0, stream, d_sizes, n_chunks, hdr, payload_base, d_container, capacity,
                        d_offsets, d_offsets + n_chunks, d_err);
     return hipGetLastError();
 }
 
-hipError_t launch_layout_decode(const uint8_t* d_container, uint64_t container_size, uint32_t n_chunks, uint64_t* d_sizes,
+hipError_t launch_layout_decode(const uint8_t* d_container, uint64_t container_size, uint32_t n_chunks, uint64_t payload_base, uint64_t* d_sizes,
                                 uint64_t* d_offsets, uint32_t* d_err, hipStream_t stream) {
-    hipLaunchKernelGGL(layout_decode_kernel, dim3(1), dim3(kScanThreads), 0, stream, d_container, container_size, n_chunks, d_sizes,
+    hipLaunchKernelGGL(layout_decode_kernel, dim3(1), dim3(kScanThreads), 0, stream, d_container, container_size, n_chunks, payload_base, d_sizes,
                        d_offsets, d_offsets + n_chunks, d_err);
     return hipGetLastError();
 }

@@ -11,21 +11,22 @@ namespace density {
 extern bool g_force_simple;   // density_hip_set_kernel_variant(1)
 // One wavefront per chunk.  Chunk c reads in[c*chunk_bytes ...) and writes its reference stream at
 // out + c*out_stride; sizes[c] receives the stream length.
+// d_index (nullable): one byte per 256-byte input block, numbered over the whole input (see include/density_hip.h).
 hipError_t launch_chameleon_encode(const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks,
-                                   uint8_t* d_out, uint64_t out_stride, uint64_t* d_sizes, hipStream_t stream);
+                                   uint8_t* d_out, uint64_t out_stride, uint64_t* d_sizes, uint8_t* d_index, hipStream_t stream);
 // Chunk c reads the stream at in + offsets[c] (sizes[c] bytes) and writes out + c*out_stride.  With `exact`, a chunk
 // that does not produce exactly min(out_stride, out_total - c*out_stride) bytes raises *d_err.
 hipError_t launch_chameleon_decode(const uint8_t* d_in, const uint64_t* d_offsets, const uint64_t* d_sizes,
                                    uint32_t n_chunks, uint8_t* d_out, uint64_t out_stride, uint64_t out_total,
-                                   bool exact, uint64_t* d_produced, uint32_t* d_err, hipStream_t stream);
+                                   bool exact, const uint8_t* d_index, uint64_t* d_produced, uint32_t* d_err, hipStream_t stream);
 
 // ---- container.hip ----
 // Exclusive scan of 16-byte-aligned chunk sizes -> payload offsets; writes the container header and the u32 size
 // table (encode side).
-hipError_t launch_layout_encode(const uint64_t* d_sizes, uint32_t n_chunks, density_hip_header_t hdr, uint8_t* d_container,
+hipError_t launch_layout_encode(const uint64_t* d_sizes, uint32_t n_chunks, density_hip_header_t hdr, uint64_t payload_base, uint8_t* d_container,
                                 uint64_t capacity, uint64_t* d_offsets, uint32_t* d_err, hipStream_t stream);
 // Decode side: reads the u32 size table of a container, produces u64 sizes + offsets, validates against container_size.
-hipError_t launch_layout_decode(const uint8_t* d_container, uint64_t container_size, uint32_t n_chunks,
+hipError_t launch_layout_decode(const uint8_t* d_container, uint64_t container_size, uint32_t n_chunks, uint64_t payload_base,
                                 uint64_t* d_sizes, uint64_t* d_offsets, uint32_t* d_err, hipStream_t stream);
 // Gathers chunk streams from their worst-case slots into the packed container.
 hipError_t launch_compact(const uint8_t* d_slots, uint64_t slot_stride, const uint64_t* d_sizes, const uint64_t* d_offsets,

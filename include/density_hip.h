@@ -79,9 +79,19 @@ enum {
  * encode and decode in parallel.  Layout (little-endian):
  *     [0,32)                 density_hip_header_t
  *     [32, 32+4*n_chunks)    u32 encoded size of each chunk payload
- *     payload i starts at the next 16-byte boundary after payload i-1 (payload 0 after the size table)
+ *     (16-byte aligned)      optional block index, one byte per 256-byte input block (flags & DENSITY_HIP_FLAG_BLOCK_INDEX)
+ *     payload i starts at the next 16-byte boundary after payload i-1 (payload 0 after the tables)
  * With one chunk (chunk_size >= total_len) the single payload IS the reference stream of the whole input.
+ *
+ * Block index (Chameleon): the reference stream marks neither record boundaries nor raw-copy blocks — both sides re-derive
+ * them by walking the records and running the same ProtectionState FSM (codec/codec.rs:35-37 vs :89-91), a serial
+ * pointer chase.  The index stores what that walk would find: byte b describes input block b (numbered over the whole
+ * input): bit 7 = raw-copy block; bits 0..6 = number of MAP flags of the block's signature, 0..64 (record length
+ * = 8 + 256 - 2*n), or 0x7f for the chunk's ragged last block (< 256 bytes).  It is redundant metadata —
+ * payloads stay plain reference streams — and a container without it (flags == 0, e.g. one assembled by a CPU producer)
+ * decodes through the record-walking path.
  */
+#define DENSITY_HIP_FLAG_BLOCK_INDEX 1u
 #define DENSITY_HIP_MAGIC 0x31434844u /* "DHC1" */
 #define DENSITY_HIP_DEFAULT_CHUNK (1u << 20)
 
@@ -89,7 +99,7 @@ typedef struct density_hip_header {
     uint32_t magic;          /* DENSITY_HIP_MAGIC */
     uint8_t  algo;           /* DENSITY_HIP_CHAMELEON ... */
     uint8_t  version;        /* 1 */
-    uint16_t reserved;       /* 0 */
+    uint16_t flags;          /* DENSITY_HIP_FLAG_* */
     uint32_t chunk_size;     /* bytes of input per chunk, multiple of 256 */
     uint32_t n_chunks;       /* ceil(total_len / chunk_size) */
     uint64_t total_len;      /* decoded length in bytes */
@@ -138,8 +148,8 @@ int density_hip_stream_decode_device(int algo, const void* d_input, size_t input
 void density_hip_set_profiling(int enabled);
 int density_hip_last_timings(float* milliseconds, const char** names, int capacity);
 
-/* Test hook: 0 = default kernels (pipelined 4-wave work-groups where the input alignment allows), 1 = force the simple
- * one-wavefront-per-chunk kernels.  Both produce identical bytes. */
+/* Test hook, bit mask: 1 = force the simple one-wavefront-per-chunk kernels instead of the pipelined 8-wave work-groups,
+ * 2 = encode containers without the block index.  Payload bytes are identical in every variant. */
 void density_hip_set_kernel_variant(int variant);
 
 /* Runs the LDS write-order self-test the kernels rely on (also run lazily before first use). 0 = pass. */

@@ -45,12 +45,14 @@ def test_safe_encode_buffer_size_matches_reference_formula():
 
 def test_container_bound_arithmetic():
     L = _lib.lib()
-    # one chunk: header 32 + table 4 -> payload at 48
-    assert L.density_hip_container_bound(0, 1000, 1 << 20) == 48 + L.chameleon_safe_encode_buffer_size(1000)
+    # one chunk: header 32 + table 4 -> block index at 48 (4 entries for 1000 bytes) -> payload at 64
+    assert L.density_hip_container_bound(0, 1000, 1 << 20) == 64 + L.chameleon_safe_encode_buffer_size(1000)
     assert L.density_hip_container_bound(0, 0, 0) == 32
     assert L.density_hip_container_bound(0, 10, 100) == 0      # chunk must be a multiple of 256
     assert L.density_hip_container_bound(7, 10, 256) == 0
     n, c = 5 * 65536 + 123, 65536
     b = L.density_hip_container_bound(0, n, c)
     per = (L.chameleon_safe_encode_buffer_size(c) + 15) // 16 * 16
-    assert b == (32 + 4 * 6 + 15) // 16 * 16 + 5 * per + L.chameleon_safe_encode_buffer_size(123)
+    index_at = (32 + 4 * 6 + 15) // 16 * 16
+    payload_at = (index_at + (n + 255) // 256 + 15) // 16 * 16
+    assert b == payload_at + 5 * per + L.chameleon_safe_encode_buffer_size(123)

@@ -17,12 +17,40 @@ KAT = json.load(open(os.path.join(HERE, "golden", "kat.json")))
 ALGO = "chameleon"
 
 
-@pytest.fixture(autouse=True, params=["pipelined", "simple"])
+@pytest.fixture(autouse=True, params=["pipelined", "pipelined-noindex", "simple"])
 def kernel_variant(request):
-    """Every test runs against both kernel families: the 4-wave pipelined work-groups and the one-wavefront kernels."""
-    container.set_kernel_variant(1 if request.param == "simple" else 0)
+    """Every test runs against the 8-wave pipelined work-groups (containers with and without the block index, i.e. the
+    index-fed and the record-walking decoder) and against the one-wavefront kernels."""
+    container.set_kernel_variant({"pipelined": 0, "pipelined-noindex": 2, "simple": 1}[request.param])
     yield request.param
     container.set_kernel_variant(0)
+
+
+def expected_block_index(data, chunk):
+    """What the block index must say, derived from the oracle's streams by walking their records with the reference FSM
+    (codec/codec.rs:88-123, protection_state.rs)."""
+    from oracle import pymodel
+    out = bytearray()
+    for c0 in range(0, len(data), chunk):
+        part = bytes(data[c0:c0 + chunk])
+        enc = pyoracle.encode(ALGO, part)
+        g, pos = pymodel.Guard(), 0
+        for b0 in range(0, len(part), 256):
+            blen = min(256, len(part) - b0)
+            ragged = blen < 256
+            if g.next_is_copy():
+                out.append(0x80 | (0x7F if ragged else 0))
+                pos += blen
+                g.decay()
+            else:
+                sig = int.from_bytes(enc[pos:pos + 8], "little")
+                hits = bin(sig).count("1")
+                out.append(0x7F if ragged else hits)
+                reclen = 8 + 4 * (blen // 4) - 2 * hits + blen % 4
+                g.update(reclen >= 256)
+                pos += reclen
+        assert pos == len(enc)
+    return bytes(out)
 
 
 def gpu_encode(data):
@@ -96,7 +124,7 @@ def test_stream_parity_large(kind, n):
 
 @pytest.mark.parametrize("chunk", [256, 512, 4096, 65536, 1 << 20])
 @pytest.mark.parametrize("kind", ["prose", "mixed"])
-def test_container_chunks_match_oracle(kind, chunk):
+def test_container_chunks_match_oracle(kind, chunk, kernel_variant):
     n = 3 * (1 << 20) + 12345 if chunk >= 65536 else 40 * chunk + 77
     data = datagen.by_kind(kind, n, seed=chunk)
     cont = np.zeros(container.container_bound(ALGO, n, chunk), dtype=np.uint8)
@@ -105,6 +133,11 @@ def test_container_chunks_match_oracle(kind, chunk):
     assert (hdr.total_len, hdr.chunk_size, hdr.n_chunks, hdr.container_len) == (n, chunk, -(-n // chunk), cn)
     for i, p in enumerate(payloads):
         assert p == pyoracle.encode(ALGO, data[i * chunk:(i + 1) * chunk]), (kind, chunk, i)
+    idx = container.block_index(cont[:cn])
+    if kernel_variant == "pipelined-noindex":
+        assert idx is None and hdr.flags == 0
+    elif chunk <= 65536:                                      # the python record walk is slow; small-chunk cases cover every marker
+        assert idx == expected_block_index(data, chunk)
     back = np.zeros(n, dtype=np.uint8)
     assert container.decode(cont[:cn], back) == n
     assert np.array_equal(back, data)
