@@ -22,6 +22,7 @@
 // leaves the table in the state the sequential reference would (last writer wins).  Lanes whose slot is shared
 // (w != lane somewhere in the group) take the value of the nearest earlier lane of the group instead of `old`;
 // groups are enumerated with wave-level ballots.
+#include <cstdio>
 #include <cstdlib>
 
 #include "common.hpp"
@@ -315,6 +316,15 @@ __device__ __forceinline__ uint32_t wlane(uint32_t vec, uint32_t value, uint32_t
 __device__ __forceinline__ uint32_t wlane_dyn(uint32_t vec, uint32_t value, uint32_t lane_sel, uint32_t lane) { return lane == lane_sel ? value : vec; }
 __device__ __forceinline__ uint32_t rlane(uint32_t vec, uint32_t lane_sel) { return (uint32_t)__builtin_amdgcn_readlane((int)vec, (int)lane_sel); }
 
+// optional cycle accounting (DENSITY_HIP_PROF=1): work-group 0 reports, per wave, cycles spent working and cycles spent at barriers
+struct WaveClock {
+    uint64_t* out; uint64_t work = 0, wait = 0, t0 = 0;
+    __device__ __forceinline__ void start() { if (out) t0 = __builtin_readcyclecounter(); }
+    __device__ __forceinline__ void work_done() { if (out) { const uint64_t t = __builtin_readcyclecounter(); work += t - t0; t0 = t; } }
+    __device__ __forceinline__ void wait_done() { if (out) { const uint64_t t = __builtin_readcyclecounter(); wait += t - t0; t0 = t; } }
+    __device__ __forceinline__ void flush(uint32_t wave, uint32_t lane) { if (out && lane == 0) { out[2 * wave] = work; out[2 * wave + 1] = wait; } }
+};
+
 // per-block state of the dictionary wave between issue and finish
 struct Issued {
     uint32_t q, key, sh, ret;     // key = (P & ~1) | (q >> 31): slot index in the high half, 16-bit entry in the low half
@@ -325,10 +335,11 @@ struct Issued {
 __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(const uint8_t* __restrict__ in, uint64_t total,
                                                                                 uint64_t chunk_bytes, uint8_t* __restrict__ out,
                                                                                 uint64_t out_stride, uint64_t* __restrict__ sizes,
-                                                                                uint8_t* __restrict__ index, uint32_t dbg) {
+                                                                                uint8_t* __restrict__ index, uint32_t dbg, uint64_t* __restrict__ prof) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = rfl(threadIdx.x >> 6);
     const uint64_t chunk = blockIdx.x;
+    WaveClock clk{blockIdx.x == 0 ? prof : nullptr};
     const uint8_t* src = in + chunk * chunk_bytes;
     const uint64_t len = (total - chunk * chunk_bytes) < chunk_bytes ? (total - chunk * chunk_bytes) : chunk_bytes;
     uint8_t* dst = out + chunk * out_stride;
@@ -365,6 +376,7 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
     }
 
     for (uint64_t t = 0; t <= nrounds; ++t) {
+        clk.start();
         if (wave == 0) {
             // ---------------- dictionary wave: round t ----------------
             if (t < nrounds) {
@@ -550,8 +562,11 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
                 }
             }
         }
+        clk.work_done();
         round_barrier();
+        clk.wait_done();
     }
+    clk.flush(wave, lane);
 
     // ragged last block (and the size word): dictionary wave, scalar-path code
     if (wave == 0) {
@@ -751,10 +766,11 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_decode_chunks_pipe(
                                                                                 uint64_t out_total, uint32_t exact,
                                                                                 const uint8_t* __restrict__ index,
                                                                                 uint64_t* __restrict__ produced,
-                                                                                uint32_t* __restrict__ err, uint32_t dbg) {
+                                                                                uint32_t* __restrict__ err, uint32_t dbg, uint64_t* __restrict__ prof) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = rfl(threadIdx.x >> 6);
     const uint64_t chunk = blockIdx.x;
+    WaveClock clk{blockIdx.x == 0 ? prof : nullptr};
     const uint8_t* src = in + offsets[chunk];
     const uint8_t* idx = index ? index + chunk * (out_stride / kBlock) : nullptr;   // this chunk's slice of the block index
     const uint64_t elen64 = sizes[chunk];
@@ -1054,15 +1070,19 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_decode_chunks_pipe(
 
     // ---- steady state: step s = parse s+2 | fetch s+1 | dictionary s | emit s-1 ----
     for (uint32_t s = 0;; ++s) {
+        clk.start();
         if (wave == 1) parse_round(s + 2);
         else if (wave == 0) { if (!(dbg & 64u)) dict_round(s); else { const uint32_t fl = rfl(*reinterpret_cast<const uint32_t*>(smem + kDDescBase + (s % kDescRing) * kDescBytes + 104)); if (fl & kFlagLast) last_round = s; } }
         else {
             if (!(dbg & 32u)) fetch_round(s + 1);
             if (s >= 1) { if (!(dbg & 16u)) emit_round(s - 1); else { const uint32_t fl = rfl(*reinterpret_cast<const uint32_t*>(smem + kDDescBase + ((s - 1) % kDescRing) * kDescBytes + 104)); if (fl & kFlagLast) last_round = s - 1; } }
         }
+        clk.work_done();
         round_barrier();
+        clk.wait_done();
         if (last_round != 0xffffffffu && s >= last_round + 1) break;
     }
+    clk.flush(wave, lane);
 
     // hand the parser's final state to wave 0, which finishes the ragged end of the stream in order
     if (wave == 1 && lane == 0) {
@@ -1089,6 +1109,25 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_decode_chunks_pipe(
 // host launchers
 // ---------------------------------------------------------------------------------------------------------------
 bool g_force_simple = false;   // test hook (density_hip_set_kernel_variant): run the one-wave kernels
+
+namespace {
+// DENSITY_HIP_PROF=1: per-wave cycle accounting of work-group 0, printed to stderr after every pipelined launch (synchronises)
+uint64_t* prof_buffer() {
+    static uint64_t* buf = nullptr;
+    if (!getenv("DENSITY_HIP_PROF")) return nullptr;
+    if (!buf && hipMalloc((void**)&buf, 16 * sizeof(uint64_t)) != hipSuccess) buf = nullptr;
+    if (buf) (void)hipMemset(buf, 0, 16 * sizeof(uint64_t));
+    return buf;
+}
+void prof_report(const char* what, uint64_t* buf, hipStream_t stream) {
+    if (!buf) return;
+    uint64_t h[16];
+    if (hipStreamSynchronize(stream) != hipSuccess || hipMemcpy(h, buf, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return;
+    fprintf(stderr, "[density_hip prof] %s work-group 0: ", what);
+    for (int w = 0; w < 8; ++w) fprintf(stderr, "w%d work %llu wait %llu | ", w, (unsigned long long)h[2 * w], (unsigned long long)h[2 * w + 1]);
+    fprintf(stderr, "\n");
+}
+}  // namespace
 hipError_t launch_chameleon_encode(const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks,
                                    uint8_t* d_out, uint64_t out_stride, uint64_t* d_sizes, uint8_t* d_index, hipStream_t stream) {
     hipError_t e = hipFuncSetAttribute((const void*)chameleon_encode_chunks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
@@ -1100,7 +1139,9 @@ hipError_t launch_chameleon_encode(const uint8_t* d_in, uint64_t total, uint64_t
         e = hipFuncSetAttribute((const void*)chameleon_encode_chunks_pipe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytesPipe);
         if (e != hipSuccess) return e;
         const uint32_t dbg = getenv("DENSITY_HIP_DBG") ? (uint32_t)atoi(getenv("DENSITY_HIP_DBG")) : 0u;
-        hipLaunchKernelGGL(chameleon_encode_chunks_pipe, dim3(n_chunks), dim3(kPipeWaves * 64), kLdsBytesPipe, stream, d_in, total, chunk_bytes, d_out, out_stride, d_sizes, d_index, dbg);
+        uint64_t* prof = prof_buffer();
+        hipLaunchKernelGGL(chameleon_encode_chunks_pipe, dim3(n_chunks), dim3(kPipeWaves * 64), kLdsBytesPipe, stream, d_in, total, chunk_bytes, d_out, out_stride, d_sizes, d_index, dbg, prof);
+        prof_report("encode", prof, stream);
     } else {
         hipLaunchKernelGGL(chameleon_encode_chunks, dim3(n_chunks), dim3(64), kLdsBytes, stream, d_in, total, chunk_bytes, d_out, out_stride, d_sizes, d_index);
     }
@@ -1120,7 +1161,9 @@ hipError_t launch_chameleon_decode(const uint8_t* d_in, const uint64_t* d_offset
         e = hipFuncSetAttribute((const void*)chameleon_decode_chunks_pipe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytesDec);
         if (e != hipSuccess) return e;
         const uint32_t dbg = getenv("DENSITY_HIP_DBG") ? (uint32_t)atoi(getenv("DENSITY_HIP_DBG")) : 0u;
-        hipLaunchKernelGGL(chameleon_decode_chunks_pipe, dim3(n_chunks), dim3(kPipeWaves * 64), kLdsBytesDec, stream, d_in, d_offsets, d_sizes, d_out, out_stride, out_total, exact ? 1u : 0u, d_index, d_produced, d_err, dbg);
+        uint64_t* prof = prof_buffer();
+        hipLaunchKernelGGL(chameleon_decode_chunks_pipe, dim3(n_chunks), dim3(kPipeWaves * 64), kLdsBytesDec, stream, d_in, d_offsets, d_sizes, d_out, out_stride, out_total, exact ? 1u : 0u, d_index, d_produced, d_err, dbg, prof);
+        prof_report("decode", prof, stream);
     } else {
         hipLaunchKernelGGL(chameleon_decode_chunks, dim3(n_chunks), dim3(64), kLdsBytes, stream, d_in, d_offsets, d_sizes, d_out, out_stride, out_total, exact ? 1u : 0u, d_produced, d_err);
     }
