@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=1 << 20)
     ap.add_argument("--cpu-sample", type=int, default=256 << 20)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--concat", action="store_true", help="also time the optional gather-to-rank-0 stitch (N > 1)")
     ap.add_argument("--variant", type=int, default=0, help="0 = default kernels, 1 = simple one-wavefront kernels")
     args = ap.parse_args()
 
@@ -162,6 +163,23 @@ def main():
         dt = float(t.item())
     assert os.environ.get("DENSITY_HIP_DBG", "0") != "0" or torch.equal(back, x), "round trip mismatch after timed steps"
 
+    # the path's only collective: all-gather of per-shard (chunks, payload bytes) -> offsets in the global container
+    from density_amd import parallel
+    hdr_l, table_l, index_l, payload_l = parallel.parse_local(cont[:E])
+    if world > 1:
+        torch.cuda.synchronize(); tg0 = time.perf_counter()
+        lay = parallel.exchange_layout(hdr_l["n_chunks"], payload_l.numel(), n, x.device)
+        torch.cuda.synchronize(); gather_ms = (time.perf_counter() - tg0) * 1e3
+        glob = parallel.global_layout(lay, chunk, hdr_l["flags"])
+    else:
+        gather_ms, glob = 0.0, {"container_len": E, "n_chunks": int(hdr.n_chunks), "total_len": n}
+    concat_ms = None
+    if world > 1 and args.concat:
+        torch.cuda.synchronize(); dist.barrier(); tc0 = time.perf_counter()
+        merged = parallel.concat_to_rank0(cont[:E], chunk)
+        torch.cuda.synchronize(); dist.barrier(); concat_ms = (time.perf_counter() - tc0) * 1e3
+        del merged
+
     if rank == 0:
         per = {}
         for name, ms in timings:
@@ -172,6 +190,18 @@ def main():
         alg = {"chameleon_encode_chunks": n + E, "chameleon_decode_chunks": n + E}
         dom = max(alg, key=lambda k: avg.get(k, 0.0))
         ach = alg[dom] / (avg[dom] * 1e-3) / 1e9 if avg.get(dom) else 0.0
+        # HBM traffic of that kernel from the committed PMC passes (rocprofv3 cannot run inside this process); only quoted
+        # when the profile was taken on this exact workload
+        traffic, traffic_src = None, None
+        try:
+            import glob as _glob
+            cand = sorted(_glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+            if cand and n == 1 << 30 and chunk == 1 << 20 and args.variant == 0:
+                pm = json.load(open(cand[-1]))
+                traffic = pm["kernels"][dom + "_pipe"]["hbm_bytes_corrected"]
+                traffic_src = os.path.relpath(cand[-1], ROOT)
+        except Exception:
+            pass
         ms_step = dt / args.steps * 1e3
         t_enc = sum(avg.get(k, 0.0) for k in ("chameleon_encode_chunks", "layout_encode", "compact"))
         t_dec = sum(avg.get(k, 0.0) for k in ("layout_decode", "chameleon_decode_chunks"))
@@ -193,8 +223,10 @@ def main():
             "kernel_ms": {k: round(v, 4) for k, v in avg.items()},
             "whole_path_hbm_frac": round((2.0 * (n + E)) / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
-                         "algorithmic_bytes_per_launch": alg[dom]},
+                         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": alg[dom], "kernel_avg_ms": round(avg[dom], 4)},
+            "multi_gpu": {"size_gather_ms": round(gather_ms, 3), "concat_to_rank0_ms": (round(concat_ms, 3) if concat_ms is not None else None),
+                          "global_container_bytes": int(glob["container_len"])},
         }
         if not args.no_cpu:
             result["cpu_baseline"] = cpu_baseline(host, chunk, args.cpu_sample)
