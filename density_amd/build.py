@@ -6,7 +6,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdensity_hip.so")
-SOURCES = ["api.hip", "chameleon.hip", "container.hip"]
+SOURCES = ["api.hip", "chameleon.hip", "container.hip", "serial_codec.hip"]
 HEADERS = ["common.hpp", "kernels.hpp", os.path.join("..", "..", "include", "density_hip.h")]
 
 

@@ -126,8 +126,12 @@ struct Profiler {
     }
 };
 
+constexpr size_t kSerialSlots = 4096;    // concurrent chunk streams of the functional Cheetah/Lion kernels (one lane each)
+inline size_t serial_slots(int algo, size_t n_chunks) { return algo == DENSITY_HIP_CHAMELEON ? 0 : (n_chunks < kSerialSlots ? n_chunks : kSerialSlots); }
+inline size_t serial_tables(int algo, size_t n_chunks) { return algo == DENSITY_HIP_CHAMELEON ? 0 : align_up(serial_slots(algo, n_chunks) * serial_table_bytes(algo), kAlign); }
+
 struct EncodePlan {
-    size_t chunk, n_chunks, stride, off_err, off_sizes, off_offsets, off_slots, total;
+    size_t chunk, n_chunks, stride, off_err, off_sizes, off_offsets, off_slots, off_tables, total;
 };
 EncodePlan plan_encode(int algo, size_t n, size_t chunk) {
     EncodePlan p{};
@@ -138,21 +142,38 @@ EncodePlan plan_encode(int algo, size_t n, size_t chunk) {
     p.off_sizes = kAlign;
     p.off_offsets = p.off_sizes + align_up(8 * p.n_chunks, kAlign);
     p.off_slots = p.off_offsets + align_up(8 * (p.n_chunks + 1), kAlign);
-    p.total = p.off_slots + (p.n_chunks > 1 ? p.n_chunks * p.stride : 0);   // one chunk encodes straight into the container
+    p.off_tables = p.off_slots + (p.n_chunks > 1 ? p.n_chunks * p.stride : 0);   // one chunk encodes straight into the container
+    p.total = p.off_tables + serial_tables(algo, p.n_chunks ? p.n_chunks : 1);
     return p;
 }
 struct DecodePlan {
-    size_t off_err, off_sizes, off_offsets, off_produced, total;
+    size_t off_err, off_sizes, off_offsets, off_produced, off_tables, total;
 };
-DecodePlan plan_decode(size_t n_chunks) {
+DecodePlan plan_decode(int algo, size_t n_chunks) {
     DecodePlan p{};
     p.off_err = 0;
     p.off_sizes = kAlign;
     p.off_offsets = p.off_sizes + align_up(8 * n_chunks, kAlign);
     p.off_produced = p.off_offsets + align_up(8 * (n_chunks + 1), kAlign);
-    p.total = p.off_produced + align_up(8 * (n_chunks ? n_chunks : 1), kAlign);
+    p.off_tables = p.off_produced + align_up(8 * (n_chunks ? n_chunks : 1), kAlign);
+    p.total = p.off_tables + serial_tables(algo, n_chunks ? n_chunks : 1);
     return p;
 }
+
+// algorithm dispatch: Chameleon has the LDS-resident pipelined kernels, Cheetah/Lion the functional one-lane-per-stream kernels
+hipError_t codec_encode(int algo, const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_out,
+                        uint64_t out_stride, uint64_t* d_sizes, uint8_t* d_index, uint8_t* d_tables, hipStream_t s) {
+    if (algo == DENSITY_HIP_CHAMELEON) return launch_chameleon_encode(d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_index, s);
+    return launch_serial_encode(algo, d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, (uint32_t)serial_slots(algo, n_chunks), s);
+}
+hipError_t codec_decode(int algo, const uint8_t* d_in, const uint64_t* d_offsets, const uint64_t* d_sizes, uint32_t n_chunks, uint8_t* d_out,
+                        uint64_t out_stride, uint64_t out_total, bool exact, const uint8_t* d_index, uint64_t* d_produced, uint32_t* d_err,
+                        uint8_t* d_tables, hipStream_t s) {
+    if (algo == DENSITY_HIP_CHAMELEON) return launch_chameleon_decode(d_in, d_offsets, d_sizes, n_chunks, d_out, out_stride, out_total, exact, d_index, d_produced, d_err, s);
+    return launch_serial_decode(algo, d_in, d_offsets, d_sizes, n_chunks, d_out, out_stride, out_total, exact, d_produced, d_err, d_tables, (uint32_t)serial_slots(algo, n_chunks), s);
+}
+const char* encode_kernel_name(int algo) { return algo == DENSITY_HIP_CHAMELEON ? "chameleon_encode_chunks" : algo == DENSITY_HIP_CHEETAH ? "cheetah_encode_chunks" : "lion_encode_chunks"; }
+const char* decode_kernel_name(int algo) { return algo == DENSITY_HIP_CHAMELEON ? "chameleon_decode_chunks" : algo == DENSITY_HIP_CHEETAH ? "cheetah_decode_chunks" : "lion_decode_chunks"; }
 
 size_t container_bound(int algo, size_t n, size_t chunk) {
     const size_t nc = chunk_count(n, chunk);
@@ -174,7 +195,6 @@ int check_header(const density_hip_header_t& h, size_t container_size) {
 
 int run_encode_container(DeviceCtx* c, int algo, const uint8_t* d_in, size_t n, uint8_t* d_out, size_t cap, size_t chunk,
                          uint8_t* ws, hipStream_t s, density_hip_header_t* header_out) {
-    if (algo != DENSITY_HIP_CHAMELEON) { set_error("this build runs Chameleon on the device; Cheetah/Lion kernels are not built in"); return DENSITY_HIP_ERR_UNSUPPORTED; }
     const EncodePlan p = plan_encode(algo, n, chunk);
     if (p.n_chunks > 0xffffffffull) { set_error("too many chunks"); return DENSITY_HIP_ERR_ARGUMENT; }
     if (cap < container_bound(algo, n, chunk)) { set_error("output capacity below density_hip_container_bound()"); return DENSITY_HIP_ERR_CAPACITY; }
@@ -194,13 +214,13 @@ int run_encode_container(DeviceCtx* c, int algo, const uint8_t* d_in, size_t n, 
     if (e != hipSuccess) { set_error("hipMemsetAsync", e); return DENSITY_HIP_ERR_RUNTIME; }
     if (p.n_chunks == 1) {
         // single chunk: its stream goes straight to its final place, no stitch pass
-        e = launch_chameleon_encode(d_in, n, chunk, 1, d_out + pbase, 0, d_sizes, d_index, s);
-        prof.mark("chameleon_encode_chunks");
+        e = codec_encode(algo, d_in, n, chunk, 1, d_out + pbase, 0, d_sizes, d_index, ws + p.off_tables, s);
+        prof.mark(encode_kernel_name(algo));
         if (e == hipSuccess) e = launch_layout_encode(d_sizes, 1, hdr, pbase, d_out, cap, d_offsets, d_err, s);
         prof.mark("layout_encode");
     } else {
-        e = launch_chameleon_encode(d_in, n, chunk, (uint32_t)p.n_chunks, d_slots, p.stride, d_sizes, d_index, s);
-        prof.mark("chameleon_encode_chunks");
+        e = codec_encode(algo, d_in, n, chunk, (uint32_t)p.n_chunks, d_slots, p.stride, d_sizes, d_index, ws + p.off_tables, s);
+        prof.mark(encode_kernel_name(algo));
         if (e == hipSuccess) e = launch_layout_encode(d_sizes, (uint32_t)p.n_chunks, hdr, pbase, d_out, cap, d_offsets, d_err, s);
         prof.mark("layout_encode");
         if (e == hipSuccess) e = launch_compact(d_slots, p.stride, d_sizes, d_offsets, (uint32_t)p.n_chunks, d_out, d_err, s);
@@ -220,9 +240,8 @@ int run_encode_container(DeviceCtx* c, int algo, const uint8_t* d_in, size_t n, 
 
 int run_decode_container(DeviceCtx* c, const uint8_t* d_in, size_t container_size, const density_hip_header_t& h, uint8_t* d_out,
                          size_t cap, uint8_t* ws, hipStream_t s, size_t* decoded_out) {
-    if (h.algo != DENSITY_HIP_CHAMELEON) { set_error("this build runs Chameleon on the device; Cheetah/Lion kernels are not built in"); return DENSITY_HIP_ERR_UNSUPPORTED; }
     if (cap < h.total_len) { set_error("output capacity below the container's total_len"); return DENSITY_HIP_ERR_CAPACITY; }
-    const DecodePlan p = plan_decode(h.n_chunks);
+    const DecodePlan p = plan_decode(h.algo, h.n_chunks);
     uint32_t* d_err = reinterpret_cast<uint32_t*>(ws + p.off_err);
     uint64_t* d_sizes = reinterpret_cast<uint64_t*>(ws + p.off_sizes);
     uint64_t* d_offsets = reinterpret_cast<uint64_t*>(ws + p.off_offsets);
@@ -233,8 +252,8 @@ int run_decode_container(DeviceCtx* c, const uint8_t* d_in, size_t container_siz
     const uint8_t* d_index = with_index ? d_in + index_base(h.n_chunks) : nullptr;
     if (e == hipSuccess) e = launch_layout_decode(d_in, container_size, h.n_chunks, payload_base(h.n_chunks, h.total_len, with_index), d_sizes, d_offsets, d_err, s);
     prof.mark("layout_decode");
-    if (e == hipSuccess) e = launch_chameleon_decode(d_in, d_offsets, d_sizes, h.n_chunks, d_out, h.chunk_size, h.total_len, true, d_index, d_produced, d_err, s);
-    prof.mark("chameleon_decode_chunks");
+    if (e == hipSuccess) e = codec_decode(h.algo, d_in, d_offsets, d_sizes, h.n_chunks, d_out, h.chunk_size, h.total_len, true, d_index, d_produced, d_err, ws + p.off_tables, s);
+    prof.mark(decode_kernel_name(h.algo));
     if (e != hipSuccess) { set_error("kernel launch (decode)", e); return DENSITY_HIP_ERR_RUNTIME; }
     if (decoded_out) {
         uint32_t h_err = 0;
@@ -249,14 +268,13 @@ int run_decode_container(DeviceCtx* c, const uint8_t* d_in, size_t container_siz
 
 int run_stream_encode(DeviceCtx* c, int algo, const uint8_t* d_in, size_t n, uint8_t* d_out, size_t cap, uint8_t* ws, hipStream_t s,
                       size_t* size_out) {
-    if (algo != DENSITY_HIP_CHAMELEON) { set_error("this build runs Chameleon on the device; Cheetah/Lion kernels are not built in"); return DENSITY_HIP_ERR_UNSUPPORTED; }
     if (cap < safe_size(algo, n)) { set_error("output capacity below safe_encode_buffer_size()"); return DENSITY_HIP_ERR_CAPACITY; }
     uint64_t* d_sizes = reinterpret_cast<uint64_t*>(ws + kAlign);
     *size_out = 0;
     if (n == 0) return DENSITY_HIP_OK;
     Profiler prof(c, s);
-    hipError_t e = launch_chameleon_encode(d_in, n, n, 1, d_out, 0, d_sizes, nullptr, s);
-    prof.mark("chameleon_encode_chunks");
+    hipError_t e = codec_encode(algo, d_in, n, n, 1, d_out, 0, d_sizes, nullptr, ws + plan_decode(algo, 1).off_tables, s);
+    prof.mark(encode_kernel_name(algo));
     uint64_t h_size = 0;
     if (e == hipSuccess) e = hipMemcpyAsync(&h_size, d_sizes, sizeof(h_size), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
@@ -267,10 +285,9 @@ int run_stream_encode(DeviceCtx* c, int algo, const uint8_t* d_in, size_t n, uin
 
 int run_stream_decode(DeviceCtx* c, int algo, const uint8_t* d_in, size_t n, uint8_t* d_out, size_t cap, uint8_t* ws, hipStream_t s,
                       size_t* size_out) {
-    if (algo != DENSITY_HIP_CHAMELEON) { set_error("this build runs Chameleon on the device; Cheetah/Lion kernels are not built in"); return DENSITY_HIP_ERR_UNSUPPORTED; }
     *size_out = 0;
     if (n == 0) return DENSITY_HIP_OK;
-    const DecodePlan p = plan_decode(1);
+    const DecodePlan p = plan_decode(algo, 1);
     uint32_t* d_err = reinterpret_cast<uint32_t*>(ws + p.off_err);
     uint64_t* d_sizes = reinterpret_cast<uint64_t*>(ws + p.off_sizes);
     uint64_t* d_offsets = reinterpret_cast<uint64_t*>(ws + p.off_offsets);
@@ -281,8 +298,8 @@ int run_stream_decode(DeviceCtx* c, int algo, const uint8_t* d_in, size_t n, uin
     if (e == hipSuccess) e = hipMemcpyAsync(d_sizes, &h_size, 8, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemcpyAsync(d_offsets, &h_off, 8, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);   // h_size/h_off live on this stack frame
-    if (e == hipSuccess) e = launch_chameleon_decode(d_in, d_offsets, d_sizes, 1, d_out, cap, cap, false, nullptr, d_produced, d_err, s);
-    prof.mark("chameleon_decode_chunks");
+    if (e == hipSuccess) e = codec_decode(algo, d_in, d_offsets, d_sizes, 1, d_out, cap, cap, false, nullptr, d_produced, d_err, ws + p.off_tables, s);
+    prof.mark(decode_kernel_name(algo));
     uint64_t h_prod = 0;
     uint32_t h_err = 0;
     if (e == hipSuccess) e = hipMemcpyAsync(&h_prod, d_produced, 8, hipMemcpyDeviceToHost, s);
@@ -306,7 +323,7 @@ size_t host_stream_codec(int algo, bool encode, const uint8_t* in, size_t n, uin
     const size_t dev_cap = encode ? safe_size(algo, n) : cap;
     hipError_t e = c->stage_in.ensure(n);
     if (e == hipSuccess) e = c->stage_out.ensure(dev_cap ? dev_cap : 1);
-    if (e == hipSuccess) e = c->work.ensure(plan_decode(1).total + kAlign);
+    if (e == hipSuccess) e = c->work.ensure(plan_decode(algo, 1).total + kAlign);
     if (e == hipSuccess) e = hipMemcpyAsync(c->stage_in.p, in, n, hipMemcpyHostToDevice, c->stream);
     if (e != hipSuccess) { set_error("staging (H2D)", e); return 0; }
     size_t produced = 0;
@@ -349,7 +366,7 @@ size_t density_hip_encode_workspace_size(int algo, size_t input_size, size_t chu
     return plan_encode(algo, input_size, chunk_size).total;
 }
 
-size_t density_hip_decode_workspace_size(uint32_t n_chunks) { return plan_decode(n_chunks).total; }
+size_t density_hip_decode_workspace_size(uint32_t n_chunks) { return plan_decode(DENSITY_HIP_LION, n_chunks).total; }   // the largest of the three
 
 int density_hip_encode_device(int algo, const void* d_input, size_t input_size, void* d_output, size_t output_capacity,
                               size_t chunk_size, void* d_workspace, size_t workspace_size, void* stream,
@@ -382,7 +399,7 @@ int density_hip_decode_device(const void* d_container, size_t container_size, co
         if (e != hipSuccess) { set_error("header read-back", e); return DENSITY_HIP_ERR_RUNTIME; }
     }
     if (check_header(h, container_size) != DENSITY_HIP_OK) { set_error("bad container header"); return DENSITY_HIP_ERR_FORMAT; }
-    const size_t need = plan_decode(h.n_chunks).total;
+    const size_t need = plan_decode(h.algo, h.n_chunks).total;
     uint8_t* ws = (uint8_t*)d_workspace;
     if (ws) { if (workspace_size < need) { set_error("workspace too small"); return DENSITY_HIP_ERR_CAPACITY; } }
     else { hipError_t e = c->work.ensure(need); if (e != hipSuccess) { set_error("workspace allocation", e); return DENSITY_HIP_ERR_RUNTIME; } ws = (uint8_t*)c->work.p; }
@@ -397,7 +414,7 @@ int density_hip_stream_encode_device(int algo, const void* d_input, size_t input
     DeviceCtx* c = acquire_ctx();
     if (!c) return DENSITY_HIP_ERR_RUNTIME;
     std::lock_guard<std::mutex> lk(c->mu);
-    hipError_t e = c->work.ensure(plan_decode(1).total + kAlign);
+    hipError_t e = c->work.ensure(plan_decode(algo, 1).total + kAlign);
     if (e != hipSuccess) { set_error("workspace allocation", e); return DENSITY_HIP_ERR_RUNTIME; }
     return run_stream_encode(c, algo, (const uint8_t*)d_input, input_size, (uint8_t*)d_output, output_capacity, (uint8_t*)c->work.p,
                              stream ? (hipStream_t)stream : c->stream, size_out);
@@ -410,7 +427,7 @@ int density_hip_stream_decode_device(int algo, const void* d_input, size_t input
     DeviceCtx* c = acquire_ctx();
     if (!c) return DENSITY_HIP_ERR_RUNTIME;
     std::lock_guard<std::mutex> lk(c->mu);
-    hipError_t e = c->work.ensure(plan_decode(1).total + kAlign);
+    hipError_t e = c->work.ensure(plan_decode(algo, 1).total + kAlign);
     if (e != hipSuccess) { set_error("workspace allocation", e); return DENSITY_HIP_ERR_RUNTIME; }
     return run_stream_decode(c, algo, (const uint8_t*)d_input, input_size, (uint8_t*)d_output, output_capacity, (uint8_t*)c->work.p,
                              stream ? (hipStream_t)stream : c->stream, size_out);
@@ -457,7 +474,7 @@ size_t density_hip_decode(const uint8_t* container, size_t container_size, uint8
     std::lock_guard<std::mutex> lk(c->mu);
     hipError_t e = c->stage_in.ensure(h.container_len);
     if (e == hipSuccess) e = c->stage_out.ensure(h.total_len);
-    if (e == hipSuccess) e = c->work.ensure(plan_decode(h.n_chunks).total);
+    if (e == hipSuccess) e = c->work.ensure(plan_decode(h.algo, h.n_chunks).total);
     if (e == hipSuccess) e = hipMemcpyAsync(c->stage_in.p, container, h.container_len, hipMemcpyHostToDevice, c->stream);
     if (e != hipSuccess) { set_error("staging (H2D)", e); return 0; }
     size_t produced = 0;

@@ -20,6 +20,14 @@ hipError_t launch_chameleon_decode(const uint8_t* d_in, const uint64_t* d_offset
                                    uint32_t n_chunks, uint8_t* d_out, uint64_t out_stride, uint64_t out_total,
                                    bool exact, const uint8_t* d_index, uint64_t* d_produced, uint32_t* d_err, hipStream_t stream);
 
+// ---- serial_codec.hip (Cheetah, Lion: functional one-lane-per-stream kernels, tables in global memory) ----
+uint64_t serial_table_bytes(int algo);
+hipError_t launch_serial_encode(int algo, const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_out,
+                                uint64_t out_stride, uint64_t* d_sizes, uint8_t* d_tables, uint32_t n_slots, hipStream_t stream);
+hipError_t launch_serial_decode(int algo, const uint8_t* d_in, const uint64_t* d_offsets, const uint64_t* d_sizes, uint32_t n_chunks,
+                                uint8_t* d_out, uint64_t out_stride, uint64_t out_total, bool exact, uint64_t* d_produced, uint32_t* d_err,
+                                uint8_t* d_tables, uint32_t n_slots, hipStream_t stream);
+
 // ---- container.hip ----
 // Exclusive scan of 16-byte-aligned chunk sizes -> payload offsets; writes the container header and the u32 size
 // table (encode side).

@@ -69,7 +69,7 @@ enum {
     DENSITY_HIP_ERR_CAPACITY = 2,     /* output or workspace too small */
     DENSITY_HIP_ERR_FORMAT = 3,       /* container header or payload malformed / truncated */
     DENSITY_HIP_ERR_RUNTIME = 4,      /* HIP runtime error, no gfx950 device, failed self-test */
-    DENSITY_HIP_ERR_UNSUPPORTED = 5   /* algorithm not available on the device path in this build */
+    DENSITY_HIP_ERR_UNSUPPORTED = 5   /* reserved: algorithm not available on the device path */
 };
 
 /*

@@ -1,0 +1,118 @@
+"""GPU parity tests for Cheetah and Lion (functional one-lane-per-stream kernels, density_amd/csrc/serial_codec.hip) through
+the same C ABI: bit-exact against the CPU oracle."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import datagen
+from density_amd import BY_NAME, DecodeError, EncodeError, container
+from oracle import pyoracle
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+KAT = json.load(open(os.path.join(HERE, "golden", "kat.json")))
+ALGOS = ["cheetah", "lion"]
+
+
+def gpu_encode(algo, data):
+    C = BY_NAME[algo]
+    data = np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+    out = np.zeros(max(C.safe_encode_buffer_size(data.size), 1), dtype=np.uint8)
+    n = C.encode(data, out)
+    return out[:n].tobytes()
+
+
+def gpu_decode(algo, enc, n):
+    out = np.zeros(max(n, 1), dtype=np.uint8)
+    m = BY_NAME[algo].decode(np.frombuffer(bytes(enc), dtype=np.uint8), out)
+    return out[:m].tobytes()
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_reference_golden_vector_on_gpu(algo):
+    """src/lib.rs:44-64 (cheetah), :66-86 (lion): exact bytes into a len(input)-byte buffer, then decode == input."""
+    data = bytes.fromhex(KAT["reference_input_hex"])
+    out = bytearray(len(data))
+    n = BY_NAME[algo].encode(data, out)
+    assert bytes(out[:n]) == bytes.fromhex(KAT["reference"][algo])
+    back = bytearray(len(data))
+    m = BY_NAME[algo].decode(bytes(out[:n]), back)
+    assert bytes(back[:m]) == data
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_committed_kat_fixtures_on_gpu(algo):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_kat", os.path.join(HERE, "golden", "make_kat.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for name, data in mod.derived_inputs().items():
+        if not data:
+            continue
+        row = KAT["derived"][name][algo]
+        enc = gpu_encode(algo, data)
+        assert (len(enc), hashlib.sha256(enc).hexdigest()) == (row["len"], row["sha256"]), name
+        assert gpu_decode(algo, enc, len(data)) == data, name
+
+
+EDGE = sorted(set(list(range(1, 20)) + [63, 64, 65, 69, 70, 71, 127, 128, 129, 135, 136, 137, 255, 256, 257, 263, 264, 265, 1023, 1024, 1025, 4093, 4096, 4099]))
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("kind", ["prose", "random", "zeros", "mixed", "samehash"])
+def test_stream_parity_edge_sizes(algo, kind):
+    big = datagen.by_kind(kind, 5000, seed=31)
+    for n in EDGE:
+        data = big[:n].copy()
+        want = pyoracle.encode(algo, data)
+        assert gpu_encode(algo, data) == want, (kind, n)
+        assert gpu_decode(algo, want, n) == data.tobytes(), (kind, n)
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("kind,n", [("prose", 200_003), ("mixed", 300_000), ("random", 50_001), ("rep", 250_000), ("binaryish", 120_001)])
+def test_stream_parity_large(algo, kind, n):
+    """Whole-stream parity: multi-block dictionary/predictor carry, MAP_B, PREDICTED (B..E for Lion), copy mode in and out."""
+    data = datagen.by_kind(kind, n, seed=78)
+    want, st = pyoracle.encode_stats(algo, data)
+    assert gpu_encode(algo, data) == want
+    if kind in ("mixed", "random"):
+        assert st["copy_blocks"] > 0
+    assert gpu_decode(algo, want, n) == data.tobytes()
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("chunk", [256, 4096, 65536])
+def test_container_chunks_match_oracle(algo, chunk):
+    n = 24 * chunk + 77 if chunk <= 4096 else 6 * chunk + 1234
+    data = datagen.by_kind("mixed", n, seed=chunk + 1)
+    cont = np.zeros(container.container_bound(algo, n, chunk), dtype=np.uint8)
+    cn = container.encode(algo, data, cont, chunk)
+    hdr, payloads = container.chunk_payloads(cont[:cn])
+    assert (hdr.algo, hdr.total_len, hdr.chunk_size, hdr.n_chunks, hdr.flags) == ({"cheetah": 1, "lion": 2}[algo], n, chunk, -(-n // chunk), 0)
+    for i, p in enumerate(payloads):
+        assert p == pyoracle.encode(algo, data[i * chunk:(i + 1) * chunk]), (chunk, i)
+    back = np.zeros(n, dtype=np.uint8)
+    assert container.decode(cont[:cn], back) == n
+    assert np.array_equal(back, data)
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_errors_are_reported(algo):
+    data = datagen.prose(3000, 41)
+    enc = pyoracle.encode(algo, data)
+    C = BY_NAME[algo]
+    with pytest.raises(DecodeError):
+        C.decode(enc, np.zeros(100, dtype=np.uint8))
+    with pytest.raises(EncodeError):
+        C.encode(datagen.random_bytes(3000, 1), np.zeros(100, dtype=np.uint8))
+    out = np.zeros(3000, dtype=np.uint8)
+    for cut in (1, 2, 5, 9, 100):
+        try:
+            m = C.decode(enc[:-cut], out)
+            assert out[:m].tobytes() != data.tobytes()
+        except DecodeError:
+            pass
