@@ -257,9 +257,9 @@ constexpr uint32_t kInRing = 6, kResRing = 2;              // input ring: kAhead
 constexpr uint32_t kAhead = kInRing - 2;                     // DMA runs this many rounds ahead of the dictionary wave
 constexpr uint32_t kInBase = kLdsBytes;                      // 139264, 16-byte aligned
 constexpr uint32_t kResBase = kInBase + kInRing * kRoundBytes;
-constexpr uint32_t kResBytes = 128;                          // dwords 0..15 signatures, 16..17 round offset, 18 copy mask
+constexpr uint32_t kResBytes = 128;                          // dwords 0..15 signatures, 16 copy mask
 constexpr uint32_t kLdsBytesPipe = kResBase + kResRing * kResBytes;
-constexpr uint32_t kPipeWaves = 8, kEmitWaves = kPipeWaves - 1;
+constexpr uint32_t kPipeWaves = 8, kEmitWaves = kPipeWaves - 2;     // wave 0 dictionary, waves 1..6 emit, wave 7 loader
 static_assert(kLdsBytesPipe <= 160u * 1024u, "LDS budget");
 static_assert(kRound == 8, "register arrays, asm operand lists and the result record are written for 8 blocks per round");
 
@@ -317,12 +317,31 @@ __device__ __forceinline__ uint32_t wlane_dyn(uint32_t vec, uint32_t value, uint
 __device__ __forceinline__ uint32_t rlane(uint32_t vec, uint32_t lane_sel) { return (uint32_t)__builtin_amdgcn_readlane((int)vec, (int)lane_sel); }
 
 // optional cycle accounting (DENSITY_HIP_PROF=1): work-group 0 reports, per wave, cycles spent working and cycles spent at barriers
-struct WaveClock {
+template <bool ON>
+struct WaveClock;
+template <>
+struct WaveClock<false> {                                     // production: compiles to nothing
+    __device__ __forceinline__ explicit WaveClock(uint64_t*) {}
+    __device__ __forceinline__ void start() {}
+    __device__ __forceinline__ void work_done() {}
+    __device__ __forceinline__ void wait_done() {}
+    __device__ __forceinline__ void flush(uint32_t, uint32_t) {}
+    __device__ __forceinline__ void phase_start() {}
+    __device__ __forceinline__ void phase(int) {}
+    __device__ __forceinline__ void flush_phases(uint32_t) {}
+};
+template <>
+struct WaveClock<true> {
     uint64_t* out; uint64_t work = 0, wait = 0, t0 = 0;
+    uint64_t ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tp = 0;       // phase split of one wave's work (dictionary wave): out[16 + k]
+    __device__ __forceinline__ explicit WaveClock(uint64_t* o) : out(o) {}
     __device__ __forceinline__ void start() { if (out) t0 = __builtin_readcyclecounter(); }
     __device__ __forceinline__ void work_done() { if (out) { const uint64_t t = __builtin_readcyclecounter(); work += t - t0; t0 = t; } }
     __device__ __forceinline__ void wait_done() { if (out) { const uint64_t t = __builtin_readcyclecounter(); wait += t - t0; t0 = t; } }
     __device__ __forceinline__ void flush(uint32_t wave, uint32_t lane) { if (out && lane == 0) { out[2 * wave] = work; out[2 * wave + 1] = wait; } }
+    __device__ __forceinline__ void phase_start() { if (out) tp = __builtin_readcyclecounter(); }
+    __device__ __forceinline__ void phase(int k) { if (out) { const uint64_t t = __builtin_readcyclecounter(); ph[k] += t - tp; tp = t; } }
+    __device__ __forceinline__ void flush_phases(uint32_t lane) { if (out && lane == 0) for (int k = 0; k < 8; ++k) out[16 + k] = ph[k]; }
 };
 
 // per-block state of the dictionary wave between issue and finish
@@ -332,6 +351,7 @@ struct Issued {
 
 }  // namespace
 
+template <bool kProf>
 __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(const uint8_t* __restrict__ in, uint64_t total,
                                                                                 uint64_t chunk_bytes, uint8_t* __restrict__ out,
                                                                                 uint64_t out_stride, uint64_t* __restrict__ sizes,
@@ -339,7 +359,7 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = rfl(threadIdx.x >> 6);
     const uint64_t chunk = blockIdx.x;
-    WaveClock clk{blockIdx.x == 0 ? prof : nullptr};
+    WaveClock<kProf> clk(blockIdx.x == 0 ? prof : nullptr);
     const uint8_t* src = in + chunk * chunk_bytes;
     const uint64_t len = (total - chunk * chunk_bytes) < chunk_bytes ? (total - chunk * chunk_bytes) : chunk_bytes;
     uint8_t* dst = out + chunk * out_stride;
@@ -356,10 +376,7 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
     const uint32_t tbl = lds0, zmap = lds0 + kTableBytes;
     round_barrier();
 
-    Guard guard;
-    uint64_t opos = 0;
-
-    // DMA of round r into ring slot r % 4 (dictionary wave only). Lanes past the last whole block stay idle.
+    // ---------------- loader (wave 7): DMA of round r into ring slot r % kInRing; lanes past the last whole block stay idle ------
     auto issue_round = [&](uint64_t r) {
         if (r >= nrounds) return;
         const uint64_t base = r * kRoundBytes;
@@ -369,21 +386,48 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
             if (off + 16 <= nfull * kBlock) dma_1k(src + off, lds0 + kInBase + (uint32_t)(r % kInRing) * kRoundBytes + j * 1024u);
         }
     };
-
-    if (wave == 0) {
+    // all rounds up to `r` have landed; rounds r+1 .. (issued - 1) may stay in flight.  vmcnt retires in order and every round
+    // before the last one issues exactly kRound/4 instructions, so the count is exact away from the chunk's end.
+    auto wait_landed = [&](uint64_t r, uint64_t issued) {
+        if (issued > r + 1 && issued - (r + 1) == kAhead - 2 && issued < nrounds && !(dbg & 1u)) wait_vm<(kAhead - 2) * (kRound / 4)>();
+        else wait_vm<0>();
+    };
+    if (wave == kPipeWaves - 1) {
 #pragma unroll
         for (uint32_t r = 0; r < kAhead; ++r) issue_round(r);
+        wait_landed(1, kAhead);
     }
+    round_barrier();
+
+    // ---------------- dictionary wave state ----------------
+    Guard guard;
+    uint32_t qn[kRound];                                      // quads of the NEXT round, fetched one step ahead
+    auto prefetch_quads = [&](uint64_t r) {
+        const uint32_t a = lds0 + kInBase + (uint32_t)(r % kInRing) * kRoundBytes + 4u * lane;
+        asm volatile("ds_read_b32 %0, %8\n\tds_read_b32 %1, %8 offset:256\n\tds_read_b32 %2, %8 offset:512\n\tds_read_b32 %3, %8 offset:768\n\t"
+                     "ds_read_b32 %4, %8 offset:1024\n\tds_read_b32 %5, %8 offset:1280\n\tds_read_b32 %6, %8 offset:1536\n\tds_read_b32 %7, %8 offset:1792"
+                     : "=&v"(qn[0]), "=&v"(qn[1]), "=&v"(qn[2]), "=&v"(qn[3]), "=&v"(qn[4]), "=&v"(qn[5]), "=&v"(qn[6]), "=&v"(qn[7])
+                     : "v"(a) : "memory");
+    };
+    auto quads_ready = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qn[0]), "+v"(qn[1]), "+v"(qn[2]), "+v"(qn[3]), "+v"(qn[4]), "+v"(qn[5]), "+v"(qn[6]), "+v"(qn[7]) :: "memory");
+    };
+    if (wave == 0 && nrounds) prefetch_quads(0);
+
+    // ---------------- emit wave state ----------------
+    uint64_t opos_run = 0;                                    // output offset of the round being emitted (every emit wave tracks it)
 
     for (uint64_t t = 0; t <= nrounds; ++t) {
         clk.start();
-        if (wave == 0) {
+        if (wave == kPipeWaves - 1) {
+            // ---------------- loader: keep kAhead rounds in flight, guarantee round t+2 for the next step ----------------
+            issue_round(t + kAhead);
+            const uint64_t issued = (t + kAhead + 1) < nrounds ? (t + kAhead + 1) : nrounds;
+            if (t + 2 < nrounds) wait_landed(t + 2, issued); else wait_vm<0>();
+        } else if (wave == 0) {
             // ---------------- dictionary wave: round t ----------------
             if (t < nrounds) {
-                issue_round(t + kAhead);
-                // Round t must have landed; rounds t+1 .. t+kAhead may stay in flight.  vmcnt retires in order, and every round
-                // before the last issues exactly kRound/4 DMA instructions, so the count is exact away from the chunk's end.
-                if (t + kAhead + 1 < nrounds && !(dbg & 1u)) wait_vm<kAhead * (kRound / 4)>(); else wait_vm<0>();
+                clk.phase_start();
                 const uint32_t qbase = kInBase + (uint32_t)(t % kInRing) * kRoundBytes;
                 const uint32_t rbase = kResBase + (uint32_t)(t % kResRing) * kResBytes;
                 const uint64_t b0 = t * kRound;
@@ -391,7 +435,6 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
 
                 uint32_t rec = 0;                                 // lane i holds dword i of the round's result record
                 uint32_t copy_mask = 0;
-                const uint64_t round_opos = opos;
 
                 auto issue = [&](Issued& b) {
                     const uint32_t P = b.q * kHashMul;
@@ -421,15 +464,16 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
                     }
                 };
 
+                Issued blk[kRound];
+                quads_ready();
+#pragma unroll
+                for (uint32_t j = 0; j < kRound; ++j) blk[j].q = qn[j];
+                if (t + 1 < nrounds) prefetch_quads(t + 1);       // older than this round's exchanges in the LDS queue
+                clk.phase(1);
+
                 uint32_t k = 0;
                 bool pending_copy = false;                        // guard already advanced for block k and said "copy"
                 if (nb == kRound && guard.penalty == 0) {
-                    Issued blk[kRound];
-#pragma unroll
-                    for (uint32_t j = 0; j < kRound; ++j) blk[j].q = *reinterpret_cast<const uint32_t*>(smem + qbase + kBlock * j + 4u * lane);
-                    // all quads in registers before the first exchange is issued, so no compiler-inserted lgkmcnt wait (which
-                    // cannot see the asm exchanges and would drain them) lands between the exchanges
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(blk[0].q), "+v"(blk[1].q), "+v"(blk[2].q), "+v"(blk[3].q), "+v"(blk[4].q), "+v"(blk[5].q), "+v"(blk[6].q), "+v"(blk[7].q) :: "memory");
                     uint32_t low_min = 0xffffu;
 #pragma unroll
                     for (uint32_t j = 0; j < kRound; ++j) {
@@ -438,8 +482,9 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
                         low_min = e < low_min ? e : low_min;
                     }
                     uint64_t sig[kRound];
-                    uint32_t hits = 0, min_hits = 64;
+                    uint32_t min_hits = 64;
                     const bool plain_round = ballot64(low_min == 0) == 0;
+                    clk.phase(2);
                     if (plain_round) {
                         // common case: no quad of this round packs to entry 0, a hit is simply "answer == entry"; computing the
                         // signatures has no side effect, so all eight are taken before the FSM is consulted
@@ -448,7 +493,6 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
                             lds_wait_keep_n(blk[j].ret, kRound - 1 - j);          // later exchanges stay in flight
                             sig[j] = ballot64(((blk[j].ret >> blk[j].sh) & 0xffffu) == (blk[j].key & 0xffffu));
                             const uint32_t nh = (uint32_t)__builtin_popcountll(sig[j]);
-                            hits += nh;
                             min_hits = nh < min_hits ? nh : min_hits;
                             rec = wlane(rec, (uint32_t)sig[j], 2 * j);
                             rec = wlane(rec, (uint32_t)(sig[j] >> 32), 2 * j + 1);
@@ -456,19 +500,19 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
                     } else {
                         lds_wait_all();
                     }
+                    clk.phase(3);
                     if (plain_round && min_hits > 4 && !guard.prev) {
                         // no incompressible record (codec.rs:68: 8 + 256 - 2*hits >= 256) in this round: the FSM only counts
-                        // blocks (protection_state.rs:19-27); at most one of 8 consecutive counters is a multiple of 16
-                        const uint32_t to16 = (16u - (guard.counter & 15u)) & 15u;
-                        if (to16 < kRound && guard.start > 1) guard.start >>= 1;
+                        // blocks (protection_state.rs:19-27); one of 8 consecutive counters is a multiple of 16 iff c == 0 or c > 8
+                        const uint32_t c = guard.counter & 15u;
+                        const uint32_t halve = (uint32_t)(c == 0u) | (uint32_t)(c > 8u);
+                        guard.start = (halve && guard.start > 1u) ? guard.start >> 1 : guard.start;
                         guard.counter += kRound;
-                        opos += kRound * (kSig + kBlock) - 2u * hits;
                         k = kRound;
                     } else {
                         // walk the FSM block by block; stop at the first block it turns into a raw copy.  With zero-entry quads
                         // in the round the signature itself updates the zero-entry map, so it is taken only for blocks the FSM
                         // has admitted.
-                        uint64_t o = opos;
 #pragma unroll
                         for (uint32_t j = 0; j < kRound; ++j) {
                             if (k == j) {
@@ -480,14 +524,11 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
                                         rec = wlane(rec, (uint32_t)sig[j], 2 * j);
                                         rec = wlane(rec, (uint32_t)(sig[j] >> 32), 2 * j + 1);
                                     }
-                                    const uint32_t nh = (uint32_t)__builtin_popcountll(sig[j]);
-                                    guard.update(nh <= 4);
-                                    o += kSig + kBlock - 2u * nh;
+                                    guard.update((uint32_t)__builtin_popcountll(sig[j]) <= 4);
                                     k = j + 1;
                                 }
                             }
                         }
-                        opos = o;
                         if (pending_copy) {
                             lds_wait_all();
 #pragma unroll
@@ -504,72 +545,71 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
                     uint64_t sg = 0;
                     if (cp) {                                     // codec.rs:35-37
                         copy_mask |= 1u << k;
-                        opos += kBlock;
                         guard.decay();
                     } else {
                         Issued b;
                         b.q = *reinterpret_cast<const uint32_t*>(smem + qbase + kBlock * k + 4u * lane);
                         issue(b);
-                        lds_wait_keep_n(b.ret, 0);
+                        lds_wait_all();
                         sg = signature(b);
-                        const uint32_t nh = (uint32_t)__builtin_popcountll(sg);
-                        guard.update(nh <= 4);                    // codec.rs:68
-                        opos += kSig + kBlock - 2u * nh;
+                        guard.update((uint32_t)__builtin_popcountll(sg) <= 4);   // codec.rs:68
                     }
                     rec = wlane_dyn(rec, (uint32_t)sg, 2 * k, lane);
                     rec = wlane_dyn(rec, (uint32_t)(sg >> 32), 2 * k + 1, lane);
                 }
-                rec = wlane(rec, (uint32_t)round_opos, 16);
-                rec = wlane(rec, (uint32_t)(round_opos >> 32), 17);
-                rec = wlane(rec, copy_mask, 18);
-                if (lane < 19) *reinterpret_cast<uint32_t*>(smem + rbase + 4u * lane) = rec;
+                rec = wlane_dyn(rec, copy_mask, 16, lane);
+                if (lane < 17) *reinterpret_cast<uint32_t*>(smem + rbase + 4u * lane) = rec;
+                clk.phase(4);
             }
         } else if (t >= 1 && !(dbg & 2u)) {
-            // ---------------- emit waves: round t-1 ----------------
+            // ---------------- emit waves 1..6: round t-1 ----------------
             const uint64_t r = t - 1;
             const uint32_t qbase = kInBase + (uint32_t)(r % kInRing) * kRoundBytes;
             const uint32_t rbase = kResBase + (uint32_t)(r % kResRing) * kResBytes;
             const uint64_t b0 = r * kRound;
             const uint32_t nb = (nfull - b0) < kRound ? (uint32_t)(nfull - b0) : kRound;
-            if (wave - 1 < nb) {
-                // lanes 0..7: signature and record length of block `lane`; exclusive prefix over the round
-                const uint32_t sl = lane & 7u;
-                const uint32_t slo = *reinterpret_cast<const uint32_t*>(smem + rbase + 8u * sl);
-                const uint32_t shi = *reinterpret_cast<const uint32_t*>(smem + rbase + 8u * sl + 4);
-                const uint32_t base_lo = *reinterpret_cast<const uint32_t*>(smem + rbase + 64);
-                const uint32_t base_hi = *reinterpret_cast<const uint32_t*>(smem + rbase + 68);
-                const uint32_t cmask = rfl(*reinterpret_cast<const uint32_t*>(smem + rbase + 72));
-                const uint32_t myhits = (uint32_t)(__builtin_popcount(slo) + __builtin_popcount(shi));
-                const uint32_t mylen = ((cmask >> sl) & 1u) ? kBlock : (kSig + kBlock - 2u * myhits);
-                if (idx && wave == 1 && lane < nb) idx[b0 + lane] = (uint8_t)(((cmask >> sl) & 1u) ? kIdxCopy : myhits);
-                for (uint32_t k = wave - 1; k < nb; k += kEmitWaves) {
-                    uint32_t before = 0;
-                    for (uint32_t j = 0; j < k; ++j) before += rlane(mylen, j);
-                    const uint64_t sig = (uint64_t)rlane(slo, k) | ((uint64_t)rlane(shi, k) << 32);
-                    const uint64_t base = (uint64_t)rfl(base_lo) | ((uint64_t)rfl(base_hi) << 32);
-                    uint8_t* recp = dst + base + before;
-                    const uint32_t q = *reinterpret_cast<const uint32_t*>(smem + qbase + kBlock * k + 4u * lane);
-                    if (dbg & 8u) {
-                        asm volatile("" ::"v"(q), "v"(recp));
-                    } else if ((cmask >> k) & 1u) {
-                        st32u(recp + 4u * lane, q);
-                    } else {
-                        const bool hit = (sig >> lane) & 1ull;
-                        const uint32_t off = kSig + 4u * lane - 2u * mbcnt64(sig);
-                        if (lane == 0) { st32u(recp, (uint32_t)sig); st32u(recp + 4, (uint32_t)(sig >> 32)); }
-                        if (hit) st16u(recp + off, (q * kHashMul) >> 16); else st32u(recp + off, q);
-                    }
+            // lanes 0..7: signature and record length of block `lane`; prefix over the round = record offsets
+            const uint32_t sl = lane & 7u;
+            const uint32_t slo = *reinterpret_cast<const uint32_t*>(smem + rbase + 8u * sl);
+            const uint32_t shi = *reinterpret_cast<const uint32_t*>(smem + rbase + 8u * sl + 4);
+            const uint32_t cmask = rfl(*reinterpret_cast<const uint32_t*>(smem + rbase + 64));
+            const uint32_t myhits = (uint32_t)(__builtin_popcount(slo) + __builtin_popcount(shi));
+            const uint32_t mylen = lane < nb ? (((cmask >> sl) & 1u) ? kBlock : (kSig + kBlock - 2u * myhits)) : 0u;
+            uint32_t incl = mylen;
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xf, 0xf, true);   // row_shr:1
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xf, 0xf, true);   // row_shr:2
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xf, 0xf, true);   // row_shr:4
+            if (idx && wave == 1 && lane < nb) idx[b0 + lane] = (uint8_t)(((cmask >> sl) & 1u) ? kIdxCopy : myhits);
+            for (uint32_t k = wave - 1; k < nb; k += kEmitWaves) {
+                const uint32_t before = rlane(incl - mylen, k);
+                const uint64_t sig = (uint64_t)rlane(slo, k) | ((uint64_t)rlane(shi, k) << 32);
+                uint8_t* recp = dst + opos_run + before;
+                const uint32_t q = *reinterpret_cast<const uint32_t*>(smem + qbase + kBlock * k + 4u * lane);
+                if (dbg & 8u) {
+                    asm volatile("" ::"v"(q), "v"(recp));
+                } else if ((cmask >> k) & 1u) {
+                    st32u(recp + 4u * lane, q);
+                } else {
+                    const bool hit = (sig >> lane) & 1ull;
+                    const uint32_t off = kSig + 4u * lane - 2u * mbcnt64(sig);
+                    if (lane == 0) { st32u(recp, (uint32_t)sig); st32u(recp + 4, (uint32_t)(sig >> 32)); }
+                    if (hit) st16u(recp + off, (q * kHashMul) >> 16); else st32u(recp + off, q);
                 }
             }
+            opos_run += rlane(incl, 7);
         }
         clk.work_done();
         round_barrier();
         clk.wait_done();
     }
     clk.flush(wave, lane);
+    if (wave == 0) clk.flush_phases(lane);
 
-    // ragged last block (and the size word): dictionary wave, scalar-path code
+    // hand the stream length so far to the dictionary wave, which finishes a ragged last block with the scalar-path code
+    if (wave == 1 && lane == 0) *reinterpret_cast<uint64_t*>(smem + kResBase) = opos_run;
+    round_barrier();
     if (wave == 0) {
+        uint64_t opos = *reinterpret_cast<const uint64_t*>(smem + kResBase);
         const uint64_t boff = nfull * kBlock;
         const uint32_t blen = (uint32_t)(len - boff);
         if (blen) {
@@ -759,6 +799,7 @@ constexpr uint32_t kD0Write = 2u, kD0Half = 1u, kD0Empty = 0x80000000u, kD0Addr 
 
 }  // namespace
 
+template <bool kProf>
 __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_decode_chunks_pipe(const uint8_t* __restrict__ in,
                                                                                 const uint64_t* __restrict__ offsets,
                                                                                 const uint64_t* __restrict__ sizes,
@@ -770,7 +811,7 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_decode_chunks_pipe(
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = rfl(threadIdx.x >> 6);
     const uint64_t chunk = blockIdx.x;
-    WaveClock clk{blockIdx.x == 0 ? prof : nullptr};
+    WaveClock<kProf> clk(blockIdx.x == 0 ? prof : nullptr);
     const uint8_t* src = in + offsets[chunk];
     const uint8_t* idx = index ? index + chunk * (out_stride / kBlock) : nullptr;   // this chunk's slice of the block index
     const uint64_t elen64 = sizes[chunk];
@@ -1115,16 +1156,18 @@ namespace {
 uint64_t* prof_buffer() {
     static uint64_t* buf = nullptr;
     if (!getenv("DENSITY_HIP_PROF")) return nullptr;
-    if (!buf && hipMalloc((void**)&buf, 16 * sizeof(uint64_t)) != hipSuccess) buf = nullptr;
-    if (buf) (void)hipMemset(buf, 0, 16 * sizeof(uint64_t));
+    if (!buf && hipMalloc((void**)&buf, 24 * sizeof(uint64_t)) != hipSuccess) buf = nullptr;
+    if (buf) (void)hipMemset(buf, 0, 24 * sizeof(uint64_t));
     return buf;
 }
 void prof_report(const char* what, uint64_t* buf, hipStream_t stream) {
     if (!buf) return;
-    uint64_t h[16];
+    uint64_t h[24];
     if (hipStreamSynchronize(stream) != hipSuccess || hipMemcpy(h, buf, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return;
     fprintf(stderr, "[density_hip prof] %s work-group 0: ", what);
     for (int w = 0; w < 8; ++w) fprintf(stderr, "w%d work %llu wait %llu | ", w, (unsigned long long)h[2 * w], (unsigned long long)h[2 * w + 1]);
+    fprintf(stderr, "\n[density_hip prof] %s wave-0 phases:", what);
+    for (int k = 0; k < 8; ++k) fprintf(stderr, " p%d %llu", k, (unsigned long long)h[16 + k]);
     fprintf(stderr, "\n");
 }
 }  // namespace
@@ -1136,11 +1179,12 @@ hipError_t launch_chameleon_encode(const uint8_t* d_in, uint64_t total, uint64_t
     // the pipelined kernel stages its input with 16-byte LDS-DMA pieces: needs 16-byte aligned chunk bases
     const bool aligned = ((uintptr_t)d_in % 16 == 0) && (n_chunks == 1 || chunk_bytes % 16 == 0);
     if (aligned && !g_force_simple) {
-        e = hipFuncSetAttribute((const void*)chameleon_encode_chunks_pipe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytesPipe);
+        uint64_t* prof = prof_buffer();
+        auto kernel = prof ? chameleon_encode_chunks_pipe<true> : chameleon_encode_chunks_pipe<false>;
+        e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytesPipe);
         if (e != hipSuccess) return e;
         const uint32_t dbg = getenv("DENSITY_HIP_DBG") ? (uint32_t)atoi(getenv("DENSITY_HIP_DBG")) : 0u;
-        uint64_t* prof = prof_buffer();
-        hipLaunchKernelGGL(chameleon_encode_chunks_pipe, dim3(n_chunks), dim3(kPipeWaves * 64), kLdsBytesPipe, stream, d_in, total, chunk_bytes, d_out, out_stride, d_sizes, d_index, dbg, prof);
+        hipLaunchKernelGGL(kernel, dim3(n_chunks), dim3(kPipeWaves * 64), kLdsBytesPipe, stream, d_in, total, chunk_bytes, d_out, out_stride, d_sizes, d_index, dbg, prof);
         prof_report("encode", prof, stream);
     } else {
         hipLaunchKernelGGL(chameleon_encode_chunks, dim3(n_chunks), dim3(64), kLdsBytes, stream, d_in, total, chunk_bytes, d_out, out_stride, d_sizes, d_index);
@@ -1158,11 +1202,12 @@ hipError_t launch_chameleon_decode(const uint8_t* d_in, const uint64_t* d_offset
     // quads with aligned dwords
     const bool aligned = ((uintptr_t)d_in % 16 == 0) && ((uintptr_t)d_out % 4 == 0) && (n_chunks == 1 || out_stride % 4 == 0);
     if (aligned && !g_force_simple) {
-        e = hipFuncSetAttribute((const void*)chameleon_decode_chunks_pipe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytesDec);
+        uint64_t* prof = prof_buffer();
+        auto kernel = prof ? chameleon_decode_chunks_pipe<true> : chameleon_decode_chunks_pipe<false>;
+        e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytesDec);
         if (e != hipSuccess) return e;
         const uint32_t dbg = getenv("DENSITY_HIP_DBG") ? (uint32_t)atoi(getenv("DENSITY_HIP_DBG")) : 0u;
-        uint64_t* prof = prof_buffer();
-        hipLaunchKernelGGL(chameleon_decode_chunks_pipe, dim3(n_chunks), dim3(kPipeWaves * 64), kLdsBytesDec, stream, d_in, d_offsets, d_sizes, d_out, out_stride, out_total, exact ? 1u : 0u, d_index, d_produced, d_err, dbg, prof);
+        hipLaunchKernelGGL(kernel, dim3(n_chunks), dim3(kPipeWaves * 64), kLdsBytesDec, stream, d_in, d_offsets, d_sizes, d_out, out_stride, out_total, exact ? 1u : 0u, d_index, d_produced, d_err, dbg, prof);
         prof_report("decode", prof, stream);
     } else {
         hipLaunchKernelGGL(chameleon_decode_chunks, dim3(n_chunks), dim3(64), kLdsBytes, stream, d_in, d_offsets, d_sizes, d_out, out_stride, out_total, exact ? 1u : 0u, d_produced, d_err);
