@@ -49,7 +49,15 @@ __device__ __forceinline__ void lds_clear(uint32_t lane) {
 }
 
 // inverse of the entry packing: slot index h and 16-bit entry e -> the quad (see file header)
-__device__ __forceinline__ uint32_t entry_to_quad(uint32_t h, uint32_t e) {
+// Stored entries are salted per slot: stored = packed ^ slot_salt(h).  The one stored value that aliases "never written"
+// (0) then belongs to one pseudo-random quad per slot instead of to every quad whose packed entry is 0 (low 15 bits and top
+// bit clear: round floats, small little-endian integers), so the zero-entry map is touched about once per 64 Ki quads on
+// any data.  slot_salt(0) == 0 keeps slot 0 / quad 0 (the reference's zero-initialised table, chameleon.rs:41) valid from
+// the start.
+__device__ __forceinline__ uint32_t slot_salt(uint32_t h) { return ((h * 0x9e5bu) ^ (h >> 5)) & 0xffffu; }
+__device__ __forceinline__ uint32_t stored_entry(uint32_t q, uint32_t P) { return ((P & 0xfffeu) | (q >> 31)) ^ slot_salt(P >> 16); }
+__device__ __forceinline__ uint32_t entry_to_quad(uint32_t h, uint32_t stored) {
+    const uint32_t e = stored ^ slot_salt(h);
     const uint32_t Pfull = (h << 16) | (e & 0xfffeu);
     return (((Pfull >> 1) * kHalfMulInv) & 0x7fffffffu) | ((e & 1u) << 31);
 }
@@ -195,7 +203,7 @@ __global__ __launch_bounds__(64) void chameleon_encode_chunks(const uint8_t* __r
 
             const uint32_t P = q * kHashMul;
             const uint32_t h = P >> 16;
-            const uint32_t e = (P & 0xfffeu) | (q >> 31);
+            const uint32_t e = stored_entry(q, P);
             uint32_t old = 0, w = lane;
             if (active) dict_step(tbl + 2u * h, lane, e, old, w);
 
@@ -438,7 +446,7 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
 
                 auto issue = [&](Issued& b) {
                     const uint32_t P = b.q * kHashMul;
-                    b.key = (P & 0xfffffffeu) | (b.q >> 31);
+                    b.key = (P & 0xffff0000u) | stored_entry(b.q, P);
                     b.sh = (P >> 12) & 16u;
                     dict_xchg_issue(tbl + ((P >> 15) & 0x1fffcu), 0xffffu << b.sh, (b.key & 0xffffu) << b.sh, b.ret);
                 };
@@ -625,7 +633,7 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
             } else {
                 const uint32_t P = q * kHashMul;
                 const uint32_t h = P >> 16;
-                const uint32_t e = (P & 0xfffeu) | (q >> 31);
+                const uint32_t e = stored_entry(q, P);
                 uint32_t old = 0, w = lane;
                 if (active) dict_step(tbl + 2u * h, lane, e, old, w);
                 bool has_pred;
@@ -698,7 +706,7 @@ __device__ __forceinline__ bool decode_in_order(const uint8_t* __restrict__ src,
         uint32_t q = 0, h = 0, e = 0;
         if (active) {
             if (hit) { h = ld16u(rec + off); }
-            else { q = ld32u(rec + off); const uint32_t P = q * kHashMul; h = P >> 16; e = (P & 0xfffeu) | (q >> 31); }
+            else { q = ld32u(rec + off); const uint32_t P = q * kHashMul; h = P >> 16; e = stored_entry(q, P); }
         }
         uint32_t old = 0, w = lane;
         if (active) dict_probe(tbl + 2u * h, lane, old, w);
@@ -1023,7 +1031,7 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_decode_chunks_pipe(
                     const uint32_t P = q * kHashMul;
                     const uint32_t h = P >> 16;
                     d0 = ((h >> 1) << 2) | (h & 1u) | kD0Write;
-                    d1 = ((P & 0xfffeu) | (q >> 31)) << ((h & 1u) << 4);
+                    d1 = stored_entry(q, P) << ((h & 1u) << 4);
                 }
             }
             *reinterpret_cast<uint2*>(smem + sbase + k * kStageRec + 8u * lane) = make_uint2(d0, d1);

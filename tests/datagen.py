@@ -97,6 +97,26 @@ def low_zero_quads(n_quads, seed=4):
     return q.astype("<u4").view(np.uint8).copy()
 
 
+def salted_zero_quads(n_quads, seed=7):
+    """Quads whose STORED dictionary entry is 0 outside slot 0 in the GPU table (packed entry == slot_salt(slot), see
+    density_amd/csrc/chameleon.hip): the one value that aliases a never-written slot and goes through the zero-entry map.
+    Mixed with ordinary quads and repeats so that hits, misses and overwrites of such slots all occur."""
+    inv = pow(0x9D6EF916 >> 1, -1, 1 << 31)
+    rng = np.random.default_rng(seed)
+    hs = rng.integers(1, 1 << 16, size=40, dtype=np.uint64)
+    salt = ((hs * np.uint64(0x9E5B)) ^ (hs >> np.uint64(5))) & np.uint64(0xFFFF)
+    pfull = (hs << np.uint64(16)) | (salt & np.uint64(0xFFFE))
+    special = (((pfull >> np.uint64(1)) * np.uint64(inv)) & np.uint64(0x7FFFFFFF)) | ((salt & np.uint64(1)) << np.uint64(31))
+    # sanity: they hash to their slot
+    assert np.all(((special * np.uint64(0x9D6EF916)) & np.uint64(0xFFFFFFFF)) >> np.uint64(16) == hs)
+    others = rng.integers(0, 1 << 32, size=24, dtype=np.uint64)
+    # quads colliding with the special slots but with other entries
+    coll = (((((hs[:16] << np.uint64(16)) | np.uint64(0x1234)) >> np.uint64(1)) * np.uint64(inv)) & np.uint64(0x7FFFFFFF))
+    pool = np.concatenate([special, others, coll, np.zeros(2, np.uint64)])
+    q = pool[rng.integers(0, pool.size, size=n_quads)]
+    return q.astype("<u4").view(np.uint8).copy()
+
+
 def binaryish(n, seed=6):
     """Little-endian 32-bit records with small values and zero padding: lots of 00 00 xx 00 style quads."""
     rng = np.random.default_rng(seed)
@@ -119,6 +139,8 @@ def by_kind(kind, n, seed=1):
         return same_hash_quads(n // 4 + 1, seed)[:n].copy()
     if kind == "lowzero":
         return low_zero_quads(n // 4 + 1, seed)[:n].copy()
+    if kind == "saltzero":
+        return salted_zero_quads(n // 4 + 1, seed)[:n].copy()
     if kind == "binaryish":
         return binaryish(n, seed)
     if kind == "rep":

@@ -94,11 +94,11 @@ EDGE_SIZES = sorted(set(list(range(1, 41)) + [63, 64, 65, 127, 128, 129, 251, 25
                                               271, 272, 273, 511, 512, 513, 519, 520, 521, 767, 768, 769, 4093, 4094, 4095, 4096, 4097, 4098, 4099]))
 
 
-@pytest.mark.parametrize("kind", ["prose", "random", "zeros", "mixed", "samehash", "lowzero"])
+@pytest.mark.parametrize("kind", ["prose", "random", "zeros", "mixed", "samehash", "lowzero", "saltzero"])
 def test_stream_parity_edge_sizes(kind):
     big = {"prose": datagen.prose(5000, 21), "random": datagen.random_bytes(5000, 22), "zeros": np.zeros(5000, np.uint8),
            "mixed": datagen.mixed(5000, 23), "samehash": datagen.same_hash_quads(1250, 24),
-           "lowzero": datagen.low_zero_quads(1250, 25)}[kind]
+           "lowzero": datagen.low_zero_quads(1250, 25), "saltzero": datagen.salted_zero_quads(1250, 26)}[kind]
     for n in EDGE_SIZES:
         data = big[:n].copy()
         want = pyoracle.encode(ALGO, data)
@@ -108,7 +108,7 @@ def test_stream_parity_edge_sizes(kind):
 
 
 @pytest.mark.parametrize("kind,n", [("prose", 1_000_003), ("random", 300_001), ("zeros", 262_144 + 2), ("mixed", 2_000_000),
-                                    ("samehash", 400_000), ("lowzero", 500_002), ("binaryish", 700_001), ("rep", 1_500_000)])
+                                    ("samehash", 400_000), ("lowzero", 500_002), ("saltzero", 600_002), ("binaryish", 700_001), ("rep", 1_500_000)])
 def test_stream_parity_large(kind, n):
     """Whole-stream (single chunk) parity at sizes the oracle finishes in well under a second: exercises multi-block
     dictionary carry, copy mode entering/leaving (random, mixed), the all-one-slot hazard and the zero-entry map."""
@@ -123,7 +123,7 @@ def test_stream_parity_large(kind, n):
 
 
 @pytest.mark.parametrize("chunk", [256, 512, 4096, 65536, 1 << 20])
-@pytest.mark.parametrize("kind", ["prose", "mixed"])
+@pytest.mark.parametrize("kind", ["prose", "mixed", "saltzero"])
 def test_container_chunks_match_oracle(kind, chunk, kernel_variant):
     n = 3 * (1 << 20) + 12345 if chunk >= 65536 else 40 * chunk + 77
     data = datagen.by_kind(kind, n, seed=chunk)
