@@ -147,8 +147,9 @@ EncodePlan plan_encode(int algo, size_t n, size_t chunk) {
     return p;
 }
 struct DecodePlan {
-    size_t off_err, off_sizes, off_offsets, off_produced, off_tables, total;
+    size_t off_err, off_sizes, off_offsets, off_produced, off_tables, off_zmap, total;
 };
+inline size_t zmap_bytes(int algo, size_t n_chunks) { return (algo == DENSITY_HIP_CHAMELEON && n_chunks <= kMaxPipelinedChunks) ? align_up((n_chunks ? n_chunks : 1) * kZmapWordsPerChunk * 4, kAlign) : 0; }
 DecodePlan plan_decode(int algo, size_t n_chunks) {
     DecodePlan p{};
     p.off_err = 0;
@@ -156,7 +157,8 @@ DecodePlan plan_decode(int algo, size_t n_chunks) {
     p.off_offsets = p.off_sizes + align_up(8 * n_chunks, kAlign);
     p.off_produced = p.off_offsets + align_up(8 * (n_chunks + 1), kAlign);
     p.off_tables = p.off_produced + align_up(8 * (n_chunks ? n_chunks : 1), kAlign);
-    p.total = p.off_tables + serial_tables(algo, n_chunks ? n_chunks : 1);
+    p.off_zmap = p.off_tables + serial_tables(algo, n_chunks ? n_chunks : 1);
+    p.total = p.off_zmap + zmap_bytes(algo, n_chunks);
     return p;
 }
 
@@ -168,8 +170,8 @@ hipError_t codec_encode(int algo, const uint8_t* d_in, uint64_t total, uint64_t 
 }
 hipError_t codec_decode(int algo, const uint8_t* d_in, const uint64_t* d_offsets, const uint64_t* d_sizes, uint32_t n_chunks, uint8_t* d_out,
                         uint64_t out_stride, uint64_t out_total, bool exact, const uint8_t* d_index, uint64_t* d_produced, uint32_t* d_err,
-                        uint8_t* d_tables, hipStream_t s) {
-    if (algo == DENSITY_HIP_CHAMELEON) return launch_chameleon_decode(d_in, d_offsets, d_sizes, n_chunks, d_out, out_stride, out_total, exact, d_index, d_produced, d_err, s);
+                        uint8_t* d_tables, uint32_t* d_zmap, hipStream_t s) {
+    if (algo == DENSITY_HIP_CHAMELEON) return launch_chameleon_decode(d_in, d_offsets, d_sizes, n_chunks, d_out, out_stride, out_total, exact, d_index, d_zmap, d_produced, d_err, s);
     return launch_serial_decode(algo, d_in, d_offsets, d_sizes, n_chunks, d_out, out_stride, out_total, exact, d_produced, d_err, d_tables, (uint32_t)serial_slots(algo, n_chunks), s);
 }
 const char* encode_kernel_name(int algo) { return algo == DENSITY_HIP_CHAMELEON ? "chameleon_encode_chunks" : algo == DENSITY_HIP_CHEETAH ? "cheetah_encode_chunks" : "lion_encode_chunks"; }
@@ -252,7 +254,7 @@ int run_decode_container(DeviceCtx* c, const uint8_t* d_in, size_t container_siz
     const uint8_t* d_index = with_index ? d_in + index_base(h.n_chunks) : nullptr;
     if (e == hipSuccess) e = launch_layout_decode(d_in, container_size, h.n_chunks, payload_base(h.n_chunks, h.total_len, with_index), d_sizes, d_offsets, d_err, s);
     prof.mark("layout_decode");
-    if (e == hipSuccess) e = codec_decode(h.algo, d_in, d_offsets, d_sizes, h.n_chunks, d_out, h.chunk_size, h.total_len, true, d_index, d_produced, d_err, ws + p.off_tables, s);
+    if (e == hipSuccess) e = codec_decode(h.algo, d_in, d_offsets, d_sizes, h.n_chunks, d_out, h.chunk_size, h.total_len, true, d_index, d_produced, d_err, ws + p.off_tables, zmap_bytes(h.algo, h.n_chunks) ? reinterpret_cast<uint32_t*>(ws + p.off_zmap) : nullptr, s);
     prof.mark(decode_kernel_name(h.algo));
     if (e != hipSuccess) { set_error("kernel launch (decode)", e); return DENSITY_HIP_ERR_RUNTIME; }
     if (decoded_out) {
@@ -298,7 +300,7 @@ int run_stream_decode(DeviceCtx* c, int algo, const uint8_t* d_in, size_t n, uin
     if (e == hipSuccess) e = hipMemcpyAsync(d_sizes, &h_size, 8, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemcpyAsync(d_offsets, &h_off, 8, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);   // h_size/h_off live on this stack frame
-    if (e == hipSuccess) e = codec_decode(algo, d_in, d_offsets, d_sizes, 1, d_out, cap, cap, false, nullptr, d_produced, d_err, ws + p.off_tables, s);
+    if (e == hipSuccess) e = codec_decode(algo, d_in, d_offsets, d_sizes, 1, d_out, cap, cap, false, nullptr, d_produced, d_err, ws + p.off_tables, zmap_bytes(algo, 1) ? reinterpret_cast<uint32_t*>(ws + p.off_zmap) : nullptr, s);
     prof.mark(decode_kernel_name(algo));
     uint64_t h_prod = 0;
     uint32_t h_err = 0;
@@ -366,7 +368,10 @@ size_t density_hip_encode_workspace_size(int algo, size_t input_size, size_t chu
     return plan_encode(algo, input_size, chunk_size).total;
 }
 
-size_t density_hip_decode_workspace_size(uint32_t n_chunks) { return plan_decode(DENSITY_HIP_LION, n_chunks).total; }   // the largest of the three
+size_t density_hip_decode_workspace_size(uint32_t n_chunks) {   // the largest of the three algorithms
+    const size_t a = plan_decode(DENSITY_HIP_LION, n_chunks).total, b = plan_decode(DENSITY_HIP_CHAMELEON, n_chunks).total;
+    return a > b ? a : b;
+}
 
 int density_hip_encode_device(int algo, const void* d_input, size_t input_size, void* d_output, size_t output_capacity,
                               size_t chunk_size, void* d_workspace, size_t workspace_size, void* stream,

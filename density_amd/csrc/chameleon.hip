@@ -123,6 +123,24 @@ __device__ __forceinline__ uint32_t zmap_test(uint32_t zbase, uint32_t h) {
 __device__ __forceinline__ void zmap_set(uint32_t zbase, uint32_t h) {
     asm volatile("ds_or_b32 %0, %1" ::"v"(zbase + (h >> 5) * 4u), "v"(1u << (h & 31u)) : "memory");
 }
+// Where the zero-entry map lives: LDS for the one-wavefront kernels and the pipelined encoder, global memory (per chunk, 8 KiB,
+// L2-resident, touched about once per 64 Ki quads) for the pipelined decoder, whose LDS is spent on rings.  Only one wavefront
+// of a work-group ever touches it, in stream order.
+struct ZmapLds {
+    uint32_t base;
+    __device__ __forceinline__ uint32_t test(uint32_t h) const { return zmap_test(base, h); }
+    __device__ __forceinline__ void set(uint32_t h) const { zmap_set(base, h); }
+};
+struct ZmapGlobal {
+    uint32_t* words;
+    __device__ __forceinline__ uint32_t test(uint32_t h) const {
+        return (__hip_atomic_load(words + (h >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (h & 31u)) & 1u;   // bypasses the (non-coherent) L1
+    }
+    __device__ __forceinline__ void set(uint32_t h) const {
+        const uint32_t old = atomicOr(words + (h >> 5), 1u << (h & 31u));
+        asm volatile("" ::"v"(old));                          // returned value consumed: the update is in L2 before the next test
+    }
+};
 
 // For every lane that shares its slot with other lanes of this block: the entry written by the nearest earlier lane
 // of its group that is in `writers` (encode: every lane writes; decode: only PLAIN lanes do).
@@ -341,7 +359,7 @@ struct WaveClock<false> {                                     // production: com
 template <>
 struct WaveClock<true> {
     uint64_t* out; uint64_t work = 0, wait = 0, t0 = 0;
-    uint64_t ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tp = 0;       // phase split of one wave's work (dictionary wave): out[16 + k]
+    uint64_t ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tp = 0;       // phase split of one wave's work (dictionary wave): out[32 + k]
     __device__ __forceinline__ explicit WaveClock(uint64_t* o) : out(o) {}
     __device__ __forceinline__ void start() { if (out) t0 = __builtin_readcyclecounter(); }
     __device__ __forceinline__ void work_done() { if (out) { const uint64_t t = __builtin_readcyclecounter(); work += t - t0; t0 = t; } }
@@ -349,7 +367,7 @@ struct WaveClock<true> {
     __device__ __forceinline__ void flush(uint32_t wave, uint32_t lane) { if (out && lane == 0) { out[2 * wave] = work; out[2 * wave + 1] = wait; } }
     __device__ __forceinline__ void phase_start() { if (out) tp = __builtin_readcyclecounter(); }
     __device__ __forceinline__ void phase(int k) { if (out) { const uint64_t t = __builtin_readcyclecounter(); ph[k] += t - tp; tp = t; } }
-    __device__ __forceinline__ void flush_phases(uint32_t lane) { if (out && lane == 0) for (int k = 0; k < 8; ++k) out[16 + k] = ph[k]; }
+    __device__ __forceinline__ void flush_phases(uint32_t lane) { if (out && lane == 0) for (int k = 0; k < 8; ++k) out[32 + k] = ph[k]; }
 };
 
 // per-block state of the dictionary wave between issue and finish
@@ -670,8 +688,9 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
 // In-order record loop shared by the one-wavefront kernel (whole stream) and the pipelined kernel (ragged end of the
 // stream).  Runs on ONE wavefront from the state (ipos, opos, guard) until the input is exhausted; returns false where the
 // reference would panic (truncated stream, output too small).
+template <typename Zmap>
 __device__ __forceinline__ bool decode_in_order(const uint8_t* __restrict__ src, uint64_t elen, uint8_t* __restrict__ dst, uint64_t cap,
-                                                Guard& guard, uint64_t& ipos, uint64_t& opos, uint32_t tbl, uint32_t zmap, uint32_t lane) {
+                                                Guard& guard, uint64_t& ipos, uint64_t& opos, uint32_t tbl, Zmap zmap, uint32_t lane) {
     while (ipos < elen) {
         const uint64_t rem = elen - ipos;
         const uint8_t* rec = src + ipos;
@@ -720,8 +739,8 @@ __device__ __forceinline__ bool decode_in_order(const uint8_t* __restrict__ src,
         const bool hsusp = active && hit && !has_pred && old == 0 && h != 0;
         const bool psusp = active && !hit && e == 0 && h != 0;
         if (ballot64(hsusp || psusp)) {
-            if (hsusp) empty = !zmap_test(zmap, h);
-            if (psusp) zmap_set(zmap, h);
+            if (hsusp) empty = !zmap.test(h);
+            if (psusp) zmap.set(h);
         }
         if (active) {
             if (hit) q = empty ? 0u : entry_to_quad(h, eff);       // chameleon.rs:64-68: quad = chunk_map[hash]
@@ -764,7 +783,7 @@ __global__ __launch_bounds__(64) void chameleon_decode_chunks(const uint8_t* __r
 
     Guard guard;
     uint64_t ipos = 0, opos = 0;
-    bool bad = !decode_in_order(src, elen, dst, cap, guard, ipos, opos, tbl, zmap, lane);
+    bool bad = !decode_in_order(src, elen, dst, cap, guard, ipos, opos, tbl, ZmapLds{zmap}, lane);
     if (exact && !bad && opos != cap) bad = true;
     if (lane == 0) {
         produced[chunk] = opos;
@@ -773,49 +792,55 @@ __global__ __launch_bounds__(64) void chameleon_decode_chunks(const uint8_t* __r
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Pipelined decoder: one work-group (8 waves) per chunk, four stages one round (<= 8 records) apart, separated by one
+// Pipelined decoder: one work-group (16 waves) per chunk, five stages one round (<= 8 records) apart, separated by one
 // s_barrier per step.  At step s:
 //
-//   wave 1   "parser"   round s+2: walks the record chain (signature -> popcount -> next record; the only inherently serial
-//                       part of the format, codec.rs:88-100) in the LDS byte ring, runs the copy-mode FSM, and publishes
-//                       a descriptor {signature, position} per record.  It also issues the global->LDS DMA that keeps the
-//                       ring filled ahead of the parse position.
-//   waves 2-7 "fetch"   round s+1: pull each lane's item out of the ring (2-byte granular), hash PLAIN quads, and stage the
-//                       operands of the dictionary step {slot address, half, write flag, value}.
-//   wave 0   "dictionary wave"   round s: one ordered LDS exchange per record (PLAIN lanes write their entry, MAP lanes
-//                       only read: mask 0), exactly the sequential chameleon.rs:56-68 semantics; stores the answers.
-//   waves 2-7 "emit"    round s-1: entry -> quad (inverse of the hash product), coalesced 256-byte stores.
+//   wave 1   "feeder"   round s+2: publishes each record's position — from the container's block index by a DPP prefix sum,
+//                       or, without an index, by walking the record chain (signature -> popcount -> next record; the only
+//                       inherently serial part of the format, codec.rs:88-100) in the LDS byte ring and running the
+//                       copy-mode FSM.  It also issues the global->LDS DMA that keeps the ring filled.
+//   waves 3-10 "fetch"  round s+1, one record each: pull every lane's item out of the ring (2-byte granular), hash PLAIN
+//                       quads, stage the operands of the dictionary step {slot address, half, write flag | entry}.
+//   wave 0   "dictionary wave"   round s: nothing but the ordered LDS exchange per record (PLAIN lanes write their entry,
+//                       MAP lanes only read: mask 0) — exactly the sequential chameleon.rs:56-68 semantics — and one
+//                       store of {entry now in the slot} per lane.  It is the critical path, so everything else is elsewhere.
+//   wave 2   "finisher" round s-1: the zero-entry disambiguation (MAP of a never-written slot yields quad 0), in stream
+//                       order; touches the zero-entry map about once per 64 Ki quads.
+//   waves 11-15 "emit"  round s-2: entry -> quad (inverse of the hash product), coalesced 256-byte stores.
 //
 // The pipeline handles whole coded records and whole raw blocks that are followed by more data; everything the reference
 // handles with per-unit checks (the ragged end: codec.rs:102-123) is left to decode_in_order on wave 0 once the
-// pipeline has drained, starting from the parser's final (position, FSM) state.
+// pipeline has drained, starting from the feeder's final (position, FSM) state.
 // ---------------------------------------------------------------------------------------------------------------
 namespace {
 
+constexpr uint32_t kDecWaves = 16;
 constexpr uint32_t kRingBytes = 8192;                        // compressed-byte ring (power of two)
 constexpr uint32_t kRingTiles = kRingBytes / 1024;
-constexpr uint32_t kDescBytes = 128, kDescRing = 4;          // dwords 16..23 record positions, 24 copy mask, 25 count, 26 flags, 27 first ordinal
-constexpr uint32_t kStageRec = 640, kStageRing = 3;          // per record: 64 x {d0, d1} + 64 x u16 answers
-constexpr uint32_t kDRingBase = kLdsBytes;
+constexpr uint32_t kDescBytes = 128, kDescRing = 6;          // dwords 16..23 record positions, 24 copy mask, 25 count, 26 flags, 27 first ordinal
+constexpr uint32_t kStageRec = 512, kStageRing = 4;          // per record: 64 x {d0, d1}; the dictionary wave turns d1 into the slot's entry
+constexpr uint32_t kDRingBase = kTableBytes;                 // no zero-entry map in LDS here (ZmapGlobal)
 constexpr uint32_t kDDescBase = kDRingBase + kRingBytes;
 constexpr uint32_t kDStageBase = kDDescBase + kDescRing * kDescBytes;
-constexpr uint32_t kDHandBase = kDStageBase + kStageRing * kRound * kStageRec;   // parser -> wave 0 hand-over (32 B)
+constexpr uint32_t kDHandBase = kDStageBase + kStageRing * kRound * kStageRec;   // feeder -> wave 0 hand-over (32 B)
 constexpr uint32_t kLdsBytesDec = kDHandBase + 32;
 static_assert(kLdsBytesDec <= 160u * 1024u, "LDS budget");
-constexpr uint32_t kFlagLast = 1u, kFlagPsusp = 2u;
+constexpr uint32_t kFlagLast = 1u;
 constexpr uint32_t kD0Write = 2u, kD0Half = 1u, kD0Empty = 0x80000000u, kD0Addr = 0x1fffcu;
+constexpr uint32_t kFetchWave0 = 3, kEmitWave0 = 11, kNumEmit = kDecWaves - kEmitWave0;
 
 }  // namespace
 
 template <bool kProf>
-__global__ __launch_bounds__(kPipeWaves * 64) void chameleon_decode_chunks_pipe(const uint8_t* __restrict__ in,
-                                                                                const uint64_t* __restrict__ offsets,
-                                                                                const uint64_t* __restrict__ sizes,
-                                                                                uint8_t* __restrict__ out, uint64_t out_stride,
-                                                                                uint64_t out_total, uint32_t exact,
-                                                                                const uint8_t* __restrict__ index,
-                                                                                uint64_t* __restrict__ produced,
-                                                                                uint32_t* __restrict__ err, uint32_t dbg, uint64_t* __restrict__ prof) {
+__global__ __launch_bounds__(kDecWaves * 64) void chameleon_decode_chunks_pipe(const uint8_t* __restrict__ in,
+                                                                               const uint64_t* __restrict__ offsets,
+                                                                               const uint64_t* __restrict__ sizes,
+                                                                               uint8_t* __restrict__ out, uint64_t out_stride,
+                                                                               uint64_t out_total, uint32_t exact,
+                                                                               const uint8_t* __restrict__ index,
+                                                                               uint32_t* __restrict__ zmap_words,
+                                                                               uint64_t* __restrict__ produced,
+                                                                               uint32_t* __restrict__ err, uint32_t dbg, uint64_t* __restrict__ prof) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = rfl(threadIdx.x >> 6);
     const uint64_t chunk = blockIdx.x;
@@ -829,15 +854,19 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_decode_chunks_pipe(
     // the pipeline addresses the stream with 32-bit offsets; longer streams (only possible through the single-stream entry
     // points) are cut off here and finished by the in-order loop
     const uint32_t elen = elen64 > 0xfff00000ull ? 0xfff00000u : (uint32_t)elen64;
+    const ZmapGlobal zmap{zmap_words + chunk * (kZmapBytes / 4)};
+    if (wave == 0) __builtin_amdgcn_s_setprio(3);              // the dictionary wave is the critical path: first pick of issue slots
 
-    {   // clear table + zero-entry map + descriptor ring
+    {   // clear table, descriptor ring and this chunk's zero-entry map
         uint4* p = reinterpret_cast<uint4*>(smem);
         const uint4 z = make_uint4(0, 0, 0, 0);
-        for (uint32_t i = threadIdx.x; i < kLdsBytes / 16; i += kPipeWaves * 64) p[i] = z;
-        for (uint32_t i = threadIdx.x; i < kDescRing * kDescBytes / 16; i += kPipeWaves * 64) reinterpret_cast<uint4*>(smem + kDDescBase)[i] = z;
+        for (uint32_t i = threadIdx.x; i < kTableBytes / 16; i += kDecWaves * 64) p[i] = z;
+        for (uint32_t i = threadIdx.x; i < kDescRing * kDescBytes / 16; i += kDecWaves * 64) reinterpret_cast<uint4*>(smem + kDDescBase)[i] = z;
+        for (uint32_t i = threadIdx.x; i < kZmapBytes / 16; i += kDecWaves * 64) reinterpret_cast<uint4*>(zmap.words)[i] = z;
+        __threadfence();                                      // the map is read back through L2 (ZmapGlobal::test)
     }
     const uint32_t lds0 = lds_addr(smem);
-    const uint32_t tbl = lds0, zmap = lds0 + kTableBytes;
+    const uint32_t tbl = lds0;
     round_barrier();
 
     // parser state (wave 1)
@@ -1004,13 +1033,14 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_decode_chunks_pipe(
         }
     };
 
-    auto fetch_round = [&](uint32_t r) {                      // waves 2..7
-        const uint32_t w = wave - 2;
+    auto fetch_round = [&](uint32_t r) {                      // waves 3..10, one record each
+        const uint32_t w = wave - kFetchWave0;
         const uint32_t dbase = kDDescBase + (r % kDescRing) * kDescBytes;
         const uint32_t sbase = kDStageBase + (r % kStageRing) * kRound * kStageRec;
-        const uint32_t n = rfl(*reinterpret_cast<const uint32_t*>(smem + dbase + 100));
-        const uint32_t copy_mask = rfl(*reinterpret_cast<const uint32_t*>(smem + dbase + 96));
-        for (uint32_t k = w; k < n; k += kPipeWaves - 2) {
+        const uint4 dt = *reinterpret_cast<const uint4*>(smem + dbase + 96);       // {copy mask, count, flags, first ordinal}
+        const uint32_t n = rfl(dt.y), copy_mask = rfl(dt.x);
+        if (rfl(dt.z) & kFlagLast) last_round = r;              // every wave must learn where to stop
+        for (uint32_t k = w; k < n; k += kEmitWave0 - kFetchWave0) {
             const uint32_t pos = rfl(*reinterpret_cast<const uint32_t*>(smem + dbase + 64 + 4u * k));
             uint32_t d0, d1;
             if ((copy_mask >> k) & 1u) {
@@ -1041,10 +1071,9 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_decode_chunks_pipe(
     auto dict_round = [&](uint32_t r) {                       // wave 0
         const uint32_t dbase = kDDescBase + (r % kDescRing) * kDescBytes;
         const uint32_t sbase = kDStageBase + (r % kStageRing) * kRound * kStageRec;
-        const uint32_t n = rfl(*reinterpret_cast<const uint32_t*>(smem + dbase + 100));
-        const uint32_t copy_mask = rfl(*reinterpret_cast<const uint32_t*>(smem + dbase + 96));
-        const uint32_t flags = rfl(*reinterpret_cast<const uint32_t*>(smem + dbase + 104));
-        if (flags & kFlagLast) last_round = r;
+        const uint4 dt = *reinterpret_cast<const uint4*>(smem + dbase + 96);       // {copy mask, count, flags, first ordinal}
+        const uint32_t n = rfl(dt.y), copy_mask = rfl(dt.x);
+        if (rfl(dt.z) & kFlagLast) last_round = r;
         if (n == 0) return;
         uint32_t d0[kRound], d1[kRound], ret[kRound];
 #pragma unroll
@@ -1054,86 +1083,115 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_decode_chunks_pipe(
         }
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d0[0]), "+v"(d0[1]), "+v"(d0[2]), "+v"(d0[3]), "+v"(d0[4]), "+v"(d0[5]), "+v"(d0[6]), "+v"(d0[7]),
                                               "+v"(d1[0]), "+v"(d1[1]), "+v"(d1[2]), "+v"(d1[3]), "+v"(d1[4]), "+v"(d1[5]), "+v"(d1[6]), "+v"(d1[7]) :: "memory");
+        const uint32_t live = ((1u << n) - 1u) & ~copy_mask;      // records that go through the table
 #pragma unroll
         for (uint32_t j = 0; j < kRound; ++j) {
-            if (j < n && !((copy_mask >> j) & 1u)) {
+            if ((live >> j) & 1u) {
                 const uint32_t sh = (d0[j] & kD0Half) << 4;
                 const uint32_t mask = (uint32_t)(((int32_t)(d0[j] << 30) >> 31) & 0xffff) << sh;   // write flag -> 0xffff or 0
                 dict_xchg_issue(tbl + (d0[j] & kD0Addr), mask, d1[j], ret[j]);
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ret[0]), "+v"(ret[1]), "+v"(ret[2]), "+v"(ret[3]), "+v"(ret[4]), "+v"(ret[5]), "+v"(ret[6]), "+v"(ret[7]) :: "memory");
+        // what the slot holds after this lane's turn: its own entry for PLAIN lanes, the entry it read for MAP lanes; the emit
+        // waves take the quad from that uniformly
 #pragma unroll
         for (uint32_t j = 0; j < kRound; ++j) {
-            if (j < n && !((copy_mask >> j) & 1u)) {
-                const uint32_t sh = (d0[j] & kD0Half) << 4;
-                const uint32_t eff = (ret[j] >> sh) & 0xffffu;
-                const bool write = d0[j] & kD0Write;
-                const bool slot0 = (d0[j] & (kD0Addr | kD0Half)) == 0;
-                // zero-entry disambiguation (rare): a MAP lane that read 0 outside slot 0, or a PLAIN lane that wrote 0 there
-                const bool hs = !write && eff == 0 && !slot0;
-                const bool ps = write && ((d1[j] >> sh) & 0xffffu) == 0 && !slot0;
-                if (ballot64(hs || ps)) {
-                    const uint32_t h = ((d0[j] & kD0Addr) >> 1) | (d0[j] & kD0Half);
-                    if (hs || ps) {
-                        uint32_t zr;                          // ordered like the exchange: MAP lanes read, PLAIN lanes set the bit
-                        asm volatile("ds_or_rtn_b32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(zr) : "v"(zmap + (h >> 5) * 4u), "v"(ps ? (1u << (h & 31u)) : 0u) : "memory");
-                        if (hs && !((zr >> (h & 31u)) & 1u)) *reinterpret_cast<uint32_t*>(smem + sbase + j * kStageRec + 8u * lane) = d0[j] | kD0Empty;
-                    }
-                }
-                *reinterpret_cast<uint16_t*>(smem + sbase + j * kStageRec + 512u + 2u * lane) = (uint16_t)eff;
+            if ((live >> j) & 1u) {
+                const uint32_t m = (d0[j] & kD0Write) ? d1[j] : ret[j];
+                *reinterpret_cast<uint32_t*>(smem + sbase + j * kStageRec + 8u * lane + 4u) = m;
             }
         }
     };
 
-    auto emit_round = [&](uint32_t r) {                       // waves 2..7
-        const uint32_t w = wave - 2;
+    // zero-entry disambiguation, in stream order (see the file header; entries are salted, so this fires about once per 64 Ki quads)
+    auto finish_round = [&](uint32_t r) {                     // wave 2
         const uint32_t dbase = kDDescBase + (r % kDescRing) * kDescBytes;
         const uint32_t sbase = kDStageBase + (r % kStageRing) * kRound * kStageRec;
-        const uint32_t n = rfl(*reinterpret_cast<const uint32_t*>(smem + dbase + 100));
-        const uint32_t copy_mask = rfl(*reinterpret_cast<const uint32_t*>(smem + dbase + 96));
-        const uint32_t flags = rfl(*reinterpret_cast<const uint32_t*>(smem + dbase + 104));
-        const uint32_t first = rfl(*reinterpret_cast<const uint32_t*>(smem + dbase + 108));
-        if (flags & kFlagLast) last_round = r;
-        for (uint32_t k = w; k < n; k += kPipeWaves - 2) {
+        const uint4 dt = *reinterpret_cast<const uint4*>(smem + dbase + 96);       // {copy mask, count, flags, first ordinal}
+        const uint32_t n = rfl(dt.y), copy_mask = rfl(dt.x);
+        if (rfl(dt.z) & kFlagLast) last_round = r;
+        if (n == 0) return;
+        // all eight records at once: one LDS round trip, eight ballots; the serial part runs only when a zero entry shows up
+        uint2 v[kRound];
+#pragma unroll
+        for (uint32_t j = 0; j < kRound; ++j) v[j] = *reinterpret_cast<const uint2*>(smem + sbase + j * kStageRec + 8u * lane);
+        const uint32_t live = ((1u << n) - 1u) & ~copy_mask;
+        uint64_t zeros[kRound];
+        uint32_t any = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < kRound; ++j) {
+            const uint32_t sh = (v[j].x & kD0Half) << 4;
+            const bool zero = ((v[j].y >> sh) & 0xffffu) == 0 && (v[j].x & (kD0Addr | kD0Half)) != 0;   // stored entry 0 outside slot 0
+            zeros[j] = ((live >> j) & 1u) ? ballot64(zero) : 0ull;
+            any |= (zeros[j] != 0) ? 1u : 0u;
+        }
+        if (!any) return;
+#pragma unroll
+        for (uint32_t j = 0; j < kRound; ++j) {
+            uint64_t todo = zeros[j];
+            while (todo) {                                        // ascending record, ascending lane == stream order
+                const uint32_t l = (uint32_t)__builtin_ctzll(todo);
+                todo &= todo - 1;
+                const uint32_t x = rlane(v[j].x, l);
+                const uint32_t h = ((x & kD0Addr) >> 1) | (x & kD0Half);
+                if (x & kD0Write) { if (lane == l) zmap.set(h); }  // PLAIN wrote a genuine zero entry
+                else if (!zmap.test(h) && lane == l)              // MAP read a never-written slot: quad 0 (chameleon.rs:64-68 on a zero word)
+                    *reinterpret_cast<uint32_t*>(smem + sbase + j * kStageRec + 8u * lane) = v[j].x | kD0Empty;
+            }
+        }
+    };
+
+    auto emit_round = [&](uint32_t r) {                       // waves 11..15
+        const uint32_t w = wave - kEmitWave0;
+        const uint32_t dbase = kDDescBase + (r % kDescRing) * kDescBytes;
+        const uint32_t sbase = kDStageBase + (r % kStageRing) * kRound * kStageRec;
+        const uint4 dt = *reinterpret_cast<const uint4*>(smem + dbase + 96);       // {copy mask, count, flags, first ordinal}
+        const uint32_t n = rfl(dt.y), copy_mask = rfl(dt.x), first = rfl(dt.w);
+        if (rfl(dt.z) & kFlagLast) last_round = r;
+        for (uint32_t k = w; k < n; k += kNumEmit) {
             const uint2 v = *reinterpret_cast<const uint2*>(smem + sbase + k * kStageRec + 8u * lane);
             uint32_t q;
             if ((copy_mask >> k) & 1u) {
                 q = v.y;
             } else {
-                const uint32_t eff = *reinterpret_cast<const uint16_t*>(smem + sbase + k * kStageRec + 512u + 2u * lane);
                 const uint32_t sh = (v.x & kD0Half) << 4;
-                const uint32_t e16 = (v.x & kD0Write) ? ((v.y >> sh) & 0xffffu) : eff;
                 const uint32_t h = ((v.x & kD0Addr) >> 1) | (v.x & kD0Half);
-                q = (v.x & kD0Empty) ? 0u : entry_to_quad(h, e16);
+                q = (v.x & kD0Empty) ? 0u : entry_to_quad(h, (v.y >> sh) & 0xffffu);
             }
+            if (dbg & 128u) asm volatile("" ::"v"(q)); else
             *reinterpret_cast<uint32_t*>(dst + (uint64_t)(first + k) * kBlock + 4u * lane) = q;
         }
     };
 
     // ---- prologue: fill the pipeline ----
+    const bool is_fetch = wave >= kFetchWave0 && wave < kEmitWave0, is_emit = wave >= kEmitWave0;
     if (wave == 1) { issue_tiles(kRingTiles); parse_round(0); parse_round(1); }
     round_barrier();
-    if (wave >= 2) fetch_round(0);
+    if (is_fetch) fetch_round(0);
     round_barrier();
 
-    // ---- steady state: step s = parse s+2 | fetch s+1 | dictionary s | emit s-1 ----
+    // ---- steady state: step s = feed s+2 | fetch s+1 | dictionary s | finish s-1 | emit s-2 ----
+    // (dbg bits 16/32/64/256 idle the emit/fetch/dictionary/finisher stage for timing experiments; a stage that is idled still
+    // has to learn the last round from the descriptor flags)
+    auto only_flags = [&](uint32_t r) {
+        if (rfl(*reinterpret_cast<const uint32_t*>(smem + kDDescBase + (r % kDescRing) * kDescBytes + 104)) & kFlagLast) last_round = r;
+    };
     for (uint32_t s = 0;; ++s) {
         clk.start();
         if (wave == 1) parse_round(s + 2);
-        else if (wave == 0) { if (!(dbg & 64u)) dict_round(s); else { const uint32_t fl = rfl(*reinterpret_cast<const uint32_t*>(smem + kDDescBase + (s % kDescRing) * kDescBytes + 104)); if (fl & kFlagLast) last_round = s; } }
-        else {
-            if (!(dbg & 32u)) fetch_round(s + 1);
-            if (s >= 1) { if (!(dbg & 16u)) emit_round(s - 1); else { const uint32_t fl = rfl(*reinterpret_cast<const uint32_t*>(smem + kDDescBase + ((s - 1) % kDescRing) * kDescBytes + 104)); if (fl & kFlagLast) last_round = s - 1; } }
-        }
+        else if (wave == 0) { if (!(dbg & 64u)) dict_round(s); else only_flags(s); }
+        else if (wave == 2) { if (s >= 1) { if (!(dbg & 256u)) finish_round(s - 1); else only_flags(s - 1); } }
+        else if (is_fetch) { if (!(dbg & 32u)) fetch_round(s + 1); else only_flags(s + 1); }
+        else if (is_emit && s >= 2) { if (!(dbg & 16u)) emit_round(s - 2); else only_flags(s - 2); }
         clk.work_done();
         round_barrier();
         clk.wait_done();
-        if (last_round != 0xffffffffu && s >= last_round + 1) break;
+        if (last_round != 0xffffffffu && s >= last_round + 2) break;
     }
     clk.flush(wave, lane);
 
-    // hand the parser's final state to wave 0, which finishes the ragged end of the stream in order
+    // hand the feeder's final state to wave 0, which finishes the ragged end of the stream in order
     if (wave == 1 && lane == 0) {
         uint32_t* hand = reinterpret_cast<uint32_t*>(smem + kDHandBase);
         hand[0] = ipos; hand[1] = recs; hand[2] = guard.penalty; hand[3] = guard.start; hand[4] = guard.prev; hand[5] = guard.counter; hand[6] = index_fault ? 1u : 0u;
@@ -1164,18 +1222,18 @@ namespace {
 uint64_t* prof_buffer() {
     static uint64_t* buf = nullptr;
     if (!getenv("DENSITY_HIP_PROF")) return nullptr;
-    if (!buf && hipMalloc((void**)&buf, 24 * sizeof(uint64_t)) != hipSuccess) buf = nullptr;
-    if (buf) (void)hipMemset(buf, 0, 24 * sizeof(uint64_t));
+    if (!buf && hipMalloc((void**)&buf, 40 * sizeof(uint64_t)) != hipSuccess) buf = nullptr;
+    if (buf) (void)hipMemset(buf, 0, 40 * sizeof(uint64_t));
     return buf;
 }
 void prof_report(const char* what, uint64_t* buf, hipStream_t stream) {
     if (!buf) return;
-    uint64_t h[24];
+    uint64_t h[40];
     if (hipStreamSynchronize(stream) != hipSuccess || hipMemcpy(h, buf, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return;
     fprintf(stderr, "[density_hip prof] %s work-group 0: ", what);
-    for (int w = 0; w < 8; ++w) fprintf(stderr, "w%d work %llu wait %llu | ", w, (unsigned long long)h[2 * w], (unsigned long long)h[2 * w + 1]);
+    for (int w = 0; w < 16; ++w) if (h[2 * w] | h[2 * w + 1]) fprintf(stderr, "w%d %lluk/%lluk | ", w, (unsigned long long)h[2 * w] / 1000, (unsigned long long)h[2 * w + 1] / 1000);
     fprintf(stderr, "\n[density_hip prof] %s wave-0 phases:", what);
-    for (int k = 0; k < 8; ++k) fprintf(stderr, " p%d %llu", k, (unsigned long long)h[16 + k]);
+    for (int k = 0; k < 8; ++k) fprintf(stderr, " p%d %llu", k, (unsigned long long)h[32 + k]);
     fprintf(stderr, "\n");
 }
 }  // namespace
@@ -1202,20 +1260,20 @@ hipError_t launch_chameleon_encode(const uint8_t* d_in, uint64_t total, uint64_t
 
 hipError_t launch_chameleon_decode(const uint8_t* d_in, const uint64_t* d_offsets, const uint64_t* d_sizes,
                                    uint32_t n_chunks, uint8_t* d_out, uint64_t out_stride, uint64_t out_total,
-                                   bool exact, const uint8_t* d_index, uint64_t* d_produced, uint32_t* d_err, hipStream_t stream) {
+                                   bool exact, const uint8_t* d_index, uint32_t* d_zmap, uint64_t* d_produced, uint32_t* d_err, hipStream_t stream) {
     hipError_t e = hipFuncSetAttribute((const void*)chameleon_decode_chunks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
     if (e != hipSuccess) return e;
     if (n_chunks == 0) return hipSuccess;
     // the pipelined kernel stages the stream with 16-byte LDS-DMA pieces (container payloads are 16-byte aligned) and stores
     // quads with aligned dwords
     const bool aligned = ((uintptr_t)d_in % 16 == 0) && ((uintptr_t)d_out % 4 == 0) && (n_chunks == 1 || out_stride % 4 == 0);
-    if (aligned && !g_force_simple) {
+    if (aligned && !g_force_simple && d_zmap && n_chunks <= kMaxPipelinedChunks) {
         uint64_t* prof = prof_buffer();
         auto kernel = prof ? chameleon_decode_chunks_pipe<true> : chameleon_decode_chunks_pipe<false>;
         e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytesDec);
         if (e != hipSuccess) return e;
         const uint32_t dbg = getenv("DENSITY_HIP_DBG") ? (uint32_t)atoi(getenv("DENSITY_HIP_DBG")) : 0u;
-        hipLaunchKernelGGL(kernel, dim3(n_chunks), dim3(kPipeWaves * 64), kLdsBytesDec, stream, d_in, d_offsets, d_sizes, d_out, out_stride, out_total, exact ? 1u : 0u, d_index, d_produced, d_err, dbg, prof);
+        hipLaunchKernelGGL(kernel, dim3(n_chunks), dim3(kDecWaves * 64), kLdsBytesDec, stream, d_in, d_offsets, d_sizes, d_out, out_stride, out_total, exact ? 1u : 0u, d_index, d_zmap, d_produced, d_err, dbg, prof);
         prof_report("decode", prof, stream);
     } else {
         hipLaunchKernelGGL(chameleon_decode_chunks, dim3(n_chunks), dim3(64), kLdsBytes, stream, d_in, d_offsets, d_sizes, d_out, out_stride, out_total, exact ? 1u : 0u, d_produced, d_err);

@@ -18,7 +18,10 @@ hipError_t launch_chameleon_encode(const uint8_t* d_in, uint64_t total, uint64_t
 // that does not produce exactly min(out_stride, out_total - c*out_stride) bytes raises *d_err.
 hipError_t launch_chameleon_decode(const uint8_t* d_in, const uint64_t* d_offsets, const uint64_t* d_sizes,
                                    uint32_t n_chunks, uint8_t* d_out, uint64_t out_stride, uint64_t out_total,
-                                   bool exact, const uint8_t* d_index, uint64_t* d_produced, uint32_t* d_err, hipStream_t stream);
+                                   bool exact, const uint8_t* d_index, uint32_t* d_zmap, uint64_t* d_produced, uint32_t* d_err, hipStream_t stream);
+// the pipelined decoder keeps its zero-entry map in global memory: kZmapWordsPerChunk u32 per chunk, for at most
+// kMaxPipelinedChunks chunks (more chunks than that, i.e. tiny chunks, run on the one-wavefront kernel)
+constexpr uint32_t kZmapWordsPerChunk = 2048, kMaxPipelinedChunks = 16384;
 
 // ---- serial_codec.hip (Cheetah, Lion: functional one-lane-per-stream kernels, tables in global memory) ----
 uint64_t serial_table_bytes(int algo);
