@@ -284,8 +284,14 @@ constexpr uint32_t kAhead = kInRing - 2;                     // DMA runs this ma
 constexpr uint32_t kInBase = kLdsBytes;                      // 139264, 16-byte aligned
 constexpr uint32_t kResBase = kInBase + kInRing * kRoundBytes;
 constexpr uint32_t kResBytes = 128;                          // dwords 0..15 signatures, 16 copy mask
-constexpr uint32_t kLdsBytesPipe = kResBase + kResRing * kResBytes;
-constexpr uint32_t kPipeWaves = 8, kEmitWaves = kPipeWaves - 2;     // wave 0 dictionary, waves 1..6 emit, wave 7 loader
+constexpr uint32_t kOpBase = kResBase + kResRing * kResBytes;    // operand ring: per block 64 x {slot dword address | half, entry << 16*half}
+constexpr uint32_t kOpRec = 512, kOpRing = 2;
+constexpr uint32_t kOpRoundBytes = kRound * kOpRec;
+constexpr uint32_t kZeroFlagBase = kOpBase + kOpRing * kOpRoundBytes;   // 4 dwords: bit k of word r % 4 = block k of round r holds a zero entry
+constexpr uint32_t kLdsBytesPipe = kZeroFlagBase + 16;               // (set while hashing at step r-1, read at r, cleared at r+1)
+constexpr uint32_t kEncHalf = 1u, kEncAddr = 0x1fffcu;       // operand dword 0
+constexpr uint32_t kPipeWaves = 16;                          // wave 0 dictionary, waves 1..8 hash, waves 7..14 emit, wave 15 loader
+constexpr uint32_t kHashWave0 = 1, kEmitWaveE0 = 7;          // hash wave w takes block w - 1, emit wave w block w - 7 (waves 7, 8 do both)
 static_assert(kLdsBytesPipe <= 160u * 1024u, "LDS budget");
 static_assert(kRound == 8, "register arrays, asm operand lists and the result record are written for 8 blocks per round");
 
@@ -372,7 +378,7 @@ struct WaveClock<true> {
 
 // per-block state of the dictionary wave between issue and finish
 struct Issued {
-    uint32_t q, key, sh, ret;     // key = (P & ~1) | (q >> 31): slot index in the high half, 16-bit entry in the low half
+    uint32_t d0, d1, ret;         // operands staged by the worker waves (slot dword address | half, entry << 16*half), dictionary answer
 };
 
 }  // namespace
@@ -425,23 +431,35 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
     }
     round_barrier();
 
+    // ---------------- worker waves 1..6: hash round r into the operand ring (one round ahead of the dictionary wave) --------
+    auto hash_round = [&](uint64_t r) {
+        if (r >= nrounds) return;
+        const uint32_t qbase = kInBase + (uint32_t)(r % kInRing) * kRoundBytes;
+        const uint32_t obase = kOpBase + (uint32_t)(r % kOpRing) * kOpRoundBytes;
+        const uint64_t b0 = r * kRound;
+        const uint32_t nb = (nfull - b0) < kRound ? (uint32_t)(nfull - b0) : kRound;
+        for (uint32_t k = wave - kHashWave0; k < nb; k += kRound) {
+            const uint32_t q = *reinterpret_cast<const uint32_t*>(smem + qbase + kBlock * k + 4u * lane);
+            const uint32_t P = q * kHashMul;
+            const uint32_t h = P >> 16;
+            const uint32_t e = stored_entry(q, P);
+            *reinterpret_cast<uint2*>(smem + obase + k * kOpRec + 8u * lane) = make_uint2(((h >> 1) << 2) | (h & 1u), e << ((h & 1u) << 4));
+            // a stored entry of 0 outside slot 0 aliases "never written": tell the dictionary wave to take the careful path
+            if (ballot64(e == 0 && h != 0) && lane == 0) atomicOr(reinterpret_cast<uint32_t*>(smem + kZeroFlagBase + 4u * (uint32_t)(r & 3u)), 1u << k);
+        }
+    };
+
     // ---------------- dictionary wave state ----------------
     Guard guard;
-    uint32_t qn[kRound];                                      // quads of the NEXT round, fetched one step ahead
-    auto prefetch_quads = [&](uint64_t r) {
-        const uint32_t a = lds0 + kInBase + (uint32_t)(r % kInRing) * kRoundBytes + 4u * lane;
-        asm volatile("ds_read_b32 %0, %8\n\tds_read_b32 %1, %8 offset:256\n\tds_read_b32 %2, %8 offset:512\n\tds_read_b32 %3, %8 offset:768\n\t"
-                     "ds_read_b32 %4, %8 offset:1024\n\tds_read_b32 %5, %8 offset:1280\n\tds_read_b32 %6, %8 offset:1536\n\tds_read_b32 %7, %8 offset:1792"
-                     : "=&v"(qn[0]), "=&v"(qn[1]), "=&v"(qn[2]), "=&v"(qn[3]), "=&v"(qn[4]), "=&v"(qn[5]), "=&v"(qn[6]), "=&v"(qn[7])
-                     : "v"(a) : "memory");
-    };
-    auto quads_ready = [&]() {
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qn[0]), "+v"(qn[1]), "+v"(qn[2]), "+v"(qn[3]), "+v"(qn[4]), "+v"(qn[5]), "+v"(qn[6]), "+v"(qn[7]) :: "memory");
-    };
-    if (wave == 0 && nrounds) prefetch_quads(0);
 
-    // ---------------- emit wave state ----------------
-    uint64_t opos_run = 0;                                    // output offset of the round being emitted (every emit wave tracks it)
+    // ---------------- emit state ----------------
+    uint64_t opos_run = 0;                                    // output offset of the round being emitted (every worker tracks it)
+
+    if (wave == 1 && lane < 4) *reinterpret_cast<uint32_t*>(smem + kZeroFlagBase + 4u * lane) = 0;
+    round_barrier();
+    const bool is_hash = wave >= kHashWave0 && wave < kHashWave0 + kRound, is_emit = wave >= kEmitWaveE0 && wave < kEmitWaveE0 + kRound;
+    if (is_hash) hash_round(0);
+    round_barrier();
 
     for (uint64_t t = 0; t <= nrounds; ++t) {
         clk.start();
@@ -454,24 +472,24 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
             // ---------------- dictionary wave: round t ----------------
             if (t < nrounds) {
                 clk.phase_start();
-                const uint32_t qbase = kInBase + (uint32_t)(t % kInRing) * kRoundBytes;
+                const uint32_t obase = kOpBase + (uint32_t)(t % kOpRing) * kOpRoundBytes;
                 const uint32_t rbase = kResBase + (uint32_t)(t % kResRing) * kResBytes;
                 const uint64_t b0 = t * kRound;
                 const uint32_t nb = (nfull - b0) < kRound ? (uint32_t)(nfull - b0) : kRound;
-
-                uint32_t rec = 0;                                 // lane i holds dword i of the round's result record
                 uint32_t copy_mask = 0;
+                uint64_t sig[kRound];
+#pragma unroll
+                for (uint32_t j = 0; j < kRound; ++j) sig[j] = 0;
 
                 auto issue = [&](Issued& b) {
-                    const uint32_t P = b.q * kHashMul;
-                    b.key = (P & 0xffff0000u) | stored_entry(b.q, P);
-                    b.sh = (P >> 12) & 16u;
-                    dict_xchg_issue(tbl + ((P >> 15) & 0x1fffcu), 0xffffu << b.sh, (b.key & 0xffffu) << b.sh, b.ret);
+                    const uint32_t sh = (b.d0 & kEncHalf) << 4;
+                    dict_xchg_issue(tbl + (b.d0 & kEncAddr), 0xffffu << sh, b.d1, b.ret);
                 };
                 // signature of a block from the dictionary answers, including the zero-entry disambiguation (rare path)
                 auto signature = [&](const Issued& b) -> uint64_t {
-                    const uint32_t e = b.key & 0xffffu, h = b.key >> 16;
-                    const uint32_t old = (b.ret >> b.sh) & 0xffffu;
+                    const uint32_t sh = (b.d0 & kEncHalf) << 4;
+                    const uint32_t e = (b.d1 >> sh) & 0xffffu, h = ((b.d0 & kEncAddr) >> 1) | (b.d0 & kEncHalf);
+                    const uint32_t old = (b.ret >> sh) & 0xffffu;
                     const bool susp = e == 0 && h != 0;
                     uint32_t zbit = 1;
                     if (ballot64(susp)) {
@@ -482,8 +500,9 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
                 // undo a speculatively applied block: the lowest lane of a slot holds the pre-block entry, so the lanes
                 // write their answers back in descending order
                 auto rollback = [&](const Issued& b) {
-                    const uint32_t a16 = tbl + 2u * (b.key >> 16);
-                    const uint32_t prev = (b.ret >> b.sh) & 0xffffu;
+                    const uint32_t sh = (b.d0 & kEncHalf) << 4;
+                    const uint32_t a16 = tbl + (b.d0 & kEncAddr) + ((b.d0 & kEncHalf) << 1);
+                    const uint32_t prev = (b.ret >> sh) & 0xffffu;
 #pragma nounroll
                     for (int l = 63; l >= 0; --l) {
                         if (lane == (uint32_t)l) dict_store(a16, prev);
@@ -491,25 +510,25 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
                 };
 
                 Issued blk[kRound];
-                quads_ready();
 #pragma unroll
-                for (uint32_t j = 0; j < kRound; ++j) blk[j].q = qn[j];
-                if (t + 1 < nrounds) prefetch_quads(t + 1);       // older than this round's exchanges in the LDS queue
+                for (uint32_t j = 0; j < kRound; ++j) {
+                    const uint2 v = *reinterpret_cast<const uint2*>(smem + obase + j * kOpRec + 8u * lane);
+                    blk[j].d0 = v.x; blk[j].d1 = v.y; blk[j].ret = 0;
+                }
+                const uint32_t zero_blocks = rfl(*reinterpret_cast<const uint32_t*>(smem + kZeroFlagBase + 4u * (uint32_t)(t & 3u)));
+                // all operands in registers before the first exchange is issued, so no compiler-inserted lgkmcnt wait (which cannot
+                // see the asm exchanges and would drain them) lands between the exchanges
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(blk[0].d0), "+v"(blk[1].d0), "+v"(blk[2].d0), "+v"(blk[3].d0), "+v"(blk[4].d0), "+v"(blk[5].d0), "+v"(blk[6].d0), "+v"(blk[7].d0),
+                                                      "+v"(blk[0].d1), "+v"(blk[1].d1), "+v"(blk[2].d1), "+v"(blk[3].d1), "+v"(blk[4].d1), "+v"(blk[5].d1), "+v"(blk[6].d1), "+v"(blk[7].d1) :: "memory");
                 clk.phase(1);
 
                 uint32_t k = 0;
                 bool pending_copy = false;                        // guard already advanced for block k and said "copy"
                 if (nb == kRound && guard.penalty == 0) {
-                    uint32_t low_min = 0xffffu;
 #pragma unroll
-                    for (uint32_t j = 0; j < kRound; ++j) {
-                        issue(blk[j]);
-                        const uint32_t e = blk[j].key & 0xffffu;
-                        low_min = e < low_min ? e : low_min;
-                    }
-                    uint64_t sig[kRound];
+                    for (uint32_t j = 0; j < kRound; ++j) issue(blk[j]);
                     uint32_t min_hits = 64;
-                    const bool plain_round = ballot64(low_min == 0) == 0;
+                    const bool plain_round = zero_blocks == 0;
                     clk.phase(2);
                     if (plain_round) {
                         // common case: no quad of this round packs to entry 0, a hit is simply "answer == entry"; computing the
@@ -517,11 +536,10 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
 #pragma unroll
                         for (uint32_t j = 0; j < kRound; ++j) {
                             lds_wait_keep_n(blk[j].ret, kRound - 1 - j);          // later exchanges stay in flight
-                            sig[j] = ballot64(((blk[j].ret >> blk[j].sh) & 0xffffu) == (blk[j].key & 0xffffu));
+                            const uint32_t sh = (blk[j].d0 & kEncHalf) << 4;
+                            sig[j] = ballot64((((blk[j].ret ^ blk[j].d1) >> sh) & 0xffffu) == 0);
                             const uint32_t nh = (uint32_t)__builtin_popcountll(sig[j]);
                             min_hits = nh < min_hits ? nh : min_hits;
-                            rec = wlane(rec, (uint32_t)sig[j], 2 * j);
-                            rec = wlane(rec, (uint32_t)(sig[j] >> 32), 2 * j + 1);
                         }
                     } else {
                         lds_wait_all();
@@ -545,11 +563,7 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
                                 if (guard.block_is_copy()) {
                                     pending_copy = true;
                                 } else {
-                                    if (!plain_round) {
-                                        sig[j] = signature(blk[j]);
-                                        rec = wlane(rec, (uint32_t)sig[j], 2 * j);
-                                        rec = wlane(rec, (uint32_t)(sig[j] >> 32), 2 * j + 1);
-                                    }
+                                    if (!plain_round) sig[j] = signature(blk[j]);
                                     guard.update((uint32_t)__builtin_popcountll(sig[j]) <= 4);
                                     k = j + 1;
                                 }
@@ -559,70 +573,82 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
                             lds_wait_all();
 #pragma unroll
                             for (int j = (int)kRound - 1; j >= 0; --j) {
-                                if ((uint32_t)j >= k) rollback(blk[j]);
+                                if ((uint32_t)j >= k) { rollback(blk[j]); sig[j] = 0; }
                             }
                             lds_wait_all();
                         }
                     }
                 }
-                for (; k < nb; ++k) {                             // in-order path: copy runs, the blocks after a mis-speculation, short rounds
-                    const bool cp = pending_copy ? true : guard.block_is_copy();
-                    pending_copy = false;
-                    uint64_t sg = 0;
-                    if (cp) {                                     // codec.rs:35-37
-                        copy_mask |= 1u << k;
-                        guard.decay();
-                    } else {
-                        Issued b;
-                        b.q = *reinterpret_cast<const uint32_t*>(smem + qbase + kBlock * k + 4u * lane);
-                        issue(b);
-                        lds_wait_all();
-                        sg = signature(b);
-                        guard.update((uint32_t)__builtin_popcountll(sg) <= 4);   // codec.rs:68
+                if (k < nb) {                                     // in-order path: copy runs, the blocks after a mis-speculation, short rounds
+#pragma unroll
+                for (uint32_t j = 0; j < kRound; ++j) {
+                    if (j >= k && j < nb) {
+                        const bool cp = pending_copy ? true : guard.block_is_copy();
+                        pending_copy = false;
+                        if (cp) {                                 // codec.rs:35-37
+                            copy_mask |= 1u << j;
+                            guard.decay();
+                        } else {
+                            issue(blk[j]);
+                            lds_wait_all();
+                            sig[j] = signature(blk[j]);
+                            guard.update((uint32_t)__builtin_popcountll(sig[j]) <= 4);   // codec.rs:68
+                        }
                     }
-                    rec = wlane_dyn(rec, (uint32_t)sg, 2 * k, lane);
-                    rec = wlane_dyn(rec, (uint32_t)(sg >> 32), 2 * k + 1, lane);
                 }
-                rec = wlane_dyn(rec, copy_mask, 16, lane);
-                if (lane < 17) *reinterpret_cast<uint32_t*>(smem + rbase + 4u * lane) = rec;
+                }
+                // publish: 8 signatures + the copy mask (lane 0, plain stores; the values are wave-uniform)
+                if (lane == 0) {
+                    uint4* rp = reinterpret_cast<uint4*>(smem + rbase);
+                    rp[0] = make_uint4((uint32_t)sig[0], (uint32_t)(sig[0] >> 32), (uint32_t)sig[1], (uint32_t)(sig[1] >> 32));
+                    rp[1] = make_uint4((uint32_t)sig[2], (uint32_t)(sig[2] >> 32), (uint32_t)sig[3], (uint32_t)(sig[3] >> 32));
+                    rp[2] = make_uint4((uint32_t)sig[4], (uint32_t)(sig[4] >> 32), (uint32_t)sig[5], (uint32_t)(sig[5] >> 32));
+                    rp[3] = make_uint4((uint32_t)sig[6], (uint32_t)(sig[6] >> 32), (uint32_t)sig[7], (uint32_t)(sig[7] >> 32));
+                    *reinterpret_cast<uint32_t*>(smem + rbase + 64) = copy_mask;
+                }
                 clk.phase(4);
             }
-        } else if (t >= 1 && !(dbg & 2u)) {
-            // ---------------- emit waves 1..6: round t-1 ----------------
-            const uint64_t r = t - 1;
-            const uint32_t qbase = kInBase + (uint32_t)(r % kInRing) * kRoundBytes;
-            const uint32_t rbase = kResBase + (uint32_t)(r % kResRing) * kResBytes;
-            const uint64_t b0 = r * kRound;
-            const uint32_t nb = (nfull - b0) < kRound ? (uint32_t)(nfull - b0) : kRound;
-            // lanes 0..7: signature and record length of block `lane`; prefix over the round = record offsets
-            const uint32_t sl = lane & 7u;
-            const uint32_t slo = *reinterpret_cast<const uint32_t*>(smem + rbase + 8u * sl);
-            const uint32_t shi = *reinterpret_cast<const uint32_t*>(smem + rbase + 8u * sl + 4);
-            const uint32_t cmask = rfl(*reinterpret_cast<const uint32_t*>(smem + rbase + 64));
-            const uint32_t myhits = (uint32_t)(__builtin_popcount(slo) + __builtin_popcount(shi));
-            const uint32_t mylen = lane < nb ? (((cmask >> sl) & 1u) ? kBlock : (kSig + kBlock - 2u * myhits)) : 0u;
-            uint32_t incl = mylen;
-            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xf, 0xf, true);   // row_shr:1
-            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xf, 0xf, true);   // row_shr:2
-            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xf, 0xf, true);   // row_shr:4
-            if (idx && wave == 1 && lane < nb) idx[b0 + lane] = (uint8_t)(((cmask >> sl) & 1u) ? kIdxCopy : myhits);
-            for (uint32_t k = wave - 1; k < nb; k += kEmitWaves) {
-                const uint32_t before = rlane(incl - mylen, k);
-                const uint64_t sig = (uint64_t)rlane(slo, k) | ((uint64_t)rlane(shi, k) << 32);
-                uint8_t* recp = dst + opos_run + before;
-                const uint32_t q = *reinterpret_cast<const uint32_t*>(smem + qbase + kBlock * k + 4u * lane);
-                if (dbg & 8u) {
-                    asm volatile("" ::"v"(q), "v"(recp));
-                } else if ((cmask >> k) & 1u) {
-                    st32u(recp + 4u * lane, q);
-                } else {
-                    const bool hit = (sig >> lane) & 1ull;
-                    const uint32_t off = kSig + 4u * lane - 2u * mbcnt64(sig);
-                    if (lane == 0) { st32u(recp, (uint32_t)sig); st32u(recp + 4, (uint32_t)(sig >> 32)); }
-                    if (hit) st16u(recp + off, (q * kHashMul) >> 16); else st32u(recp + off, q);
+        } else {
+            // ---------------- worker waves 1..6: hash round t+1, emit round t-1 ----------------
+            // round t-1's zero-entry flags were read by the dictionary wave during the previous step; the word is next used for round t+3
+            if (t >= 1 && wave == 1 && lane == 0) *reinterpret_cast<uint32_t*>(smem + kZeroFlagBase + 4u * (uint32_t)((t - 1) & 3u)) = 0;
+            if (is_emit && t >= 1 && !(dbg & 2u)) {
+                const uint64_t r = t - 1;
+                const uint32_t qbase = kInBase + (uint32_t)(r % kInRing) * kRoundBytes;
+                const uint32_t rbase = kResBase + (uint32_t)(r % kResRing) * kResBytes;
+                const uint64_t b0 = r * kRound;
+                const uint32_t nb = (nfull - b0) < kRound ? (uint32_t)(nfull - b0) : kRound;
+                // lanes 0..7: signature and record length of block `lane`; prefix over the round = record offsets
+                const uint32_t sl = lane & 7u;
+                const uint32_t slo = *reinterpret_cast<const uint32_t*>(smem + rbase + 8u * sl);
+                const uint32_t shi = *reinterpret_cast<const uint32_t*>(smem + rbase + 8u * sl + 4);
+                const uint32_t cmask = rfl(*reinterpret_cast<const uint32_t*>(smem + rbase + 64));
+                const uint32_t myhits = (uint32_t)(__builtin_popcount(slo) + __builtin_popcount(shi));
+                const uint32_t mylen = lane < nb ? (((cmask >> sl) & 1u) ? kBlock : (kSig + kBlock - 2u * myhits)) : 0u;
+                uint32_t incl = mylen;
+                incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xf, 0xf, true);   // row_shr:1
+                incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xf, 0xf, true);   // row_shr:2
+                incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xf, 0xf, true);   // row_shr:4
+                if (idx && wave == kEmitWaveE0 && lane < nb) idx[b0 + lane] = (uint8_t)(((cmask >> sl) & 1u) ? kIdxCopy : myhits);
+                for (uint32_t k = wave - kEmitWaveE0; k < nb; k += kRound) {
+                    const uint32_t before = rlane(incl - mylen, k);
+                    const uint64_t sg = (uint64_t)rlane(slo, k) | ((uint64_t)rlane(shi, k) << 32);
+                    uint8_t* recp = dst + opos_run + before;
+                    const uint32_t q = *reinterpret_cast<const uint32_t*>(smem + qbase + kBlock * k + 4u * lane);
+                    if (dbg & 8u) {
+                        asm volatile("" ::"v"(q), "v"(recp));
+                    } else if ((cmask >> k) & 1u) {
+                        st32u(recp + 4u * lane, q);
+                    } else {
+                        const bool hit = (sg >> lane) & 1ull;
+                        const uint32_t off = kSig + 4u * lane - 2u * mbcnt64(sg);
+                        if (lane == 0) { st32u(recp, (uint32_t)sg); st32u(recp + 4, (uint32_t)(sg >> 32)); }
+                        if (hit) st16u(recp + off, (q * kHashMul) >> 16); else st32u(recp + off, q);
+                    }
                 }
+                opos_run += rlane(incl, 7);
             }
-            opos_run += rlane(incl, 7);
+            if (is_hash) hash_round(t + 1);
         }
         clk.work_done();
         round_barrier();
@@ -632,7 +658,7 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
     if (wave == 0) clk.flush_phases(lane);
 
     // hand the stream length so far to the dictionary wave, which finishes a ragged last block with the scalar-path code
-    if (wave == 1 && lane == 0) *reinterpret_cast<uint64_t*>(smem + kResBase) = opos_run;
+    if (wave == kEmitWaveE0 && lane == 0) *reinterpret_cast<uint64_t*>(smem + kResBase) = opos_run;
     round_barrier();
     if (wave == 0) {
         uint64_t opos = *reinterpret_cast<const uint64_t*>(smem + kResBase);
