@@ -849,7 +849,8 @@ constexpr uint32_t kDRingBase = kTableBytes;                 // no zero-entry ma
 constexpr uint32_t kDDescBase = kDRingBase + kRingBytes;
 constexpr uint32_t kDStageBase = kDDescBase + kDescRing * kDescBytes;
 constexpr uint32_t kDHandBase = kDStageBase + kStageRing * kRound * kStageRec;   // feeder -> wave 0 hand-over (32 B)
-constexpr uint32_t kLdsBytesDec = kDHandBase + 32;
+constexpr uint32_t kDIdxBase = kDHandBase + 32;              // block-index staging: 512 entries (two LDS-DMA pieces of 256)
+constexpr uint32_t kLdsBytesDec = kDIdxBase + 512;
 static_assert(kLdsBytesDec <= 160u * 1024u, "LDS budget");
 constexpr uint32_t kFlagLast = 1u;
 constexpr uint32_t kD0Write = 2u, kD0Half = 1u, kD0Empty = 0x80000000u, kD0Addr = 0x1fffcu;
@@ -901,12 +902,6 @@ __global__ __launch_bounds__(kDecWaves * 64) void chameleon_decode_chunks_pipe(c
     uint32_t tiles = 0;                       // DMA tiles issued
     uint32_t keep = 0;                        // start of the round parsed by the previous parse_round call
     uint32_t idle = 0;                        // consecutive rounds without progress (watchdog)
-    // block index window (wave 1): lane l of idx_cur holds the entry of record idx_base + l, idx_next the 64 entries after those
-    auto load_index = [&](uint32_t first) -> uint32_t {
-        return (idx && (uint64_t)(first + lane) * kBlock < cap) ? (uint32_t)idx[first + lane] : kIdxRagged;
-    };
-    uint32_t idx_base = 0, idx_cur = kIdxRagged, idx_next = kIdxRagged;
-    if (wave == 1) { idx_cur = load_index(0); idx_next = load_index(64); }
     bool parse_done = false, index_fault = false;
     uint32_t last_round = 0xffffffffu;        // every wave learns it from the descriptor flags
 
@@ -935,50 +930,13 @@ __global__ __launch_bounds__(kDecWaves * 64) void chameleon_decode_chunks_pipe(c
     auto parse_round = [&](uint32_t r) {                      // wave 1
         // the record walker reads the stream here, so everything issued so far must have landed; the indexed feeder reads
         // nothing and waits at the end of the call, only for the tiles the next fetch needs
-        if (!idx) wait_vm<0>();
+        wait_vm<0>();
         const uint32_t landed = tiles * 1024u < elen ? tiles * 1024u : elen;
         const uint32_t dbase = kDDescBase + (r % kDescRing) * kDescBytes;
         const uint32_t round_start = ipos, recs_before = recs;
         uint32_t rec = 0, copy_mask = 0, n = 0;
         constexpr uint32_t kMaxRound = kRound * (kSig + kBlock);
-        if (idx) {
-            // Indexed container: the block index says where every record starts and which blocks are raw copies, so there is
-            // no record chain to walk, no FSM to run and no stream byte to read here (include/density_hip.h).
-            const uint32_t nblocks_out = (uint32_t)((cap + kBlock - 1) / kBlock);
-            if (recs + kRound > idx_base + 64) {
-                // slide the 64-entry window so that it starts at `recs`: entries still in idx_cur, then the prefetched idx_next
-                const uint32_t shift = recs - idx_base;            // 57..64
-                const uint32_t from_cur = bperm((lane + shift) & 63u, idx_cur), from_next = bperm((lane + shift) & 63u, idx_next);
-                idx_cur = (lane + shift < 64) ? from_cur : from_next;
-                idx_base = recs;
-                idx_next = load_index(idx_base + 64);              // used at the next slide, >= 7 rounds from now
-            }
-            if (!parse_done) {
-                // lanes 0..7 work on this round's eight entries in parallel: record length, exclusive prefix = position, first
-                // entry that ends the pipelined part
-                const uint32_t ent = bperm((lane + recs - idx_base) & 63u, idx_cur);
-                const bool is_copy = (ent & kIdxCopy) != 0;
-                const uint32_t mylen = lane < kRound ? (is_copy ? kBlock : (kSig + kBlock - 2u * (ent & 0x7fu))) : 0u;
-                uint32_t incl = mylen;
-                incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xf, 0xf, true);   // row_shr:1
-                incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xf, 0xf, true);   // row_shr:2
-                incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xf, 0xf, true);   // row_shr:4
-                const uint32_t pos = ipos + incl - mylen;
-                // ragged last block, last block of the chunk, or an index that disagrees with the stream length: the in-order
-                // loop finishes from there, told whether its (single) block is a raw copy
-                const bool stop = lane < kRound && ((ent & 0x7fu) == kIdxRagged || recs + lane >= nblocks_out || elen - pos <= mylen || pos >= elen);
-                const uint32_t stopm = (uint32_t)ballot64(stop);
-                n = stopm ? (uint32_t)__builtin_ctz(stopm) : kRound;
-                copy_mask = (uint32_t)ballot64(is_copy && lane < n);
-                if (lane < n) *reinterpret_cast<uint32_t*>(smem + dbase + 64 + 4u * lane) = pos;
-                if (n < kRound) {
-                    parse_done = true;
-                    guard.penalty = (rlane(ent, n) & kIdxCopy) ? 1u : 0u; guard.start = 1; guard.prev = 0; guard.counter = 1;
-                }
-                ipos = n ? rlane(pos + mylen, n - 1) : ipos;
-                recs += n;
-            }
-        } else if (!parse_done && guard.penalty == 0 && !guard.prev && ipos + kMaxRound <= landed && elen - ipos > kMaxRound &&
+        if (!parse_done && guard.penalty == 0 && !guard.prev && ipos + kMaxRound <= landed && elen - ipos > kMaxRound &&
             ((uint64_t)recs + kRound) * kBlock <= cap) {
             // Fast round: eight coded records are certainly staged, complete and followed by more data, so the per-record work
             // is just the chain  signature -> popcount -> next position.  The FSM is advanced once per round unless a record
@@ -1002,7 +960,7 @@ __global__ __launch_bounds__(kDecWaves * 64) void chameleon_decode_chunks_pipe(c
             }
             // else: nothing committed; reparse the round record by record with the full FSM
         }
-        while (!idx && n < kRound && !parse_done) {
+        while (n < kRound && !parse_done) {
             const uint32_t rem = elen - ipos;
             if ((uint64_t)recs * kBlock + kBlock > cap) { parse_done = true; break; }   // the in-order loop reports the overflow
             if (guard.penalty > 0) {                          // raw block; the last one of a stream is left to the in-order loop
@@ -1030,32 +988,96 @@ __global__ __launch_bounds__(kDecWaves * 64) void chameleon_decode_chunks_pipe(c
         // watchdog: the ring always has room for the next round, so an empty round means the DMA has not
         // landed yet; after a few of them give the rest of the stream to the in-order loop rather than spin
         idle = (n == 0 && !parse_done) ? idle + 1 : 0;
-        if (idle >= 8) { parse_done = true; index_fault = idx != nullptr; }   // without the FSM the in-order loop cannot take over mid-stream
+        if (idle >= 8) parse_done = true;
         if (parse_done && last_round == 0xffffffffu) last_round = r;
         rec = wlane_dyn(rec, copy_mask, 24, lane);
         rec = wlane_dyn(rec, n, 25, lane);
         rec = wlane_dyn(rec, (last_round == r) ? kFlagLast : 0u, 26, lane);
         rec = wlane_dyn(rec, recs_before, 27, lane);
-        if (lane >= (idx ? 24u : 16u) && lane < 28) *reinterpret_cast<uint32_t*>(smem + dbase + 4u * lane) = rec;
+        if (lane >= 16 && lane < 28) *reinterpret_cast<uint32_t*>(smem + dbase + 4u * lane) = rec;
         // Refill.  While these tiles land, the fetch waves read the round parsed by the PREVIOUS call (it starts at `keep`),
         // so tile i may only replace tile i-8 if that one ends at or before `keep`.
         issue_tiles(keep / 1024u + kRingTiles);
         keep = round_start;
-        if (idx) {
-            // The fetch waves read this round's bytes [round_start, ipos) during the next step.  Tiles retire in order, so
-            // allow exactly the tiles issued beyond that range to stay in flight (an index load in flight only makes the wait
-            // stricter).  The tile limit above always covers the range (ring 8 KiB >= a round of 2112 bytes + a tile).
-            const uint32_t need = (ipos + 1023u) / 1024u;        // tiles [0, need) must have landed
-            const uint32_t in_flight_ok = tiles > need ? tiles - need : 0u;
-            switch (in_flight_ok) {
-                case 0: wait_vm<0>(); break;
-                case 1: wait_vm<1>(); break;
-                case 2: wait_vm<2>(); break;
-                case 3: wait_vm<3>(); break;
-                case 4: wait_vm<4>(); break;
-                case 5: wait_vm<5>(); break;
-                default: wait_vm<6>(); break;
+    };
+
+    // ---- indexed feeder (wave 1): the block index says where every record starts and which blocks are raw copies, so there is
+    // no record chain to walk, no FSM to run and no stream byte to read (include/density_hip.h).  The index itself is staged in
+    // LDS by DMA, 256 entries at a time; positions are computed for a window of 64 records at once (one per lane, wave-wide
+    // prefix sum of the record lengths); a round then only publishes its eight.  Kept to a minimum of instructions: a lone
+    // wavefront retires roughly one instruction per 8 cycles.
+    const uint32_t nblocks_out = (uint32_t)((cap + kBlock - 1) / kBlock);
+    uint32_t win_pos = 0, win_end = 0;                        // per lane: position / end of record idx_base + lane
+    uint32_t win_base = 0, win_used = 64, win_stop = 0;       // first record of the window, records consumed, first lane that stops the pipeline
+    uint64_t win_copy = 0;
+    uint32_t idx_staged = 0;                                  // index entries [0, idx_staged) have been requested
+    auto stage_index = [&]() {                                // one DMA: entries idx_staged .. +255 -> LDS (4 per lane)
+        const uint32_t first = idx_staged + 4u * lane;
+        if (first < nblocks_out) {
+            uint32_t keepm0;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keepm0) : "v"(idx + first), "s"(rfl(lds0 + kDIdxBase + (idx_staged & 511u))) : "memory");
+        }
+        idx_staged += 256;
+    };
+    auto feed_round = [&](uint32_t r) {
+        const uint32_t dbase = kDDescBase + (r % kDescRing) * kDescBytes;
+        const uint32_t round_start = ipos, recs_before = recs;
+        uint32_t n = 0, copy_mask = 0;
+        if (!parse_done) {
+            if (win_used == 64) {                                 // next window of 64 records
+                win_base = recs;
+                if (win_base + 128 > idx_staged && idx_staged < nblocks_out) stage_index();   // two windows ahead; landed long before use
+                const uint32_t rec_no = win_base + lane;
+                const uint32_t ent = rec_no < nblocks_out ? (uint32_t)*reinterpret_cast<const uint8_t*>(smem + kDIdxBase + (rec_no & 511u)) : kIdxRagged;
+                const uint32_t mylen = (ent & kIdxCopy) ? kBlock : (kSig + kBlock - 2u * (ent & 0x7fu));
+                uint32_t incl = mylen;                            // inclusive scan: within rows of 16 by DPP, then the three row totals
+                incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xf, 0xf, true);   // row_shr:1
+                incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xf, 0xf, true);   // row_shr:2
+                incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xf, 0xf, true);   // row_shr:4
+                incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xf, 0xf, true);   // row_shr:8
+                const uint32_t t0 = rlane(incl, 15), t1 = rlane(incl, 31), t2 = rlane(incl, 47);
+                incl += (lane >= 16 ? t0 : 0u) + (lane >= 32 ? t1 : 0u) + (lane >= 48 ? t2 : 0u);
+                win_end = ipos + incl;
+                win_pos = win_end - mylen;
+                // ragged last block, last block of the chunk, or an index that disagrees with the stream length: the in-order loop
+                // finishes from there, told whether its (single) block is a raw copy
+                const bool stop = (ent & 0x7fu) == kIdxRagged || win_pos >= elen || elen - win_pos <= mylen;
+                const uint64_t stopm = ballot64(stop);
+                win_stop = stopm ? (uint32_t)__builtin_ctzll(stopm) : 64u;
+                win_copy = ballot64((ent & kIdxCopy) != 0);
+                win_used = 0;
             }
+            const uint32_t left = win_stop - win_used;           // win_stop >= win_used while !parse_done
+            n = left < kRound ? left : kRound;
+            copy_mask = (uint32_t)(win_copy >> win_used) & ((1u << n) - 1u);
+            if (lane >= win_used && lane < win_used + n) *reinterpret_cast<uint32_t*>(smem + dbase + 64 + 4u * (lane - win_used)) = win_pos;
+            if (n) ipos = rlane(win_end, win_used + n - 1);
+            recs += n;
+            if (n < kRound) {
+                parse_done = true;
+                guard.penalty = ((win_copy >> (win_used + n)) & 1ull) ? 1u : 0u; guard.start = 1; guard.prev = 0; guard.counter = 1;
+                if (last_round == 0xffffffffu) last_round = r;
+            }
+            win_used += n;
+        }
+        if (lane == 0) *reinterpret_cast<uint4*>(smem + dbase + 96) = make_uint4(copy_mask, n, (last_round == r) ? kFlagLast : 0u, recs_before);
+        // Refill.  While these tiles land, the fetch waves read the round published by the PREVIOUS call (it starts at `keep`),
+        // so tile i may only replace tile i-8 if that one ends at or before `keep`.
+        issue_tiles(keep / 1024u + kRingTiles);
+        keep = round_start;
+        // The fetch waves read this round's bytes [round_start, ipos) during the next step.  DMA retires in order, so exactly
+        // the tiles issued beyond that range may stay in flight (an index piece in the queue only makes the wait stricter).
+        const uint32_t need = (ipos + 1023u) / 1024u;            // tiles [0, need) must have landed
+        const uint32_t in_flight_ok = tiles > need ? tiles - need : 0u;
+        switch (in_flight_ok) {
+            case 0: wait_vm<0>(); break;
+            case 1: wait_vm<1>(); break;
+            case 2: wait_vm<2>(); break;
+            case 3: wait_vm<3>(); break;
+            case 4: wait_vm<4>(); break;
+            case 5: wait_vm<5>(); break;
+            default: wait_vm<6>(); break;
         }
     };
 
@@ -1192,7 +1214,10 @@ __global__ __launch_bounds__(kDecWaves * 64) void chameleon_decode_chunks_pipe(c
 
     // ---- prologue: fill the pipeline ----
     const bool is_fetch = wave >= kFetchWave0 && wave < kEmitWave0, is_emit = wave >= kEmitWave0;
-    if (wave == 1) { issue_tiles(kRingTiles); parse_round(0); parse_round(1); }
+    if (wave == 1) {
+        if (idx) { stage_index(); issue_tiles(kRingTiles); wait_vm<0>(); feed_round(0); feed_round(1); }
+        else { issue_tiles(kRingTiles); parse_round(0); parse_round(1); }
+    }
     round_barrier();
     if (is_fetch) fetch_round(0);
     round_barrier();
@@ -1205,7 +1230,7 @@ __global__ __launch_bounds__(kDecWaves * 64) void chameleon_decode_chunks_pipe(c
     };
     for (uint32_t s = 0;; ++s) {
         clk.start();
-        if (wave == 1) parse_round(s + 2);
+        if (wave == 1) { if (idx) feed_round(s + 2); else parse_round(s + 2); }
         else if (wave == 0) { if (!(dbg & 64u)) dict_round(s); else only_flags(s); }
         else if (wave == 2) { if (s >= 1) { if (!(dbg & 256u)) finish_round(s - 1); else only_flags(s - 1); } }
         else if (is_fetch) { if (!(dbg & 32u)) fetch_round(s + 1); else only_flags(s + 1); }
@@ -1299,7 +1324,9 @@ hipError_t launch_chameleon_decode(const uint8_t* d_in, const uint64_t* d_offset
         e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytesDec);
         if (e != hipSuccess) return e;
         const uint32_t dbg = getenv("DENSITY_HIP_DBG") ? (uint32_t)atoi(getenv("DENSITY_HIP_DBG")) : 0u;
-        hipLaunchKernelGGL(kernel, dim3(n_chunks), dim3(kDecWaves * 64), kLdsBytesDec, stream, d_in, d_offsets, d_sizes, d_out, out_stride, out_total, exact ? 1u : 0u, d_index, d_zmap, d_produced, d_err, dbg, prof);
+        hipLaunchKernelGGL(kernel, dim3(n_chunks), dim3(kDecWaves * 64), kLdsBytesDec, stream, d_in, d_offsets, d_sizes, d_out, out_stride, out_total, exact ? 1u : 0u,
+                           // the feeder stages the index with 4-byte DMA pieces: per-chunk slices must start 4-byte aligned
+                           (d_index && (out_stride / 256) % 4 == 0 && (uintptr_t)d_index % 4 == 0) ? d_index : nullptr, d_zmap, d_produced, d_err, dbg, prof);
         prof_report("decode", prof, stream);
     } else {
         hipLaunchKernelGGL(chameleon_decode_chunks, dim3(n_chunks), dim3(64), kLdsBytes, stream, d_in, d_offsets, d_sizes, d_out, out_stride, out_total, exact ? 1u : 0u, d_produced, d_err);
