@@ -27,28 +27,28 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
 
 
-def cpu_baseline(host, chunk, sample_bytes, reps=3):
+def cpu_baseline(host, chunk, sample_bytes, algo="chameleon", reps=3):
     """Times the CPU oracle (C restatement of the Rust reference, single thread like the reference's bench) on a bounded
     sample of the same workload.  Checker/baseline only — never part of the measured GPU path."""
     from oracle import pyoracle
     n = min(sample_bytes, host.size)
     src = np.ascontiguousarray(host[:n])
-    cap = pyoracle.safe_encode_buffer_size("chameleon", n)
+    cap = pyoracle.safe_encode_buffer_size(algo, n)
     enc = np.empty(cap, dtype=np.uint8)
     dec = np.empty(n, dtype=np.uint8)
     best_e = best_d = 1e30
     esize = 0
     for _ in range(reps):
         t0 = time.perf_counter()
-        esize = pyoracle.encode_into("chameleon", src.ctypes.data, n, enc.ctypes.data, cap)
+        esize = pyoracle.encode_into(algo, src.ctypes.data, n, enc.ctypes.data, cap)
         t1 = time.perf_counter()
-        got = pyoracle.decode_into("chameleon", enc.ctypes.data, esize, dec.ctypes.data, n)
+        got = pyoracle.decode_into(algo, enc.ctypes.data, esize, dec.ctypes.data, n)
         t2 = time.perf_counter()
         assert got == n
         best_e, best_d = min(best_e, t1 - t0), min(best_d, t2 - t1)
     assert np.array_equal(dec, src)
     out = {"value": round(n / (best_e + best_d) / 1e6, 1), "unit": "MB/s", "cores": 1, "kind": "port",
-           "sample": f"first {n >> 20} MiB of the rank-0 buffer, whole-stream Chameleon encode+decode, best of {reps}, "
+           "sample": f"first {n >> 20} MiB of the rank-0 buffer, whole-stream {algo} encode+decode, best of {reps}, "
                      f"C restatement of density-rs 0.16.6 (oracle/density_oracle.c), 1 thread",
            "encode_MBps": round(n / best_e / 1e6, 1), "decode_MBps": round(n / best_d / 1e6, 1),
            "ratio_whole_stream": round(n / esize, 4)}
@@ -57,17 +57,17 @@ def cpu_baseline(host, chunk, sample_bytes, reps=3):
         from concurrent.futures import ThreadPoolExecutor
         ncpu = os.cpu_count() or 1
         nchunks = (n + chunk - 1) // chunk
-        ccap = pyoracle.safe_encode_buffer_size("chameleon", chunk)
+        ccap = pyoracle.safe_encode_buffer_size(algo, chunk)
         encs = np.empty((nchunks, ccap), dtype=np.uint8)
         sizes = [0] * nchunks
 
         def enc_task(i):
             ln = min(chunk, n - i * chunk)
-            sizes[i] = pyoracle.encode_into("chameleon", src.ctypes.data + i * chunk, ln, encs[i].ctypes.data, ccap)
+            sizes[i] = pyoracle.encode_into(algo, src.ctypes.data + i * chunk, ln, encs[i].ctypes.data, ccap)
 
         def dec_task(i):
             ln = min(chunk, n - i * chunk)
-            pyoracle.decode_into("chameleon", encs[i].ctypes.data, sizes[i], dec.ctypes.data + i * chunk, ln)
+            pyoracle.decode_into(algo, encs[i].ctypes.data, sizes[i], dec.ctypes.data + i * chunk, ln)
 
         with ThreadPoolExecutor(ncpu) as ex:
             list(ex.map(enc_task, range(nchunks)))     # warm
@@ -92,6 +92,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--concat", action="store_true", help="also time the optional gather-to-rank-0 stitch (N > 1)")
     ap.add_argument("--variant", type=int, default=0, help="0 = default kernels, 1 = simple one-wavefront kernels")
+    ap.add_argument("--algo", default="chameleon", choices=["chameleon", "cheetah", "lion"],
+                    help="chameleon is the headline workload; cheetah/lion run on the functional device kernels (use a smaller --size)")
     args = ap.parse_args()
 
     import torch
@@ -117,27 +119,28 @@ def main():
     # config 2 / 5 of BASELINE.json: rep-text, per-shard seed = seed + rank
     host = datagen.rep_text(n, seed=0x9E3779B97F4A7C15 + rank)
     x = torch.from_numpy(host).cuda()
-    cap = container.container_bound("chameleon", n, chunk)
+    algo = args.algo
+    cap = container.container_bound(algo, n, chunk)
     cont = torch.empty(cap, dtype=torch.uint8, device="cuda")
     back = torch.empty(n, dtype=torch.uint8, device="cuda")
-    ws_size = max(int(density_ws(container, n, chunk)), 1)
+    ws_size = max(int(density_ws(container, n, chunk, args.algo)), 1)
     ws = torch.empty(ws_size, dtype=torch.uint8, device="cuda")
     stream = torch.cuda.current_stream()
     s = stream.cuda_stream
 
     # correctness before any timing: decode(encode(x)) == x, and a sample of chunk streams equals the oracle's
-    hdr = container.encode_device("chameleon", x.data_ptr(), n, cont.data_ptr(), cap, chunk, stream=s, workspace=(ws.data_ptr(), ws_size))
+    hdr = container.encode_device(algo, x.data_ptr(), n, cont.data_ptr(), cap, chunk, stream=s, workspace=(ws.data_ptr(), ws_size))
     got = container.decode_device(cont.data_ptr(), hdr.container_len, back.data_ptr(), n, header=hdr, stream=s, workspace=(ws.data_ptr(), ws_size))
     assert got == n and torch.equal(back, x), "round trip mismatch"
     raw = cont[:hdr.container_len].cpu().numpy()
     _, payloads = container.chunk_payloads(raw)
     for i in sorted(set([0, hdr.n_chunks // 3, hdr.n_chunks - 1])):
-        assert payloads[i] == pyoracle.encode("chameleon", host[i * chunk:(i + 1) * chunk]), f"chunk {i} differs from the oracle"
+        assert payloads[i] == pyoracle.encode(algo, host[i * chunk:(i + 1) * chunk]), f"chunk {i} differs from the oracle"
     E = int(hdr.container_len)
     del raw, payloads
 
     def step():
-        container.encode_device("chameleon", x.data_ptr(), n, cont.data_ptr(), cap, chunk, stream=s, workspace=(ws.data_ptr(), ws_size), want_header=False)
+        container.encode_device(algo, x.data_ptr(), n, cont.data_ptr(), cap, chunk, stream=s, workspace=(ws.data_ptr(), ws_size), want_header=False)
         container.decode_device(cont.data_ptr(), E, back.data_ptr(), n, header=hdr, stream=s, workspace=(ws.data_ptr(), ws_size), sync=False)
 
     for _ in range(args.warmup):
@@ -187,7 +190,7 @@ def main():
         avg = {k: sum(v) / len(v) for k, v in per.items()}
         # algorithmic bytes per launch: encode reads N writes E, decode reads E writes N; the stitch pass
         # (layout + compact) moves no algorithmic bytes — it is overhead that lowers the whole-path fraction.
-        alg = {"chameleon_encode_chunks": n + E, "chameleon_decode_chunks": n + E}
+        alg = {f"{algo}_encode_chunks": n + E, f"{algo}_decode_chunks": n + E}
         dom = max(alg, key=lambda k: avg.get(k, 0.0))
         ach = alg[dom] / (avg[dom] * 1e-3) / 1e9 if avg.get(dom) else 0.0
         # HBM traffic of that kernel from the committed PMC passes (rocprofv3 cannot run inside this process); only quoted
@@ -196,15 +199,15 @@ def main():
         try:
             import glob as _glob
             cand = sorted(_glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
-            if cand and n == 1 << 30 and chunk == 1 << 20 and args.variant == 0:
+            if cand and n == 1 << 30 and chunk == 1 << 20 and args.variant == 0 and algo == "chameleon":
                 pm = json.load(open(cand[-1]))
                 traffic = pm["kernels"][dom + "_pipe"]["hbm_bytes_corrected"]
                 traffic_src = os.path.relpath(cand[-1], ROOT)
         except Exception:
             pass
         ms_step = dt / args.steps * 1e3
-        t_enc = sum(avg.get(k, 0.0) for k in ("chameleon_encode_chunks", "layout_encode", "compact"))
-        t_dec = sum(avg.get(k, 0.0) for k in ("layout_decode", "chameleon_decode_chunks"))
+        t_enc = sum(avg.get(k, 0.0) for k in (f"{algo}_encode_chunks", "layout_encode", "compact"))
+        t_dec = sum(avg.get(k, 0.0) for k in ("layout_decode", f"{algo}_decode_chunks"))
         result = {
             "metric": "MB/s encode+decode (round-trip) per GPU + compression ratio, dickens/enwik8",
             "value": round(world * n * args.steps / dt / 1e6, 1),
@@ -213,9 +216,9 @@ def main():
             "ms_per_step": round(ms_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
-            "config": {"workload": f"chameleon rep-text {n >> 20} MiB per GPU (BASELINE config 2: 1 GiB synthetic repeating text, "
+            "config": {"workload": f"{algo} rep-text {n >> 20} MiB per GPU (BASELINE config 2: 1 GiB synthetic repeating text, "
                                    f"period 1000003 B), device-resident container encode+decode, chunk {chunk >> 10} KiB",
-                       "algorithm": "chameleon", "bytes_per_gpu": n, "chunk_bytes": chunk, "n_chunks": int(hdr.n_chunks),
+                       "algorithm": algo, "bytes_per_gpu": n, "chunk_bytes": chunk, "n_chunks": int(hdr.n_chunks),
                        "parallelism": f"chunk-sharded x{world}, no data-path collective"},
             "compression_ratio": round(n / E, 4),
             "encoded_bytes": E,
@@ -229,16 +232,16 @@ def main():
                           "global_container_bytes": int(glob["container_len"])},
         }
         if not args.no_cpu:
-            result["cpu_baseline"] = cpu_baseline(host, chunk, args.cpu_sample)
+            result["cpu_baseline"] = cpu_baseline(host, chunk, args.cpu_sample, algo)
         print(json.dumps(result))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def density_ws(container, n, chunk):
+def density_ws(container, n, chunk, algo="chameleon"):
     from density_amd import _lib
-    return max(_lib.lib().density_hip_encode_workspace_size(0, n, chunk), _lib.lib().density_hip_decode_workspace_size((n + chunk - 1) // chunk))
+    return max(_lib.lib().density_hip_encode_workspace_size(_lib.ALGO_IDS[algo], n, chunk), _lib.lib().density_hip_decode_workspace_size((n + chunk - 1) // chunk))
 
 
 if __name__ == "__main__":
