@@ -126,7 +126,7 @@ struct Profiler {
     }
 };
 
-constexpr size_t kSerialSlots = 4096;    // concurrent chunk streams of the functional Cheetah/Lion kernels (one lane each)
+constexpr size_t kSerialSlots = 16384;   // concurrent chunk streams of the functional Cheetah/Lion kernels (one lane each; 12 / 28 GiB of tables when all are in use)
 inline size_t serial_slots(int algo, size_t n_chunks) { return algo == DENSITY_HIP_CHAMELEON ? 0 : (n_chunks < kSerialSlots ? n_chunks : kSerialSlots); }
 inline size_t serial_tables(int algo, size_t n_chunks) { return algo == DENSITY_HIP_CHAMELEON ? 0 : align_up(serial_slots(algo, n_chunks) * serial_table_bytes(algo), kAlign); }
 

@@ -153,6 +153,8 @@ template <int ALGO>
 __global__ __launch_bounds__(64) void serial_encode_chunks(const uint8_t* __restrict__ in, uint64_t total, uint64_t chunk_bytes,
                                                            uint32_t n_chunks, uint8_t* __restrict__ out, uint64_t out_stride,
                                                            uint64_t* __restrict__ sizes, uint8_t* __restrict__ tables, uint32_t n_slots) {
+    // `tables` arrives zeroed (the launcher clears the slots in use with one memset), so a lane clears its own tables
+    // only before its second and later chunks
     using G = Geo<ALGO>;
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= n_slots) return;
@@ -164,7 +166,8 @@ __global__ __launch_bounds__(64) void serial_encode_chunks(const uint8_t* __rest
         const uint8_t* src = in + chunk * chunk_bytes;
         const uint64_t len = (total - chunk * chunk_bytes) < chunk_bytes ? (total - chunk * chunk_bytes) : chunk_bytes;
         uint8_t* dst = out + chunk * out_stride;
-        t.clear();
+        if (chunk != slot) t.clear();
+        t.last_hash = 0;
         Guard guard;
         uint64_t opos = 0;
         for (uint64_t pos = 0; pos < len; pos += G::kBlock) {
@@ -216,7 +219,8 @@ __global__ __launch_bounds__(64) void serial_decode_chunks(const uint8_t* __rest
         uint8_t* dst = out + chunk * out_stride;
         const uint64_t room_all = out_total - chunk * out_stride;
         const uint64_t cap = room_all < out_stride ? room_all : out_stride;
-        t.clear();
+        if (chunk != slot) t.clear();
+        t.last_hash = 0;
         Guard guard;
         uint64_t ipos = 0, opos = 0;
         bool bad = false, done = false;
@@ -268,6 +272,8 @@ hipError_t launch_serial_encode(int algo, const uint8_t* d_in, uint64_t total, u
                                 uint64_t out_stride, uint64_t* d_sizes, uint8_t* d_tables, uint32_t n_slots, hipStream_t stream) {
     if (n_chunks == 0) return hipSuccess;
     const uint32_t blocks = (n_slots + 63) / 64;
+    hipError_t e = hipMemsetAsync(d_tables, 0, (size_t)n_slots * serial_table_bytes(algo), stream);
+    if (e != hipSuccess) return e;
     if (algo == DENSITY_HIP_CHEETAH)
         hipLaunchKernelGGL(serial_encode_chunks<DENSITY_HIP_CHEETAH>, dim3(blocks), dim3(64), 0, stream, d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, n_slots);
     else
@@ -280,6 +286,8 @@ hipError_t launch_serial_decode(int algo, const uint8_t* d_in, const uint64_t* d
                                 uint8_t* d_tables, uint32_t n_slots, hipStream_t stream) {
     if (n_chunks == 0) return hipSuccess;
     const uint32_t blocks = (n_slots + 63) / 64;
+    hipError_t e = hipMemsetAsync(d_tables, 0, (size_t)n_slots * serial_table_bytes(algo), stream);
+    if (e != hipSuccess) return e;
     if (algo == DENSITY_HIP_CHEETAH)
         hipLaunchKernelGGL(serial_decode_chunks<DENSITY_HIP_CHEETAH>, dim3(blocks), dim3(64), 0, stream, d_in, d_offsets, d_sizes, n_chunks, d_out, out_stride, out_total, exact ? 1u : 0u, d_produced, d_err, d_tables, n_slots);
     else
