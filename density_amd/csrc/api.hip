@@ -130,8 +130,10 @@ constexpr size_t kSerialSlots = 16384;   // concurrent chunk streams of the func
 inline size_t serial_slots(int algo, size_t n_chunks) { return algo == DENSITY_HIP_CHAMELEON ? 0 : (n_chunks < kSerialSlots ? n_chunks : kSerialSlots); }
 inline size_t serial_tables(int algo, size_t n_chunks) { return algo == DENSITY_HIP_CHAMELEON ? 0 : align_up(serial_slots(algo, n_chunks) * serial_table_bytes(algo), kAlign); }
 
+inline size_t zmap_bytes(int algo, size_t n_chunks) { return (algo == DENSITY_HIP_CHAMELEON && n_chunks <= kMaxPipelinedChunks) ? align_up((n_chunks ? n_chunks : 1) * kZmapWordsPerChunk * 4, kAlign) : 0; }
+
 struct EncodePlan {
-    size_t chunk, n_chunks, stride, off_err, off_sizes, off_offsets, off_slots, off_tables, total;
+    size_t chunk, n_chunks, stride, off_err, off_sizes, off_offsets, off_slots, off_tables, off_zmap, total;
 };
 EncodePlan plan_encode(int algo, size_t n, size_t chunk) {
     EncodePlan p{};
@@ -143,13 +145,13 @@ EncodePlan plan_encode(int algo, size_t n, size_t chunk) {
     p.off_offsets = p.off_sizes + align_up(8 * p.n_chunks, kAlign);
     p.off_slots = p.off_offsets + align_up(8 * (p.n_chunks + 1), kAlign);
     p.off_tables = p.off_slots + (p.n_chunks > 1 ? p.n_chunks * p.stride : 0);   // one chunk encodes straight into the container
-    p.total = p.off_tables + serial_tables(algo, p.n_chunks ? p.n_chunks : 1);
+    p.off_zmap = p.off_tables + serial_tables(algo, p.n_chunks ? p.n_chunks : 1);
+    p.total = p.off_zmap + zmap_bytes(algo, p.n_chunks);
     return p;
 }
 struct DecodePlan {
     size_t off_err, off_sizes, off_offsets, off_produced, off_tables, off_zmap, total;
 };
-inline size_t zmap_bytes(int algo, size_t n_chunks) { return (algo == DENSITY_HIP_CHAMELEON && n_chunks <= kMaxPipelinedChunks) ? align_up((n_chunks ? n_chunks : 1) * kZmapWordsPerChunk * 4, kAlign) : 0; }
 DecodePlan plan_decode(int algo, size_t n_chunks) {
     DecodePlan p{};
     p.off_err = 0;
@@ -164,8 +166,8 @@ DecodePlan plan_decode(int algo, size_t n_chunks) {
 
 // algorithm dispatch: Chameleon has the LDS-resident pipelined kernels, Cheetah/Lion the functional one-lane-per-stream kernels
 hipError_t codec_encode(int algo, const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_out,
-                        uint64_t out_stride, uint64_t* d_sizes, uint8_t* d_index, uint8_t* d_tables, hipStream_t s) {
-    if (algo == DENSITY_HIP_CHAMELEON) return launch_chameleon_encode(d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_index, s);
+                        uint64_t out_stride, uint64_t* d_sizes, uint8_t* d_index, uint8_t* d_tables, uint32_t* d_zmap, hipStream_t s) {
+    if (algo == DENSITY_HIP_CHAMELEON) return launch_chameleon_encode(d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_index, d_zmap, s);
     return launch_serial_encode(algo, d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, (uint32_t)serial_slots(algo, n_chunks), s);
 }
 hipError_t codec_decode(int algo, const uint8_t* d_in, const uint64_t* d_offsets, const uint64_t* d_sizes, uint32_t n_chunks, uint8_t* d_out,
@@ -204,6 +206,7 @@ int run_encode_container(DeviceCtx* c, int algo, const uint8_t* d_in, size_t n, 
     uint64_t* d_sizes = reinterpret_cast<uint64_t*>(ws + p.off_sizes);
     uint64_t* d_offsets = reinterpret_cast<uint64_t*>(ws + p.off_offsets);
     uint8_t* d_slots = ws + p.off_slots;
+    uint32_t* d_zmap = zmap_bytes(algo, p.n_chunks) ? reinterpret_cast<uint32_t*>(ws + p.off_zmap) : nullptr;
     density_hip_header_t hdr{};
     hdr.magic = DENSITY_HIP_MAGIC; hdr.algo = (uint8_t)algo; hdr.version = 1; hdr.flags = want_index(algo) ? DENSITY_HIP_FLAG_BLOCK_INDEX : 0;
     hdr.chunk_size = (uint32_t)chunk; hdr.n_chunks = (uint32_t)p.n_chunks; hdr.total_len = n; hdr.container_len = 0;
@@ -216,12 +219,12 @@ int run_encode_container(DeviceCtx* c, int algo, const uint8_t* d_in, size_t n, 
     if (e != hipSuccess) { set_error("hipMemsetAsync", e); return DENSITY_HIP_ERR_RUNTIME; }
     if (p.n_chunks == 1) {
         // single chunk: its stream goes straight to its final place, no stitch pass
-        e = codec_encode(algo, d_in, n, chunk, 1, d_out + pbase, 0, d_sizes, d_index, ws + p.off_tables, s);
+        e = codec_encode(algo, d_in, n, chunk, 1, d_out + pbase, 0, d_sizes, d_index, ws + p.off_tables, d_zmap, s);
         prof.mark(encode_kernel_name(algo));
         if (e == hipSuccess) e = launch_layout_encode(d_sizes, 1, hdr, pbase, d_out, cap, d_offsets, d_err, s);
         prof.mark("layout_encode");
     } else {
-        e = codec_encode(algo, d_in, n, chunk, (uint32_t)p.n_chunks, d_slots, p.stride, d_sizes, d_index, ws + p.off_tables, s);
+        e = codec_encode(algo, d_in, n, chunk, (uint32_t)p.n_chunks, d_slots, p.stride, d_sizes, d_index, ws + p.off_tables, d_zmap, s);
         prof.mark(encode_kernel_name(algo));
         if (e == hipSuccess) e = launch_layout_encode(d_sizes, (uint32_t)p.n_chunks, hdr, pbase, d_out, cap, d_offsets, d_err, s);
         prof.mark("layout_encode");
@@ -275,7 +278,8 @@ int run_stream_encode(DeviceCtx* c, int algo, const uint8_t* d_in, size_t n, uin
     *size_out = 0;
     if (n == 0) return DENSITY_HIP_OK;
     Profiler prof(c, s);
-    hipError_t e = codec_encode(algo, d_in, n, n, 1, d_out, 0, d_sizes, nullptr, ws + plan_decode(algo, 1).off_tables, s);
+    const DecodePlan sp = plan_decode(algo, 1);   // stream calls share the one-chunk decode layout
+    hipError_t e = codec_encode(algo, d_in, n, n, 1, d_out, 0, d_sizes, nullptr, ws + sp.off_tables, zmap_bytes(algo, 1) ? reinterpret_cast<uint32_t*>(ws + sp.off_zmap) : nullptr, s);
     prof.mark(encode_kernel_name(algo));
     uint64_t h_size = 0;
     if (e == hipSuccess) e = hipMemcpyAsync(&h_size, d_sizes, sizeof(h_size), hipMemcpyDeviceToHost, s);

@@ -140,6 +140,7 @@ struct ZmapGlobal {
         const uint32_t old = atomicOr(words + (h >> 5), 1u << (h & 31u));
         asm volatile("" ::"v"(old));                          // returned value consumed: the update is in L2 before the next test
     }
+    __device__ __forceinline__ uint32_t test_and_set(uint32_t h) const { return (atomicOr(words + (h >> 5), 1u << (h & 31u)) >> (h & 31u)) & 1u; }
 };
 
 // For every lane that shares its slot with other lanes of this block: the entry written by the nearest earlier lane
@@ -279,19 +280,25 @@ namespace {
 
 constexpr uint32_t kRound = 8;                               // blocks per round
 constexpr uint32_t kRoundBytes = kRound * kBlock;            // 2 KiB
-constexpr uint32_t kInRing = 6, kResRing = 2;              // input ring: kAhead rounds in flight + hashed + emitted
-constexpr uint32_t kAhead = kInRing - 2;                     // DMA runs this many rounds ahead of the dictionary wave
-constexpr uint32_t kInBase = kLdsBytes;                      // 139264, 16-byte aligned
+constexpr uint32_t kInRing = 8, kResRing = 2;              // input ring (power of two): kAhead rounds in flight + hashed + emitted
+constexpr uint32_t kAhead = 4;                               // DMA runs this many rounds ahead of the dictionary wave (deeper measured slower)
+constexpr uint32_t kInBase = kTableBytes;                    // the pipelined kernels keep the zero-entry map in global memory (ZmapGlobal)
 constexpr uint32_t kResBase = kInBase + kInRing * kRoundBytes;
 constexpr uint32_t kResBytes = 128;                          // dwords 0..15 signatures, 16 copy mask
-constexpr uint32_t kOpBase = kResBase + kResRing * kResBytes;    // operand ring: per block 64 x {slot dword address | half, entry << 16*half}
+constexpr uint32_t kOpBase = kResBase + kResRing * kResBytes;    // operand ring: per block 64 x {byte address of the slot, entry << 16*half}
 constexpr uint32_t kOpRec = 512, kOpRing = 2;
 constexpr uint32_t kOpRoundBytes = kRound * kOpRec;
 constexpr uint32_t kZeroFlagBase = kOpBase + kOpRing * kOpRoundBytes;   // 4 dwords: bit k of word r % 4 = block k of round r holds a zero entry
 constexpr uint32_t kLdsBytesPipe = kZeroFlagBase + 16;               // (set while hashing at step r-1, read at r, cleared at r+1)
-constexpr uint32_t kEncHalf = 1u, kEncAddr = 0x1fffcu;       // operand dword 0
-constexpr uint32_t kPipeWaves = 16;                          // wave 0 dictionary, waves 1..8 hash, waves 7..14 emit, wave 15 loader
-constexpr uint32_t kHashWave0 = 1, kEmitWaveE0 = 7;          // hash wave w takes block w - 1, emit wave w block w - 7 (waves 7, 8 do both)
+constexpr uint32_t kEncAddr = 0x1fffcu;                      // operand dword 0 = 2 * slot: bits 2..16 the dword address, bit 1 the half
+constexpr uint32_t kPipeWaves = 16;
+// Roles by wave, one nibble per wave (8 = none).  A work-group's wave w runs on SIMD w % 4 and the four waves of a SIMD share
+// its issue slots, so the dictionary wave (0) shares SIMD 0 only with the loader (4) and two single-block hash waves (8, 12);
+// the eight emit waves and the double-block hash waves are spread over SIMDs 1-3.
+constexpr uint32_t kDictWave = 0, kLoadWave = 4;
+constexpr uint64_t kHashFirstTbl = 0x7421688088888888ull;    // first block hashed by wave w (nibble w)
+constexpr uint64_t kHashCountTbl = 0x1221100100000000ull;    // number of consecutive blocks hashed by wave w
+constexpr uint64_t kEmitBlockTbl = 0x8888852874186308ull;    // block emitted by wave w
 static_assert(kLdsBytesPipe <= 160u * 1024u, "LDS budget");
 static_assert(kRound == 8, "register arrays, asm operand lists and the result record are written for 8 blocks per round");
 
@@ -312,6 +319,17 @@ template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 // all of this wave's LDS traffic retired, then the work-group barrier; no vmcnt: stores and DMA stay in flight
 __device__ __forceinline__ void round_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// Stores of the emit waves: wave-uniform base in SGPRs + 32-bit lane offset.  Written as asm so that the compiler neither
+// builds 64-bit lane addresses nor tracks the stores with vmcnt (it would drain them at every loop head).
+__device__ __forceinline__ void gstore32(uint8_t* base, uint32_t off, uint32_t v) {
+    asm volatile("global_store_dword %0, %1, %2" ::"v"(off), "v"(v), "s"(base) : "memory");
+}
+__device__ __forceinline__ void gstore16_hi(uint8_t* base, uint32_t off, uint32_t v) {   // stores bits 16..31 of v
+    asm volatile("global_store_short_d16_hi %0, %1, %2" ::"v"(off), "v"(v), "s"(base) : "memory");
+}
+__device__ __forceinline__ void gstore8(uint8_t* base, uint32_t off, uint32_t v) {
+    asm volatile("global_store_byte %0, %1, %2" ::"v"(off), "v"(v), "s"(base) : "memory");
+}
 
 // vec[L] = value (value wave-uniform).  gfx9 allows one SGPR operand per VALU instruction, so the lane is an immediate.
 template <int L>
@@ -378,8 +396,20 @@ struct WaveClock<true> {
 
 // per-block state of the dictionary wave between issue and finish
 struct Issued {
-    uint32_t d0, d1, ret;         // operands staged by the worker waves (slot dword address | half, entry << 16*half), dictionary answer
+    uint32_t d0, d1, ret;         // operands staged by the hash waves (2 * slot, entry << 16*half), dictionary answer
 };
+
+// zero-entry map, stream order: the lanes holding a zero entry claim their slots one at a time (rare: about one quad in 64 Ki)
+__device__ __forceinline__ uint32_t zmap_claim(const ZmapGlobal& zmap, bool susp, uint32_t h, uint32_t lane) {
+    uint32_t zbit = 1;
+    uint64_t m = ballot64(susp);
+    while (m) {
+        const uint32_t l = (uint32_t)__builtin_ctzll(m);
+        m &= m - 1;
+        if (lane == l) zbit = zmap.test_and_set(h);
+    }
+    return zbit;
+}
 
 }  // namespace
 
@@ -387,7 +417,8 @@ template <bool kProf>
 __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(const uint8_t* __restrict__ in, uint64_t total,
                                                                                 uint64_t chunk_bytes, uint8_t* __restrict__ out,
                                                                                 uint64_t out_stride, uint64_t* __restrict__ sizes,
-                                                                                uint8_t* __restrict__ index, uint32_t dbg, uint64_t* __restrict__ prof) {
+                                                                                uint8_t* __restrict__ index, uint32_t* __restrict__ zmap_words,
+                                                                                uint32_t dbg, uint64_t* __restrict__ prof) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = rfl(threadIdx.x >> 6);
     const uint64_t chunk = blockIdx.x;
@@ -396,112 +427,121 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
     const uint64_t len = (total - chunk * chunk_bytes) < chunk_bytes ? (total - chunk * chunk_bytes) : chunk_bytes;
     uint8_t* dst = out + chunk * out_stride;
     uint8_t* idx = index ? index + chunk * (chunk_bytes / kBlock) : nullptr;     // this chunk's slice of the block index
-    const uint64_t nfull = len / kBlock;                       // whole blocks: these go through the pipeline
-    const uint64_t nrounds = (nfull + kRound - 1) / kRound;
+    const uint32_t nfull = (uint32_t)(len / kBlock);           // whole blocks: these go through the pipeline (the launcher bounds len)
+    const uint32_t nrounds = (nfull + kRound - 1) / kRound;
+    const ZmapGlobal zmap{zmap_words + chunk * (kZmapBytes / 4)};
+    if (wave == kDictWave) __builtin_amdgcn_s_setprio(3);      // the dictionary wave is the critical path: first pick of issue slots
 
-    {   // clear table + zero-entry map
+    {   // clear table, zero-entry flags and this chunk's zero-entry map
         uint4* p = reinterpret_cast<uint4*>(smem);
         const uint4 z = make_uint4(0, 0, 0, 0);
-        for (uint32_t i = threadIdx.x; i < kLdsBytes / 16; i += kPipeWaves * 64) p[i] = z;
+        for (uint32_t i = threadIdx.x; i < kTableBytes / 16; i += kPipeWaves * 64) p[i] = z;
+        for (uint32_t i = threadIdx.x; i < kZmapBytes / 16; i += kPipeWaves * 64) reinterpret_cast<uint4*>(zmap.words)[i] = z;
+        if (threadIdx.x < 4) *reinterpret_cast<uint32_t*>(smem + kZeroFlagBase + 4u * threadIdx.x) = 0;
+        __threadfence();                                      // the map is used through L2 atomics
     }
     const uint32_t lds0 = lds_addr(smem);
-    const uint32_t tbl = lds0, zmap = lds0 + kTableBytes;
+    const uint32_t tbl = lds0;
     round_barrier();
 
-    // ---------------- loader (wave 7): DMA of round r into ring slot r % kInRing; lanes past the last whole block stay idle ------
-    auto issue_round = [&](uint64_t r) {
+    // ---------------- loader: DMA of round r into ring slot r % kInRing; lanes past the last whole block stay idle ------
+    auto issue_round = [&](uint32_t r) {
         if (r >= nrounds) return;
-        const uint64_t base = r * kRoundBytes;
+        const uint64_t base = (uint64_t)r * kRoundBytes;
 #pragma unroll
         for (uint32_t j = 0; j < kRound / 4; ++j) {
             const uint64_t off = base + j * 1024u + 16u * lane;
-            if (off + 16 <= nfull * kBlock) dma_1k(src + off, lds0 + kInBase + (uint32_t)(r % kInRing) * kRoundBytes + j * 1024u);
+            if (off + 16 <= (uint64_t)nfull * kBlock) dma_1k(src + off, lds0 + kInBase + (r & (kInRing - 1u)) * kRoundBytes + j * 1024u);
         }
     };
     // all rounds up to `r` have landed; rounds r+1 .. (issued - 1) may stay in flight.  vmcnt retires in order and every round
     // before the last one issues exactly kRound/4 instructions, so the count is exact away from the chunk's end.
-    auto wait_landed = [&](uint64_t r, uint64_t issued) {
+    auto wait_landed = [&](uint32_t r, uint32_t issued) {
         if (issued > r + 1 && issued - (r + 1) == kAhead - 2 && issued < nrounds && !(dbg & 1u)) wait_vm<(kAhead - 2) * (kRound / 4)>();
         else wait_vm<0>();
     };
-    if (wave == kPipeWaves - 1) {
+    if (wave == kLoadWave) {
 #pragma unroll
         for (uint32_t r = 0; r < kAhead; ++r) issue_round(r);
         wait_landed(1, kAhead);
     }
     round_barrier();
 
-    // ---------------- worker waves 1..6: hash round r into the operand ring (one round ahead of the dictionary wave) --------
-    auto hash_round = [&](uint64_t r) {
+    // ---------------- hash waves: round r into the operand ring (one round ahead of the dictionary wave) --------
+    const uint32_t hb0 = (uint32_t)(kHashFirstTbl >> (4u * wave)) & 15u, hbn = (uint32_t)(kHashCountTbl >> (4u * wave)) & 15u;
+    const uint32_t eb = (uint32_t)(kEmitBlockTbl >> (4u * wave)) & 15u;
+    auto hash_round = [&](uint32_t r) {
         if (r >= nrounds) return;
-        const uint32_t qbase = kInBase + (uint32_t)(r % kInRing) * kRoundBytes;
-        const uint32_t obase = kOpBase + (uint32_t)(r % kOpRing) * kOpRoundBytes;
-        const uint64_t b0 = r * kRound;
-        const uint32_t nb = (nfull - b0) < kRound ? (uint32_t)(nfull - b0) : kRound;
-        for (uint32_t k = wave - kHashWave0; k < nb; k += kRound) {
-            const uint32_t q = *reinterpret_cast<const uint32_t*>(smem + qbase + kBlock * k + 4u * lane);
-            const uint32_t P = q * kHashMul;
-            const uint32_t h = P >> 16;
-            const uint32_t e = stored_entry(q, P);
-            *reinterpret_cast<uint2*>(smem + obase + k * kOpRec + 8u * lane) = make_uint2(((h >> 1) << 2) | (h & 1u), e << ((h & 1u) << 4));
-            // a stored entry of 0 outside slot 0 aliases "never written": tell the dictionary wave to take the careful path
-            if (ballot64(e == 0 && h != 0) && lane == 0) atomicOr(reinterpret_cast<uint32_t*>(smem + kZeroFlagBase + 4u * (uint32_t)(r & 3u)), 1u << k);
+        const uint32_t qbase = kInBase + (r & (kInRing - 1u)) * kRoundBytes + 4u * lane;
+        const uint32_t obase = kOpBase + (r & (kOpRing - 1u)) * kOpRoundBytes + 8u * lane;
+        const uint32_t left = nfull - r * kRound;
+        const uint32_t nb = left < kRound ? left : kRound;
+#pragma unroll
+        for (uint32_t i = 0; i < 2; ++i) {
+            const uint32_t k = hb0 + i;
+            if (i < hbn && k < nb) {
+                const uint32_t q = *reinterpret_cast<const uint32_t*>(smem + qbase + kBlock * k);
+                const uint32_t P = q * kHashMul;
+                const uint32_t h = P >> 16;
+                const uint32_t e = stored_entry(q, P);
+                *reinterpret_cast<uint2*>(smem + obase + k * kOpRec) = make_uint2(h << 1, e << ((h & 1u) << 4));
+                // a stored entry of 0 outside slot 0 aliases "never written": tell the dictionary wave to take the careful path
+                if (ballot64(e == 0)) {
+                    if (ballot64(e == 0 && h != 0) && lane == 0) atomicOr(reinterpret_cast<uint32_t*>(smem + kZeroFlagBase + 4u * (r & 3u)), 1u << k);
+                }
+            }
         }
     };
-
-    // ---------------- dictionary wave state ----------------
-    Guard guard;
-
-    // ---------------- emit state ----------------
-    uint64_t opos_run = 0;                                    // output offset of the round being emitted (every worker tracks it)
-
-    if (wave == 1 && lane < 4) *reinterpret_cast<uint32_t*>(smem + kZeroFlagBase + 4u * lane) = 0;
-    round_barrier();
-    const bool is_hash = wave >= kHashWave0 && wave < kHashWave0 + kRound, is_emit = wave >= kEmitWaveE0 && wave < kEmitWaveE0 + kRound;
-    if (is_hash) hash_round(0);
+    if (hbn) hash_round(0);
     round_barrier();
 
-    for (uint64_t t = 0; t <= nrounds; ++t) {
-        clk.start();
-        if (wave == kPipeWaves - 1) {
-            // ---------------- loader: keep kAhead rounds in flight, guarantee round t+2 for the next step ----------------
+    uint64_t opos_run = 0;                                    // emit waves: output offset of the round being emitted (each tracks it)
+    Guard guard;                                              // dictionary wave
+
+    if (wave == kLoadWave) {
+        // ---------------- loader: keep kAhead rounds in flight, guarantee round t+2 for the next step ----------------
+        for (uint32_t t = 0; t <= nrounds; ++t) {
+            clk.start();
             issue_round(t + kAhead);
-            const uint64_t issued = (t + kAhead + 1) < nrounds ? (t + kAhead + 1) : nrounds;
+            const uint32_t issued = (t + kAhead + 1) < nrounds ? (t + kAhead + 1) : nrounds;
             if (t + 2 < nrounds) wait_landed(t + 2, issued); else wait_vm<0>();
-        } else if (wave == 0) {
-            // ---------------- dictionary wave: round t ----------------
+            clk.work_done();
+            round_barrier();
+            clk.wait_done();
+        }
+    } else if (wave == kDictWave) {
+        // ---------------- dictionary wave: round t ----------------
+        for (uint32_t t = 0; t <= nrounds; ++t) {
+            clk.start();
             if (t < nrounds) {
                 clk.phase_start();
-                const uint32_t obase = kOpBase + (uint32_t)(t % kOpRing) * kOpRoundBytes;
-                const uint32_t rbase = kResBase + (uint32_t)(t % kResRing) * kResBytes;
-                const uint64_t b0 = t * kRound;
-                const uint32_t nb = (nfull - b0) < kRound ? (uint32_t)(nfull - b0) : kRound;
+                const uint32_t obase = kOpBase + (t & (kOpRing - 1u)) * kOpRoundBytes;
+                const uint32_t rbase = kResBase + (t & (kResRing - 1u)) * kResBytes;
+                const uint32_t left = nfull - t * kRound;
+                const uint32_t nb = left < kRound ? left : kRound;
                 uint32_t copy_mask = 0;
                 uint64_t sig[kRound];
 #pragma unroll
                 for (uint32_t j = 0; j < kRound; ++j) sig[j] = 0;
 
                 auto issue = [&](Issued& b) {
-                    const uint32_t sh = (b.d0 & kEncHalf) << 4;
+                    const uint32_t sh = b.d0 << 3;            // shift counts use bits 0..4: (d0 & 2) << 3
                     dict_xchg_issue(tbl + (b.d0 & kEncAddr), 0xffffu << sh, b.d1, b.ret);
                 };
                 // signature of a block from the dictionary answers, including the zero-entry disambiguation (rare path)
                 auto signature = [&](const Issued& b) -> uint64_t {
-                    const uint32_t sh = (b.d0 & kEncHalf) << 4;
-                    const uint32_t e = (b.d1 >> sh) & 0xffffu, h = ((b.d0 & kEncAddr) >> 1) | (b.d0 & kEncHalf);
+                    const uint32_t sh = (b.d0 & 2u) << 3;
+                    const uint32_t e = (b.d1 >> sh) & 0xffffu, h = b.d0 >> 1;
                     const uint32_t old = (b.ret >> sh) & 0xffffu;
                     const bool susp = e == 0 && h != 0;
-                    uint32_t zbit = 1;
-                    if (ballot64(susp)) {
-                        if (susp) zbit = zmap_test_and_set(zmap, h);
-                    }
+                    const uint32_t zbit = zmap_claim(zmap, susp, h, lane);
                     return ballot64(old == e && (!susp || zbit));
                 };
                 // undo a speculatively applied block: the lowest lane of a slot holds the pre-block entry, so the lanes
                 // write their answers back in descending order
                 auto rollback = [&](const Issued& b) {
-                    const uint32_t sh = (b.d0 & kEncHalf) << 4;
-                    const uint32_t a16 = tbl + (b.d0 & kEncAddr) + ((b.d0 & kEncHalf) << 1);
+                    const uint32_t sh = (b.d0 & 2u) << 3;
+                    const uint32_t a16 = tbl + b.d0;
                     const uint32_t prev = (b.ret >> sh) & 0xffffu;
 #pragma nounroll
                     for (int l = 63; l >= 0; --l) {
@@ -515,7 +555,7 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
                     const uint2 v = *reinterpret_cast<const uint2*>(smem + obase + j * kOpRec + 8u * lane);
                     blk[j].d0 = v.x; blk[j].d1 = v.y; blk[j].ret = 0;
                 }
-                const uint32_t zero_blocks = rfl(*reinterpret_cast<const uint32_t*>(smem + kZeroFlagBase + 4u * (uint32_t)(t & 3u)));
+                const uint32_t zero_blocks = rfl(*reinterpret_cast<const uint32_t*>(smem + kZeroFlagBase + 4u * (t & 3u)));
                 // all operands in registers before the first exchange is issued, so no compiler-inserted lgkmcnt wait (which cannot
                 // see the asm exchanges and would drain them) lands between the exchanges
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(blk[0].d0), "+v"(blk[1].d0), "+v"(blk[2].d0), "+v"(blk[3].d0), "+v"(blk[4].d0), "+v"(blk[5].d0), "+v"(blk[6].d0), "+v"(blk[7].d0),
@@ -536,8 +576,8 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
 #pragma unroll
                         for (uint32_t j = 0; j < kRound; ++j) {
                             lds_wait_keep_n(blk[j].ret, kRound - 1 - j);          // later exchanges stay in flight
-                            const uint32_t sh = (blk[j].d0 & kEncHalf) << 4;
-                            sig[j] = ballot64((((blk[j].ret ^ blk[j].d1) >> sh) & 0xffffu) == 0);
+                            const uint32_t sh = blk[j].d0 << 3;
+                            sig[j] = ballot64(((blk[j].ret ^ blk[j].d1) & (0xffffu << sh)) == 0);
                             const uint32_t nh = (uint32_t)__builtin_popcountll(sig[j]);
                             min_hits = nh < min_hits ? nh : min_hits;
                         }
@@ -581,21 +621,21 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
                 }
                 if (k < nb) {                                     // in-order path: copy runs, the blocks after a mis-speculation, short rounds
 #pragma unroll
-                for (uint32_t j = 0; j < kRound; ++j) {
-                    if (j >= k && j < nb) {
-                        const bool cp = pending_copy ? true : guard.block_is_copy();
-                        pending_copy = false;
-                        if (cp) {                                 // codec.rs:35-37
-                            copy_mask |= 1u << j;
-                            guard.decay();
-                        } else {
-                            issue(blk[j]);
-                            lds_wait_all();
-                            sig[j] = signature(blk[j]);
-                            guard.update((uint32_t)__builtin_popcountll(sig[j]) <= 4);   // codec.rs:68
+                    for (uint32_t j = 0; j < kRound; ++j) {
+                        if (j >= k && j < nb) {
+                            const bool cp = pending_copy ? true : guard.block_is_copy();
+                            pending_copy = false;
+                            if (cp) {                             // codec.rs:35-37
+                                copy_mask |= 1u << j;
+                                guard.decay();
+                            } else {
+                                issue(blk[j]);
+                                lds_wait_all();
+                                sig[j] = signature(blk[j]);
+                                guard.update((uint32_t)__builtin_popcountll(sig[j]) <= 4);   // codec.rs:68
+                            }
                         }
                     }
-                }
                 }
                 // publish: 8 signatures + the copy mask (lane 0, plain stores; the values are wave-uniform)
                 if (lane == 0) {
@@ -608,61 +648,68 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
                 }
                 clk.phase(4);
             }
-        } else {
-            // ---------------- worker waves 1..6: hash round t+1, emit round t-1 ----------------
+            clk.work_done();
+            round_barrier();
+            clk.wait_done();
+        }
+    } else {
+        // ---------------- emit waves: round t-1; hash waves: round t+1 ----------------
+        const uint32_t c_off = kSig + 4u * lane;              // item offset of this lane in a record without MAP flags
+        const uint32_t sl = lane & 7u;
+        for (uint32_t t = 0; t <= nrounds; ++t) {
+            clk.start();
             // round t-1's zero-entry flags were read by the dictionary wave during the previous step; the word is next used for round t+3
-            if (t >= 1 && wave == 1 && lane == 0) *reinterpret_cast<uint32_t*>(smem + kZeroFlagBase + 4u * (uint32_t)((t - 1) & 3u)) = 0;
-            if (is_emit && t >= 1 && !(dbg & 2u)) {
-                const uint64_t r = t - 1;
-                const uint32_t qbase = kInBase + (uint32_t)(r % kInRing) * kRoundBytes;
-                const uint32_t rbase = kResBase + (uint32_t)(r % kResRing) * kResBytes;
-                const uint64_t b0 = r * kRound;
-                const uint32_t nb = (nfull - b0) < kRound ? (uint32_t)(nfull - b0) : kRound;
-                // lanes 0..7: signature and record length of block `lane`; prefix over the round = record offsets
-                const uint32_t sl = lane & 7u;
-                const uint32_t slo = *reinterpret_cast<const uint32_t*>(smem + rbase + 8u * sl);
-                const uint32_t shi = *reinterpret_cast<const uint32_t*>(smem + rbase + 8u * sl + 4);
+            if (hb0 == 0 && t >= 1 && lane == 0) *reinterpret_cast<uint32_t*>(smem + kZeroFlagBase + 4u * ((t - 1) & 3u)) = 0;
+            if (eb < kRound && t >= 1 && !(dbg & 2u)) {
+                const uint32_t r = t - 1;
+                const uint32_t rbase = kResBase + (r & (kResRing - 1u)) * kResBytes;
+                const uint32_t left = nfull - r * kRound;
+                // lanes 0..7 (and their images): signature and record length of block `lane & 7`; prefix over the round = record offsets
+                const uint2 sg = *reinterpret_cast<const uint2*>(smem + rbase + 8u * sl);
                 const uint32_t cmask = rfl(*reinterpret_cast<const uint32_t*>(smem + rbase + 64));
-                const uint32_t myhits = (uint32_t)(__builtin_popcount(slo) + __builtin_popcount(shi));
-                const uint32_t mylen = lane < nb ? (((cmask >> sl) & 1u) ? kBlock : (kSig + kBlock - 2u * myhits)) : 0u;
+                const uint32_t q = *reinterpret_cast<const uint32_t*>(smem + kInBase + (r & (kInRing - 1u)) * kRoundBytes + kBlock * eb + 4u * lane);
+                const uint32_t myhits = (uint32_t)(__builtin_popcount(sg.x) + __builtin_popcount(sg.y));
+                uint32_t mylen = kSig + kBlock - 2u * myhits;
+                if (cmask | (uint32_t)(left < kRound)) {         // raw-copy blocks in the round, or the chunk's last (short) round
+                    mylen = ((cmask >> sl) & 1u) ? kBlock : mylen;
+                    mylen = sl < left ? mylen : 0u;
+                }
                 uint32_t incl = mylen;
                 incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xf, 0xf, true);   // row_shr:1
                 incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xf, 0xf, true);   // row_shr:2
                 incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xf, 0xf, true);   // row_shr:4
-                if (idx && wave == kEmitWaveE0 && lane < nb) idx[b0 + lane] = (uint8_t)(((cmask >> sl) & 1u) ? kIdxCopy : myhits);
-                for (uint32_t k = wave - kEmitWaveE0; k < nb; k += kRound) {
-                    const uint32_t before = rlane(incl - mylen, k);
-                    const uint64_t sg = (uint64_t)rlane(slo, k) | ((uint64_t)rlane(shi, k) << 32);
-                    uint8_t* recp = dst + opos_run + before;
-                    const uint32_t q = *reinterpret_cast<const uint32_t*>(smem + qbase + kBlock * k + 4u * lane);
-                    if (dbg & 8u) {
-                        asm volatile("" ::"v"(q), "v"(recp));
-                    } else if ((cmask >> k) & 1u) {
-                        st32u(recp + 4u * lane, q);
+                const uint32_t before = rlane(incl - mylen, eb), round_len = rlane(incl, 7);
+                const uint32_t slo = rlane(sg.x, eb), shi = rlane(sg.y, eb);
+                uint8_t* recp = dst + (opos_run + before);
+                if (eb == 0 && idx && lane < kRound && lane < left)
+                    gstore8(idx + (uint64_t)r * kRound, lane, ((cmask >> sl) & 1u) ? kIdxCopy : myhits);
+                if (eb < left) {
+                    if ((cmask >> eb) & 1u) {
+                        gstore32(recp, 4u * lane, q);
                     } else {
-                        const bool hit = (sg >> lane) & 1ull;
-                        const uint32_t off = kSig + 4u * lane - 2u * mbcnt64(sg);
-                        if (lane == 0) { st32u(recp, (uint32_t)sg); st32u(recp + 4, (uint32_t)(sg >> 32)); }
-                        if (hit) st16u(recp + off, (q * kHashMul) >> 16); else st32u(recp + off, q);
+                        const uint64_t sgk = (uint64_t)slo | ((uint64_t)shi << 32);
+                        const uint32_t off = c_off - 2u * mbcnt64(sgk);
+                        if (lane < 2) gstore32(recp, 4u * lane, lane ? shi : slo);
+                        if ((sgk >> lane) & 1ull) gstore16_hi(recp, off, q * kHashMul); else gstore32(recp, off, q);
                     }
                 }
-                opos_run += rlane(incl, 7);
+                opos_run += round_len;
             }
-            if (is_hash) hash_round(t + 1);
+            if (hbn) hash_round(t + 1);
+            clk.work_done();
+            round_barrier();
+            clk.wait_done();
         }
-        clk.work_done();
-        round_barrier();
-        clk.wait_done();
     }
     clk.flush(wave, lane);
-    if (wave == 0) clk.flush_phases(lane);
+    if (wave == kDictWave) clk.flush_phases(lane);
 
     // hand the stream length so far to the dictionary wave, which finishes a ragged last block with the scalar-path code
-    if (wave == kEmitWaveE0 && lane == 0) *reinterpret_cast<uint64_t*>(smem + kResBase) = opos_run;
+    if (eb == 0 && lane == 0) *reinterpret_cast<uint64_t*>(smem + kResBase) = opos_run;
     round_barrier();
-    if (wave == 0) {
+    if (wave == kDictWave) {
         uint64_t opos = *reinterpret_cast<const uint64_t*>(smem + kResBase);
-        const uint64_t boff = nfull * kBlock;
+        const uint64_t boff = (uint64_t)nfull * kBlock;
         const uint32_t blen = (uint32_t)(len - boff);
         if (blen) {
             const uint32_t nq = blen >> 2, tail = blen & 3u;
@@ -684,10 +731,7 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
                 uint32_t pred_e;
                 resolve_groups(active, lane, w, e, ~0ull, has_pred, pred_e);
                 const bool susp = active && e == 0 && h != 0;
-                uint32_t zbit = 1;
-                if (ballot64(susp)) {
-                    if (susp) zbit = zmap_test_and_set(zmap, h);
-                }
+                const uint32_t zbit = zmap_claim(zmap, susp, h, lane);
                 const bool hit = active && (has_pred ? (pred_e == e) : (old == e && (!susp || zbit)));
                 const uint64_t sig = ballot64(hit);
                 const uint32_t nhit = (uint32_t)__builtin_popcountll(sig);
@@ -1289,19 +1333,21 @@ void prof_report(const char* what, uint64_t* buf, hipStream_t stream) {
 }
 }  // namespace
 hipError_t launch_chameleon_encode(const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks,
-                                   uint8_t* d_out, uint64_t out_stride, uint64_t* d_sizes, uint8_t* d_index, hipStream_t stream) {
+                                   uint8_t* d_out, uint64_t out_stride, uint64_t* d_sizes, uint8_t* d_index, uint32_t* d_zmap, hipStream_t stream) {
     hipError_t e = hipFuncSetAttribute((const void*)chameleon_encode_chunks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
     if (e != hipSuccess) return e;
     if (n_chunks == 0) return hipSuccess;
     // the pipelined kernel stages its input with 16-byte LDS-DMA pieces: needs 16-byte aligned chunk bases
+    // (and counts blocks in 32 bits, keeps its zero-entry maps in the workspace)
     const bool aligned = ((uintptr_t)d_in % 16 == 0) && (n_chunks == 1 || chunk_bytes % 16 == 0);
-    if (aligned && !g_force_simple) {
+    const bool fits = (n_chunks == 1 ? total : chunk_bytes) < (1ull << 40) && d_zmap && n_chunks <= kMaxPipelinedChunks;
+    if (aligned && fits && !g_force_simple) {
         uint64_t* prof = prof_buffer();
         auto kernel = prof ? chameleon_encode_chunks_pipe<true> : chameleon_encode_chunks_pipe<false>;
         e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytesPipe);
         if (e != hipSuccess) return e;
         const uint32_t dbg = getenv("DENSITY_HIP_DBG") ? (uint32_t)atoi(getenv("DENSITY_HIP_DBG")) : 0u;
-        hipLaunchKernelGGL(kernel, dim3(n_chunks), dim3(kPipeWaves * 64), kLdsBytesPipe, stream, d_in, total, chunk_bytes, d_out, out_stride, d_sizes, d_index, dbg, prof);
+        hipLaunchKernelGGL(kernel, dim3(n_chunks), dim3(kPipeWaves * 64), kLdsBytesPipe, stream, d_in, total, chunk_bytes, d_out, out_stride, d_sizes, d_index, d_zmap, dbg, prof);
         prof_report("encode", prof, stream);
     } else {
         hipLaunchKernelGGL(chameleon_encode_chunks, dim3(n_chunks), dim3(64), kLdsBytes, stream, d_in, total, chunk_bytes, d_out, out_stride, d_sizes, d_index);

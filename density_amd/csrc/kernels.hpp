@@ -13,7 +13,8 @@ extern bool g_force_simple;   // density_hip_set_kernel_variant(1)
 // out + c*out_stride; sizes[c] receives the stream length.
 // d_index (nullable): one byte per 256-byte input block, numbered over the whole input (see include/density_hip.h).
 hipError_t launch_chameleon_encode(const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks,
-                                   uint8_t* d_out, uint64_t out_stride, uint64_t* d_sizes, uint8_t* d_index, hipStream_t stream);
+                                   uint8_t* d_out, uint64_t out_stride, uint64_t* d_sizes, uint8_t* d_index, uint32_t* d_zmap, hipStream_t stream);
+// d_zmap (nullable -> one-wavefront kernels): kZmapWordsPerChunk words per chunk of scratch for the pipelined kernels' zero-entry maps.
 // Chunk c reads the stream at in + offsets[c] (sizes[c] bytes) and writes out + c*out_stride.  With `exact`, a chunk
 // that does not produce exactly min(out_stride, out_total - c*out_stride) bytes raises *d_err.
 hipError_t launch_chameleon_decode(const uint8_t* d_in, const uint64_t* d_offsets, const uint64_t* d_sizes,
