@@ -379,19 +379,40 @@ struct WaveClock<false> {                                     // production: com
     __device__ __forceinline__ void phase_start() {}
     __device__ __forceinline__ void phase(int) {}
     __device__ __forceinline__ void flush_phases(uint32_t) {}
+    __device__ __forceinline__ void stat_post(uint32_t, uint32_t, uint32_t) {}
+    __device__ __forceinline__ void stat_take(uint32_t, uint32_t, uint32_t) {}
+    __device__ __forceinline__ void flush_stat(uint32_t, uint32_t) {}
 };
 template <>
 struct WaveClock<true> {
     uint64_t* out; uint64_t work = 0, wait = 0, t0 = 0;
     uint64_t ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tp = 0;       // phase split of one wave's work (dictionary wave): out[32 + k]
+    uint32_t stat = 0, last = 0, hist = 0; uint64_t summax = 0;   // straggler statistics (wave 0): LDS scratch, per-lane counts
     __device__ __forceinline__ explicit WaveClock(uint64_t* o) : out(o) {}
     __device__ __forceinline__ void start() { if (out) t0 = __builtin_readcyclecounter(); }
-    __device__ __forceinline__ void work_done() { if (out) { const uint64_t t = __builtin_readcyclecounter(); work += t - t0; t0 = t; } }
+    __device__ __forceinline__ void work_done() { if (out) { const uint64_t t = __builtin_readcyclecounter(); work += t - t0; last = (uint32_t)(t - t0); t0 = t; } }
     __device__ __forceinline__ void wait_done() { if (out) { const uint64_t t = __builtin_readcyclecounter(); wait += t - t0; t0 = t; } }
     __device__ __forceinline__ void flush(uint32_t wave, uint32_t lane) { if (out && lane == 0) { out[2 * wave] = work; out[2 * wave + 1] = wait; } }
     __device__ __forceinline__ void phase_start() { if (out) tp = __builtin_readcyclecounter(); }
     __device__ __forceinline__ void phase(int k) { if (out) { const uint64_t t = __builtin_readcyclecounter(); ph[k] += t - tp; tp = t; } }
     __device__ __forceinline__ void flush_phases(uint32_t lane) { if (out && lane == 0) for (int k = 0; k < 8; ++k) out[32 + k] = ph[k]; }
+    // which wave was the last to reach the barrier, per step: every wave posts its work time before the barrier (stat_post),
+    // wave 0 reads the 16 values after it (stat_take) and counts, per lane = wave, how often that wave was the slowest
+    __device__ __forceinline__ void stat_post(uint32_t stat_base, uint32_t wave, uint32_t lane) {
+        if (out && lane == 0) *reinterpret_cast<uint32_t*>(smem + stat_base + 4u * wave) = last;
+    }
+    __device__ __forceinline__ void stat_take(uint32_t stat_base, uint32_t wave, uint32_t lane) {
+        if (out && wave == 0) {
+            const uint32_t v = lane < 16 ? *reinterpret_cast<const uint32_t*>(smem + stat_base + 4u * lane) : 0u;
+            uint32_t m = v;
+            for (int d = 1; d < 16; d <<= 1) { const uint32_t o = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((lane ^ d) & 63u) << 2), (int)m); m = o > m ? o : m; }
+            hist += (v == m && lane < 16) ? 1u : 0u;
+            summax += m;
+        }
+    }
+    __device__ __forceinline__ void flush_stat(uint32_t wave, uint32_t lane) {
+        if (out && wave == 0 && lane < 16) { out[48 + lane] = hist; if (lane == 0) out[47] = summax; }
+    }
 };
 
 // per-block state of the dictionary wave between issue and finish
@@ -1108,7 +1129,7 @@ __global__ __launch_bounds__(kDecWaves * 64) void chameleon_decode_chunks_pipe(c
         if (lane == 0) *reinterpret_cast<uint4*>(smem + dbase + 96) = make_uint4(copy_mask, n, (last_round == r) ? kFlagLast : 0u, recs_before);
         // Refill.  While these tiles land, the fetch waves read the round published by the PREVIOUS call (it starts at `keep`),
         // so tile i may only replace tile i-8 if that one ends at or before `keep`.
-        issue_tiles(keep / 1024u + kRingTiles);
+        issue_tiles(keep / 1024u + ((dbg & 512u) ? kRingTiles - 2u : kRingTiles));
         keep = round_start;
         // The fetch waves read this round's bytes [round_start, ipos) during the next step.  DMA retires in order, so exactly
         // the tiles issued beyond that range may stay in flight (an index piece in the queue only makes the wait stricter).
@@ -1257,7 +1278,7 @@ __global__ __launch_bounds__(kDecWaves * 64) void chameleon_decode_chunks_pipe(c
     };
 
     // ---- prologue: fill the pipeline ----
-    const bool is_fetch = wave >= kFetchWave0 && wave < kEmitWave0, is_emit = wave >= kEmitWave0;
+    const bool is_fetch = wave >= kFetchWave0 && wave < kEmitWave0;
     if (wave == 1) {
         if (idx) { stage_index(); issue_tiles(kRingTiles); wait_vm<0>(); feed_round(0); feed_round(1); }
         else { issue_tiles(kRingTiles); parse_round(0); parse_round(1); }
@@ -1272,19 +1293,30 @@ __global__ __launch_bounds__(kDecWaves * 64) void chameleon_decode_chunks_pipe(c
     auto only_flags = [&](uint32_t r) {
         if (rfl(*reinterpret_cast<const uint32_t*>(smem + kDDescBase + (r % kDescRing) * kDescBytes + 104)) & kFlagLast) last_round = r;
     };
-    for (uint32_t s = 0;; ++s) {
-        clk.start();
-        if (wave == 1) { if (idx) feed_round(s + 2); else parse_round(s + 2); }
-        else if (wave == 0) { if (!(dbg & 64u)) dict_round(s); else only_flags(s); }
-        else if (wave == 2) { if (s >= 1) { if (!(dbg & 256u)) finish_round(s - 1); else only_flags(s - 1); } }
-        else if (is_fetch) { if (!(dbg & 32u)) fetch_round(s + 1); else only_flags(s + 1); }
-        else if (is_emit && s >= 2) { if (!(dbg & 16u)) emit_round(s - 2); else only_flags(s - 2); }
+    // one loop per role (the role never changes): the compiler keeps only that role's state live in each loop
+    auto step_end = [&](uint32_t s) -> bool {
         clk.work_done();
+        clk.stat_post(kLdsBytesDec, wave, lane);
         round_barrier();
         clk.wait_done();
-        if (last_round != 0xffffffffu && s >= last_round + 2) break;
+        clk.stat_take(kLdsBytesDec, wave, lane);
+        return last_round != 0xffffffffu && s >= last_round + 2;
+    };
+#define DENSITY_ROLE_LOOP(BODY) for (uint32_t s = 0;; ++s) { clk.start(); BODY; if (step_end(s)) break; }
+    if (wave == 1) {
+        if (idx) DENSITY_ROLE_LOOP(feed_round(s + 2)) else DENSITY_ROLE_LOOP(parse_round(s + 2))
+    } else if (wave == 0) {
+        if (!(dbg & 64u)) DENSITY_ROLE_LOOP(dict_round(s)) else DENSITY_ROLE_LOOP(only_flags(s))
+    } else if (wave == 2) {
+        if (!(dbg & 256u)) DENSITY_ROLE_LOOP(if (s >= 1) finish_round(s - 1)) else DENSITY_ROLE_LOOP(if (s >= 1) only_flags(s - 1))
+    } else if (is_fetch) {
+        if (!(dbg & 32u)) DENSITY_ROLE_LOOP(fetch_round(s + 1)) else DENSITY_ROLE_LOOP(only_flags(s + 1))
+    } else {
+        if (!(dbg & 16u)) DENSITY_ROLE_LOOP(if (s >= 2) emit_round(s - 2)) else DENSITY_ROLE_LOOP(if (s >= 2) only_flags(s - 2))
     }
+#undef DENSITY_ROLE_LOOP
     clk.flush(wave, lane);
+    clk.flush_stat(wave, lane);
 
     // hand the feeder's final state to wave 0, which finishes the ragged end of the stream in order
     if (wave == 1 && lane == 0) {
@@ -1317,19 +1349,21 @@ namespace {
 uint64_t* prof_buffer() {
     static uint64_t* buf = nullptr;
     if (!getenv("DENSITY_HIP_PROF")) return nullptr;
-    if (!buf && hipMalloc((void**)&buf, 40 * sizeof(uint64_t)) != hipSuccess) buf = nullptr;
-    if (buf) (void)hipMemset(buf, 0, 40 * sizeof(uint64_t));
+    if (!buf && hipMalloc((void**)&buf, 72 * sizeof(uint64_t)) != hipSuccess) buf = nullptr;
+    if (buf) (void)hipMemset(buf, 0, 72 * sizeof(uint64_t));
     return buf;
 }
 void prof_report(const char* what, uint64_t* buf, hipStream_t stream) {
     if (!buf) return;
-    uint64_t h[40];
+    uint64_t h[72];
     if (hipStreamSynchronize(stream) != hipSuccess || hipMemcpy(h, buf, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return;
     fprintf(stderr, "[density_hip prof] %s work-group 0: ", what);
     for (int w = 0; w < 16; ++w) if (h[2 * w] | h[2 * w + 1]) fprintf(stderr, "w%d %lluk/%lluk | ", w, (unsigned long long)h[2 * w] / 1000, (unsigned long long)h[2 * w + 1] / 1000);
     fprintf(stderr, "\n[density_hip prof] %s wave-0 phases:", what);
     for (int k = 0; k < 8; ++k) fprintf(stderr, " p%d %llu", k, (unsigned long long)h[32 + k]);
-    fprintf(stderr, "\n");
+    fprintf(stderr, "\n[density_hip prof] %s slowest wave per step (count):", what);
+    for (int w = 0; w < 16; ++w) fprintf(stderr, " w%d %llu", w, (unsigned long long)h[48 + w]);
+    fprintf(stderr, " | sum of per-step maxima %lluk\n", (unsigned long long)h[47] / 1000);
 }
 }  // namespace
 hipError_t launch_chameleon_encode(const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks,
@@ -1367,10 +1401,10 @@ hipError_t launch_chameleon_decode(const uint8_t* d_in, const uint64_t* d_offset
     if (aligned && !g_force_simple && d_zmap && n_chunks <= kMaxPipelinedChunks) {
         uint64_t* prof = prof_buffer();
         auto kernel = prof ? chameleon_decode_chunks_pipe<true> : chameleon_decode_chunks_pipe<false>;
-        e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytesDec);
+        e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytesDec + 64);
         if (e != hipSuccess) return e;
         const uint32_t dbg = getenv("DENSITY_HIP_DBG") ? (uint32_t)atoi(getenv("DENSITY_HIP_DBG")) : 0u;
-        hipLaunchKernelGGL(kernel, dim3(n_chunks), dim3(kDecWaves * 64), kLdsBytesDec, stream, d_in, d_offsets, d_sizes, d_out, out_stride, out_total, exact ? 1u : 0u,
+        hipLaunchKernelGGL(kernel, dim3(n_chunks), dim3(kDecWaves * 64), kLdsBytesDec + 64, stream, d_in, d_offsets, d_sizes, d_out, out_stride, out_total, exact ? 1u : 0u,
                            // the feeder stages the index with 4-byte DMA pieces: per-chunk slices must start 4-byte aligned
                            (d_index && (out_stride / 256) % 4 == 0 && (uintptr_t)d_index % 4 == 0) ? d_index : nullptr, d_zmap, d_produced, d_err, dbg, prof);
         prof_report("decode", prof, stream);
