@@ -1184,35 +1184,49 @@ __global__ __launch_bounds__(kDecWaves * 64) void chameleon_decode_chunks_pipe(c
     auto dict_round = [&](uint32_t r) {                       // wave 0
         const uint32_t dbase = kDDescBase + (r % kDescRing) * kDescBytes;
         const uint32_t sbase = kDStageBase + (r % kStageRing) * kRound * kStageRec;
+        // descriptor and all eight staged records in one LDS round trip (records beyond the round's count are read but unused)
         const uint4 dt = *reinterpret_cast<const uint4*>(smem + dbase + 96);       // {copy mask, count, flags, first ordinal}
-        const uint32_t n = rfl(dt.y), copy_mask = rfl(dt.x);
-        if (rfl(dt.z) & kFlagLast) last_round = r;
-        if (n == 0) return;
         uint32_t d0[kRound], d1[kRound], ret[kRound];
 #pragma unroll
         for (uint32_t j = 0; j < kRound; ++j) {
             const uint2 v = *reinterpret_cast<const uint2*>(smem + sbase + j * kStageRec + 8u * lane);
             d0[j] = v.x; d1[j] = v.y; ret[j] = 0;
         }
+        const uint32_t n = rfl(dt.y), copy_mask = rfl(dt.x);
+        if (rfl(dt.z) & kFlagLast) last_round = r;
+        if (n == 0) return;
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d0[0]), "+v"(d0[1]), "+v"(d0[2]), "+v"(d0[3]), "+v"(d0[4]), "+v"(d0[5]), "+v"(d0[6]), "+v"(d0[7]),
                                               "+v"(d1[0]), "+v"(d1[1]), "+v"(d1[2]), "+v"(d1[3]), "+v"(d1[4]), "+v"(d1[5]), "+v"(d1[6]), "+v"(d1[7]) :: "memory");
         const uint32_t live = ((1u << n) - 1u) & ~copy_mask;      // records that go through the table
-#pragma unroll
-        for (uint32_t j = 0; j < kRound; ++j) {
-            if ((live >> j) & 1u) {
-                const uint32_t sh = (d0[j] & kD0Half) << 4;
-                const uint32_t mask = (uint32_t)(((int32_t)(d0[j] << 30) >> 31) & 0xffff) << sh;   // write flag -> 0xffff or 0
-                dict_xchg_issue(tbl + (d0[j] & kD0Addr), mask, d1[j], ret[j]);
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ret[0]), "+v"(ret[1]), "+v"(ret[2]), "+v"(ret[3]), "+v"(ret[4]), "+v"(ret[5]), "+v"(ret[6]), "+v"(ret[7]) :: "memory");
+        auto issue = [&](uint32_t j) {
+            const uint32_t sh = (d0[j] & kD0Half) << 4;
+            const uint32_t mask = (uint32_t)(((int32_t)(d0[j] << 30) >> 31) & 0xffff) << sh;   // write flag -> 0xffff or 0
+            dict_xchg_issue(tbl + (d0[j] & kD0Addr), mask, d1[j], ret[j]);
+        };
         // what the slot holds after this lane's turn: its own entry for PLAIN lanes, the entry it read for MAP lanes; the emit
         // waves take the quad from that uniformly
+        auto finish = [&](uint32_t j) {
+            const uint32_t m = (d0[j] & kD0Write) ? d1[j] : ret[j];
+            asm volatile("ds_write_b32 %0, %1 offset:4" ::"v"(lds0 + sbase + j * kStageRec + 8u * lane), "v"(m) : "memory");
+        };
+        if (live == 0xffu) {                                      // the common round: eight coded records, straight-line code
 #pragma unroll
-        for (uint32_t j = 0; j < kRound; ++j) {
-            if ((live >> j) & 1u) {
-                const uint32_t m = (d0[j] & kD0Write) ? d1[j] : ret[j];
-                *reinterpret_cast<uint32_t*>(smem + sbase + j * kStageRec + 8u * lane + 4u) = m;
+            for (uint32_t j = 0; j < kRound; ++j) issue(j);
+#pragma unroll
+            for (uint32_t j = 0; j < kRound; ++j) {
+                // outstanding: the exchanges after j and the j results already written back
+                asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(ret[j]) :: "memory");
+                finish(j);
+            }
+        } else {
+#pragma unroll
+            for (uint32_t j = 0; j < kRound; ++j) {
+                if ((live >> j) & 1u) issue(j);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ret[0]), "+v"(ret[1]), "+v"(ret[2]), "+v"(ret[3]), "+v"(ret[4]), "+v"(ret[5]), "+v"(ret[6]), "+v"(ret[7]) :: "memory");
+#pragma unroll
+            for (uint32_t j = 0; j < kRound; ++j) {
+                if ((live >> j) & 1u) finish(j);
             }
         }
     };
@@ -1255,26 +1269,25 @@ __global__ __launch_bounds__(kDecWaves * 64) void chameleon_decode_chunks_pipe(c
         }
     };
 
-    auto emit_round = [&](uint32_t r) {                       // waves 11..15
+    auto emit_round = [&](uint32_t r) {                       // waves 11..15: records w and w + 5 of the round
         const uint32_t w = wave - kEmitWave0;
         const uint32_t dbase = kDDescBase + (r % kDescRing) * kDescBytes;
-        const uint32_t sbase = kDStageBase + (r % kStageRing) * kRound * kStageRec;
+        const uint32_t sbase = kDStageBase + (r % kStageRing) * kRound * kStageRec + 8u * lane;
+        // descriptor and both staged records in one LDS round trip (a record beyond the round's count is read but unused)
         const uint4 dt = *reinterpret_cast<const uint4*>(smem + dbase + 96);       // {copy mask, count, flags, first ordinal}
+        const uint2 va = *reinterpret_cast<const uint2*>(smem + sbase + w * kStageRec);
+        const uint2 vb = *reinterpret_cast<const uint2*>(smem + sbase + ((w + kNumEmit) & (kRound - 1u)) * kStageRec);
         const uint32_t n = rfl(dt.y), copy_mask = rfl(dt.x), first = rfl(dt.w);
         if (rfl(dt.z) & kFlagLast) last_round = r;
-        for (uint32_t k = w; k < n; k += kNumEmit) {
-            const uint2 v = *reinterpret_cast<const uint2*>(smem + sbase + k * kStageRec + 8u * lane);
-            uint32_t q;
-            if ((copy_mask >> k) & 1u) {
-                q = v.y;
-            } else {
-                const uint32_t sh = (v.x & kD0Half) << 4;
-                const uint32_t h = ((v.x & kD0Addr) >> 1) | (v.x & kD0Half);
-                q = (v.x & kD0Empty) ? 0u : entry_to_quad(h, (v.y >> sh) & 0xffffu);
-            }
-            if (dbg & 128u) asm volatile("" ::"v"(q)); else
-            *reinterpret_cast<uint32_t*>(dst + (uint64_t)(first + k) * kBlock + 4u * lane) = q;
-        }
+        auto quad_of = [&](const uint2& v, uint32_t k) -> uint32_t {
+            const uint32_t sh = (v.x & kD0Half) << 4;
+            const uint32_t h = ((v.x & kD0Addr) >> 1) | (v.x & kD0Half);
+            const uint32_t q = (v.x & kD0Empty) ? 0u : entry_to_quad(h, (v.y >> sh) & 0xffffu);
+            return ((copy_mask >> k) & 1u) ? v.y : q;
+        };
+        uint8_t* base = dst + (uint64_t)first * kBlock;           // wave-uniform
+        if (w < n) gstore32(base + w * kBlock, 4u * lane, quad_of(va, w));
+        if (w + kNumEmit < n) gstore32(base + (w + kNumEmit) * kBlock, 4u * lane, quad_of(vb, w + kNumEmit));
     };
 
     // ---- prologue: fill the pipeline ----
