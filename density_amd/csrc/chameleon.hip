@@ -1235,14 +1235,23 @@ __global__ __launch_bounds__(kDecWaves * 64) void chameleon_decode_chunks_pipe(c
     auto finish_round = [&](uint32_t r) {                     // wave 2
         const uint32_t dbase = kDDescBase + (r % kDescRing) * kDescBytes;
         const uint32_t sbase = kDStageBase + (r % kStageRing) * kRound * kStageRec;
+        // descriptor and all eight records in one LDS round trip; a per-lane OR of "stored entry 0 outside slot 0"; the ballots and
+        // the serial part run only when a zero entry shows up (records beyond the round's count hold stale data: filtered there)
         const uint4 dt = *reinterpret_cast<const uint4*>(smem + dbase + 96);       // {copy mask, count, flags, first ordinal}
-        const uint32_t n = rfl(dt.y), copy_mask = rfl(dt.x);
-        if (rfl(dt.z) & kFlagLast) last_round = r;
-        if (n == 0) return;
-        // all eight records at once: one LDS round trip, eight ballots; the serial part runs only when a zero entry shows up
         uint2 v[kRound];
 #pragma unroll
         for (uint32_t j = 0; j < kRound; ++j) v[j] = *reinterpret_cast<const uint2*>(smem + sbase + j * kStageRec + 8u * lane);
+        const uint32_t n = rfl(dt.y), copy_mask = rfl(dt.x);
+        if (rfl(dt.z) & kFlagLast) last_round = r;
+        if (n == 0) return;
+        uint32_t zacc = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < kRound; ++j) {
+            const uint32_t sh = (v[j].x & kD0Half) << 4;
+            const uint32_t e16 = (v[j].y >> sh) & 0xffffu;
+            zacc |= e16 == 0 ? (v[j].x & (kD0Addr | kD0Half)) : 0u;
+        }
+        if (!ballot64(zacc != 0)) return;
         const uint32_t live = ((1u << n) - 1u) & ~copy_mask;
         uint64_t zeros[kRound];
         uint32_t any = 0;
