@@ -106,7 +106,15 @@ __device__ __forceinline__ void lds_wait_keep_n(uint32_t& r, uint32_t n) {   // 
         case 4: lds_wait_keep<4>(r); break;
         case 5: lds_wait_keep<5>(r); break;
         case 6: lds_wait_keep<6>(r); break;
-        default: lds_wait_keep<7>(r); break;
+        case 7: lds_wait_keep<7>(r); break;
+        case 8: lds_wait_keep<8>(r); break;
+        case 9: lds_wait_keep<9>(r); break;
+        case 10: lds_wait_keep<10>(r); break;
+        case 11: lds_wait_keep<11>(r); break;
+        case 12: lds_wait_keep<12>(r); break;
+        case 13: lds_wait_keep<13>(r); break;
+        case 14: lds_wait_keep<14>(r); break;
+        default: lds_wait_keep<15>(r); break;
     }
 }
 __device__ __forceinline__ void lds_wait_all() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
@@ -280,8 +288,8 @@ namespace {
 
 constexpr uint32_t kRound = 8;                               // blocks per round
 constexpr uint32_t kRoundBytes = kRound * kBlock;            // 2 KiB
-constexpr uint32_t kInRing = 8, kResRing = 2;              // input ring (power of two): kAhead rounds in flight + hashed + emitted
-constexpr uint32_t kAhead = 4;                               // DMA runs this many rounds ahead of the dictionary wave (deeper measured slower)
+constexpr uint32_t kInRing = 8, kResRing = 2;              // input ring (power of two): emitted, finished, hashed x2, kAhead - 3 rounds in flight
+constexpr uint32_t kAhead = 6;                               // the loader issues round t + kAhead during step t
 constexpr uint32_t kInBase = kTableBytes;                    // the pipelined kernels keep the zero-entry map in global memory (ZmapGlobal)
 constexpr uint32_t kResBase = kInBase + kInRing * kRoundBytes;
 constexpr uint32_t kResBytes = 128;                          // dwords 0..15 signatures, 16 copy mask
@@ -475,20 +483,19 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
             if (off + 16 <= (uint64_t)nfull * kBlock) dma_1k(src + off, lds0 + kInBase + (r & (kInRing - 1u)) * kRoundBytes + j * 1024u);
         }
     };
-    // all rounds up to `r` have landed; rounds r+1 .. (issued - 1) may stay in flight.  vmcnt retires in order and every round
-    // before the last one issues exactly kRound/4 instructions, so the count is exact away from the chunk's end.
-    auto wait_landed = [&](uint32_t r, uint32_t issued) {
-        if (issued > r + 1 && issued - (r + 1) == kAhead - 2 && issued < nrounds && !(dbg & 1u)) wait_vm<(kAhead - 2) * (kRound / 4)>();
-        else wait_vm<0>();
-    };
+    // Loader invariant: before the barrier that ends step t, rounds <= t + 3 have landed (the hash waves read round t + 3 in
+    // step t + 1) and rounds up to t + kAhead have been issued.  vmcnt retires in order and every round before the last one is
+    // exactly kRound / 4 instructions, so the wait is exact away from the chunk's end.
+    constexpr uint32_t kInFlight = (kAhead - 3) * (kRound / 4);
     if (wave == kLoadWave) {
 #pragma unroll
         for (uint32_t r = 0; r < kAhead; ++r) issue_round(r);
-        wait_landed(1, kAhead);
+        if (kAhead < nrounds && !(dbg & 1u)) wait_vm<kInFlight>(); else wait_vm<0>();      // rounds 0..2 landed
     }
     round_barrier();
 
-    // ---------------- hash waves: round r into the operand ring (one round ahead of the dictionary wave) --------
+    // ---------------- hash waves: round r into the operand ring (two rounds ahead of the dictionary wave, which fetches the
+    // operands of round t+1 while the exchanges of round t run) --------
     const uint32_t hb0 = (uint32_t)(kHashFirstTbl >> (4u * wave)) & 15u, hbn = (uint32_t)(kHashCountTbl >> (4u * wave)) & 15u;
     const uint32_t eb = (uint32_t)(kEmitBlockTbl >> (4u * wave)) & 15u;
     auto hash_round = [&](uint32_t r) {
@@ -513,30 +520,80 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
             }
         }
     };
-    if (hbn) hash_round(0);
+    if (hbn) { hash_round(0); hash_round(1); }
     round_barrier();
 
     uint64_t opos_run = 0;                                    // emit waves: output offset of the round being emitted (each tracks it)
     Guard guard;                                              // dictionary wave
+    // the dictionary wave takes the operands of round 0 before the hash waves reuse that ring slot for round 2
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 nx0[kRound / 2];
+    uint32_t zero0 = 0;
+    if (wave == kDictWave) {
+        const uint32_t a = lds0 + kOpBase + 8u * lane, z = lds0 + kZeroFlagBase;
+        asm volatile(
+            "ds_read2st64_b64 %0, %5 offset1:1\n\t"
+            "ds_read2st64_b64 %1, %5 offset0:2 offset1:3\n\t"
+            "ds_read2st64_b64 %2, %5 offset0:4 offset1:5\n\t"
+            "ds_read2st64_b64 %3, %5 offset0:6 offset1:7\n\t"
+            "ds_read_b32 %4, %6\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(nx0[0]), "=&v"(nx0[1]), "=&v"(nx0[2]), "=&v"(nx0[3]), "=&v"(zero0)
+            : "v"(a), "v"(z)
+            : "memory");
+    }
+    round_barrier();
 
     if (wave == kLoadWave) {
-        // ---------------- loader: keep kAhead rounds in flight, guarantee round t+2 for the next step ----------------
+        // ---------------- loader ----------------
         for (uint32_t t = 0; t <= nrounds; ++t) {
             clk.start();
             issue_round(t + kAhead);
-            const uint32_t issued = (t + kAhead + 1) < nrounds ? (t + kAhead + 1) : nrounds;
-            if (t + 2 < nrounds) wait_landed(t + 2, issued); else wait_vm<0>();
+            if (t + kAhead + 1 < nrounds && !(dbg & 1u)) wait_vm<kInFlight>(); else wait_vm<0>();
             clk.work_done();
             round_barrier();
             clk.wait_done();
         }
     } else if (wave == kDictWave) {
         // ---------------- dictionary wave: round t ----------------
+        // (the compiler lays this branch out behind the other roles' loops and carries their pending LDS accesses into it: clear
+        // its scoreboard with a wait it can see, or it guards registers here with lgkmcnt waits that drain the exchanges)
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        Issued blk[kRound];
+        u32x4 nx[kRound / 2];                                 // operands of the next round: {d0, d1} of blocks 2i, 2i+1
+        uint32_t zero_blocks = rfl(zero0), zero_nxt = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < kRound / 2; ++i) {
+            blk[2 * i].d0 = nx0[i].x; blk[2 * i].d1 = nx0[i].y; blk[2 * i + 1].d0 = nx0[i].z; blk[2 * i + 1].d1 = nx0[i].w;
+            blk[2 * i].ret = 0; blk[2 * i + 1].ret = 0;
+        }
+        // operands (and zero-entry flags) of round r: five LDS reads, asynchronous — pair with ops_take()
+        auto load_ops = [&](uint32_t r) {
+            const uint32_t a = lds0 + kOpBase + (r & (kOpRing - 1u)) * kOpRoundBytes + 8u * lane;
+            const uint32_t z = lds0 + kZeroFlagBase + 4u * (r & 3u);
+            asm volatile(
+                "ds_read2st64_b64 %0, %5 offset1:1\n\t"
+                "ds_read2st64_b64 %1, %5 offset0:2 offset1:3\n\t"
+                "ds_read2st64_b64 %2, %5 offset0:4 offset1:5\n\t"
+                "ds_read2st64_b64 %3, %5 offset0:6 offset1:7\n\t"
+                "ds_read_b32 %4, %6"
+                : "=&v"(nx[0]), "=&v"(nx[1]), "=&v"(nx[2]), "=&v"(nx[3]), "=&v"(zero_nxt)
+                : "v"(a), "v"(z)
+                : "memory");
+        };
+        auto ops_take = [&]() {                               // all LDS traffic of this wave retired; the prefetched operands become current
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(nx[0]), "+v"(nx[1]), "+v"(nx[2]), "+v"(nx[3]), "+v"(zero_nxt) :: "memory");
+#pragma unroll
+            for (uint32_t i = 0; i < kRound / 2; ++i) {
+                blk[2 * i].d0 = nx[i].x; blk[2 * i].d1 = nx[i].y; blk[2 * i + 1].d0 = nx[i].z; blk[2 * i + 1].d1 = nx[i].w;
+                blk[2 * i].ret = 0; blk[2 * i + 1].ret = 0;
+            }
+            zero_blocks = rfl(zero_nxt);
+        };
         for (uint32_t t = 0; t <= nrounds; ++t) {
             clk.start();
             if (t < nrounds) {
                 clk.phase_start();
-                const uint32_t obase = kOpBase + (t & (kOpRing - 1u)) * kOpRoundBytes;
                 const uint32_t rbase = kResBase + (t & (kResRing - 1u)) * kResBytes;
                 const uint32_t left = nfull - t * kRound;
                 const uint32_t nb = left < kRound ? left : kRound;
@@ -546,7 +603,7 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
                 for (uint32_t j = 0; j < kRound; ++j) sig[j] = 0;
 
                 auto issue = [&](Issued& b) {
-                    const uint32_t sh = b.d0 << 3;            // shift counts use bits 0..4: (d0 & 2) << 3
+                    const uint32_t sh = (b.d0 << 3) & 31u;       // (d0 & 2) << 3: the half of the dword the slot lives in
                     dict_xchg_issue(tbl + (b.d0 & kEncAddr), 0xffffu << sh, b.d1, b.ret);
                 };
                 // signature of a block from the dictionary answers, including the zero-entry disambiguation (rare path)
@@ -570,22 +627,13 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
                     }
                 };
 
-                Issued blk[kRound];
-#pragma unroll
-                for (uint32_t j = 0; j < kRound; ++j) {
-                    const uint2 v = *reinterpret_cast<const uint2*>(smem + obase + j * kOpRec + 8u * lane);
-                    blk[j].d0 = v.x; blk[j].d1 = v.y; blk[j].ret = 0;
-                }
-                const uint32_t zero_blocks = rfl(*reinterpret_cast<const uint32_t*>(smem + kZeroFlagBase + 4u * (t & 3u)));
-                // all operands in registers before the first exchange is issued, so no compiler-inserted lgkmcnt wait (which cannot
-                // see the asm exchanges and would drain them) lands between the exchanges
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(blk[0].d0), "+v"(blk[1].d0), "+v"(blk[2].d0), "+v"(blk[3].d0), "+v"(blk[4].d0), "+v"(blk[5].d0), "+v"(blk[6].d0), "+v"(blk[7].d0),
-                                                      "+v"(blk[0].d1), "+v"(blk[1].d1), "+v"(blk[2].d1), "+v"(blk[3].d1), "+v"(blk[4].d1), "+v"(blk[5].d1), "+v"(blk[6].d1), "+v"(blk[7].d1) :: "memory");
                 clk.phase(1);
 
                 uint32_t k = 0;
                 bool pending_copy = false;                        // guard already advanced for block k and said "copy"
-                if (nb == kRound && guard.penalty == 0) {
+                const bool spec = nb == kRound && guard.penalty == 0;
+                if (!spec) load_ops(t + 1);
+                if (spec) {
 #pragma unroll
                     for (uint32_t j = 0; j < kRound; ++j) issue(blk[j]);
                     uint32_t min_hits = 64;
@@ -597,7 +645,7 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
 #pragma unroll
                         for (uint32_t j = 0; j < kRound; ++j) {
                             lds_wait_keep_n(blk[j].ret, kRound - 1 - j);          // later exchanges stay in flight
-                            const uint32_t sh = blk[j].d0 << 3;
+                            const uint32_t sh = (blk[j].d0 << 3) & 31u;
                             sig[j] = ballot64(((blk[j].ret ^ blk[j].d1) & (0xffffu << sh)) == 0);
                             const uint32_t nh = (uint32_t)__builtin_popcountll(sig[j]);
                             min_hits = nh < min_hits ? nh : min_hits;
@@ -606,6 +654,9 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
                         lds_wait_all();
                     }
                     clk.phase(3);
+                    // operands of the next round (past the last round: stale ones, unused), fetched while the FSM and the publishing
+                    // below run; issued only now because anything queued behind the exchanges blocks this wave until they drain
+                    load_ops(t + 1);
                     if (plain_round && min_hits > 4 && !guard.prev) {
                         // no incompressible record (codec.rs:68: 8 + 256 - 2*hits >= 256) in this round: the FSM only counts
                         // blocks (protection_state.rs:19-27); one of 8 consecutive counters is a multiple of 16 iff c == 0 or c > 8
@@ -668,6 +719,8 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
                     *reinterpret_cast<uint32_t*>(smem + rbase + 64) = copy_mask;
                 }
                 clk.phase(4);
+                ops_take();
+                clk.phase(5);
             }
             clk.work_done();
             round_barrier();
@@ -716,7 +769,7 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
                 }
                 opos_run += round_len;
             }
-            if (hbn) hash_round(t + 1);
+            if (hbn) hash_round(t + 2);
             clk.work_done();
             round_barrier();
             clk.wait_done();
