@@ -567,7 +567,10 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
             blk[2 * i].d0 = nx0[i].x; blk[2 * i].d1 = nx0[i].y; blk[2 * i + 1].d0 = nx0[i].z; blk[2 * i + 1].d1 = nx0[i].w;
             blk[2 * i].ret = 0; blk[2 * i + 1].ret = 0;
         }
-        // operands (and zero-entry flags) of round r: five LDS reads, asynchronous — pair with ops_take()
+        // Operands (and zero-entry flags) of round r: five LDS reads, asynchronous — pair with ops_take().  The compiler believes an
+        // asm's outputs are valid when the asm ends, so it is free to copy them elsewhere before the wait (it did: copies of
+        // registers still in flight).  Both ends are therefore pinned to fixed registers the allocator never has a reason to move,
+        // and the copies into the working registers happen inside the same asm as the wait.
         auto load_ops = [&](uint32_t r) {
             const uint32_t a = lds0 + kOpBase + (r & (kOpRing - 1u)) * kOpRoundBytes + 8u * lane;
             const uint32_t z = lds0 + kZeroFlagBase + 4u * (r & 3u);
@@ -577,18 +580,26 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
                 "ds_read2st64_b64 %2, %5 offset0:4 offset1:5\n\t"
                 "ds_read2st64_b64 %3, %5 offset0:6 offset1:7\n\t"
                 "ds_read_b32 %4, %6"
-                : "=&v"(nx[0]), "=&v"(nx[1]), "=&v"(nx[2]), "=&v"(nx[3]), "=&v"(zero_nxt)
+                : "={v[100:103]}"(nx[0]), "={v[104:107]}"(nx[1]), "={v[108:111]}"(nx[2]), "={v[112:115]}"(nx[3]), "={v116}"(zero_nxt)
                 : "v"(a), "v"(z)
                 : "memory");
         };
         auto ops_take = [&]() {                               // all LDS traffic of this wave retired; the prefetched operands become current
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(nx[0]), "+v"(nx[1]), "+v"(nx[2]), "+v"(nx[3]), "+v"(zero_nxt) :: "memory");
+            uint32_t zf;
+            asm volatile(
+                "s_waitcnt lgkmcnt(0)\n\t"
+                "v_mov_b32 %0, v100\n\tv_mov_b32 %1, v101\n\tv_mov_b32 %2, v102\n\tv_mov_b32 %3, v103\n\t"
+                "v_mov_b32 %4, v104\n\tv_mov_b32 %5, v105\n\tv_mov_b32 %6, v106\n\tv_mov_b32 %7, v107\n\t"
+                "v_mov_b32 %8, v108\n\tv_mov_b32 %9, v109\n\tv_mov_b32 %10, v110\n\tv_mov_b32 %11, v111\n\t"
+                "v_mov_b32 %12, v112\n\tv_mov_b32 %13, v113\n\tv_mov_b32 %14, v114\n\tv_mov_b32 %15, v115\n\t"
+                "v_mov_b32 %16, v116"
+                : "=&v"(blk[0].d0), "=&v"(blk[0].d1), "=&v"(blk[1].d0), "=&v"(blk[1].d1), "=&v"(blk[2].d0), "=&v"(blk[2].d1), "=&v"(blk[3].d0), "=&v"(blk[3].d1),
+                  "=&v"(blk[4].d0), "=&v"(blk[4].d1), "=&v"(blk[5].d0), "=&v"(blk[5].d1), "=&v"(blk[6].d0), "=&v"(blk[6].d1), "=&v"(blk[7].d0), "=&v"(blk[7].d1), "=&v"(zf)
+                : "{v[100:103]}"(nx[0]), "{v[104:107]}"(nx[1]), "{v[108:111]}"(nx[2]), "{v[112:115]}"(nx[3]), "{v116}"(zero_nxt)
+                : "memory");
 #pragma unroll
-            for (uint32_t i = 0; i < kRound / 2; ++i) {
-                blk[2 * i].d0 = nx[i].x; blk[2 * i].d1 = nx[i].y; blk[2 * i + 1].d0 = nx[i].z; blk[2 * i + 1].d1 = nx[i].w;
-                blk[2 * i].ret = 0; blk[2 * i + 1].ret = 0;
-            }
-            zero_blocks = rfl(zero_nxt);
+            for (uint32_t j = 0; j < kRound; ++j) blk[j].ret = 0;
+            zero_blocks = rfl(zf);
         };
         for (uint32_t t = 0; t <= nrounds; ++t) {
             clk.start();
@@ -629,10 +640,27 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
 
                 clk.phase(1);
 
+                // results for the emit waves: 8 signatures + the copy mask, written by lane 0 (the values are wave-uniform)
+                auto publish = [&]() {
+                    if (lane == 0) {
+                        const u32x4 s01 = {(uint32_t)sig[0], (uint32_t)(sig[0] >> 32), (uint32_t)sig[1], (uint32_t)(sig[1] >> 32)};
+                        const u32x4 s23 = {(uint32_t)sig[2], (uint32_t)(sig[2] >> 32), (uint32_t)sig[3], (uint32_t)(sig[3] >> 32)};
+                        const u32x4 s45 = {(uint32_t)sig[4], (uint32_t)(sig[4] >> 32), (uint32_t)sig[5], (uint32_t)(sig[5] >> 32)};
+                        const u32x4 s67 = {(uint32_t)sig[6], (uint32_t)(sig[6] >> 32), (uint32_t)sig[7], (uint32_t)(sig[7] >> 32)};
+                        asm volatile(
+                            "ds_write_b128 %0, %1\n\t"
+                            "ds_write_b128 %0, %2 offset:16\n\t"
+                            "ds_write_b128 %0, %3 offset:32\n\t"
+                            "ds_write_b128 %0, %4 offset:48\n\t"
+                            "ds_write_b32 %0, %5 offset:64"
+                            ::"v"(lds0 + rbase), "v"(s01), "v"(s23), "v"(s45), "v"(s67), "v"(copy_mask) : "memory");
+                    }
+                };
+
                 uint32_t k = 0;
                 bool pending_copy = false;                        // guard already advanced for block k and said "copy"
+                bool done = false;
                 const bool spec = nb == kRound && guard.penalty == 0;
-                if (!spec) load_ops(t + 1);
                 if (spec) {
 #pragma unroll
                     for (uint32_t j = 0; j < kRound; ++j) issue(blk[j]);
@@ -658,13 +686,16 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
                     // below run; issued only now because anything queued behind the exchanges blocks this wave until they drain
                     load_ops(t + 1);
                     if (plain_round && min_hits > 4 && !guard.prev) {
-                        // no incompressible record (codec.rs:68: 8 + 256 - 2*hits >= 256) in this round: the FSM only counts
-                        // blocks (protection_state.rs:19-27); one of 8 consecutive counters is a multiple of 16 iff c == 0 or c > 8
+                        // The common round, kept in one straight block.  No incompressible record (codec.rs:68: 8 + 256 - 2*hits >=
+                        // 256) in it: the FSM only counts blocks (protection_state.rs:19-27); one of 8 consecutive counters is a
+                        // multiple of 16 iff c == 0 or c > 8.
                         const uint32_t c = guard.counter & 15u;
-                        const uint32_t halve = (uint32_t)(c == 0u) | (uint32_t)(c > 8u);
-                        guard.start = (halve && guard.start > 1u) ? guard.start >> 1 : guard.start;
+                        guard.start >>= (uint32_t)((c - 1u) >= 8u) & (uint32_t)(guard.start > 1u);
                         guard.counter += kRound;
-                        k = kRound;
+                        publish();
+                        clk.phase(4);
+                        ops_take();
+                        done = true;
                     } else {
                         // walk the FSM block by block; stop at the first block it turns into a raw copy.  With zero-entry quads
                         // in the round the signature itself updates the zero-entry map, so it is taken only for blocks the FSM
@@ -690,36 +721,32 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
                             lds_wait_all();
                         }
                     }
+                } else {
+                    load_ops(t + 1);
                 }
-                if (k < nb) {                                     // in-order path: copy runs, the blocks after a mis-speculation, short rounds
+                if (!done) {
+                    if (k < nb) {                                 // in-order path: copy runs, the blocks after a mis-speculation, short rounds
 #pragma unroll
-                    for (uint32_t j = 0; j < kRound; ++j) {
-                        if (j >= k && j < nb) {
-                            const bool cp = pending_copy ? true : guard.block_is_copy();
-                            pending_copy = false;
-                            if (cp) {                             // codec.rs:35-37
-                                copy_mask |= 1u << j;
-                                guard.decay();
-                            } else {
-                                issue(blk[j]);
-                                lds_wait_all();
-                                sig[j] = signature(blk[j]);
-                                guard.update((uint32_t)__builtin_popcountll(sig[j]) <= 4);   // codec.rs:68
+                        for (uint32_t j = 0; j < kRound; ++j) {
+                            if (j >= k && j < nb) {
+                                const bool cp = pending_copy ? true : guard.block_is_copy();
+                                pending_copy = false;
+                                if (cp) {                         // codec.rs:35-37
+                                    copy_mask |= 1u << j;
+                                    guard.decay();
+                                } else {
+                                    issue(blk[j]);
+                                    lds_wait_all();
+                                    sig[j] = signature(blk[j]);
+                                    guard.update((uint32_t)__builtin_popcountll(sig[j]) <= 4);   // codec.rs:68
+                                }
                             }
                         }
                     }
+                    publish();
+                    clk.phase(4);
+                    ops_take();
                 }
-                // publish: 8 signatures + the copy mask (lane 0, plain stores; the values are wave-uniform)
-                if (lane == 0) {
-                    uint4* rp = reinterpret_cast<uint4*>(smem + rbase);
-                    rp[0] = make_uint4((uint32_t)sig[0], (uint32_t)(sig[0] >> 32), (uint32_t)sig[1], (uint32_t)(sig[1] >> 32));
-                    rp[1] = make_uint4((uint32_t)sig[2], (uint32_t)(sig[2] >> 32), (uint32_t)sig[3], (uint32_t)(sig[3] >> 32));
-                    rp[2] = make_uint4((uint32_t)sig[4], (uint32_t)(sig[4] >> 32), (uint32_t)sig[5], (uint32_t)(sig[5] >> 32));
-                    rp[3] = make_uint4((uint32_t)sig[6], (uint32_t)(sig[6] >> 32), (uint32_t)sig[7], (uint32_t)(sig[7] >> 32));
-                    *reinterpret_cast<uint32_t*>(smem + rbase + 64) = copy_mask;
-                }
-                clk.phase(4);
-                ops_take();
                 clk.phase(5);
             }
             clk.work_done();
