@@ -988,7 +988,7 @@ namespace {
 constexpr uint32_t kDecWaves = 16;
 constexpr uint32_t kRingBytes = 8192;                        // compressed-byte ring (power of two)
 constexpr uint32_t kRingTiles = kRingBytes / 1024;
-constexpr uint32_t kDescBytes = 128, kDescRing = 6;          // dwords 16..23 record positions, 24 copy mask, 25 count, 26 flags, 27 first ordinal
+constexpr uint32_t kDescBytes = 128, kDescRing = 8;          // dwords 16..23 record positions, 24 copy mask, 25 count, 26 flags, 27 first ordinal
 constexpr uint32_t kStageRec = 512, kStageRing = 4;          // per record: 64 x {d0, d1}; the dictionary wave turns d1 into the slot's entry
 constexpr uint32_t kDRingBase = kTableBytes;                 // no zero-entry map in LDS here (ZmapGlobal)
 constexpr uint32_t kDDescBase = kDRingBase + kRingBytes;
@@ -1215,50 +1215,40 @@ __global__ __launch_bounds__(kDecWaves * 64) void chameleon_decode_chunks_pipe(c
         // the tiles issued beyond that range may stay in flight (an index piece in the queue only makes the wait stricter).
         const uint32_t need = (ipos + 1023u) / 1024u;            // tiles [0, need) must have landed
         const uint32_t in_flight_ok = tiles > need ? tiles - need : 0u;
-        switch (in_flight_ok) {
-            case 0: wait_vm<0>(); break;
-            case 1: wait_vm<1>(); break;
-            case 2: wait_vm<2>(); break;
-            case 3: wait_vm<3>(); break;
-            case 4: wait_vm<4>(); break;
-            case 5: wait_vm<5>(); break;
-            default: wait_vm<6>(); break;
-        }
+        if (in_flight_ok >= 4) wait_vm<4>(); else wait_vm<0>();   // (steady state keeps 4-5 tiles in flight)
     };
 
-    auto fetch_round = [&](uint32_t r) {                      // waves 3..10, one record each
+    auto fetch_round = [&](uint32_t r) {                      // waves 3..10, record w of the round
         const uint32_t w = wave - kFetchWave0;
         const uint32_t dbase = kDDescBase + (r % kDescRing) * kDescBytes;
         const uint32_t sbase = kDStageBase + (r % kStageRing) * kRound * kStageRec;
+        // descriptor and this wave's record position in one LDS round trip
         const uint4 dt = *reinterpret_cast<const uint4*>(smem + dbase + 96);       // {copy mask, count, flags, first ordinal}
+        const uint32_t posv = *reinterpret_cast<const uint32_t*>(smem + dbase + 64 + 4u * w);
         const uint32_t n = rfl(dt.y), copy_mask = rfl(dt.x);
         if (rfl(dt.z) & kFlagLast) last_round = r;              // every wave must learn where to stop
-        for (uint32_t k = w; k < n; k += kEmitWave0 - kFetchWave0) {
-            const uint32_t pos = rfl(*reinterpret_cast<const uint32_t*>(smem + dbase + 64 + 4u * k));
-            uint32_t d0, d1;
-            if ((copy_mask >> k) & 1u) {
-                const uint32_t a = pos + 4u * lane;
-                d0 = 0;
-                d1 = ring16(a) | (ring16(a + 2) << 16);
-            } else {
-                const uint32_t part = lane < 4 ? ring16(pos + 2u * lane) : 0u;       // the record's signature (codec.rs:28-31)
-                const uint64_t sig = (uint64_t)(rlane(part, 0) | (rlane(part, 1) << 16)) | ((uint64_t)(rlane(part, 2) | (rlane(part, 3) << 16)) << 32);
-                const bool hit = (sig >> lane) & 1ull;
-                const uint32_t a = pos + kSig + 4u * lane - 2u * mbcnt64(sig);
-                const uint32_t lo = ring16(a), hi = ring16(a + 2);
-                if (hit) {                                    // MAP: the item is the slot index (chameleon.rs:64-68)
-                    d0 = ((lo >> 1) << 2) | (lo & 1u);
-                    d1 = 0;
-                } else {                                      // PLAIN: hash the quad, stage its entry (chameleon.rs:56-61)
-                    const uint32_t q = lo | (hi << 16);
-                    const uint32_t P = q * kHashMul;
-                    const uint32_t h = P >> 16;
-                    d0 = ((h >> 1) << 2) | (h & 1u) | kD0Write;
-                    d1 = stored_entry(q, P) << ((h & 1u) << 4);
-                }
-            }
-            *reinterpret_cast<uint2*>(smem + sbase + k * kStageRec + 8u * lane) = make_uint2(d0, d1);
+        if (w >= n) return;
+        const uint32_t pos = rfl(posv);
+        uint32_t d0, d1;
+        if ((copy_mask >> w) & 1u) {
+            const uint32_t a = pos + 4u * lane;
+            d0 = 0;
+            d1 = ring16(a) | (ring16(a + 2) << 16);
+        } else {
+            const uint32_t part = lane < 4 ? ring16(pos + 2u * lane) : 0u;       // the record's signature (codec.rs:28-31)
+            const uint64_t sig = (uint64_t)(rlane(part, 0) | (rlane(part, 1) << 16)) | ((uint64_t)(rlane(part, 2) | (rlane(part, 3) << 16)) << 32);
+            const bool hit = (sig >> lane) & 1ull;
+            const uint32_t a = pos + kSig + 4u * lane - 2u * mbcnt64(sig);
+            // both halves of a possible quad are read whether or not the lane holds a MAP item (2 bytes): no divergence, one wait
+            const uint32_t lo = ring16(a), hi = ring16(a + 2);
+            // MAP: the item is the slot index (chameleon.rs:64-68).  PLAIN: hash the quad, stage its entry (chameleon.rs:56-61).
+            const uint32_t q = lo | (hi << 16);
+            const uint32_t P = q * kHashMul;
+            const uint32_t h = hit ? lo : (P >> 16);
+            d0 = ((h >> 1) << 2) | (h & 1u) | (hit ? 0u : kD0Write);
+            d1 = hit ? 0u : (stored_entry(q, P) << ((h & 1u) << 4));
         }
+        *reinterpret_cast<uint2*>(smem + sbase + w * kStageRec + 8u * lane) = make_uint2(d0, d1);
     };
 
     auto dict_round = [&](uint32_t r) {                       // wave 0
