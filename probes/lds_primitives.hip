@@ -1,0 +1,61 @@
+// Probe: cost of the dictionary primitives for one wavefront on a 128 KiB LDS table with random slots (cycles per 64-lane op):
+// ordered exchange (ds_mskor_rtn_b32) vs plain 16-bit read + write vs 32-bit read/write, issued back to back.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#define ITERS 2000
+extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+template <int mode>
+__global__ __launch_bounds__(1024) void k(uint64_t* out, int busy_waves) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t i = threadIdx.x; i < 32768; i += blockDim.x) reinterpret_cast<uint32_t*>(smem)[i] = i;
+    __syncthreads();
+    uint32_t x = lane * 2654435761u + 12345u, acc = 0;
+    if (wave == 0) {
+        uint64_t t0 = __builtin_readcyclecounter();
+        for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+            for (int rep = 0; rep < 8; ++rep) {
+                x = x * 1664525u + 1013904223u;
+                const uint32_t slot = x >> 16;                       // 64 Ki slots of u16
+                const uint32_t a32 = (slot >> 1) << 2, sh = (slot & 1u) << 4, a16 = slot << 1;
+                uint32_t r = 0;
+                if (mode == 0) asm volatile("ds_mskor_rtn_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a32), "v"(0xffffu << sh), "v"((x & 0xffffu) << sh) : "memory");
+                if (mode == 1) asm volatile("ds_read_u16 %0, %1\n\tds_write_b16 %1, %2" : "=&v"(r) : "v"(a16), "v"(x) : "memory");
+                if (mode == 2) asm volatile("ds_read_u16 %0, %1" : "=v"(r) : "v"(a16) : "memory");
+                if (mode == 3) asm volatile("ds_write_b16 %0, %1" :: "v"(a16), "v"(x) : "memory");
+                if (mode == 4) asm volatile("ds_wrxchg_rtn_b32 %0, %1, %2" : "=v"(r) : "v"(a32), "v"(x) : "memory");
+                if (mode == 5) asm volatile("ds_read_b32 %0, %1\n\tds_write_b32 %1, %2" : "=&v"(r) : "v"(a32), "v"(x) : "memory");
+                acc += r;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(acc));
+        }
+        uint64_t t1 = __builtin_readcyclecounter();
+        if (lane == 0) out[mode] = t1 - t0;
+    } else if ((int)wave <= busy_waves) {
+        // background LDS traffic from other waves: streaming b64 reads/writes of a private 2 KiB window
+        uint32_t* w = reinterpret_cast<uint32_t*>(smem + 131072 + wave * 2048);
+        for (int it = 0; it < ITERS * 6; ++it) { acc += w[(lane + it) & 511]; w[(lane * 2 + it) & 511] = acc; }
+    }
+    if (acc == 0x12345678) out[31] = acc;
+}
+template <int m> static void run(uint64_t* d, const char* name, int busy) {
+    (void)hipFuncSetAttribute((const void*)k<m>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+    hipLaunchKernelGGL(k<m>, dim3(1), dim3(1024), 163840, 0, d, busy);
+    (void)hipDeviceSynchronize();
+    uint64_t h[32]; (void)hipMemcpy(h, d, 256, hipMemcpyDeviceToHost);
+    printf("  %-44s %7.1f cycles per 64-lane step (%d other waves streaming)\n", name, (double)h[m] / (ITERS * 8.0), busy);
+    fflush(stdout);
+}
+int main() {
+    uint64_t* d; (void)hipMalloc(&d, 256); (void)hipMemset(d, 0, 256);
+    for (int busy : {0, 15}) {
+        run<0>(d, "ds_mskor_rtn_b32 (ordered exchange)", busy);
+        run<1>(d, "ds_read_u16 + ds_write_b16", busy);
+        run<2>(d, "ds_read_u16", busy);
+        run<3>(d, "ds_write_b16", busy);
+        run<4>(d, "ds_wrxchg_rtn_b32", busy);
+        run<5>(d, "ds_read_b32 + ds_write_b32", busy);
+    }
+    return 0;
+}
