@@ -47,11 +47,14 @@ __device__ __forceinline__ uint32_t hash16(uint32_t q) { return (q * kHashMul) >
 __device__ __forceinline__ uint32_t enc_quad(Tables<DENSITY_HIP_CHEETAH>& t, uint32_t q, uint32_t& item, uint32_t& item_len) {
     const uint32_t h = hash16(q);
     uint32_t* guess = t.pred + t.last_hash;
+    Pair* e = t.dict + h;
+    // both table reads are issued before either is needed (the dictionary entry is unused for a predicted quad): one memory
+    // round trip per quad instead of two
+    const uint32_t predicted = *guess;
+    const Pair cur = *e;
     uint32_t flag;
-    if (*guess == q) { flag = 3; item_len = 0; }
+    if (predicted == q) { flag = 3; item_len = 0; }
     else {
-        Pair* e = t.dict + h;
-        const Pair cur = *e;
         if (cur.a == q) { flag = 1; item = h; item_len = 2; }
         else {
             if (cur.b == q) { flag = 2; item = h; item_len = 2; } else { flag = 0; item = q; item_len = 4; }
@@ -67,7 +70,9 @@ __device__ __forceinline__ uint32_t enc_quad(Tables<DENSITY_HIP_CHEETAH>& t, uin
 __device__ __forceinline__ uint32_t enc_quad(Tables<DENSITY_HIP_LION>& t, uint32_t q, uint32_t& item, uint32_t& item_len) {
     const uint32_t h = hash16(q);
     uint32_t* p = t.pred + 5u * t.last_hash;
+    Pair* e = t.dict + h;
     uint32_t n0 = p[0], n1 = p[1], n2 = p[2], n3 = p[3], n4 = p[4];
+    const Pair cur = *e;                                      // issued with the predictions: one memory round trip per quad
     uint32_t flag;
     item_len = 0;
     if (n0 == q) { flag = 1; }
@@ -77,8 +82,6 @@ __device__ __forceinline__ uint32_t enc_quad(Tables<DENSITY_HIP_LION>& t, uint32
     else {
         if (n4 == q) { flag = 5; }
         else {
-            Pair* e = t.dict + h;
-            const Pair cur = *e;
             if (cur.a == q) { flag = 6; item = h; item_len = 2; }
             else {
                 if (cur.b == q) { flag = 7; item = h; item_len = 2; } else { flag = 0; item = q; item_len = 4; }
