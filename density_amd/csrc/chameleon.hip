@@ -265,24 +265,25 @@ __global__ __launch_bounds__(64) void chameleon_encode_chunks(const uint8_t* __r
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Pipelined encoder: one work-group (8 waves) per chunk.
+// Pipelined encoder: one work-group of 16 waves per chunk, every role in its own loop, one s_barrier per round of 8 blocks.
 //
-//   wave 0  "dictionary wave": the only wave that touches the table, so the in-order LDS pipeline gives the sequential
-//           dictionary semantics for free.  It also issues the global->LDS DMA (global_load_lds_dwordx4, 1 KiB = 4
-//           blocks per instruction) that stages the chunk through a ring in LDS two rounds ahead, runs the copy-mode FSM,
-//           and publishes one record per round: the 8 signatures, the output offset of the round, the raw-copy mask.
-//   waves 1-7 "emit waves": one round behind, they turn (signature, quads) into record bytes: a prefix sum of the 8
-//           record lengths, a pair of mbcnt's per lane, then 2-/4-byte stores straight to global memory.
+//   wave 0   "dictionary wave": the only wave that touches the table, so the in-order LDS pipeline gives the sequential
+//            dictionary semantics.  Per block: one ordered exchange with operands read from the operand ring, one bit-op +
+//            compare (= the signature), one popcount.  It runs the copy-mode FSM (protection_state.rs) per ROUND: in a round
+//            without an incompressible block (< 5 hits of 64) the FSM only advances its block counter; the exchanges of a
+//            round are issued speculatively "no raw-copy block in this round", and a round in which the FSM does switch to
+//            copy mode is rolled back from the first copied block and redone in order.  It publishes the 8 signatures and the
+//            raw-copy mask of the round and fetches the next round's operands while its last exchanges drain.
+//   wave 4   "loader": global->LDS DMA (global_load_lds_dwordx4, 1 KiB = 4 blocks per instruction) of round t + kAhead into the
+//            input ring, counted vmcnt.
+//   6 waves  "hash" (kHashFirstTbl): two rounds ahead, quads -> {slot address, salted entry} in the operand ring; blocks holding
+//            a stored entry 0 outside slot 0 are flagged for the dictionary wave's careful path (zero-entry map).
+//   8 waves  "emit" (kEmitBlockTbl): one round behind, (signature, quads) -> record bytes: a prefix sum of the 8 record
+//            lengths, a pair of mbcnt's per lane, 2-/4-byte stores through an SGPR base, the block-index bytes.
 //
-// A round is kRound = 8 blocks; rounds are separated by one s_barrier.  Buffers: input ring of kInRing rounds (DMA issued at
-// t-kAhead, hashed at t, emitted at t+1), result ring of 2 rounds.  Only whole 256-byte blocks go through the pipeline; a ragged last block
-// (codec.rs:51-63) is finished by the dictionary wave with the scalar-path code of chameleon_encode_chunks.
-//
-// The dictionary wave is the critical path (one stream = one dependency chain), so its per-block work is pared down to:
-// hash, one ordered LDS exchange, one compare (= the signature), one popcount.  The copy-mode FSM (protection_state.rs) is
-// evaluated per ROUND: in a round without an incompressible block (< 5 hits of 64) it only advances its block counter; the
-// exchanges of a round are issued speculatively "no raw-copy block in this round", and a round in which the FSM does switch
-// to copy mode is rolled back from the first copied block and redone in order.
+// Buffers: input ring of kInRing rounds, operand ring and result ring of 2 rounds; the zero-entry map lives in global memory
+// (workspace).  Only whole 256-byte blocks go through the pipeline; a ragged last block (codec.rs:51-63) is finished by the
+// dictionary wave with the scalar-path code of chameleon_encode_chunks.
 // ---------------------------------------------------------------------------------------------------------------
 namespace {
 
@@ -339,37 +340,6 @@ __device__ __forceinline__ void gstore8(uint8_t* base, uint32_t off, uint32_t v)
     asm volatile("global_store_byte %0, %1, %2" ::"v"(off), "v"(v), "s"(base) : "memory");
 }
 
-// vec[L] = value (value wave-uniform).  gfx9 allows one SGPR operand per VALU instruction, so the lane is an immediate.
-template <int L>
-__device__ __forceinline__ uint32_t wlane_c(uint32_t vec, uint32_t value) {
-    asm volatile("s_nop 4\n\tv_writelane_b32 %0, %1, %2\n\ts_nop 1" : "+v"(vec) : "s"(rfl(value)), "n"(L));
-    return vec;
-}
-// lane_sel is a compile-time constant after unrolling (the switch folds away)
-__device__ __forceinline__ uint32_t wlane(uint32_t vec, uint32_t value, uint32_t lane_sel) {
-    switch (lane_sel) {
-        case 0: return wlane_c<0>(vec, value);
-        case 1: return wlane_c<1>(vec, value);
-        case 2: return wlane_c<2>(vec, value);
-        case 3: return wlane_c<3>(vec, value);
-        case 4: return wlane_c<4>(vec, value);
-        case 5: return wlane_c<5>(vec, value);
-        case 6: return wlane_c<6>(vec, value);
-        case 7: return wlane_c<7>(vec, value);
-        case 8: return wlane_c<8>(vec, value);
-        case 9: return wlane_c<9>(vec, value);
-        case 10: return wlane_c<10>(vec, value);
-        case 11: return wlane_c<11>(vec, value);
-        case 12: return wlane_c<12>(vec, value);
-        case 13: return wlane_c<13>(vec, value);
-        case 14: return wlane_c<14>(vec, value);
-        case 15: return wlane_c<15>(vec, value);
-        case 16: return wlane_c<16>(vec, value);
-        case 17: return wlane_c<17>(vec, value);
-        case 18: return wlane_c<18>(vec, value);
-        default: return vec;
-    }
-}
 // run-time lane select (in-order path only)
 __device__ __forceinline__ uint32_t wlane_dyn(uint32_t vec, uint32_t value, uint32_t lane_sel, uint32_t lane) { return lane == lane_sel ? value : vec; }
 __device__ __forceinline__ uint32_t rlane(uint32_t vec, uint32_t lane_sel) { return (uint32_t)__builtin_amdgcn_readlane((int)vec, (int)lane_sel); }
