@@ -437,7 +437,10 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
         for (uint32_t i = threadIdx.x; i < kTableBytes / 16; i += kPipeWaves * 64) p[i] = z;
         for (uint32_t i = threadIdx.x; i < kZmapBytes / 16; i += kPipeWaves * 64) reinterpret_cast<uint4*>(zmap.words)[i] = z;
         if (threadIdx.x < 4) *reinterpret_cast<uint32_t*>(smem + kZeroFlagBase + 4u * threadIdx.x) = 0;
-        __threadfence();                                      // the map is used through L2 atomics
+        // The map is used through L2 atomics by this work-group only, so all that is needed is that these stores have reached
+        // L2 (the L1 is write-through): vmcnt(0), then the barrier below.  __threadfence() here would write back and invalidate
+        // the whole L2 of the XCD (buffer_wbl2 / buffer_inv, once per wave), ~0.1 ms per chunk.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     const uint32_t lds0 = lds_addr(smem);
     const uint32_t tbl = lds0;
@@ -1005,7 +1008,9 @@ __global__ __launch_bounds__(kDecWaves * 64) void chameleon_decode_chunks_pipe(c
         for (uint32_t i = threadIdx.x; i < kTableBytes / 16; i += kDecWaves * 64) p[i] = z;
         for (uint32_t i = threadIdx.x; i < kDescRing * kDescBytes / 16; i += kDecWaves * 64) reinterpret_cast<uint4*>(smem + kDDescBase)[i] = z;
         for (uint32_t i = threadIdx.x; i < kZmapBytes / 16; i += kDecWaves * 64) reinterpret_cast<uint4*>(zmap.words)[i] = z;
-        __threadfence();                                      // the map is read back through L2 (ZmapGlobal::test)
+        // the map is read back through L2 (ZmapGlobal::test) by this work-group only: the stores must have reached L2 (vmcnt(0),
+        // then the barrier below); a device-scope fence would write back and invalidate the XCD's whole L2
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     const uint32_t lds0 = lds_addr(smem);
     const uint32_t tbl = lds0;
