@@ -289,8 +289,8 @@ namespace {
 
 constexpr uint32_t kRound = 8;                               // blocks per round
 constexpr uint32_t kRoundBytes = kRound * kBlock;            // 2 KiB
-constexpr uint32_t kInRing = 8, kResRing = 2;              // input ring (power of two): emitted, finished, hashed x2, kAhead - 3 rounds in flight
-constexpr uint32_t kAhead = 6;                               // the loader issues round t + kAhead during step t
+constexpr uint32_t kInRing = 8, kResRing = 2;              // input ring (power of two): emitted, published, finished, hashed x2, kAhead - 3 rounds in flight
+constexpr uint32_t kAhead = 5;                               // the loader issues round t + kAhead during step t
 constexpr uint32_t kInBase = kTableBytes;                    // the pipelined kernels keep the zero-entry map in global memory (ZmapGlobal)
 constexpr uint32_t kResBase = kInBase + kInRing * kRoundBytes;
 constexpr uint32_t kResBytes = 128;                          // dwords 0..15 signatures, 16 copy mask
@@ -298,15 +298,16 @@ constexpr uint32_t kOpBase = kResBase + kResRing * kResBytes;    // operand ring
 constexpr uint32_t kOpRec = 512, kOpRing = 2;
 constexpr uint32_t kOpRoundBytes = kRound * kOpRec;
 constexpr uint32_t kZeroFlagBase = kOpBase + kOpRing * kOpRoundBytes;   // 4 dwords: bit k of word r % 4 = block k of round r holds a zero entry
-constexpr uint32_t kLdsBytesPipe = kZeroFlagBase + 16;               // (set while hashing at step r-1, read at r, cleared at r+1)
+constexpr uint32_t kGuardBase = kZeroFlagBase + 16;                   // FSM state handed from one dictionary wave to the other: {penalty, start, prev, counter}
+constexpr uint32_t kLdsBytesPipe = kGuardBase + 16;
 constexpr uint32_t kEncAddr = 0x1fffcu;                      // operand dword 0 = 2 * slot: bits 2..16 the dword address, bit 1 the half
 constexpr uint32_t kPipeWaves = 16;
 // Roles by wave, one nibble per wave (8 = none).  A work-group's wave w runs on SIMD w % 4 and the four waves of a SIMD share
 // its issue slots, so the dictionary wave (0) shares SIMD 0 only with the loader (4) and two single-block hash waves (8, 12);
 // the eight emit waves and the double-block hash waves are spread over SIMDs 1-3.
-constexpr uint32_t kDictWave = 0, kLoadWave = 4;
-constexpr uint64_t kHashFirstTbl = 0x7421688088888888ull;    // first block hashed by wave w (nibble w)
-constexpr uint64_t kHashCountTbl = 0x1221100100000000ull;    // number of consecutive blocks hashed by wave w
+constexpr uint32_t kDictWave = 0, kDictWaveB = 12, kLoadWave = 4;   // two dictionary waves: even rounds on wave 0, odd rounds on wave 12
+constexpr uint64_t kHashFirstTbl = 0x7428688088888888ull;    // first block hashed by wave w (nibble w)
+constexpr uint64_t kHashCountTbl = 0x1220100200000000ull;    // number of consecutive blocks hashed by wave w
 constexpr uint64_t kEmitBlockTbl = 0x8888852874186308ull;    // block emitted by wave w
 static_assert(kLdsBytesPipe <= 160u * 1024u, "LDS budget");
 static_assert(kRound == 8, "register arrays, asm operand lists and the result record are written for 8 blocks per round");
@@ -429,7 +430,9 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
     const uint32_t nfull = (uint32_t)(len / kBlock);           // whole blocks: these go through the pipeline (the launcher bounds len)
     const uint32_t nrounds = (nfull + kRound - 1) / kRound;
     const ZmapGlobal zmap{zmap_words + chunk * (kZmapBytes / 4)};
-    if (wave == kDictWave) __builtin_amdgcn_s_setprio(3);      // the dictionary wave is the critical path: first pick of issue slots
+    const bool is_dict = wave == kDictWave || wave == kDictWaveB;
+    const uint32_t par = wave == kDictWave ? 0u : 1u;          // this dictionary wave owns the rounds of this parity
+    if (is_dict) __builtin_amdgcn_s_setprio(3);                // the dictionary waves are the critical path: first pick of issue slots
 
     {   // clear table, zero-entry flags and this chunk's zero-entry map
         uint4* p = reinterpret_cast<uint4*>(smem);
@@ -437,6 +440,7 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
         for (uint32_t i = threadIdx.x; i < kTableBytes / 16; i += kPipeWaves * 64) p[i] = z;
         for (uint32_t i = threadIdx.x; i < kZmapBytes / 16; i += kPipeWaves * 64) reinterpret_cast<uint4*>(zmap.words)[i] = z;
         if (threadIdx.x < 4) *reinterpret_cast<uint32_t*>(smem + kZeroFlagBase + 4u * threadIdx.x) = 0;
+        if (threadIdx.x == 0) *reinterpret_cast<uint4*>(smem + kGuardBase) = make_uint4(0u, 1u, 0u, 0u);   // Guard{} (common.hpp)
         // The map is used through L2 atomics by this work-group only, so all that is needed is that these stores have reached
         // L2 (the L1 is write-through): vmcnt(0), then the barrier below.  __threadfence() here would write back and invalidate
         // the whole L2 of the XCD (buffer_wbl2 / buffer_inv, once per wave), ~0.1 ms per chunk.
@@ -519,7 +523,7 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
 
     if (wave == kLoadWave) {
         // ---------------- loader ----------------
-        for (uint32_t t = 0; t <= nrounds; ++t) {
+        for (uint32_t t = 0; t <= nrounds + 1; ++t) {
             clk.start();
             issue_round(t + kAhead);
             if (t + kAhead + 1 < nrounds && !(dbg & 1u)) wait_vm<kInFlight>(); else wait_vm<0>();
@@ -527,8 +531,10 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
             round_barrier();
             clk.wait_done();
         }
-    } else if (wave == kDictWave) {
-        // ---------------- dictionary wave: round t ----------------
+    } else if (is_dict) {
+        // ---------------- dictionary waves: wave 0 runs the even rounds, wave 12 the odd ones.  While one of them works
+        // through the exchanges of round t, the other publishes its results of round t-1 and fetches its operands of round t+1;
+        // the FSM state travels through LDS (kGuardBase).  The barrier between steps orders their accesses to the table. ----
         // (the compiler lays this branch out behind the other roles' loops and carries their pending LDS accesses into it: clear
         // its scoreboard with a wait it can see, or it guards registers here with lgkmcnt waits that drain the exchanges)
         __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -574,17 +580,44 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
             for (uint32_t j = 0; j < kRound; ++j) blk[j].ret = 0;
             zero_blocks = rfl(zf);
         };
-        for (uint32_t t = 0; t <= nrounds; ++t) {
+        uint32_t copy_mask = 0;                               // results of this wave's last round, published one step later
+        uint64_t sig[kRound];
+#pragma unroll
+        for (uint32_t j = 0; j < kRound; ++j) sig[j] = 0;
+        bool unpublished = false;
+        // results for the emit waves: 8 signatures + the copy mask of round r, written by lane 0 (the values are wave-uniform)
+        auto publish = [&](uint32_t r) {
+            if (lane == 0) {
+                const u32x4 s01 = {(uint32_t)sig[0], (uint32_t)(sig[0] >> 32), (uint32_t)sig[1], (uint32_t)(sig[1] >> 32)};
+                const u32x4 s23 = {(uint32_t)sig[2], (uint32_t)(sig[2] >> 32), (uint32_t)sig[3], (uint32_t)(sig[3] >> 32)};
+                const u32x4 s45 = {(uint32_t)sig[4], (uint32_t)(sig[4] >> 32), (uint32_t)sig[5], (uint32_t)(sig[5] >> 32)};
+                const u32x4 s67 = {(uint32_t)sig[6], (uint32_t)(sig[6] >> 32), (uint32_t)sig[7], (uint32_t)(sig[7] >> 32)};
+                asm volatile(
+                    "ds_write_b128 %0, %1\n\t"
+                    "ds_write_b128 %0, %2 offset:16\n\t"
+                    "ds_write_b128 %0, %3 offset:32\n\t"
+                    "ds_write_b128 %0, %4 offset:48\n\t"
+                    "ds_write_b32 %0, %5 offset:64"
+                    ::"v"(lds0 + kResBase + (r & (kResRing - 1u)) * kResBytes), "v"(s01), "v"(s23), "v"(s45), "v"(s67), "v"(copy_mask) : "memory");
+            }
+        };
+        for (uint32_t t = 0; t <= nrounds + 1; ++t) {
             clk.start();
-            if (t < nrounds) {
+            if ((t & 1u) != par) {
+                // passive step: hand round t-1 to the emit waves, take the operands of round t+1 (hashed during step t-1)
+                if (unpublished) { publish(t - 1); unpublished = false; }
+                if (t + 1 < nrounds) { load_ops(t + 1); ops_take(); }
+            } else if (t < nrounds) {
                 clk.phase_start();
-                const uint32_t rbase = kResBase + (t & (kResRing - 1u)) * kResBytes;
                 const uint32_t left = nfull - t * kRound;
                 const uint32_t nb = left < kRound ? left : kRound;
-                uint32_t copy_mask = 0;
-                uint64_t sig[kRound];
+                copy_mask = 0;
 #pragma unroll
                 for (uint32_t j = 0; j < kRound; ++j) sig[j] = 0;
+                if (t > 0) {                                      // the FSM as the other wave left it after round t-1
+                    const uint4 g = *reinterpret_cast<const uint4*>(smem + kGuardBase);
+                    guard.penalty = rfl(g.x); guard.start = rfl(g.y); guard.prev = rfl(g.z); guard.counter = rfl(g.w);
+                }
 
                 auto issue = [&](Issued& b) {
                     const uint32_t sh = (b.d0 << 3) & 31u;       // (d0 & 2) << 3: the half of the dword the slot lives in
@@ -613,23 +646,6 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
 
                 clk.phase(1);
 
-                // results for the emit waves: 8 signatures + the copy mask, written by lane 0 (the values are wave-uniform)
-                auto publish = [&]() {
-                    if (lane == 0) {
-                        const u32x4 s01 = {(uint32_t)sig[0], (uint32_t)(sig[0] >> 32), (uint32_t)sig[1], (uint32_t)(sig[1] >> 32)};
-                        const u32x4 s23 = {(uint32_t)sig[2], (uint32_t)(sig[2] >> 32), (uint32_t)sig[3], (uint32_t)(sig[3] >> 32)};
-                        const u32x4 s45 = {(uint32_t)sig[4], (uint32_t)(sig[4] >> 32), (uint32_t)sig[5], (uint32_t)(sig[5] >> 32)};
-                        const u32x4 s67 = {(uint32_t)sig[6], (uint32_t)(sig[6] >> 32), (uint32_t)sig[7], (uint32_t)(sig[7] >> 32)};
-                        asm volatile(
-                            "ds_write_b128 %0, %1\n\t"
-                            "ds_write_b128 %0, %2 offset:16\n\t"
-                            "ds_write_b128 %0, %3 offset:32\n\t"
-                            "ds_write_b128 %0, %4 offset:48\n\t"
-                            "ds_write_b32 %0, %5 offset:64"
-                            ::"v"(lds0 + rbase), "v"(s01), "v"(s23), "v"(s45), "v"(s67), "v"(copy_mask) : "memory");
-                    }
-                };
-
                 uint32_t k = 0;
                 bool pending_copy = false;                        // guard already advanced for block k and said "copy"
                 bool done = false;
@@ -655,9 +671,6 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
                         lds_wait_all();
                     }
                     clk.phase(3);
-                    // operands of the next round (past the last round: stale ones, unused), fetched while the FSM and the publishing
-                    // below run; issued only now because anything queued behind the exchanges blocks this wave until they drain
-                    load_ops(t + 1);
                     if (plain_round && min_hits > 4 && !guard.prev) {
                         // The common round, kept in one straight block.  No incompressible record (codec.rs:68: 8 + 256 - 2*hits >=
                         // 256) in it: the FSM only counts blocks (protection_state.rs:19-27); one of 8 consecutive counters is a
@@ -665,9 +678,6 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
                         const uint32_t c = guard.counter & 15u;
                         guard.start >>= (uint32_t)((c - 1u) >= 8u) & (uint32_t)(guard.start > 1u);
                         guard.counter += kRound;
-                        publish();
-                        clk.phase(4);
-                        ops_take();
                         done = true;
                     } else {
                         // walk the FSM block by block; stop at the first block it turns into a raw copy.  With zero-entry quads
@@ -694,8 +704,6 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
                             lds_wait_all();
                         }
                     }
-                } else {
-                    load_ops(t + 1);
                 }
                 if (!done) {
                     if (k < nb) {                                 // in-order path: copy runs, the blocks after a mis-speculation, short rounds
@@ -716,10 +724,11 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
                             }
                         }
                     }
-                    publish();
-                    clk.phase(4);
-                    ops_take();
                 }
+                clk.phase(4);
+                // the FSM state for the other wave, the results for the next (passive) step
+                if (lane == 0) *reinterpret_cast<uint4*>(smem + kGuardBase) = make_uint4(guard.penalty, guard.start, guard.prev, guard.counter);
+                unpublished = true;
                 clk.phase(5);
             }
             clk.work_done();
@@ -730,12 +739,12 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
         // ---------------- emit waves: round t-1; hash waves: round t+1 ----------------
         const uint32_t c_off = kSig + 4u * lane;              // item offset of this lane in a record without MAP flags
         const uint32_t sl = lane & 7u;
-        for (uint32_t t = 0; t <= nrounds; ++t) {
+        for (uint32_t t = 0; t <= nrounds + 1; ++t) {
             clk.start();
             // round t-1's zero-entry flags were read by the dictionary wave during the previous step; the word is next used for round t+3
             if (hb0 == 0 && t >= 1 && lane == 0) *reinterpret_cast<uint32_t*>(smem + kZeroFlagBase + 4u * ((t - 1) & 3u)) = 0;
-            if (eb < kRound && t >= 1 && !(dbg & 2u)) {
-                const uint32_t r = t - 1;
+            if (eb < kRound && t >= 2 && !(dbg & 2u)) {
+                const uint32_t r = t - 2;
                 const uint32_t rbase = kResBase + (r & (kResRing - 1u)) * kResBytes;
                 const uint32_t left = nfull - r * kRound;
                 // lanes 0..7 (and their images): signature and record length of block `lane & 7`; prefix over the round = record offsets
@@ -782,6 +791,10 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
     if (eb == 0 && lane == 0) *reinterpret_cast<uint64_t*>(smem + kResBase) = opos_run;
     round_barrier();
     if (wave == kDictWave) {
+        {
+            const uint4 g = *reinterpret_cast<const uint4*>(smem + kGuardBase);       // as the last round's wave left it
+            guard.penalty = rfl(g.x); guard.start = rfl(g.y); guard.prev = rfl(g.z); guard.counter = rfl(g.w);
+        }
         uint64_t opos = *reinterpret_cast<const uint64_t*>(smem + kResBase);
         const uint64_t boff = (uint64_t)nfull * kBlock;
         const uint32_t blen = (uint32_t)(len - boff);
