@@ -267,18 +267,20 @@ __global__ __launch_bounds__(64) void chameleon_encode_chunks(const uint8_t* __r
 // ---------------------------------------------------------------------------------------------------------------
 // Pipelined encoder: one work-group of 16 waves per chunk, every role in its own loop, one s_barrier per round of 8 blocks.
 //
-//   wave 0   "dictionary wave": the only wave that touches the table, so the in-order LDS pipeline gives the sequential
-//            dictionary semantics.  Per block: one ordered exchange with operands read from the operand ring, one bit-op +
-//            compare (= the signature), one popcount.  It runs the copy-mode FSM (protection_state.rs) per ROUND: in a round
+//   waves 0, 12  "dictionary waves": the only waves that touch the table, taking turns (even rounds on wave 0, odd rounds on
+//            wave 12; the step barrier separates their accesses), so the in-order LDS pipeline gives the sequential dictionary
+//            semantics.  Per block: one ordered exchange with operands held in registers, one bit-op + compare (= the
+//            signature), one popcount.  The active wave runs the copy-mode FSM (protection_state.rs) per ROUND: in a round
 //            without an incompressible block (< 5 hits of 64) the FSM only advances its block counter; the exchanges of a
 //            round are issued speculatively "no raw-copy block in this round", and a round in which the FSM does switch to
-//            copy mode is rolled back from the first copied block and redone in order.  It publishes the 8 signatures and the
-//            raw-copy mask of the round and fetches the next round's operands while its last exchanges drain.
+//            copy mode is rolled back from the first copied block and redone in order.  It leaves the FSM state in LDS for
+//            the other wave; in its passive step it publishes the 8 signatures and the raw-copy mask of its last round and
+//            fetches the operands of its next one.
 //   wave 4   "loader": global->LDS DMA (global_load_lds_dwordx4, 1 KiB = 4 blocks per instruction) of round t + kAhead into the
 //            input ring, counted vmcnt.
-//   6 waves  "hash" (kHashFirstTbl): two rounds ahead, quads -> {slot address, salted entry} in the operand ring; blocks holding
+//   5 waves  "hash" (kHashFirstTbl): two rounds ahead, quads -> {slot address, salted entry} in the operand ring; blocks holding
 //            a stored entry 0 outside slot 0 are flagged for the dictionary wave's careful path (zero-entry map).
-//   8 waves  "emit" (kEmitBlockTbl): one round behind, (signature, quads) -> record bytes: a prefix sum of the 8 record
+//   8 waves  "emit" (kEmitBlockTbl): two rounds behind, (signature, quads) -> record bytes: a prefix sum of the 8 record
 //            lengths, a pair of mbcnt's per lane, 2-/4-byte stores through an SGPR base, the block-index bytes.
 //
 // Buffers: input ring of kInRing rounds, operand ring and result ring of 2 rounds; the zero-entry map lives in global memory
