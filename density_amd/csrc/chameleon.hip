@@ -360,6 +360,7 @@ struct WaveClock<false> {                                     // production: com
     __device__ __forceinline__ void phase_start() {}
     __device__ __forceinline__ void phase(int) {}
     __device__ __forceinline__ void flush_phases(uint32_t) {}
+    __device__ __forceinline__ void set_fine(bool) {}
     __device__ __forceinline__ void stat_post(uint32_t, uint32_t, uint32_t) {}
     __device__ __forceinline__ void stat_take(uint32_t, uint32_t, uint32_t) {}
     __device__ __forceinline__ void flush_stat(uint32_t, uint32_t) {}
@@ -374,9 +375,11 @@ struct WaveClock<true> {
     __device__ __forceinline__ void work_done() { if (out) { const uint64_t t = __builtin_readcyclecounter(); work += t - t0; last = (uint32_t)(t - t0); t0 = t; } }
     __device__ __forceinline__ void wait_done() { if (out) { const uint64_t t = __builtin_readcyclecounter(); wait += t - t0; t0 = t; } }
     __device__ __forceinline__ void flush(uint32_t wave, uint32_t lane) { if (out && lane == 0) { out[2 * wave] = work; out[2 * wave + 1] = wait; } }
-    __device__ __forceinline__ void phase_start() { if (out) tp = __builtin_readcyclecounter(); }
-    __device__ __forceinline__ void phase(int k) { if (out) { const uint64_t t = __builtin_readcyclecounter(); ph[k] += t - tp; tp = t; } }
+    bool fine = false;                                        // per-phase timing costs ~100 cycles a call: only on request (DENSITY_HIP_DBG bit 5)
+    __device__ __forceinline__ void phase_start() { if (out && fine) tp = __builtin_readcyclecounter(); }
+    __device__ __forceinline__ void phase(int k) { if (out && fine) { const uint64_t t = __builtin_readcyclecounter(); ph[k] += t - tp; tp = t; } }
     __device__ __forceinline__ void flush_phases(uint32_t lane) { if (out && lane == 0) for (int k = 0; k < 8; ++k) out[32 + k] = ph[k]; }
+    __device__ __forceinline__ void set_fine(bool f) { fine = f; }
     // which wave was the last to reach the barrier, per step: every wave posts its work time before the barrier (stat_post),
     // wave 0 reads the 16 values after it (stat_take) and counts, per lane = wave, how often that wave was the slowest
     __device__ __forceinline__ void stat_post(uint32_t stat_base, uint32_t wave, uint32_t lane) {
@@ -425,6 +428,7 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
     const uint32_t wave = rfl(threadIdx.x >> 6);
     const uint64_t chunk = blockIdx.x;
     WaveClock<kProf> clk(blockIdx.x == 0 ? prof : nullptr);
+    clk.set_fine((dbg & 32u) != 0);
     const uint8_t* src = in + chunk * chunk_bytes;
     const uint64_t len = (total - chunk * chunk_bytes) < chunk_bytes ? (total - chunk * chunk_bytes) : chunk_bytes;
     uint8_t* dst = out + chunk * out_stride;
@@ -530,8 +534,10 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
             issue_round(t + kAhead);
             if (t + kAhead + 1 < nrounds && !(dbg & 1u)) wait_vm<kInFlight>(); else wait_vm<0>();
             clk.work_done();
+            clk.stat_post(kLdsBytesPipe, wave, lane);
             round_barrier();
             clk.wait_done();
+            clk.stat_take(kLdsBytesPipe, wave, lane);
         }
     } else if (is_dict) {
         // ---------------- dictionary waves: wave 0 runs the even rounds, wave 12 the odd ones.  While one of them works
@@ -734,8 +740,10 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
                 clk.phase(5);
             }
             clk.work_done();
+            clk.stat_post(kLdsBytesPipe, wave, lane);
             round_barrier();
             clk.wait_done();
+            clk.stat_take(kLdsBytesPipe, wave, lane);
         }
     } else {
         // ---------------- emit waves: round t-1; hash waves: round t+1 ----------------
@@ -782,11 +790,14 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
             }
             if (hbn) hash_round(t + 2);
             clk.work_done();
+            clk.stat_post(kLdsBytesPipe, wave, lane);
             round_barrier();
             clk.wait_done();
+            clk.stat_take(kLdsBytesPipe, wave, lane);
         }
     }
     clk.flush(wave, lane);
+    clk.flush_stat(wave, lane);
     if (wave == kDictWave) clk.flush_phases(lane);
 
     // hand the stream length so far to the dictionary wave, which finishes a ragged last block with the scalar-path code
@@ -1460,10 +1471,10 @@ hipError_t launch_chameleon_encode(const uint8_t* d_in, uint64_t total, uint64_t
     if (aligned && fits && !g_force_simple) {
         uint64_t* prof = prof_buffer();
         auto kernel = prof ? chameleon_encode_chunks_pipe<true> : chameleon_encode_chunks_pipe<false>;
-        e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytesPipe);
+        e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytesPipe + 64);
         if (e != hipSuccess) return e;
         const uint32_t dbg = getenv("DENSITY_HIP_DBG") ? (uint32_t)atoi(getenv("DENSITY_HIP_DBG")) : 0u;
-        hipLaunchKernelGGL(kernel, dim3(n_chunks), dim3(kPipeWaves * 64), kLdsBytesPipe, stream, d_in, total, chunk_bytes, d_out, out_stride, d_sizes, d_index, d_zmap, dbg, prof);
+        hipLaunchKernelGGL(kernel, dim3(n_chunks), dim3(kPipeWaves * 64), kLdsBytesPipe + 64, stream, d_in, total, chunk_bytes, d_out, out_stride, d_sizes, d_index, d_zmap, dbg, prof);
         prof_report("encode", prof, stream);
     } else {
         hipLaunchKernelGGL(chameleon_encode_chunks, dim3(n_chunks), dim3(64), kLdsBytes, stream, d_in, total, chunk_bytes, d_out, out_stride, d_sizes, d_index);

@@ -11,7 +11,28 @@ __global__ __launch_bounds__(1024) void k(uint64_t* out, int busy_waves) {
     for (uint32_t i = threadIdx.x; i < 32768; i += blockDim.x) reinterpret_cast<uint32_t*>(smem)[i] = i;
     __syncthreads();
     uint32_t x = lane * 2654435761u + 12345u, acc = 0;
-    if (wave == 0) {
+    if (mode >= 6) {
+        // eight exchanges back to back from registers prepared outside the timed loop, one wait: does one wave's atomic stream pipeline?
+        if (wave == 0 || (busy_waves < 0 && (int)wave < -busy_waves)) {
+            uint32_t a[8], m[8], d[8], r[8];
+            for (int j = 0; j < 8; ++j) { x = x * 1664525u + 1013904223u; const uint32_t slot = x >> 16; a[j] = (slot >> 1) << 2; m[j] = 0xffffu << ((slot & 1u) << 4); d[j] = x & m[j]; }
+            uint64_t t0 = __builtin_readcyclecounter();
+            for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (mode == 6) asm volatile("ds_mskor_rtn_b32 %0, %1, %2, %3" : "=v"(r[j]) : "v"(a[j]), "v"(m[j]), "v"(d[j]) : "memory");
+                    if (mode == 7) asm volatile("ds_read_u16 %0, %1\n\tds_write_b16 %1, %2" : "=&v"(r[j]) : "v"(a[j]), "v"(d[j]) : "memory");
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]));
+                acc += r[0] ^ r[7];
+            }
+            uint64_t t1 = __builtin_readcyclecounter();
+            if (lane == 0 && wave == 0) out[mode] = t1 - t0;
+        }
+        if (acc == 0x12345678) out[31] = acc;
+        return;
+    }
+    if (wave == 0 || (busy_waves < 0 && (int)wave < -busy_waves)) {
         uint64_t t0 = __builtin_readcyclecounter();
         for (int it = 0; it < ITERS; ++it) {
 #pragma unroll
@@ -31,7 +52,7 @@ __global__ __launch_bounds__(1024) void k(uint64_t* out, int busy_waves) {
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(acc));
         }
         uint64_t t1 = __builtin_readcyclecounter();
-        if (lane == 0) out[mode] = t1 - t0;
+        if (lane == 0 && wave == 0) out[mode] = t1 - t0;
     } else if ((int)wave <= busy_waves) {
         // background LDS traffic from other waves: streaming b64 reads/writes of a private 2 KiB window
         uint32_t* w = reinterpret_cast<uint32_t*>(smem + 131072 + wave * 2048);
@@ -49,13 +70,15 @@ template <int m> static void run(uint64_t* d, const char* name, int busy) {
 }
 int main() {
     uint64_t* d; (void)hipMalloc(&d, 256); (void)hipMemset(d, 0, 256);
-    for (int busy : {0, 15}) {
+    for (int busy : {0, 15, -2, -4, -8}) {   // negative: that many waves run the measured loop concurrently
         run<0>(d, "ds_mskor_rtn_b32 (ordered exchange)", busy);
         run<1>(d, "ds_read_u16 + ds_write_b16", busy);
         run<2>(d, "ds_read_u16", busy);
         run<3>(d, "ds_write_b16", busy);
         run<4>(d, "ds_wrxchg_rtn_b32", busy);
         run<5>(d, "ds_read_b32 + ds_write_b32", busy);
+        run<6>(d, "8 x ds_mskor_rtn_b32 back to back (per op)", busy);
+        run<7>(d, "8 x (ds_read_u16 + ds_write_b16) back to back", busy);
     }
     return 0;
 }
