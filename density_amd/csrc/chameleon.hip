@@ -654,40 +654,54 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
 
                 clk.phase(1);
 
-                uint32_t k = 0;
-                bool pending_copy = false;                        // guard already advanced for block k and said "copy"
-                bool done = false;
-                const bool spec = nb == kRound && guard.penalty == 0;
-                if (spec) {
+                // what the other wave needs to know: the FSM state after this round
+                auto leave_guard = [&]() {
+                    if (lane == 0) *reinterpret_cast<uint4*>(smem + kGuardBase) = make_uint4(guard.penalty, guard.start, guard.prev, guard.counter);
+                };
+                // eight answers -> eight signatures and the smallest MAP count (plain rounds: a hit is simply "answer == entry")
+                uint32_t min_hits = 64;
+                auto take_signatures = [&]() {
+#pragma unroll
+                    for (uint32_t j = 0; j < kRound; ++j) {
+                        lds_wait_keep_n(blk[j].ret, kRound - 1 - j);              // later exchanges stay in flight
+                        const uint32_t sh = (blk[j].d0 << 3) & 31u;
+                        sig[j] = ballot64(((blk[j].ret ^ blk[j].d1) & (0xffffu << sh)) == 0);
+                        const uint32_t nh = (uint32_t)__builtin_popcountll(sig[j]);
+                        min_hits = nh < min_hits ? nh : min_hits;
+                    }
+                };
+                bool handled = false, already = false;
+                if (__builtin_expect(nb == kRound && guard.penalty == 0 && !guard.prev && zero_blocks == 0, 1)) {
+                    // The common round, one straight block: a whole round, the FSM calm, no quad that packs to entry 0.  Computing
+                    // the signatures has no side effect, so all eight are taken before the FSM is consulted.
 #pragma unroll
                     for (uint32_t j = 0; j < kRound; ++j) issue(blk[j]);
-                    uint32_t min_hits = 64;
-                    const bool plain_round = zero_blocks == 0;
                     clk.phase(2);
-                    if (plain_round) {
-                        // common case: no quad of this round packs to entry 0, a hit is simply "answer == entry"; computing the
-                        // signatures has no side effect, so all eight are taken before the FSM is consulted
-#pragma unroll
-                        for (uint32_t j = 0; j < kRound; ++j) {
-                            lds_wait_keep_n(blk[j].ret, kRound - 1 - j);          // later exchanges stay in flight
-                            const uint32_t sh = (blk[j].d0 << 3) & 31u;
-                            sig[j] = ballot64(((blk[j].ret ^ blk[j].d1) & (0xffffu << sh)) == 0);
-                            const uint32_t nh = (uint32_t)__builtin_popcountll(sig[j]);
-                            min_hits = nh < min_hits ? nh : min_hits;
-                        }
-                    } else {
-                        lds_wait_all();
-                    }
+                    take_signatures();
                     clk.phase(3);
-                    if (plain_round && min_hits > 4 && !guard.prev) {
-                        // The common round, kept in one straight block.  No incompressible record (codec.rs:68: 8 + 256 - 2*hits >=
-                        // 256) in it: the FSM only counts blocks (protection_state.rs:19-27); one of 8 consecutive counters is a
-                        // multiple of 16 iff c == 0 or c > 8.
+                    if (__builtin_expect(min_hits > 4, 1)) {
+                        // no incompressible record (codec.rs:68: 8 + 256 - 2*hits >= 256): the FSM only counts blocks
+                        // (protection_state.rs:19-27); one of 8 consecutive counters is a multiple of 16 iff c == 0 or c > 8
                         const uint32_t c = guard.counter & 15u;
                         guard.start >>= (uint32_t)((c - 1u) >= 8u) & (uint32_t)(guard.start > 1u);
                         guard.counter += kRound;
-                        done = true;
+                        leave_guard();
+                        handled = true;
                     } else {
+                        already = true;                           // the FSM has to look at the blocks one by one
+                    }
+                }
+                if (!handled) {
+                    uint32_t k = 0;
+                    bool pending_copy = false;                    // guard already advanced for block k and said "copy"
+                    const bool spec = nb == kRound && guard.penalty == 0;
+                    if (spec) {
+                        const bool plain_round = zero_blocks == 0;
+                        if (!already) {
+#pragma unroll
+                            for (uint32_t j = 0; j < kRound; ++j) issue(blk[j]);
+                            if (plain_round) take_signatures(); else lds_wait_all();
+                        }
                         // walk the FSM block by block; stop at the first block it turns into a raw copy.  With zero-entry quads
                         // in the round the signature itself updates the zero-entry map, so it is taken only for blocks the FSM
                         // has admitted.
@@ -712,8 +726,6 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
                             lds_wait_all();
                         }
                     }
-                }
-                if (!done) {
                     if (k < nb) {                                 // in-order path: copy runs, the blocks after a mis-speculation, short rounds
 #pragma unroll
                         for (uint32_t j = 0; j < kRound; ++j) {
@@ -732,11 +744,10 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
                             }
                         }
                     }
+                    leave_guard();
                 }
                 clk.phase(4);
-                // the FSM state for the other wave, the results for the next (passive) step
-                if (lane == 0) *reinterpret_cast<uint4*>(smem + kGuardBase) = make_uint4(guard.penalty, guard.start, guard.prev, guard.counter);
-                unpublished = true;
+                unpublished = true;                               // the results go out in the next (passive) step
                 clk.phase(5);
             }
             clk.work_done();
