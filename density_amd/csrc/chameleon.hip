@@ -670,38 +670,12 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
                         min_hits = nh < min_hits ? nh : min_hits;
                     }
                 };
-                bool handled = false, already = false;
-                if (__builtin_expect(nb == kRound && guard.penalty == 0 && !guard.prev && zero_blocks == 0, 1)) {
-                    // The common round, one straight block: a whole round, the FSM calm, no quad that packs to entry 0.  Computing
-                    // the signatures has no side effect, so all eight are taken before the FSM is consulted.
-#pragma unroll
-                    for (uint32_t j = 0; j < kRound; ++j) issue(blk[j]);
-                    clk.phase(2);
-                    take_signatures();
-                    clk.phase(3);
-                    if (__builtin_expect(min_hits > 4, 1)) {
-                        // no incompressible record (codec.rs:68: 8 + 256 - 2*hits >= 256): the FSM only counts blocks
-                        // (protection_state.rs:19-27); one of 8 consecutive counters is a multiple of 16 iff c == 0 or c > 8
-                        const uint32_t c = guard.counter & 15u;
-                        guard.start >>= (uint32_t)((c - 1u) >= 8u) & (uint32_t)(guard.start > 1u);
-                        guard.counter += kRound;
-                        leave_guard();
-                        handled = true;
-                    } else {
-                        already = true;                           // the FSM has to look at the blocks one by one
-                    }
-                }
-                if (!handled) {
+                // Everything that is not the common round.  `issued_all`: the eight exchanges of the round are done (speculatively: "no
+                // raw-copy block in this round") and, in a plain round, the signatures are taken.
+                auto slow_round = [&](bool issued_all, bool plain_round) {
                     uint32_t k = 0;
                     bool pending_copy = false;                    // guard already advanced for block k and said "copy"
-                    const bool spec = nb == kRound && guard.penalty == 0;
-                    if (spec) {
-                        const bool plain_round = zero_blocks == 0;
-                        if (!already) {
-#pragma unroll
-                            for (uint32_t j = 0; j < kRound; ++j) issue(blk[j]);
-                            if (plain_round) take_signatures(); else lds_wait_all();
-                        }
+                    if (issued_all) {
                         // walk the FSM block by block; stop at the first block it turns into a raw copy.  With zero-entry quads
                         // in the round the signature itself updates the zero-entry map, so it is taken only for blocks the FSM
                         // has admitted.
@@ -744,6 +718,34 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
                             }
                         }
                     }
+                };
+                if (__builtin_expect(nb == kRound && guard.penalty == 0 && !guard.prev && zero_blocks == 0, 1)) {
+                    // The common round, one straight block: a whole round, the FSM calm, no quad that packs to entry 0.  Computing
+                    // the signatures has no side effect, so all eight are taken before the FSM is consulted.
+#pragma unroll
+                    for (uint32_t j = 0; j < kRound; ++j) issue(blk[j]);
+                    clk.phase(2);
+                    take_signatures();
+                    clk.phase(3);
+                    if (__builtin_expect(min_hits > 4, 1)) {
+                        // no incompressible record (codec.rs:68: 8 + 256 - 2*hits >= 256): the FSM only counts blocks
+                        // (protection_state.rs:19-27); one of 8 consecutive counters is a multiple of 16 iff c == 0 or c > 8
+                        const uint32_t c = guard.counter & 15u;
+                        guard.start >>= (uint32_t)((c - 1u) >= 8u) & (uint32_t)(guard.start > 1u);
+                        guard.counter += kRound;
+                    } else {
+                        slow_round(true, true);                   // the FSM has to look at the blocks one by one
+                    }
+                    leave_guard();
+                } else {
+                    const bool spec = nb == kRound && guard.penalty == 0;
+                    const bool plain_round = zero_blocks == 0;
+                    if (spec) {
+#pragma unroll
+                        for (uint32_t j = 0; j < kRound; ++j) issue(blk[j]);
+                        if (plain_round) take_signatures(); else lds_wait_all();
+                    }
+                    slow_round(spec, plain_round);
                     leave_guard();
                 }
                 clk.phase(4);
