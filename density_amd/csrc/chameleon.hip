@@ -622,7 +622,7 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
                 copy_mask = 0;
 #pragma unroll
                 for (uint32_t j = 0; j < kRound; ++j) sig[j] = 0;
-                if (t > 0) {                                      // the FSM as the other wave left it after round t-1
+                {                                                 // the FSM as the other wave left it after round t-1 (Guard{} before round 0)
                     const uint4 g = *reinterpret_cast<const uint4*>(smem + kGuardBase);
                     guard.penalty = rfl(g.x); guard.start = rfl(g.y); guard.prev = rfl(g.z); guard.counter = rfl(g.w);
                 }
@@ -719,7 +719,7 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
                         }
                     }
                 };
-                if (__builtin_expect(nb == kRound && guard.penalty == 0 && !guard.prev && zero_blocks == 0, 1)) {
+                if (__builtin_expect((guard.penalty | guard.prev | zero_blocks) == 0 && left >= kRound, 1)) {
                     // The common round, one straight block: a whole round, the FSM calm, no quad that packs to entry 0.  Computing
                     // the signatures has no side effect, so all eight are taken before the FSM is consulted.
 #pragma unroll
