@@ -1239,16 +1239,10 @@ __global__ __launch_bounds__(kDecWaves * 64) void chameleon_decode_chunks_pipe(c
         // descriptor and this wave's record position in one LDS round trip
         const uint4 dt = *reinterpret_cast<const uint4*>(smem + dbase + 96);       // {copy mask, count, flags, first ordinal}
         const uint32_t posv = *reinterpret_cast<const uint32_t*>(smem + dbase + 64 + 4u * w);
-        const uint32_t n = rfl(dt.y), copy_mask = rfl(dt.x);
-        if (rfl(dt.z) & kFlagLast) last_round = r;              // every wave must learn where to stop
-        if (w >= n) return;
+        const uint32_t n = rfl(dt.y), copy_mask = rfl(dt.x), flags = rfl(dt.z);
         const uint32_t pos = rfl(posv);
-        uint32_t d0, d1;
-        if ((copy_mask >> w) & 1u) {
-            const uint32_t a = pos + 4u * lane;
-            d0 = 0;
-            d1 = ring16(a) | (ring16(a + 2) << 16);
-        } else {
+        // a coded record: signature, then one 2- or 4-byte item per lane
+        auto stage_coded = [&]() {
             const uint32_t part = lane < 4 ? ring16(pos + 2u * lane) : 0u;       // the record's signature (codec.rs:28-31)
             const uint64_t sig = (uint64_t)(rlane(part, 0) | (rlane(part, 1) << 16)) | ((uint64_t)(rlane(part, 2) | (rlane(part, 3) << 16)) << 32);
             const bool hit = (sig >> lane) & 1ull;
@@ -1259,10 +1253,19 @@ __global__ __launch_bounds__(kDecWaves * 64) void chameleon_decode_chunks_pipe(c
             const uint32_t q = lo | (hi << 16);
             const uint32_t P = q * kHashMul;
             const uint32_t h = hit ? lo : (P >> 16);
-            d0 = ((h >> 1) << 2) | (h & 1u) | (hit ? 0u : kD0Write);
-            d1 = hit ? 0u : (stored_entry(q, P) << ((h & 1u) << 4));
+            const uint32_t d0 = ((h >> 1) << 2) | (h & 1u) | (hit ? 0u : kD0Write);
+            const uint32_t d1 = hit ? 0u : (stored_entry(q, P) << ((h & 1u) << 4));
+            *reinterpret_cast<uint2*>(smem + sbase + w * kStageRec + 8u * lane) = make_uint2(d0, d1);
+        };
+        if (__builtin_expect((copy_mask | flags) == 0 && n == kRound, 1)) { stage_coded(); return; }   // the common round: eight coded records
+        if (flags & kFlagLast) last_round = r;                  // every wave must learn where to stop
+        if (w >= n) return;
+        if ((copy_mask >> w) & 1u) {
+            const uint32_t a = pos + 4u * lane;
+            *reinterpret_cast<uint2*>(smem + sbase + w * kStageRec + 8u * lane) = make_uint2(0u, ring16(a) | (ring16(a + 2) << 16));
+        } else {
+            stage_coded();
         }
-        *reinterpret_cast<uint2*>(smem + sbase + w * kStageRec + 8u * lane) = make_uint2(d0, d1);
     };
 
     auto dict_round = [&](uint32_t r) {                       // wave 0
@@ -1276,12 +1279,15 @@ __global__ __launch_bounds__(kDecWaves * 64) void chameleon_decode_chunks_pipe(c
             const uint2 v = *reinterpret_cast<const uint2*>(smem + sbase + j * kStageRec + 8u * lane);
             d0[j] = v.x; d1[j] = v.y; ret[j] = 0;
         }
-        const uint32_t n = rfl(dt.y), copy_mask = rfl(dt.x);
-        if (rfl(dt.z) & kFlagLast) last_round = r;
-        if (n == 0) return;
+        const uint32_t n = rfl(dt.y), copy_mask = rfl(dt.x), flags = rfl(dt.z);
+        const bool common = (copy_mask | flags) == 0 && n == kRound;   // eight coded records, not the last round
+        if (!common) {
+            if (flags & kFlagLast) last_round = r;
+            if (n == 0) return;
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d0[0]), "+v"(d0[1]), "+v"(d0[2]), "+v"(d0[3]), "+v"(d0[4]), "+v"(d0[5]), "+v"(d0[6]), "+v"(d0[7]),
                                               "+v"(d1[0]), "+v"(d1[1]), "+v"(d1[2]), "+v"(d1[3]), "+v"(d1[4]), "+v"(d1[5]), "+v"(d1[6]), "+v"(d1[7]) :: "memory");
-        const uint32_t live = ((1u << n) - 1u) & ~copy_mask;      // records that go through the table
+        const uint32_t live = common ? 0xffu : (((1u << n) - 1u) & ~copy_mask);      // records that go through the table
         auto issue = [&](uint32_t j) {
             const uint32_t sh = (d0[j] & kD0Half) << 4;
             const uint32_t mask = (uint32_t)(((int32_t)(d0[j] << 30) >> 31) & 0xffff) << sh;   // write flag -> 0xffff or 0
@@ -1370,17 +1376,21 @@ __global__ __launch_bounds__(kDecWaves * 64) void chameleon_decode_chunks_pipe(c
         const uint4 dt = *reinterpret_cast<const uint4*>(smem + dbase + 96);       // {copy mask, count, flags, first ordinal}
         const uint2 va = *reinterpret_cast<const uint2*>(smem + sbase + w * kStageRec);
         const uint2 vb = *reinterpret_cast<const uint2*>(smem + sbase + ((w + kNumEmit) & (kRound - 1u)) * kStageRec);
-        const uint32_t n = rfl(dt.y), copy_mask = rfl(dt.x), first = rfl(dt.w);
-        if (rfl(dt.z) & kFlagLast) last_round = r;
-        auto quad_of = [&](const uint2& v, uint32_t k) -> uint32_t {
+        const uint32_t n = rfl(dt.y), copy_mask = rfl(dt.x), flags = rfl(dt.z), first = rfl(dt.w);
+        auto quad_coded = [&](const uint2& v) -> uint32_t {
             const uint32_t sh = (v.x & kD0Half) << 4;
             const uint32_t h = ((v.x & kD0Addr) >> 1) | (v.x & kD0Half);
-            const uint32_t q = (v.x & kD0Empty) ? 0u : entry_to_quad(h, (v.y >> sh) & 0xffffu);
-            return ((copy_mask >> k) & 1u) ? v.y : q;
+            return (v.x & kD0Empty) ? 0u : entry_to_quad(h, (v.y >> sh) & 0xffffu);
         };
         uint8_t* base = dst + (uint64_t)first * kBlock;           // wave-uniform
-        if (w < n) gstore32(base + w * kBlock, 4u * lane, quad_of(va, w));
-        if (w + kNumEmit < n) gstore32(base + (w + kNumEmit) * kBlock, 4u * lane, quad_of(vb, w + kNumEmit));
+        if (__builtin_expect((copy_mask | flags) == 0 && n == kRound, 1)) {          // the common round: eight coded records
+            gstore32(base + w * kBlock, 4u * lane, quad_coded(va));
+            if (w + kNumEmit < kRound) gstore32(base + (w + kNumEmit) * kBlock, 4u * lane, quad_coded(vb));
+            return;
+        }
+        if (flags & kFlagLast) last_round = r;
+        if (w < n) gstore32(base + w * kBlock, 4u * lane, ((copy_mask >> w) & 1u) ? va.y : quad_coded(va));
+        if (w + kNumEmit < n) gstore32(base + (w + kNumEmit) * kBlock, 4u * lane, ((copy_mask >> (w + kNumEmit)) & 1u) ? vb.y : quad_coded(vb));
     };
 
     // ---- prologue: fill the pipeline ----
