@@ -1287,7 +1287,7 @@ __global__ __launch_bounds__(kDecWaves * 64) void chameleon_decode_chunks_pipe(c
         }
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d0[0]), "+v"(d0[1]), "+v"(d0[2]), "+v"(d0[3]), "+v"(d0[4]), "+v"(d0[5]), "+v"(d0[6]), "+v"(d0[7]),
                                               "+v"(d1[0]), "+v"(d1[1]), "+v"(d1[2]), "+v"(d1[3]), "+v"(d1[4]), "+v"(d1[5]), "+v"(d1[6]), "+v"(d1[7]) :: "memory");
-        const uint32_t live = common ? 0xffu : (((1u << n) - 1u) & ~copy_mask);      // records that go through the table
+        const uint32_t live = ((1u << n) - 1u) & ~copy_mask;      // records that go through the table
         auto issue = [&](uint32_t j) {
             const uint32_t sh = (d0[j] & kD0Half) << 4;
             const uint32_t mask = (uint32_t)(((int32_t)(d0[j] << 30) >> 31) & 0xffff) << sh;   // write flag -> 0xffff or 0
@@ -1299,7 +1299,7 @@ __global__ __launch_bounds__(kDecWaves * 64) void chameleon_decode_chunks_pipe(c
             const uint32_t m = (d0[j] & kD0Write) ? d1[j] : ret[j];
             asm volatile("ds_write_b32 %0, %1 offset:4" ::"v"(lds0 + sbase + j * kStageRec + 8u * lane), "v"(m) : "memory");
         };
-        if (live == 0xffu) {                                      // the common round: eight coded records, straight-line code
+        if (__builtin_expect(common, 1)) {                        // the common round: eight coded records, straight-line code
 #pragma unroll
             for (uint32_t j = 0; j < kRound; ++j) issue(j);
 #pragma unroll
