@@ -1288,16 +1288,27 @@ __global__ __launch_bounds__(kDecWaves * 64) void chameleon_decode_chunks_pipe(c
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d0[0]), "+v"(d0[1]), "+v"(d0[2]), "+v"(d0[3]), "+v"(d0[4]), "+v"(d0[5]), "+v"(d0[6]), "+v"(d0[7]),
                                               "+v"(d1[0]), "+v"(d1[1]), "+v"(d1[2]), "+v"(d1[3]), "+v"(d1[4]), "+v"(d1[5]), "+v"(d1[6]), "+v"(d1[7]) :: "memory");
         const uint32_t live = ((1u << n) - 1u) & ~copy_mask;      // records that go through the table
+        uint32_t mask[kRound];
         auto issue = [&](uint32_t j) {
             const uint32_t sh = (d0[j] & kD0Half) << 4;
-            const uint32_t mask = (uint32_t)(((int32_t)(d0[j] << 30) >> 31) & 0xffff) << sh;   // write flag -> 0xffff or 0
-            dict_xchg_issue(tbl + (d0[j] & kD0Addr), mask, d1[j], ret[j]);
+            mask[j] = (uint32_t)(((int32_t)(d0[j] << 30) >> 31) & 0xffff) << sh;   // write flag -> 0xffff or 0
+            dict_xchg_issue(tbl + (d0[j] & kD0Addr), mask[j], d1[j], ret[j]);
         };
-        // what the slot holds after this lane's turn: its own entry for PLAIN lanes, the entry it read for MAP lanes; the emit
-        // waves take the quad from that uniformly
+        // the dword as it stands after this lane's turn — (old & ~mask) | entry: its own entry for PLAIN lanes, what it read for MAP
+        // lanes (mask and entry are 0 there) — goes back in place of the operand; the emit waves pick the lane's half
+        const uint32_t wbase = lds0 + sbase + 8u * lane;
         auto finish = [&](uint32_t j) {
-            const uint32_t m = (d0[j] & kD0Write) ? d1[j] : ret[j];
-            asm volatile("ds_write_b32 %0, %1 offset:4" ::"v"(lds0 + sbase + j * kStageRec + 8u * lane), "v"(m) : "memory");
+            const uint32_t m = (ret[j] & ~mask[j]) | d1[j];
+            switch (j) {                                          // (offsets are instruction immediates)
+                case 0: asm volatile("ds_write_b32 %0, %1 offset:4" ::"v"(wbase), "v"(m) : "memory"); break;
+                case 1: asm volatile("ds_write_b32 %0, %1 offset:516" ::"v"(wbase), "v"(m) : "memory"); break;
+                case 2: asm volatile("ds_write_b32 %0, %1 offset:1028" ::"v"(wbase), "v"(m) : "memory"); break;
+                case 3: asm volatile("ds_write_b32 %0, %1 offset:1540" ::"v"(wbase), "v"(m) : "memory"); break;
+                case 4: asm volatile("ds_write_b32 %0, %1 offset:2052" ::"v"(wbase), "v"(m) : "memory"); break;
+                case 5: asm volatile("ds_write_b32 %0, %1 offset:2564" ::"v"(wbase), "v"(m) : "memory"); break;
+                case 6: asm volatile("ds_write_b32 %0, %1 offset:3076" ::"v"(wbase), "v"(m) : "memory"); break;
+                default: asm volatile("ds_write_b32 %0, %1 offset:3588" ::"v"(wbase), "v"(m) : "memory"); break;
+            }
         };
         if (__builtin_expect(common, 1)) {                        // the common round: eight coded records, straight-line code
 #pragma unroll
