@@ -1281,13 +1281,10 @@ __global__ __launch_bounds__(kDecWaves * 64) void chameleon_decode_chunks_pipe(c
         }
         const uint32_t n = rfl(dt.y), copy_mask = rfl(dt.x), flags = rfl(dt.z);
         const bool common = (copy_mask | flags) == 0 && n == kRound;   // eight coded records, not the last round
-        if (!common) {
-            if (flags & kFlagLast) last_round = r;
-            if (n == 0) return;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d0[0]), "+v"(d0[1]), "+v"(d0[2]), "+v"(d0[3]), "+v"(d0[4]), "+v"(d0[5]), "+v"(d0[6]), "+v"(d0[7]),
-                                              "+v"(d1[0]), "+v"(d1[1]), "+v"(d1[2]), "+v"(d1[3]), "+v"(d1[4]), "+v"(d1[5]), "+v"(d1[6]), "+v"(d1[7]) :: "memory");
-        const uint32_t live = ((1u << n) - 1u) & ~copy_mask;      // records that go through the table
+        auto operands_landed = [&]() {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d0[0]), "+v"(d0[1]), "+v"(d0[2]), "+v"(d0[3]), "+v"(d0[4]), "+v"(d0[5]), "+v"(d0[6]), "+v"(d0[7]),
+                                                  "+v"(d1[0]), "+v"(d1[1]), "+v"(d1[2]), "+v"(d1[3]), "+v"(d1[4]), "+v"(d1[5]), "+v"(d1[6]), "+v"(d1[7]) :: "memory");
+        };
         uint32_t mask[kRound];
         auto issue = [&](uint32_t j) {
             const uint32_t sh = (d0[j] & kD0Half) << 4;
@@ -1311,6 +1308,7 @@ __global__ __launch_bounds__(kDecWaves * 64) void chameleon_decode_chunks_pipe(c
             }
         };
         if (__builtin_expect(common, 1)) {                        // the common round: eight coded records, straight-line code
+            operands_landed();
 #pragma unroll
             for (uint32_t j = 0; j < kRound; ++j) issue(j);
 #pragma unroll
@@ -1320,6 +1318,10 @@ __global__ __launch_bounds__(kDecWaves * 64) void chameleon_decode_chunks_pipe(c
                 finish(j);
             }
         } else {
+            if (flags & kFlagLast) last_round = r;
+            if (n == 0) return;
+            operands_landed();
+            const uint32_t live = ((1u << n) - 1u) & ~copy_mask;  // records that go through the table
 #pragma unroll
             for (uint32_t j = 0; j < kRound; ++j) {
                 if ((live >> j) & 1u) issue(j);
