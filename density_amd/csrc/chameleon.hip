@@ -660,10 +660,10 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
                 };
                 // eight answers -> eight signatures and the smallest MAP count (plain rounds: a hit is simply "answer == entry")
                 uint32_t min_hits = 64;
-                auto take_signatures = [&]() {
+                auto take_signatures = [&](uint32_t younger = 0) {               // `younger`: LDS operations issued after the exchanges
 #pragma unroll
                     for (uint32_t j = 0; j < kRound; ++j) {
-                        lds_wait_keep_n(blk[j].ret, kRound - 1 - j);              // later exchanges stay in flight
+                        lds_wait_keep_n(blk[j].ret, kRound - 1 - j + younger);    // later exchanges stay in flight
                         const uint32_t sh = (blk[j].d0 << 3) & 31u;
                         sig[j] = ballot64(((blk[j].ret ^ blk[j].d1) & (0xffffu << sh)) == 0);
                         const uint32_t nh = (uint32_t)__builtin_popcountll(sig[j]);
@@ -725,18 +725,25 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
 #pragma unroll
                     for (uint32_t j = 0; j < kRound; ++j) issue(blk[j]);
                     clk.phase(2);
-                    take_signatures();
-                    clk.phase(3);
-                    if (__builtin_expect(min_hits > 4, 1)) {
-                        // no incompressible record (codec.rs:68: 8 + 256 - 2*hits >= 256): the FSM only counts blocks
-                        // (protection_state.rs:19-27); one of 8 consecutive counters is a multiple of 16 iff c == 0 or c > 8
-                        const uint32_t c = guard.counter & 15u;
-                        guard.start >>= (uint32_t)((c - 1u) >= 8u) & (uint32_t)(guard.start > 1u);
-                        guard.counter += kRound;
-                    } else {
-                        slow_round(true, true);                   // the FSM has to look at the blocks one by one
+                    // What the FSM will look like if no record of the round is incompressible (codec.rs:68: 8 + 256 - 2*hits >= 256):
+                    // it only counts blocks (protection_state.rs:19-27), and one of 8 consecutive counters is a multiple of 16 iff
+                    // c == 0 or c > 8.  That state goes to LDS right away, behind the exchanges, so the end of the step does not
+                    // wait for the write; any other outcome overwrites it.
+                    const Guard before = guard;
+                    const uint32_t c = guard.counter & 15u;
+                    guard.start >>= (uint32_t)((c - 1u) >= 8u) & (uint32_t)(guard.start > 1u);
+                    guard.counter += kRound;
+                    if (lane == 0) {
+                        const u32x4 gv = {guard.penalty, guard.start, guard.prev, guard.counter};
+                        asm volatile("ds_write_b128 %0, %1" ::"v"(lds0 + kGuardBase), "v"(gv) : "memory");
                     }
-                    leave_guard();
+                    take_signatures(1);
+                    clk.phase(3);
+                    if (__builtin_expect(min_hits <= 4, 0)) {
+                        guard = before;
+                        slow_round(true, true);                   // the FSM has to look at the blocks one by one
+                        leave_guard();
+                    }
                 } else {
                     const bool spec = nb == kRound && guard.penalty == 0;
                     const bool plain_round = zero_blocks == 0;
