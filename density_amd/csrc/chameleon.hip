@@ -613,8 +613,10 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
             clk.start();
             if ((t & 1u) != par) {
                 // passive step: hand round t-1 to the emit waves, take the operands of round t+1 (hashed during step t-1)
+                // (the reads first: they are back by the time the results are written out)
+                if (t + 1 < nrounds) load_ops(t + 1);
                 if (unpublished) { publish(t - 1); unpublished = false; }
-                if (t + 1 < nrounds) { load_ops(t + 1); ops_take(); }
+                if (t + 1 < nrounds) ops_take();
             } else if (t < nrounds) {
                 clk.phase_start();
                 const uint32_t left = nfull - t * kRound;
