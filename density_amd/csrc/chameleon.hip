@@ -622,8 +622,6 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
                 const uint32_t left = nfull - t * kRound;
                 const uint32_t nb = left < kRound ? left : kRound;
                 copy_mask = 0;
-#pragma unroll
-                for (uint32_t j = 0; j < kRound; ++j) sig[j] = 0;
                 {                                                 // the FSM as the other wave left it after round t-1 (Guard{} before round 0)
                     const uint4 g = *reinterpret_cast<const uint4*>(smem + kGuardBase);
                     guard.penalty = rfl(g.x); guard.start = rfl(g.y); guard.prev = rfl(g.z); guard.counter = rfl(g.w);
@@ -747,6 +745,8 @@ __global__ __launch_bounds__(kPipeWaves * 64) void chameleon_encode_chunks_pipe(
                         leave_guard();
                     }
                 } else {
+#pragma unroll
+                    for (uint32_t j = 0; j < kRound; ++j) sig[j] = 0;     // raw-copy blocks and blocks past a short round's end keep 0
                     const bool spec = nb == kRound && guard.penalty == 0;
                     const bool plain_round = zero_blocks == 0;
                     if (spec) {
