@@ -47,6 +47,7 @@ SYMBOLS.update({
     "density_hip_set_kernel_variant": (None, [_I]),
     "density_hip_last_timings": (_I, [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_char_p), _I]),
     "density_hip_selftest": (_I, []),
+    "density_hip_selftest_bits": (_I, []),
     "density_hip_last_error": (ctypes.c_char_p, []),
     "density_hip_version": (ctypes.c_char_p, []),
 })

@@ -6,8 +6,8 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdensity_hip.so")
-SOURCES = ["api.hip", "chameleon.hip", "container.hip", "serial_codec.hip"]
-HEADERS = ["common.hpp", "kernels.hpp", os.path.join("..", "..", "include", "density_hip.h")]
+SOURCES = ["api.hip", "chameleon.hip", "rotor.hip", "container.hip", "serial_codec.hip"]
+HEADERS = ["common.hpp", "chameleon_dev.hpp", "kernels.hpp", os.path.join("..", "..", "include", "density_hip.h")]
 
 
 def _hipcc():

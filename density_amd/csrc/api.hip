@@ -65,6 +65,7 @@ struct Buffer {
 struct DeviceCtx {
     std::mutex mu;
     bool ready = false, selftest_ok = false;
+    uint32_t selftest_bits = 0;
     hipStream_t stream = nullptr;
     Buffer work, stage_in, stage_out;
     // profiling: event marks accumulated since the last density_hip_last_timings() (name == nullptr opens a call)
@@ -96,11 +97,18 @@ DeviceCtx* acquire_ctx() {
         e = hipMalloc((void**)&d_fail, sizeof(uint32_t));
         if (e == hipSuccess) e = hipMemsetAsync(d_fail, 0, sizeof(uint32_t), c->stream);
         if (e == hipSuccess) e = launch_selftest(d_fail, c->stream);
+        if (e == hipSuccess) e = launch_rotor_selftest(d_fail, c->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(&h_fail, d_fail, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (d_fail) (void)hipFree(d_fail);
         if (e != hipSuccess) { set_error("LDS self-test launch", e); return nullptr; }
-        c->selftest_ok = (h_fail == 0);
+        // bits 0..7 (container.hip): plain 16-bit LDS writes in lane order — every kernel needs it; bits 8..11 (rotor.hip): lane order of the
+        // ordered exchange ds_mskor_rtn_b32 — all but the one-wavefront kernels need it; bits 12, 13: lane-reversed rollback and the token
+        // hand-off behind the exchanges — only the wave-rotation kernels need them.  A device that fails a later group runs on what is left.
+        c->selftest_bits = h_fail;
+        c->selftest_ok = (h_fail & 0xffu) == 0;
+        density::g_exchange_unsafe = (h_fail & 0x0f00u) != 0;
+        density::g_rotor_unsafe = (h_fail & 0xff00u) != 0;
         c->ready = true;
     }
     if (!c->selftest_ok) { set_error("LDS write-order self-test failed on this device; refusing to run"); return nullptr; }
@@ -166,8 +174,8 @@ DecodePlan plan_decode(int algo, size_t n_chunks) {
 
 // algorithm dispatch: Chameleon has the LDS-resident pipelined kernels, Cheetah/Lion the functional one-lane-per-stream kernels
 hipError_t codec_encode(int algo, const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_out,
-                        uint64_t out_stride, uint64_t* d_sizes, uint8_t* d_index, uint8_t* d_tables, uint32_t* d_zmap, hipStream_t s) {
-    if (algo == DENSITY_HIP_CHAMELEON) return launch_chameleon_encode(d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_index, d_zmap, s);
+                        uint64_t out_stride, uint64_t* d_sizes, uint8_t* d_index, uint8_t* d_tables, uint32_t* d_zmap, uint32_t* d_err, hipStream_t s) {
+    if (algo == DENSITY_HIP_CHAMELEON) return launch_chameleon_encode(d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_index, d_zmap, d_err, s);
     return launch_serial_encode(algo, d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, (uint32_t)serial_slots(algo, n_chunks), s);
 }
 hipError_t codec_decode(int algo, const uint8_t* d_in, const uint64_t* d_offsets, const uint64_t* d_sizes, uint32_t n_chunks, uint8_t* d_out,
@@ -219,12 +227,12 @@ int run_encode_container(DeviceCtx* c, int algo, const uint8_t* d_in, size_t n, 
     if (e != hipSuccess) { set_error("hipMemsetAsync", e); return DENSITY_HIP_ERR_RUNTIME; }
     if (p.n_chunks == 1) {
         // single chunk: its stream goes straight to its final place, no stitch pass
-        e = codec_encode(algo, d_in, n, chunk, 1, d_out + pbase, 0, d_sizes, d_index, ws + p.off_tables, d_zmap, s);
+        e = codec_encode(algo, d_in, n, chunk, 1, d_out + pbase, 0, d_sizes, d_index, ws + p.off_tables, d_zmap, d_err, s);
         prof.mark(encode_kernel_name(algo));
         if (e == hipSuccess) e = launch_layout_encode(d_sizes, 1, hdr, pbase, d_out, cap, d_offsets, d_err, s);
         prof.mark("layout_encode");
     } else {
-        e = codec_encode(algo, d_in, n, chunk, (uint32_t)p.n_chunks, d_slots, p.stride, d_sizes, d_index, ws + p.off_tables, d_zmap, s);
+        e = codec_encode(algo, d_in, n, chunk, (uint32_t)p.n_chunks, d_slots, p.stride, d_sizes, d_index, ws + p.off_tables, d_zmap, d_err, s);
         prof.mark(encode_kernel_name(algo));
         if (e == hipSuccess) e = launch_layout_encode(d_sizes, (uint32_t)p.n_chunks, hdr, pbase, d_out, cap, d_offsets, d_err, s);
         prof.mark("layout_encode");
@@ -238,6 +246,7 @@ int run_encode_container(DeviceCtx* c, int algo, const uint8_t* d_in, size_t n, 
         if (e == hipSuccess) e = hipMemcpyAsync(&h_err, d_err, sizeof(h_err), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (e != hipSuccess) { set_error("encode (device)", e); return DENSITY_HIP_ERR_RUNTIME; }
+        if (h_err & 16u) { set_error("encode: device-side watchdog"); return DENSITY_HIP_ERR_RUNTIME; }
         if (h_err) { set_error("container does not fit the output capacity"); return DENSITY_HIP_ERR_CAPACITY; }
     }
     return DENSITY_HIP_OK;
@@ -279,12 +288,17 @@ int run_stream_encode(DeviceCtx* c, int algo, const uint8_t* d_in, size_t n, uin
     if (n == 0) return DENSITY_HIP_OK;
     Profiler prof(c, s);
     const DecodePlan sp = plan_decode(algo, 1);   // stream calls share the one-chunk decode layout
-    hipError_t e = codec_encode(algo, d_in, n, n, 1, d_out, 0, d_sizes, nullptr, ws + sp.off_tables, zmap_bytes(algo, 1) ? reinterpret_cast<uint32_t*>(ws + sp.off_zmap) : nullptr, s);
+    uint32_t* d_err = reinterpret_cast<uint32_t*>(ws + sp.off_err);
+    hipError_t e = hipMemsetAsync(d_err, 0, sizeof(uint32_t), s);
+    if (e == hipSuccess) e = codec_encode(algo, d_in, n, n, 1, d_out, 0, d_sizes, nullptr, ws + sp.off_tables, zmap_bytes(algo, 1) ? reinterpret_cast<uint32_t*>(ws + sp.off_zmap) : nullptr, d_err, s);
     prof.mark(encode_kernel_name(algo));
     uint64_t h_size = 0;
+    uint32_t h_err = 0;
     if (e == hipSuccess) e = hipMemcpyAsync(&h_size, d_sizes, sizeof(h_size), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(&h_err, d_err, sizeof(h_err), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) { set_error("stream encode", e); return DENSITY_HIP_ERR_RUNTIME; }
+    if (h_err) { set_error("stream encode: device-side watchdog"); return DENSITY_HIP_ERR_RUNTIME; }
     *size_out = (size_t)h_size;
     return DENSITY_HIP_OK;
 }
@@ -404,7 +418,10 @@ int density_hip_decode_device(const void* d_container, size_t container_size, co
     density_hip_header_t h;
     if (header) h = *header;
     else {
-        hipError_t e = hipMemcpy(&h, d_container, sizeof(h), hipMemcpyDeviceToHost);
+        // ordered behind whatever produced the container on the caller's stream (streams here are non-blocking: a plain hipMemcpy is not)
+        hipStream_t hs = stream ? (hipStream_t)stream : c->stream;
+        hipError_t e = hipMemcpyAsync(&h, d_container, sizeof(h), hipMemcpyDeviceToHost, hs);
+        if (e == hipSuccess) e = hipStreamSynchronize(hs);
         if (e != hipSuccess) { set_error("header read-back", e); return DENSITY_HIP_ERR_RUNTIME; }
     }
     if (check_header(h, container_size) != DENSITY_HIP_OK) { set_error("bad container header"); return DENSITY_HIP_ERR_FORMAT; }
@@ -494,7 +511,7 @@ size_t density_hip_decode(const uint8_t* container, size_t container_size, uint8
 }
 
 void density_hip_set_profiling(int enabled) { g_profiling = enabled; }
-void density_hip_set_kernel_variant(int variant) { g_variant = variant; density::g_force_simple = (variant & 1) != 0; }
+void density_hip_set_kernel_variant(int variant) { g_variant = variant; density::g_force_simple = (variant & 1) != 0; density::g_force_pipeline = (variant & 4) != 0; }
 
 int density_hip_last_timings(float* milliseconds, const char** names, int capacity) {
     int dev = -1;
@@ -519,6 +536,14 @@ int density_hip_last_timings(float* milliseconds, const char** names, int capaci
 int density_hip_selftest(void) {
     g_last_error.clear();
     return acquire_ctx() ? 0 : 1;
+}
+
+int density_hip_selftest_bits(void) {
+    g_last_error.clear();
+    int dev = -1;
+    (void)acquire_ctx();
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices || !g_ctx[dev].ready) return -1;
+    return (int)g_ctx[dev].selftest_bits;
 }
 
 const char* density_hip_last_error(void) { return g_last_error.c_str(); }

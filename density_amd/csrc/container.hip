@@ -41,7 +41,7 @@ __device__ __forceinline__ uint64_t block_inclusive_scan(uint64_t v, uint64_t* w
 template <typename SizeT>
 __device__ __forceinline__ void layout_common(const SizeT* __restrict__ sizes_in, uint32_t n, uint64_t base,
                                               uint64_t* __restrict__ sizes_out, uint32_t* __restrict__ table_out,
-                                              uint64_t* __restrict__ offsets, uint64_t* end_out) {
+                                              uint64_t* __restrict__ offsets, uint64_t* end_out, uint64_t limit, uint32_t* __restrict__ err) {
     __shared__ uint64_t wave_sums[kScanThreads / 64];
     uint64_t carry = base, last_end = base;
     for (uint32_t t0 = 0; t0 < n; t0 += kScanThreads) {
@@ -50,9 +50,14 @@ __device__ __forceinline__ void layout_common(const SizeT* __restrict__ sizes_in
         uint64_t tile_total;
         const uint64_t incl = block_inclusive_scan(align16(sz), wave_sums, &tile_total);
         if (i < n) {
-            const uint64_t off = carry + incl - align16(sz);
+            uint64_t off = carry + incl - align16(sz);
+            uint64_t keep = sz;
+            if (off + sz > limit) {                     // a size table that runs past the container: the codec kernels must not follow it
+                off = base; keep = 0;
+                atomicOr(err, 4u);
+            }
             offsets[i] = off;
-            if (sizes_out) sizes_out[i] = sz;
+            if (sizes_out) sizes_out[i] = keep;
             if (table_out) table_out[i] = (uint32_t)sz;
             if (i == n - 1) *end_out = off + sz;     // single writer
         }
@@ -67,7 +72,7 @@ __global__ __launch_bounds__(kScanThreads) void layout_encode_kernel(const uint6
                                                                      uint64_t* __restrict__ end_scratch, uint32_t* __restrict__ err) {
     if (threadIdx.x == 0) *end_scratch = base;
     __syncthreads();
-    layout_common<uint64_t>(sizes, n, base, nullptr, reinterpret_cast<uint32_t*>(container + kHeaderBytes), offsets, end_scratch);
+    layout_common<uint64_t>(sizes, n, base, nullptr, reinterpret_cast<uint32_t*>(container + kHeaderBytes), offsets, end_scratch, ~0ull, err);
     __syncthreads();
     if (threadIdx.x == 0) {
         hdr.container_len = *end_scratch;
@@ -82,7 +87,7 @@ __global__ __launch_bounds__(kScanThreads) void layout_decode_kernel(const uint8
                                                                      uint32_t* __restrict__ err) {
     if (threadIdx.x == 0) *end_scratch = base;
     __syncthreads();
-    layout_common<uint32_t>(reinterpret_cast<const uint32_t*>(container + kHeaderBytes), n, base, sizes, nullptr, offsets, end_scratch);
+    layout_common<uint32_t>(reinterpret_cast<const uint32_t*>(container + kHeaderBytes), n, base, sizes, nullptr, offsets, end_scratch, container_size, err);
     __syncthreads();
     if (threadIdx.x == 0 && *end_scratch > container_size) atomicOr(err, 4u);   // truncated container
 }

@@ -13,7 +13,7 @@ extern bool g_force_simple;   // density_hip_set_kernel_variant(1)
 // out + c*out_stride; sizes[c] receives the stream length.
 // d_index (nullable): one byte per 256-byte input block, numbered over the whole input (see include/density_hip.h).
 hipError_t launch_chameleon_encode(const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks,
-                                   uint8_t* d_out, uint64_t out_stride, uint64_t* d_sizes, uint8_t* d_index, uint32_t* d_zmap, hipStream_t stream);
+                                   uint8_t* d_out, uint64_t out_stride, uint64_t* d_sizes, uint8_t* d_index, uint32_t* d_zmap, uint32_t* d_err, hipStream_t stream);
 // d_zmap (nullable -> one-wavefront kernels): kZmapWordsPerChunk words per chunk of scratch for the pipelined kernels' zero-entry maps.
 // Chunk c reads the stream at in + offsets[c] (sizes[c] bytes) and writes out + c*out_stride.  With `exact`, a chunk
 // that does not produce exactly min(out_stride, out_total - c*out_stride) bytes raises *d_err.
@@ -23,6 +23,19 @@ hipError_t launch_chameleon_decode(const uint8_t* d_in, const uint64_t* d_offset
 // the pipelined decoder keeps its zero-entry map in global memory: kZmapWordsPerChunk u32 per chunk, for at most
 // kMaxPipelinedChunks chunks (more chunks than that, i.e. tiny chunks, run on the one-wavefront kernel)
 constexpr uint32_t kZmapWordsPerChunk = 2048, kMaxPipelinedChunks = 16384;
+
+// ---- rotor.hip (Chameleon wave-rotation kernels: the default encode / index-fed decode path) ----
+bool rotor_encode_eligible(const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks);
+hipError_t launch_rotor_encode(const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_out, uint64_t out_stride,
+                               uint64_t* d_sizes, uint8_t* d_index, uint32_t* d_err, hipStream_t stream);
+bool rotor_decode_eligible(const uint8_t* d_out, uint32_t n_chunks, uint64_t out_stride, uint64_t out_total, const uint8_t* d_index, const uint32_t* d_zmap);
+hipError_t launch_rotor_decode(const uint8_t* d_in, const uint64_t* d_offsets, const uint64_t* d_sizes, uint32_t n_chunks, uint8_t* d_out,
+                               uint64_t out_stride, uint64_t out_total, bool exact, const uint8_t* d_index, uint32_t* d_zmap,
+                               uint64_t* d_produced, uint32_t* d_err, hipStream_t stream);
+// LDS assumptions of the rotation kernels (ordered exchange lane order, token hand-off behind the exchanges, lane-reversed rollback)
+hipError_t launch_rotor_selftest(uint32_t* d_fail, hipStream_t stream);
+extern bool g_force_pipeline;  // density_hip_set_kernel_variant(4): the 16-wave role pipelines of chameleon.hip instead
+extern bool g_exchange_unsafe, g_rotor_unsafe;   // start-up self-test verdicts (api.hip::acquire_ctx)
 
 // ---- serial_codec.hip (Cheetah, Lion: functional one-lane-per-stream kernels, tables in global memory) ----
 uint64_t serial_table_bytes(int algo);

@@ -1,0 +1,812 @@
+// rotor.hip — Chameleon wave-rotation kernels for gfx950 (MI355X): the default encode / index-fed decode path.
+//
+// One work-group of 16 wavefronts owns one chunk (= one independent reference stream, chameleon.rs:45-53) and its dictionary
+// (64 Ki exact 16-bit entries = 128 KiB of LDS, chameleon_dev.hpp).  The chunk is cut into ROUNDS of 8 blocks (2 KiB); wave w
+// takes the rounds r = w, w + 16, w + 32, ... and does EVERYTHING for its round itself, in registers: global loads, hashing,
+// the dictionary step, signatures, the copy-mode FSM, record offsets, stores.  There are no staging rings and no per-round
+// work-group barrier.  What IS sequential in the reference — the dictionary (every quad sees the table its predecessors left,
+// chameleon.rs:88-100) and the running output position / ProtectionState (codec.rs:34-70) — is passed from round to round by
+// two token chains through LDS:
+//
+//   D chain  "dictionary token".  The holder issues its 8 ordered exchanges (ds_mskor_rtn_b32: one instruction = the 64
+//            sequential dictionary steps of a block, LDS lane order; chameleon_dev.hpp) back to back from prepared registers
+//            and writes the token for the next round BEHIND them in its own LDS instruction stream.  A wave's LDS
+//            instructions execute in issue order, so whoever sees the new token also sees the table after those exchanges.
+//            This chain is the critical path of the kernel: ~8 x 23 cycles of exchanges + one LDS write->read hand-off per round.
+//   O chain  "commit token" + payload {output position, FSM state}.  After its exchanges a wave turns the 8 answers into 8
+//            signatures (hit == answer equals own entry; __ballot == the signature word, io/write_signature.rs:14-17), waits for
+//            the commit token, runs the FSM over its 8 blocks in closed form, passes position + state on, and only then stores.
+//
+// Copy mode (protection_state.rs) is a feedback from the signatures to "which blocks touch the dictionary at all", so the
+// exchanges of a round are speculative: "no raw-copy block in this round".  The commit step knows the truth.  When it finds
+// a block that had to be a raw copy it raises an abort: all 16 waves meet at a barrier, the rounds that exchanged after the
+// last committed one roll their blocks back in reverse order (the lowest lane of a slot holds the pre-block entry, so the
+// answers are written back lane-reversed with one ds_write_b16 per block), and the chain restarts at the failed round in SLOW
+// mode: the token holder first waits for its commit payload and then walks its blocks one by one with the full FSM
+// (raw-copy blocks skip the dictionary).  Slow mode ends after a round that leaves the FSM calm.  Every chunk starts in slow
+// mode (its first blocks are incompressible by construction: empty dictionary).  Rounds that contain a zero entry outside
+// slot 0 (zero-entry map, about one quad in 64 Ki) and the chunk's last partial round are also walked in order.
+//
+// Decode (index-fed: the container's block index gives record lengths and raw-copy blocks, include/density_hip.h) uses the
+// same D chain for the dictionary (MAP lanes exchange with mask 0 = read, PLAIN lanes write: chameleon.rs:56-68); record
+// positions of the whole chunk come from one prefix sum over the index at kernel start; a Z chain orders the rare
+// zero-entry-map accesses.  Streams without an index, chunks above 4 MiB and unaligned buffers run on chameleon.hip's kernels.
+#include <cstdio>
+#include <cstdlib>
+
+#include "chameleon_dev.hpp"
+#include "kernels.hpp"
+
+namespace density {
+
+namespace {
+
+constexpr uint32_t kRotWaves = 16, kRotThreads = kRotWaves * 64;
+constexpr uint32_t kR = 8;                                   // blocks per round
+constexpr uint32_t kNone = 0xffffffffu;
+// sync block (bytes from its base): D line {D, A}; O line {O, A', P0, P1}; a 256-byte sink for the idle lanes of a token write
+constexpr uint32_t kSyD = 0, kSyO = 16, kSyZ = 32, kSyEnd = 48, kSySink = 64, kSyBytes = 64 + 256;
+// encoder LDS: table | zero-entry map | sync
+constexpr uint32_t kEncZmap = kTableBytes, kEncSync = kTableBytes + kZmapBytes, kEncLds = kEncSync + kSyBytes;
+// decoder LDS: table | block-index copy | round positions | sync   (zero-entry map in global memory: ZmapGlobal)
+constexpr uint32_t kRotMaxBlocks = 16384;                    // blocks per chunk the decoder keeps an index copy for (4 MiB chunks)
+constexpr uint32_t kDecIdx = kTableBytes, kDecPos = kDecIdx + kRotMaxBlocks, kDecSync = kDecPos + (kRotMaxBlocks / kR) * 4u,
+                   kDecLds = kDecSync + kSyBytes;
+static_assert(kEncLds <= 160u * 1024u && kDecLds <= 160u * 1024u, "LDS budget");
+static_assert(kR == 8, "asm operand lists, the FSM closed form and the index word are written for 8 blocks per round");
+
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef u32x2 u32x2_u __attribute__((aligned(1)));
+
+// token polls: every lane reads the same address (broadcast), the caller takes lane 0's copy
+__device__ __forceinline__ u32x2 lds_peek2(uint32_t addr) {
+    u32x2 v;
+    asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
+    return v;
+}
+__device__ __forceinline__ u32x4 lds_peek4(uint32_t addr) {
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
+    return v;
+}
+__device__ __forceinline__ uint32_t lds_peek1(uint32_t addr) {
+    uint32_t v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
+    return v;
+}
+__device__ __forceinline__ uint32_t rlane_u(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+__device__ __forceinline__ void lds_poke(uint32_t addr, uint32_t v) { asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
+__device__ __forceinline__ void lds_poke2(uint32_t addr, uint32_t a, uint32_t b) {
+    const u32x2 v = {a, b};
+    asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+// the work-group barrier of the (rare) abort protocol and of the kernel's end: own LDS traffic retired first
+__device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// The critical section of a round: 8 ordered exchanges from prepared registers, then the token for the next round written
+// behind them (lane 0 writes the token word, the other lanes a sink, so the store has no bank conflict), then the answers.
+// One asm statement: the answers are valid when it ends, nothing the compiler does can touch a register still in flight.
+#define DENSITY_ROT_XCHG8                                   \
+    "ds_mskor_rtn_b32 %0, %8, %16, %24\n\t"                 \
+    "ds_mskor_rtn_b32 %1, %9, %17, %25\n\t"                 \
+    "ds_mskor_rtn_b32 %2, %10, %18, %26\n\t"                \
+    "ds_mskor_rtn_b32 %3, %11, %19, %27\n\t"                \
+    "ds_mskor_rtn_b32 %4, %12, %20, %28\n\t"                \
+    "ds_mskor_rtn_b32 %5, %13, %21, %29\n\t"                \
+    "ds_mskor_rtn_b32 %6, %14, %22, %30\n\t"                \
+    "ds_mskor_rtn_b32 %7, %15, %23, %31\n\t"
+#define DENSITY_ROT_OPERANDS(ret, addr, mask, val, tokaddr, tokval)                                                                     \
+    : "=&v"(ret[0]), "=&v"(ret[1]), "=&v"(ret[2]), "=&v"(ret[3]), "=&v"(ret[4]), "=&v"(ret[5]), "=&v"(ret[6]), "=&v"(ret[7])              \
+    : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "v"(addr[4]), "v"(addr[5]), "v"(addr[6]), "v"(addr[7]),                     \
+      "v"(mask[0]), "v"(mask[1]), "v"(mask[2]), "v"(mask[3]), "v"(mask[4]), "v"(mask[5]), "v"(mask[6]), "v"(mask[7]),                     \
+      "v"(val[0]), "v"(val[1]), "v"(val[2]), "v"(val[3]), "v"(val[4]), "v"(val[5]), "v"(val[6]), "v"(val[7]), "v"(tokaddr), "v"(tokval)  \
+    : "memory"
+__device__ __forceinline__ void exchange_round(uint32_t (&ret)[kR], const uint32_t (&addr)[kR], const uint32_t (&mask)[kR], const uint32_t (&val)[kR],
+                                               uint32_t tokaddr, uint32_t tokval, bool token_after_answers) {
+    if (!token_after_answers) {
+        asm volatile(DENSITY_ROT_XCHG8 "ds_write_b32 %32, %33\n\ts_waitcnt lgkmcnt(0)" DENSITY_ROT_OPERANDS(ret, addr, mask, val, tokaddr, tokval));
+    } else {   // tuning / fall-back form: the token leaves only after the last answer is back
+        asm volatile(DENSITY_ROT_XCHG8 "s_waitcnt lgkmcnt(0)\n\tds_write_b32 %32, %33" DENSITY_ROT_OPERANDS(ret, addr, mask, val, tokaddr, tokval));
+    }
+}
+__device__ __forceinline__ uint32_t exchange_block(uint32_t addr, uint32_t mask, uint32_t val) {
+    uint32_t ret;
+    asm volatile("ds_mskor_rtn_b32 %0, %1, %2, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(ret) : "v"(addr), "v"(mask), "v"(val) : "memory");
+    return ret;
+}
+
+// Commit payload {stream position (32 bits: the launcher bounds the chunk), FSM state}: penalty [0,8) | start-1 [8,16) | prev [16] | counter&15 [17,21)
+// (protection_state.rs: copy_penalty, copy_penalty_start are u8, only counter & 0xf is ever tested).  Calm state with start == 1: low 17 bits 0.
+__device__ __forceinline__ uint32_t pack_guard(const Guard& g) { return (g.penalty & 0xffu) | (((g.start - 1u) & 0xffu) << 8) | ((g.prev & 1u) << 16) | ((g.counter & 15u) << 17); }
+__device__ __forceinline__ Guard unpack_guard(uint32_t w) {
+    Guard g;
+    g.penalty = w & 0xffu; g.start = ((w >> 8) & 0xffu) + 1u; g.prev = (w >> 16) & 1u; g.counter = (w >> 17) & 15u;
+    return g;
+}
+
+// Every spin is bounded: a wave that polls one token ~4 M times in a row (>= 0.2 s; a legitimate wait is microseconds) declares the
+// work-group dead — error bit 16 for the host, a poison value in the token words so that the other waves leave too — instead of
+// hanging the device.  Nothing should ever get here; it turns a protocol bug into an error code.
+constexpr uint32_t kSpinLimit = 1u << 22, kPoison = 0xfffffffeu, kErrWatchdog = 16u;
+__device__ __forceinline__ void wave_exit() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_endpgm" ::: "memory"); }
+__device__ __forceinline__ void watchdog(uint32_t& spins, uint32_t sync_base, uint32_t* err, uint32_t lane) {
+    if (__builtin_expect(++spins > kSpinLimit, 0)) {
+        if (lane == 0) {
+            if (err) atomicOr(err, kErrWatchdog);
+            lds_poke(sync_base + kSyD, kPoison); lds_poke(sync_base + kSyD + 4, kPoison);
+            lds_poke(sync_base + kSyO, kPoison); lds_poke(sync_base + kSyO + 4, kPoison);
+            lds_poke(sync_base + kSyZ, kPoison);
+        }
+        wave_exit();
+    }
+}
+
+__device__ __forceinline__ void backoff(uint32_t dist) {        // rounds until this wave's turn -> how long to stay off the LDS
+    if (dist > 4) __builtin_amdgcn_s_sleep(8);
+    else if (dist > 1) __builtin_amdgcn_s_sleep(2);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------
+// encode: Codec::encode / encode_block (codec/codec.rs:34-80), Chameleon::encode_quad (chameleon.rs:88-100)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kRotThreads) void chameleon_encode_rot(const uint8_t* __restrict__ in, uint64_t total, uint64_t chunk_bytes,
+                                                                   uint8_t* __restrict__ out, uint64_t out_stride, uint64_t* __restrict__ sizes,
+                                                                   uint8_t* __restrict__ index, uint32_t* __restrict__ err, uint32_t tune) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = rfl(threadIdx.x >> 6);
+    const uint64_t chunk = blockIdx.x;
+    const uint8_t* src = in + chunk * chunk_bytes;
+    const uint64_t len = (total - chunk * chunk_bytes) < chunk_bytes ? (total - chunk * chunk_bytes) : chunk_bytes;
+    uint8_t* dst = out + chunk * out_stride;
+    uint8_t* idx = index ? index + chunk * (chunk_bytes / kBlock) : nullptr;     // this chunk's slice of the block index
+    const uint32_t nfull = (uint32_t)(len / kBlock);                              // whole blocks (the launcher bounds len)
+    const uint32_t nrounds = nfull / kR;                                           // whole rounds: these rotate; the rest (< 8 blocks + a ragged one) is the epilogue
+    const uint32_t lds0 = lds_addr(smem), tbl = lds0, sy = lds0 + kEncSync;
+    const ZmapLds zmap{lds0 + kEncZmap};
+    const bool late_token = (tune & 1u) != 0;
+
+    {   // fresh state per chunk (chameleon.rs:45-48): zero table, zero-entry map, tokens: round 0 in slow mode, nothing committed
+        uint4* p = reinterpret_cast<uint4*>(smem);
+        const uint4 z = make_uint4(0, 0, 0, 0);
+        for (uint32_t i = threadIdx.x; i < (kTableBytes + kZmapBytes) / 16; i += kRotThreads) p[i] = z;
+        if (threadIdx.x == 0) {
+            *reinterpret_cast<uint4*>(smem + kEncSync + kSyD) = make_uint4(1u, kNone, 0u, 0u);
+            *reinterpret_cast<uint4*>(smem + kEncSync + kSyO) = make_uint4(0u, kNone, 0u, pack_guard(Guard{}));
+        }
+    }
+    __syncthreads();
+
+    uint32_t q[kR], qn[kR];
+    auto load_round = [&](uint32_t (&d)[kR], uint32_t r) {
+        if (r < nrounds) {
+            const uint8_t* p = src + (uint64_t)r * (kR * kBlock);
+#pragma unroll
+            for (uint32_t j = 0; j < kR; ++j) d[j] = *reinterpret_cast<const uint32_t*>(p + j * kBlock + 4u * lane);
+        }
+    };
+    // quad -> exchange operands {dword address, half mask, entry << 16*half} (chameleon.rs:89, chameleon_dev.hpp)
+    auto operands = [&](uint32_t qv, uint32_t& P, uint32_t& a, uint32_t& m, uint32_t& v) {
+        P = qv * kHashMul;
+        const uint32_t sh = (P >> 12) & 16u;                                      // (h & 1) << 4
+        a = tbl + ((P >> 15) & 0x1fffcu);                                         // (h >> 1) << 2
+        m = 0xffffu << sh;
+        v = stored_entry(qv, P) << sh;
+    };
+    // one record (codec.rs:39-67, io/write_buffer.rs) or raw block (codec.rs:35-37) to its place in the stream
+    auto emit_block = [&](uint8_t* rec, uint32_t qv, uint64_t s, bool raw) {
+        if (raw) {
+            st32u(rec + 4u * lane, qv);
+        } else {
+            const uint32_t off = kSig + 4u * lane - 2u * mbcnt64(s);
+            if (lane < 2) st32u(rec + 4u * lane, lane ? (uint32_t)(s >> 32) : (uint32_t)s);     // codec.rs:24-26
+            if ((s >> lane) & 1ull) st16u(rec + off, (qv * kHashMul) >> 16); else st32u(rec + off, qv);
+        }
+    };
+    // one block in order: FSM, then either a raw copy or the dictionary step with the zero-entry map (slow rounds, epilogue)
+    auto block_in_order = [&](Guard& g, uint32_t qv, uint32_t a, uint32_t m, uint32_t v, uint64_t& s, bool& raw) {
+        s = 0;
+        raw = g.block_is_copy();                                                  // codec.rs:35
+        if (raw) { g.decay(); return; }
+        const uint32_t old = exchange_block(a, m, v);
+        const bool susp = v == 0 && qv != 0;                                       // stored entry 0 outside slot 0 (entry 0 in slot 0 is the zero quad)
+        const uint32_t zbit = zmap_claim_in_order(zmap, susp, (qv * kHashMul) >> 16, lane);
+        s = ballot64(((old ^ v) & m) == 0 && (!susp || zbit));                     // chameleon.rs:90-99
+        g.update((uint32_t)__builtin_popcountll(s) <= 4u);                         // codec.rs:68: 8 + 256 - 2*hits >= 256
+    };
+
+    uint32_t prod[kR], addr[kR], mask[kR], val[kR], ret[kR];
+#pragma unroll
+    for (uint32_t j = 0; j < kR; ++j) { q[j] = 0; qn[j] = 0; prod[j] = 0; addr[j] = tbl; mask[j] = 0; val[j] = 0; ret[j] = 0; }
+    // The records of a round without raw blocks, straight-line: the 8 signatures and the 8 index bytes leave from lanes 0..7 in one
+    // store each (lane j: record j, offsets by a DPP prefix over the record lengths); per block the MAP lanes store the 2-byte slot
+    // index (the upper half of the hash product), the PLAIN lanes the quad, through an SGPR base (io/write_buffer.rs:13-27).
+    const uint32_t c_off = kSig + 4u * lane;
+    auto emit_round_coded = [&](uint32_t pos0, uint8_t* idxp, const uint64_t (&sg)[kR]) {
+        uint32_t slo = 0, shi = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < kR; ++j) {
+            asm("v_writelane_b32 %0, %1, %2" : "+v"(slo) : "s"((uint32_t)sg[j]), "n"(j));
+            asm("v_writelane_b32 %0, %1, %2" : "+v"(shi) : "s"((uint32_t)(sg[j] >> 32)), "n"(j));
+        }
+        const uint32_t nhv = (uint32_t)(__builtin_popcount(slo) + __builtin_popcount(shi));
+        const uint32_t lenv = kSig + kBlock - 2u * nhv;
+        uint32_t incl = lenv;
+        incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xf, 0xf, true);   // row_shr:1
+        incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xf, 0xf, true);   // row_shr:2
+        incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xf, 0xf, true);   // row_shr:4
+        if (lane < kR) {
+            *reinterpret_cast<u32x2_u*>(dst + (pos0 + incl - lenv)) = u32x2{slo, shi};         // codec.rs:24-26
+            if (idxp) idxp[lane] = (uint8_t)nhv;
+        }
+        uint32_t pos = pos0;
+#pragma unroll
+        for (uint32_t j = 0; j < kR; ++j) {
+            const uint32_t off = pos + c_off - 2u * mbcnt64(sg[j]);
+            const uint64_t plain = ~sg[j];
+            asm volatile(
+                "s_mov_b64 exec, %4\n\t"
+                "global_store_short_d16_hi %0, %1, %3\n\t"
+                "s_mov_b64 exec, %5\n\t"
+                "global_store_dword %0, %2, %3\n\t"
+                "s_mov_b64 exec, -1"
+                ::"v"(off), "v"(prod[j]), "v"(q[j]), "s"(dst), "s"(sg[j]), "s"(plain) : "memory");
+            pos += kSig + kBlock - 2u * (uint32_t)__builtin_popcountll(sg[j]);
+        }
+    };
+
+    // undo the exchanges of this wave's round, last block first: the lowest lane of a slot holds the pre-block entry, so the
+    // answers go back lane-reversed in ONE ds_write_b16 (ascending lane service order: the highest physical lane = the
+    // lowest original lane wins)
+    auto rollback_round = [&]() {
+#pragma unroll
+        for (int j = (int)kR - 1; j >= 0; --j) {
+            uint32_t mk = mask[j];
+            asm volatile("" : "+v"(mk));                                           // (keeps this arithmetic out of the common path)
+            const uint32_t hi = mk >> 31;                                          // 1: the slot is the upper half of its dword
+            const uint32_t a16 = addr[j] + 2u * hi;
+            const uint32_t prev = hi ? (ret[j] >> 16) : (ret[j] & 0xffffu);
+            const uint32_t ar = bperm(63u - lane, a16), pr = bperm(63u - lane, prev);
+            dict_store(ar, pr);
+        }
+    };
+    // Abort protocol (all 16 waves; `holding`: this wave has exchanged `hold_round` and not committed it).  After the first
+    // barrier nobody is inside a critical section, D says how far the dictionary got (rounds < d exchanged), A which round
+    // failed; rounds d-1 .. A are rolled back one per barrier step by their owners, then the chain restarts at A in slow mode.
+    auto abort_sync = [&](bool holding, uint32_t hold_round) {
+        wg_barrier();
+        const u32x2 v = lds_peek2(sy + kSyD);
+        const uint32_t d = rfl(v.x) >> 1, a = rfl(v.y);
+        for (uint32_t x = d; x-- > a;) {
+            if (holding && hold_round == x) rollback_round();
+            wg_barrier();
+        }
+        if (wave == (a & (kRotWaves - 1u)) && lane == 0) {
+            lds_poke(sy + kSyD, (a << 1) | 1u);
+            lds_poke(sy + kSyD + 4, kNone);
+            lds_poke(sy + kSyO + 4, kNone);
+        }
+        wg_barrier();
+    };
+
+    load_round(q, wave);
+    for (uint32_t r = wave; r < nrounds; r += kRotWaves) {
+        load_round(qn, r + kRotWaves);                                            // next round's quads: in flight for the whole iteration
+
+        bool zero_entry = false;
+#pragma unroll
+        for (uint32_t j = 0; j < kR; ++j) {
+            operands(q[j], prod[j], addr[j], mask[j], val[j]);
+            zero_entry |= val[j] == 0 && q[j] != 0;                                // needs the zero-entry map: about one quad in 64 Ki
+        }
+        const bool in_order_round = ballot64(zero_entry) != 0;                    // walked block by block whatever the mode
+
+        uint64_t sig[kR];
+        uint32_t copy_mask = 0, opos = 0;
+        for (;;) {   // (re-entered after an abort)
+            // ---- D chain: wait for this round's turn ----
+            uint32_t slow;
+            for (uint32_t spins = 0;;) {
+                const u32x2 v = lds_peek2(sy + kSyD);
+                const uint32_t D = rfl(v.x), A = rfl(v.y);
+                if (__builtin_expect(A != kNone, 0)) { if (A == kPoison) wave_exit(); abort_sync(false, 0); continue; }
+                if ((D >> 1) == r) { slow = D & 1u; break; }
+                backoff(r - (D >> 1));
+                watchdog(spins, sy, err, lane);
+            }
+            if (__builtin_expect(!slow && !in_order_round, 1)) {
+                // ---- fast round: 8 speculative exchanges, token passed behind them ----
+                __builtin_amdgcn_s_setprio(3);
+                exchange_round(ret, addr, mask, val, lane == 0 ? sy + kSyD : sy + kSySink + 4u * lane, (r + 1u) << 1, late_token);
+                __builtin_amdgcn_s_setprio(0);
+                uint32_t inc = 0, hits = 0, min_hits = 64;
+#pragma unroll
+                for (uint32_t j = 0; j < kR; ++j) {
+                    sig[j] = ballot64(((ret[j] ^ val[j]) & mask[j]) == 0);         // chameleon.rs:90-99: MAP flag = 1 iff the slot held this quad
+                    const uint32_t nh = (uint32_t)__builtin_popcountll(sig[j]);
+                    min_hits = nh < min_hits ? nh : min_hits;
+                    hits += nh;
+                }
+                if (__builtin_expect(min_hits <= 4u, 0)) {                         // an incompressible record (codec.rs:68: 8 + 256 - 2*hits >= 256)
+#pragma unroll
+                    for (uint32_t j = 0; j < kR; ++j) inc |= ((uint32_t)__builtin_popcountll(sig[j]) <= 4u ? 1u : 0u) << j;
+                }
+                const uint32_t sum = kR * (kSig + kBlock) - 2u * hits;
+                // ---- O chain: commit ----
+                uint32_t P0, P1;
+                bool aborted = false;
+                for (uint32_t spins = 0;;) {
+                    const u32x4 v = lds_peek4(sy + kSyO);
+                    const uint32_t O = rfl(v.x), A = rfl(v.y);
+                    if (O == r) { P0 = rfl(v.z); P1 = rfl(v.w); break; }
+                    if (__builtin_expect(A != kNone, 0)) { if (A == kPoison) wave_exit(); abort_sync(true, r); aborted = true; break; }
+                    backoff(r - O);
+                    watchdog(spins, sy, err, lane);
+                }
+                if (aborted) continue;
+                // which blocks the FSM would have turned into raw copies: block j+1 iff inc[j] && prev[j] (protection_state.rs:38-47)
+                const uint32_t t = inc & ((inc << 1) | ((P1 >> 16) & 1u));
+                if (__builtin_expect((P1 & 0xffu) != 0 || (t & ((1u << (kR - 1)) - 1u)) != 0, 0)) {
+                    if (lane == 0) { lds_poke(sy + kSyD + 4, r); lds_poke(sy + kSyO + 4, r); }
+                    abort_sync(true, r);
+                    continue;
+                }
+                uint32_t g_out;
+                if (__builtin_expect((P1 & 0x1ffffu) == 0 && inc == 0, 1)) {
+                    g_out = (P1 & 0xffe1ffffu) | ((((P1 >> 17) + kR) & 15u) << 17);   // calm, start == 1: only the block counter moves
+                } else {
+                    Guard g = unpack_guard(P1);
+#pragma unroll
+                    for (uint32_t j = 0; j < kR; ++j) (void)g.block_is_copy();       // no block was a copy: bookkeeping only (:19-27)
+                    g.penalty = ((t >> (kR - 1)) & 1u) ? g.start : 0u;
+                    g.prev = (inc >> (kR - 1)) & 1u;
+                    g_out = pack_guard(g);
+                }
+                opos = P0;
+                if (lane == 0) {
+                    lds_poke2(sy + kSyO + 8, opos + sum, g_out);
+                    lds_poke(sy + kSyO, r + 1u);
+                }
+                copy_mask = 0;
+                break;
+            }
+            // ---- in-order round: wait until everything before it is final, then walk the blocks with the FSM ----
+            uint32_t P0, P1;
+            bool aborted = false;
+            for (uint32_t spins = 0;;) {
+                const u32x4 v = lds_peek4(sy + kSyO);
+                const uint32_t O = rfl(v.x), A = rfl(v.y);
+                if (O == r) { P0 = rfl(v.z); P1 = rfl(v.w); break; }
+                if (A != kNone) { if (A == kPoison) wave_exit(); abort_sync(false, 0); aborted = true; break; }
+                backoff(r - O);
+                watchdog(spins, sy, err, lane);
+            }
+            if (aborted) continue;
+            Guard g = unpack_guard(P1);
+            uint32_t sum = 0, unrest = 0;
+            copy_mask = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < kR; ++j) {
+                bool raw;
+                block_in_order(g, q[j], addr[j], mask[j], val[j], sig[j], raw);
+                copy_mask |= (raw ? 1u : 0u) << j;
+                unrest |= g.prev;
+                sum += raw ? kBlock : kSig + kBlock - 2u * (uint32_t)__builtin_popcountll(sig[j]);
+            }
+            opos = P0;
+            const uint32_t stay_slow = (g.penalty | copy_mask | unrest) != 0 ? 1u : 0u;   // back to speculation only after a round without an incompressible or raw block
+            if (lane == 0) {
+                lds_poke2(sy + kSyO + 8, opos + sum, pack_guard(g));
+                lds_poke(sy + kSyO, r + 1u);
+                lds_poke(sy + kSyD, ((r + 1u) << 1) | stay_slow);
+            }
+            break;
+        }
+
+        // ---- the next round's quads must have landed before this round's stores go out behind them (memory operations retire in order) ----
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(qn[0]), "+v"(qn[1]), "+v"(qn[2]), "+v"(qn[3]), "+v"(qn[4]), "+v"(qn[5]), "+v"(qn[6]), "+v"(qn[7]) :: "memory");
+
+        // ---- emit: records of this round and their block-index bytes ----
+        if (__builtin_expect(copy_mask == 0, 1)) {
+            emit_round_coded(opos, idx ? idx + (uint64_t)r * kR : nullptr, sig);
+        } else {
+            uint8_t* rec = dst + opos;
+            uint64_t idxw = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < kR; ++j) {
+                const bool raw = (copy_mask >> j) & 1u;
+                const uint32_t nh = (uint32_t)__builtin_popcountll(sig[j]);
+                emit_block(rec, q[j], sig[j], raw);
+                idxw |= (uint64_t)(raw ? kIdxCopy : nh) << (8u * j);
+                rec += raw ? kBlock : kSig + kBlock - 2u * nh;
+            }
+            if (idx && lane < kR) idx[(uint64_t)r * kR + lane] = (uint8_t)(idxw >> (8u * lane));
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < kR; ++j) q[j] = qn[j];
+    }
+
+    // ---- end of the chunk: every round committed (no abort can follow) ----
+    for (uint32_t spins = 0;;) {
+        const u32x4 v = lds_peek4(sy + kSyO);
+        if (rfl(v.x) == nrounds) break;
+        if (rfl(v.y) == kPoison) wave_exit();
+        if (rfl(v.y) != kNone) abort_sync(false, 0); else __builtin_amdgcn_s_sleep(4);
+        watchdog(spins, sy, err, lane);
+    }
+    wg_barrier();
+    // ---- epilogue on one wave: the blocks of the last, partial round in order, then the ragged block (codec.rs:51-63) ----
+    if (wave == 0) {
+        const u32x4 v = lds_peek4(sy + kSyO);
+        Guard g = unpack_guard(rfl(v.w));
+        uint64_t opos = rfl(v.z);
+        for (uint32_t b = nrounds * kR; b < nfull; ++b) {
+            const uint32_t qv = *reinterpret_cast<const uint32_t*>(src + (uint64_t)b * kBlock + 4u * lane);
+            uint32_t P, a, m, vv;
+            operands(qv, P, a, m, vv);
+            uint64_t s;
+            bool raw;
+            block_in_order(g, qv, a, m, vv, s, raw);
+            emit_block(dst + opos, qv, s, raw);
+            const uint32_t nh = (uint32_t)__builtin_popcountll(s);
+            if (idx && lane == 0) idx[b] = (uint8_t)(raw ? kIdxCopy : nh);
+            opos += raw ? kBlock : kSig + kBlock - 2u * nh;
+        }
+        const uint64_t end = encode_ragged_block(src, len, nfull, dst, opos, g, idx, tbl, zmap, lane);
+        if (lane == 0) sizes[chunk] = end;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// decode (index-fed): Codec::decode (codec/codec.rs:82-126), Chameleon::decode_plain / decode_map (chameleon.rs:56-68)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kRotThreads) void chameleon_decode_rot(const uint8_t* __restrict__ in, const uint64_t* __restrict__ offsets,
+                                                                   const uint64_t* __restrict__ sizes, uint8_t* __restrict__ out,
+                                                                   uint64_t out_stride, uint64_t out_total, uint32_t exact,
+                                                                   const uint8_t* __restrict__ index, uint32_t* __restrict__ zmap_words,
+                                                                   uint64_t* __restrict__ produced, uint32_t* __restrict__ err, uint32_t tune) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = rfl(threadIdx.x >> 6);
+    const uint64_t chunk = blockIdx.x;
+    const uint8_t* src = in + offsets[chunk];
+    const uint8_t* idx = index + chunk * (out_stride / kBlock);                 // this chunk's slice of the block index (4-byte aligned: launcher)
+    const uint64_t elen64 = sizes[chunk];
+    uint8_t* dst = out + chunk * out_stride;
+    const uint64_t room_all = out_total - chunk * out_stride;
+    const uint64_t cap = room_all < out_stride ? room_all : out_stride;
+    const uint32_t elen = elen64 > 0xfff00000ull ? 0xfff00000u : (uint32_t)elen64;   // 32-bit stream offsets in the pipeline; the in-order loop finishes longer streams
+    const uint32_t nblk = (uint32_t)((cap + kBlock - 1) / kBlock);               // <= kRotMaxBlocks (launcher)
+    const ZmapGlobal zmap{zmap_words + chunk * (kZmapBytes / 4)};
+    const uint32_t lds0 = lds_addr(smem), tbl = lds0, sy = lds0 + kDecSync;
+    const bool late_token = (tune & 1u) != 0;
+
+    {   // fresh dictionary, this chunk's zero-entry map, the block index into LDS
+        uint4* p = reinterpret_cast<uint4*>(smem);
+        const uint4 z = make_uint4(0, 0, 0, 0);
+        for (uint32_t i = threadIdx.x; i < kTableBytes / 16; i += kRotThreads) p[i] = z;
+        for (uint32_t i = threadIdx.x; i < kZmapBytes / 16; i += kRotThreads) reinterpret_cast<uint4*>(zmap.words)[i] = z;
+        const uint32_t* iw = reinterpret_cast<const uint32_t*>(idx);
+        uint32_t* lw = reinterpret_cast<uint32_t*>(smem + kDecIdx);
+        for (uint32_t i = threadIdx.x; i < kRotMaxBlocks / 4; i += kRotThreads) lw[i] = i < (nblk + 3u) / 4u ? iw[i] : 0x7f7f7f7fu;   // beyond the chunk: "ragged" = stop
+        if (threadIdx.x == 0) {
+            *reinterpret_cast<uint4*>(smem + kDecSync + kSyD) = make_uint4(0u, kNone, 0u, 0u);
+            *reinterpret_cast<uint4*>(smem + kDecSync + kSyZ) = make_uint4(0u, 0u, 0u, 0u);
+            *reinterpret_cast<uint64_t*>(smem + kDecSync + kSyEnd) = ~0ull;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         // the map is used through L2 atomics by this work-group only (chameleon.hip)
+    }
+    __syncthreads();
+
+    // ---- record positions of the whole chunk: one prefix sum over the index (16 consecutive entries per thread).  A record is
+    // pipelined only if it is complete and followed by at least 2 more stream bytes (a MAP item is fetched as a dword); the first
+    // one that is not (ragged block, end of the stream, end of the output, an index that disagrees with the stream length) and
+    // everything behind it is finished by the in-order loop (codec.rs:102-123).
+    {
+        __shared__ uint32_t wave_sums[kRotWaves];
+        const uint32_t first = threadIdx.x * 16u;
+        const uint4 ev = *reinterpret_cast<const uint4*>(smem + kDecIdx + first);
+        const uint32_t ew[4] = {ev.x, ev.y, ev.z, ev.w};
+        auto entry_at = [&](uint32_t k) -> uint32_t { return (ew[k >> 2] >> (8u * (k & 3u))) & 0xffu; };
+        auto rec_len = [&](uint32_t ent) -> uint32_t { return (ent & kIdxCopy) ? kBlock : kSig + kBlock - 2u * (ent & 0x7fu); };
+        uint32_t mine = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 16; ++k) mine += rec_len(entry_at(k));
+        uint32_t incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = bperm(lane >= (uint32_t)d ? lane - d : lane, incl);
+            if (lane >= (uint32_t)d) incl += o;
+        }
+        if (lane == 63) wave_sums[wave] = incl;
+        __syncthreads();
+        uint32_t pos = incl - mine;
+        for (uint32_t w = 0; w < wave; ++w) pos += wave_sums[w];
+        uint64_t stop_key = ~0ull;
+#pragma unroll
+        for (uint32_t k = 0; k < 16; ++k) {
+            const uint32_t i = first + k, ent = entry_at(k), l = rec_len(ent);
+            if ((k & 7u) == 0) *reinterpret_cast<uint32_t*>(smem + kDecPos + (i / kR) * 4u) = pos;
+            const bool stop = (ent & 0x7fu) == kIdxRagged || i >= nblk || ((uint64_t)i + 1) * kBlock > cap || pos >= elen || elen - pos < l + 2u;
+            if (stop && stop_key == ~0ull) stop_key = ((uint64_t)i << 33) | ((uint64_t)((ent & kIdxCopy) && i < nblk ? 1u : 0u) << 32) | pos;
+            pos += l;
+        }
+        if (threadIdx.x == kRotThreads - 1 && stop_key == ~0ull) stop_key = ((uint64_t)kRotMaxBlocks << 33) | pos;
+        if (stop_key != ~0ull) atomicMin(reinterpret_cast<unsigned long long*>(smem + kDecSync + kSyEnd), (unsigned long long)stop_key);
+    }
+    __syncthreads();
+    const uint64_t end_key = *reinterpret_cast<const uint64_t*>(smem + kDecSync + kSyEnd);
+    const uint32_t nvalid = rfl((uint32_t)(end_key >> 33));                      // records [0, nvalid) go through the pipeline
+    const uint32_t npr = (nvalid + kR - 1) / kR;
+
+    // ---- three-stage software pipeline per wave: A(x+32) signature loads | B(x+16) item loads | C(x) dictionary + stores ----
+    // Per round in flight: lane j < 8 holds record j's position and (one 8-byte load) its signature; after stage B every lane
+    // holds its 8 items and its 8 MAP/PLAIN flags (bit j of `hits`).
+    struct Meta { uint32_t posv, cnt; u32x2 sgv; uint32_t n, copy_mask; };
+    auto stage_a = [&](uint32_t x, Meta& m) {                                    // positions of round x; signatures requested
+        m.n = 0; m.copy_mask = 0; m.posv = 0; m.cnt = 0; m.sgv = u32x2{0u, 0u};
+        if (x >= npr) return;
+        const u32x2 ent = lds_peek2(lds0 + kDecIdx + x * kR);
+        const uint32_t base = rfl(lds_peek1(lds0 + kDecPos + x * 4u));
+        const uint64_t ents = ((uint64_t)rfl(ent.y) << 32) | rfl(ent.x);
+        m.n = nvalid - x * kR < kR ? nvalid - x * kR : kR;
+        const uint32_t e = (uint32_t)(ents >> (8u * (lane & 7u))) & 0xffu;       // lane j (and its images): entry of record j
+        const uint32_t mylen = (e & kIdxCopy) ? kBlock : kSig + kBlock - 2u * (e & 0x7fu);
+        uint32_t incl = mylen;                                                    // prefix over rows of 8 lanes
+        incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xf, 0xf, true);   // row_shr:1
+        incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xf, 0xf, true);   // row_shr:2
+        incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xf, 0xf, true);   // row_shr:4
+        m.posv = base + incl - mylen;
+        m.copy_mask = (uint32_t)ballot64((e & kIdxCopy) != 0 && lane < m.n);
+        if (lane < m.n && !(e & kIdxCopy)) m.sgv = *reinterpret_cast<const u32x2_u*>(src + m.posv);     // codec.rs:28-31
+        m.cnt = e & 0x7fu;                                                        // the entry's MAP count: checked against the signature in stage B
+    };
+    uint32_t bad_index = 0;
+    auto stage_b = [&](const Meta& m, uint32_t& hits, uint32_t (&item)[kR]) {   // signatures -> MAP/PLAIN flags, item loads
+        hits = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < kR; ++j) {
+            item[j] = 0;
+            if (j < m.n) {
+                const uint32_t pos = rlane_u(m.posv, (int)j);
+                if ((m.copy_mask >> j) & 1u) {
+                    item[j] = ld32u(src + pos + 4u * lane);                       // codec.rs:89-91: raw block
+                } else {
+                    const uint64_t sig = ((uint64_t)rlane_u(m.sgv.y, (int)j) << 32) | rlane_u(m.sgv.x, (int)j);
+                    // the index must agree with the stream it describes: a record's MAP count is its signature's popcount
+                    bad_index |= (uint32_t)__builtin_popcountll(sig) != rlane_u(m.cnt, (int)j) ? 1u : 0u;
+                    hits |= (uint32_t)((sig >> lane) & 1ull) << j;
+                    item[j] = ld32u(src + pos + kSig + 4u * lane - 2u * mbcnt64(sig));
+                }
+            }
+        }
+    };
+
+    Meta ma, mb, mc;
+    uint32_t itemb[kR], itemc[kR], hitsb = 0, hitsc = 0;
+    // prologue: B(w) needs A(w); A(w + 16) goes out behind it
+    stage_a(wave, mb);
+    stage_b(mb, hitsc, itemc);
+    mc = mb;
+    stage_a(wave + kRotWaves, mb);
+
+    uint32_t addr[kR], mask[kR], val[kR], ret[kR];
+    for (uint32_t x = wave; x < npr; x += kRotWaves) {
+        stage_a(x + 2 * kRotWaves, ma);
+        stage_b(mb, hitsb, itemb);
+
+        // ---- C: operands of the dictionary step ----
+        const uint32_t coded_mask = ((1u << mc.n) - 1u) & ~mc.copy_mask;          // records that go through the dictionary
+        uint32_t zacc = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < kR; ++j) {
+            const bool coded = (coded_mask >> j) & 1u;
+            const bool hit = (hitsc >> j) & 1u;
+            const uint32_t qv = itemc[j];
+            const uint32_t P = qv * kHashMul;
+            const uint32_t h = hit ? (qv & 0xffffu) : (P >> 16);                  // MAP: the item is the slot (chameleon.rs:64-68)
+            const uint32_t sh = (h & 1u) << 4;
+            const uint32_t e = stored_entry(qv, P);
+            const bool writes = coded && !hit;                                    // PLAIN writes its entry (chameleon.rs:56-61), MAP only reads
+            addr[j] = coded ? tbl + ((h >> 1) << 2) : tbl + 4u * lane;            // raw / absent records: a harmless conflict-free read
+            mask[j] = writes ? (0xffffu << sh) : 0u;
+            val[j] = writes ? (e << sh) : 0u;
+            zacc |= (writes && e == 0 && h != 0) ? 1u : 0u;
+        }
+        // ---- D chain ----
+        for (uint32_t spins = 0;;) {
+            const uint32_t D = rfl(lds_peek1(sy + kSyD));
+            if (D == x) break;
+            if (D == kPoison) wave_exit();
+            backoff(x - D);
+            watchdog(spins, sy, err, lane);
+        }
+        __builtin_amdgcn_s_setprio(3);
+        exchange_round(ret, addr, mask, val, lane == 0 ? sy + kSyD : sy + kSySink + 4u * lane, x + 1u, late_token);
+        __builtin_amdgcn_s_setprio(0);
+
+        // ---- what each slot holds at this lane's turn -> quads (in place of the items) ----
+#pragma unroll
+        for (uint32_t j = 0; j < kR; ++j) {
+            const bool maps = ((coded_mask & hitsc) >> j) & 1u;
+            const uint32_t h = itemc[j] & 0xffffu;
+            const uint32_t cur = (ret[j] >> ((h & 1u) << 4)) & 0xffffu;
+            zacc |= (maps && cur == 0 && h != 0) ? 2u : 0u;                       // MAP of a slot holding 0: never written, or a genuine zero entry?
+            ret[j] = maps ? entry_to_quad(h, cur) : itemc[j];
+        }
+        // ---- Z chain: zero-entry map in stream order (rare: stored entries are salted) ----
+        const bool zany = ballot64(zacc != 0) != 0;
+        for (uint32_t spins = 0;;) {
+            const uint32_t Z = rfl(lds_peek1(sy + kSyZ));
+            if (Z == x) break;
+            if (Z == kPoison) wave_exit();
+            backoff(x - Z);
+            watchdog(spins, sy, err, lane);
+        }
+        if (zany) {
+#pragma unroll
+            for (uint32_t j = 0; j < kR; ++j) {
+                const bool coded = (coded_mask >> j) & 1u;
+                const bool hit = (hitsc >> j) & 1u;
+                const uint32_t qv = itemc[j];
+                const uint32_t P = qv * kHashMul;
+                const uint32_t h = hit ? (qv & 0xffffu) : (P >> 16);
+                const bool zset = coded && !hit && stored_entry(qv, P) == 0 && h != 0;
+                const bool ztest = coded && hit && h != 0 && ret[j] == entry_to_quad(h, 0);   // the slot held stored entry 0
+                uint64_t todo = ballot64(zset || ztest);
+                while (todo) {                                                    // ascending lane == stream order
+                    const uint32_t l = (uint32_t)__builtin_ctzll(todo);
+                    todo &= todo - 1;
+                    if (lane == l) {
+                        if (zset) zmap.set(h);
+                        else if (!zmap.test(h)) ret[j] = 0;                       // chameleon.rs:64-68 on a never-written (zero) word
+                    }
+                }
+            }
+        }
+        if (lane == 0) lds_poke(sy + kSyZ, x + 1u);
+
+        // ---- stores: 256 coalesced bytes per record ----
+        uint8_t* base = dst + (uint64_t)x * kR * kBlock;
+#pragma unroll
+        for (uint32_t j = 0; j < kR; ++j) {
+            if (j < mc.n) *reinterpret_cast<uint32_t*>(base + j * kBlock + 4u * lane) = ret[j];
+        }
+        // ---- rotate the pipeline ----
+        mc = mb; mb = ma; hitsc = hitsb;
+#pragma unroll
+        for (uint32_t j = 0; j < kR; ++j) itemc[j] = itemb[j];
+    }
+
+    if (bad_index && lane == 0) atomicOr(err, 8u);
+    wg_barrier();
+    // ---- the ragged end of the stream, in order, on one wave (codec.rs:102-123) ----
+    if (wave == 0) {
+        Guard g;
+        g.penalty = (uint32_t)(end_key >> 32) & 1u; g.start = 1; g.prev = 0; g.counter = 1;    // the stopping block's raw-copy flag is all that is left of the FSM
+        uint64_t ip = (uint32_t)end_key, op = (uint64_t)nvalid * kBlock;
+        bool bad = !decode_in_order(src, elen64, dst, cap, g, ip, op, tbl, zmap, lane);
+        if (exact && !bad && op != cap) bad = true;
+        if (lane == 0) {
+            produced[chunk] = op;
+            if (bad) atomicOr(err, 1u);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Start-up self-test of what these kernels assume about the LDS (density_hip_selftest / acquire_ctx):
+//  (1) ds_mskor_rtn_b32 services the lanes of one instruction in ascending lane order — same half-dword, alternating halves of
+//      one dword, mask-0 readers between writers, back-to-back instructions;
+//  (2) a plain ds_write_b32 issued behind a wave's exchanges is not visible before them (the token hand-off), checked by 16
+//      waves rotating exactly like the kernels do, all hammering the same few dictionary slots;
+//  (3) the lane-reversed ds_write_b16 restores a block (rollback).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kRotThreads) void rotor_selftest_kernel(uint32_t* __restrict__ fail, uint32_t tune) {
+    __shared__ __attribute__((aligned(16))) uint32_t cell[64];
+    __shared__ __attribute__((aligned(16))) uint32_t syn[kSyBytes / 4];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = rfl(threadIdx.x >> 6);
+    uint32_t bad = 0;
+    if (threadIdx.x < 64) cell[threadIdx.x] = 0;
+    if (threadIdx.x == 0) { syn[kSyD / 4] = 0; syn[kSyD / 4 + 1] = kNone; }
+    __syncthreads();
+    const uint32_t c0 = lds_addr(cell), sy = lds_addr(syn);
+    if (wave == 0) {
+        // (1a) all lanes, one half-dword, two instructions back to back: lane l must get lane l-1's entry
+        uint32_t r0, r1, r2, r3;
+        const uint32_t e0 = (lane + 1u) << 16, e1 = (lane + 101u) << 16;
+        asm volatile("ds_mskor_rtn_b32 %0, %2, %3, %4\n\tds_mskor_rtn_b32 %1, %2, %3, %5\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(r0), "=&v"(r1) : "v"(c0), "v"(0xffff0000u), "v"(e0), "v"(e1) : "memory");
+        if ((r0 >> 16) != lane) bad |= 1u;
+        if ((r1 >> 16) != (lane == 0 ? 64u : lane + 100u)) bad |= 2u;
+        // (1b) alternating halves of one dword: even lanes the low half, odd lanes the high half; each half is its own chain
+        const uint32_t sh = (lane & 1u) << 4;
+        asm volatile("ds_mskor_rtn_b32 %0, %1, %2, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r2) : "v"(c0 + 4u), "v"(0xffffu << sh), "v"((lane + 1u) << sh) : "memory");
+        if (((r2 >> sh) & 0xffffu) != (lane < 2 ? 0u : lane - 1u)) bad |= 4u;
+        // (1c) mask-0 readers between writers: lanes = 3 (mod 4) write, the others read what the last writer below them left
+        const bool wr = (lane & 3u) == 3u;
+        asm volatile("ds_mskor_rtn_b32 %0, %1, %2, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r3) : "v"(c0 + 8u), "v"(wr ? 0xffffu : 0u), "v"(wr ? lane + 1u : 0u) : "memory");
+        if ((r3 & 0xffffu) != (lane < 4 ? 0u : (lane & ~3u))) bad |= 8u;
+        // (3) rollback of (1a)'s second instruction, then of its first: the cell must read 0 again
+        uint32_t back;
+        dict_store(bperm(63u - lane, c0 + 2u), bperm(63u - lane, r1 >> 16));
+        dict_store(bperm(63u - lane, c0 + 2u), bperm(63u - lane, r0 >> 16));
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(back) : "v"(c0) : "memory");
+        if (back != 0) bad |= 16u;
+    }
+    __syncthreads();
+    // (2) token rotation: round r (wave r % 16) appends to four chains (two dwords x two halves); the value a lane gets back
+    // must be the entry of its predecessor in that chain: previous lane of the chain, previous block, previous round
+    {
+        const uint32_t chain = lane & 3u;                                         // dword (chain >> 1), half (chain & 1)
+        const uint32_t a = c0 + 16u + 4u * (chain >> 1), sh = (chain & 1u) << 4;
+        uint32_t addr[kR], mask[kR], val[kR], ret[kR];
+        constexpr uint32_t kRounds = 192;
+        for (uint32_t r = wave; r < kRounds; r += kRotWaves) {
+#pragma unroll
+            for (uint32_t j = 0; j < kR; ++j) {
+                addr[j] = a; mask[j] = 0xffffu << sh;
+                val[j] = ((((r * kR + j) * 16u + (lane >> 2)) + 1u) & 0xffffu) << sh;   // position in the chain + 1 (mod 2^16)
+            }
+            for (uint32_t spins = 0;; ++spins) {
+                const uint32_t D = rfl(lds_peek2(sy + kSyD).x);
+                if (D == r) break;
+                if (D == kPoison) wave_exit();
+                if (spins > kSpinLimit) { if (lane == 0) { atomicOr(fail, 64u << 8); lds_poke(sy + kSyD, kPoison); } wave_exit(); }
+            }
+            exchange_round(ret, addr, mask, val, lane == 0 ? sy + kSyD : sy + kSySink + 4u * lane, r + 1u, (tune & 1u) != 0);
+#pragma unroll
+            for (uint32_t j = 0; j < kR; ++j) {
+                const uint32_t want = ((r * kR + j) * 16u + (lane >> 2)) & 0xffffu;
+                if (((ret[j] >> sh) & 0xffffu) != want) bad |= 32u;
+            }
+        }
+    }
+    if (bad) atomicOr(fail, bad << 8);                                           // (bits 0..7 belong to container.hip's selftest_kernel)
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host launchers
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+uint32_t rot_tune() {
+    static const uint32_t t = getenv("DENSITY_HIP_TUNE") ? (uint32_t)atoi(getenv("DENSITY_HIP_TUNE")) : 0u;   // read once: bit 0 = token after answers
+    return t;
+}
+}  // namespace
+
+bool rotor_encode_eligible(const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks) {
+    const bool aligned = ((uintptr_t)d_in % 4 == 0) && (n_chunks == 1 || chunk_bytes % 4 == 0);
+    return aligned && (n_chunks == 1 ? total : chunk_bytes) < (1ull << 31);   // 32-bit stream positions
+}
+hipError_t launch_rotor_encode(const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_out, uint64_t out_stride,
+                               uint64_t* d_sizes, uint8_t* d_index, uint32_t* d_err, hipStream_t stream) {
+    hipError_t e = hipFuncSetAttribute((const void*)chameleon_encode_rot, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEncLds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(chameleon_encode_rot, dim3(n_chunks), dim3(kRotThreads), kEncLds, stream, d_in, total, chunk_bytes, d_out, out_stride, d_sizes, d_index, d_err, rot_tune());
+    return hipGetLastError();
+}
+bool rotor_decode_eligible(const uint8_t* d_out, uint32_t n_chunks, uint64_t out_stride, uint64_t out_total, const uint8_t* d_index, const uint32_t* d_zmap) {
+    if (!d_index || !d_zmap || n_chunks > kMaxPipelinedChunks) return false;
+    const uint64_t per_chunk = n_chunks == 1 ? (out_total < out_stride ? out_total : out_stride) : out_stride;
+    if ((per_chunk + kBlock - 1) / kBlock > kRotMaxBlocks) return false;
+    if ((uintptr_t)d_index % 4 != 0 || (n_chunks > 1 && (out_stride / kBlock) % 4 != 0)) return false;
+    return (uintptr_t)d_out % 4 == 0 && (n_chunks == 1 || out_stride % 4 == 0);
+}
+hipError_t launch_rotor_decode(const uint8_t* d_in, const uint64_t* d_offsets, const uint64_t* d_sizes, uint32_t n_chunks, uint8_t* d_out,
+                               uint64_t out_stride, uint64_t out_total, bool exact, const uint8_t* d_index, uint32_t* d_zmap,
+                               uint64_t* d_produced, uint32_t* d_err, hipStream_t stream) {
+    hipError_t e = hipFuncSetAttribute((const void*)chameleon_decode_rot, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDecLds + 64);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(chameleon_decode_rot, dim3(n_chunks), dim3(kRotThreads), kDecLds, stream, d_in, d_offsets, d_sizes, d_out, out_stride, out_total,
+                       exact ? 1u : 0u, d_index, d_zmap, d_produced, d_err, rot_tune());
+    return hipGetLastError();
+}
+hipError_t launch_rotor_selftest(uint32_t* d_fail, hipStream_t stream) {
+    hipLaunchKernelGGL(rotor_selftest_kernel, dim3(1), dim3(kRotThreads), 0, stream, d_fail, rot_tune());
+    return hipGetLastError();
+}
+
+}  // namespace density

@@ -148,12 +148,18 @@ int density_hip_stream_decode_device(int algo, const void* d_input, size_t input
 void density_hip_set_profiling(int enabled);
 int density_hip_last_timings(float* milliseconds, const char** names, int capacity);
 
-/* Test hook, bit mask: 1 = force the simple one-wavefront-per-chunk kernels instead of the pipelined 8-wave work-groups,
- * 2 = encode containers without the block index.  Payload bytes are identical in every variant. */
+/* Test hook, bit mask: 1 = force the simple one-wavefront-per-chunk kernels, 2 = encode containers without the block index,
+ * 4 = force the 16-wave role pipelines (chameleon.hip) instead of the default wave-rotation kernels (rotor.hip).
+ * Payload bytes are identical in every variant. */
 void density_hip_set_kernel_variant(int variant);
 
-/* Runs the LDS write-order self-test the kernels rely on (also run lazily before first use). 0 = pass. */
+/* Runs the LDS ordering self-tests the kernels rely on (also run lazily before first use). 0 = the library can run.
+ * density_hip_selftest_bits() returns the raw failure mask (0 = everything passed, -1 = no usable device): bits 0..7 plain 16-bit
+ * LDS write order (fatal), bits 8..11 lane order of the ordered exchange ds_mskor_rtn_b32 (only the one-wavefront kernels run),
+ * bits 12..13 lane-reversed rollback / token hand-off behind the exchanges (the 16-wave role pipelines run instead of the
+ * wave-rotation kernels). */
 int density_hip_selftest(void);
+int density_hip_selftest_bits(void);
 /* Thread-local description of the last failure in this thread ("" if none). */
 const char* density_hip_last_error(void);
 const char* density_hip_version(void);

@@ -17,11 +17,15 @@ KAT = json.load(open(os.path.join(HERE, "golden", "kat.json")))
 ALGO = "chameleon"
 
 
-@pytest.fixture(autouse=True, params=["pipelined", "pipelined-noindex", "simple"])
+VARIANTS = {"rotor": 0, "rotor-noindex": 2, "pipelined": 4, "pipelined-noindex": 6, "simple": 1}
+
+
+@pytest.fixture(autouse=True, params=list(VARIANTS))
 def kernel_variant(request):
-    """Every test runs against the 8-wave pipelined work-groups (containers with and without the block index, i.e. the
-    index-fed and the record-walking decoder) and against the one-wavefront kernels."""
-    container.set_kernel_variant({"pipelined": 0, "pipelined-noindex": 2, "simple": 1}[request.param])
+    """Every test runs against the default wave-rotation kernels (rotor.hip; containers with the block index = index-fed rotation
+    decoder, without it = record-walking decoder), the 16-wave role pipelines (chameleon.hip, with and without the index) and the
+    one-wavefront kernels: three independent implementations of the same stream semantics cross-checking each other."""
+    container.set_kernel_variant(VARIANTS[request.param])
     yield request.param
     container.set_kernel_variant(0)
 
@@ -134,7 +138,7 @@ def test_container_chunks_match_oracle(kind, chunk, kernel_variant):
     for i, p in enumerate(payloads):
         assert p == pyoracle.encode(ALGO, data[i * chunk:(i + 1) * chunk]), (kind, chunk, i)
     idx = container.block_index(cont[:cn])
-    if kernel_variant == "pipelined-noindex":
+    if kernel_variant.endswith("-noindex"):
         assert idx is None and hdr.flags == 0
     elif chunk <= 65536:                                      # the python record walk is slow; small-chunk cases cover every marker
         assert idx == expected_block_index(data, chunk)
@@ -192,6 +196,80 @@ def test_errors_are_reported_not_crashes():
     short = cont[:cn - 40].copy()
     with pytest.raises(DecodeError):
         container.decode(short, out)
+
+
+def test_selftest_bits_all_clear():
+    """Every LDS ordering assumption holds on this device, so the default (wave-rotation) kernels are what the other tests ran."""
+    from density_amd import _lib
+    assert _lib.lib().density_hip_selftest_bits() == 0
+
+
+def test_corrupt_block_index_is_a_format_error(kernel_variant):
+    """The index-fed decoder cross-checks every index entry it uses against the signature it describes: a container whose index
+    lies is DENSITY_HIP_ERR_FORMAT (DecodeError), never silently wrong bytes."""
+    if kernel_variant != "rotor":
+        pytest.skip("index validation is a property of the default decoder")
+    n, chunk = 600_000, 65536
+    data = datagen.prose(n, seed=9)
+    cont = np.zeros(container.container_bound(ALGO, n, chunk), dtype=np.uint8)
+    cn = container.encode(ALGO, data, cont, chunk)
+    good = cont[:cn].copy()
+    hdr = container.parse_header(good)
+    base = (32 + 4 * hdr.n_chunks + 15) // 16 * 16
+    out = np.zeros(n, dtype=np.uint8)
+    assert container.decode(good, out) == n and np.array_equal(out, data)
+    rng = np.random.default_rng(3)
+    for trial in range(12):
+        bad = good.copy()
+        b = int(rng.integers(0, n // 256))
+        if bad[base + b] & 0x80 or (bad[base + b] & 0x7F) == 0x7F:
+            continue
+        bad[base + b] = (int(bad[base + b]) + int(rng.integers(1, 5))) % 65
+        with pytest.raises(DecodeError):
+            container.decode(bad, out)
+
+
+def test_corrupt_size_table_is_a_format_error():
+    """A valid header with a size-table entry that runs past the container must not be followed by the kernels."""
+    n, chunk = 300_000, 65536
+    data = datagen.prose(n, seed=10)
+    cont = np.zeros(container.container_bound(ALGO, n, chunk), dtype=np.uint8)
+    cn = container.encode(ALGO, data, cont, chunk)
+    out = np.zeros(n, dtype=np.uint8)
+    for entry, value in ((0, 0xFFFFFFFF), (2, 0x7FFFFFF0), (4, cn)):
+        bad = cont[:cn].copy()
+        bad[32 + 4 * entry:36 + 4 * entry] = np.frombuffer(int(value).to_bytes(4, "little"), dtype=np.uint8)
+        with pytest.raises(DecodeError):
+            container.decode(bad, out)
+
+
+def test_abort_and_recovery_paths(kernel_variant):
+    """Inputs that flip between compressible and incompressible regions every few KiB: the rotation encoder's speculation
+    ("no raw-copy block in this round") fails again and again, so roll-back, slow mode and the way back to fast mode all run."""
+    rng = np.random.default_rng(17)
+    text = datagen.prose(1 << 20, seed=31)
+    parts, pos = [], 0
+    while pos < (3 << 20):
+        k = int(rng.integers(1, 40)) * 256 + int(rng.integers(0, 2)) * int(rng.integers(0, 256))
+        if rng.integers(0, 2):
+            parts.append(text[(pos % (1 << 19)):(pos % (1 << 19)) + k])
+        else:
+            parts.append(rng.integers(0, 256, size=k, dtype=np.uint8))
+        pos += k
+    data = np.concatenate(parts)
+    want, st = pyoracle.encode_stats(ALGO, data)
+    assert st["copy_blocks"] > 100
+    got = gpu_encode(data)
+    assert got == want
+    assert gpu_decode(want, data.size) == data.tobytes()
+    chunk = 1 << 19
+    cont = np.zeros(container.container_bound(ALGO, data.size, chunk), dtype=np.uint8)
+    cn = container.encode(ALGO, data, cont, chunk)
+    _, payloads = container.chunk_payloads(cont[:cn])
+    for i, p in enumerate(payloads):
+        assert p == pyoracle.encode(ALGO, data[i * chunk:(i + 1) * chunk]), i
+    back = np.zeros(data.size, dtype=np.uint8)
+    assert container.decode(cont[:cn], back) == data.size and np.array_equal(back, data)
 
 
 def test_full_size_properties_device_resident():
