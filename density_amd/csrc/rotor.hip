@@ -44,8 +44,9 @@ namespace {
 constexpr uint32_t kRotWaves = 16, kRotThreads = kRotWaves * 64;
 constexpr uint32_t kR = 8;                                   // blocks per round
 constexpr uint32_t kNone = 0xffffffffu;
-// sync block (bytes from its base): D line {D, A}; O line {O, A', P0, P1}; a 256-byte sink for the idle lanes of a token write
-constexpr uint32_t kSyD = 0, kSyO = 16, kSyZ = 32, kSyEnd = 48, kSySink = 64, kSyBytes = 64 + 256;
+// sync block (bytes from its base): D line {D, A}; O line {O, A', P0, P1}; a 256-byte sink for the idle lanes of a token write;
+// 16 words "rounds whose zero-entry-map phase this wave has finished" (decoder)
+constexpr uint32_t kSyD = 0, kSyO = 16, kSyZ = 32, kSyEnd = 48, kSySink = 64, kSyZdone = 64 + 256, kSyBytes = 64 + 256 + 64;
 // encoder LDS: table | zero-entry map | sync
 constexpr uint32_t kEncZmap = kTableBytes, kEncSync = kTableBytes + kZmapBytes, kEncLds = kEncSync + kSyBytes;
 // decoder LDS: table | block-index copy | round positions | sync   (zero-entry map in global memory: ZmapGlobal)
@@ -142,9 +143,46 @@ __device__ __forceinline__ void watchdog(uint32_t& spins, uint32_t sync_base, ui
     }
 }
 
-__device__ __forceinline__ void backoff(uint32_t dist) {        // rounds until this wave's turn -> how long to stay off the LDS
-    if (dist > 4) __builtin_amdgcn_s_sleep(8);
-    else if (dist > 1) __builtin_amdgcn_s_sleep(2);
+// optional cycle accounting (DENSITY_HIP_PROF=1): work-group 0 reports, per wave, the cycles spent in each phase of its iterations
+constexpr uint32_t kProfRounds = 2048;
+template <bool ON>
+struct PhaseClock;
+template <>
+struct PhaseClock<false> {
+    __device__ __forceinline__ explicit PhaseClock(uint64_t*) {}
+    __device__ __forceinline__ void start() {}
+    __device__ __forceinline__ void mark(int) {}
+    __device__ __forceinline__ void stamp(uint32_t, uint32_t, uint32_t) {}
+    __device__ __forceinline__ void flush(uint32_t, uint32_t) {}
+};
+template <>
+struct PhaseClock<true> {
+    uint64_t* out; uint64_t t0 = 0; uint64_t ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    __device__ __forceinline__ explicit PhaseClock(uint64_t* o) : out(o) {}
+    __device__ __forceinline__ void start() { if (out) t0 = __builtin_readcyclecounter(); }
+    __device__ __forceinline__ void mark(int k) { if (out) { const uint64_t t = __builtin_readcyclecounter(); ph[k] += t - t0; t0 = t; } }
+    // per-round time stamps of the D chain (rounds < kProfRounds): 0 = started polling, 1 = token seen, 2 = exchanges + token done
+    __device__ __forceinline__ void stamp(uint32_t r, uint32_t what, uint32_t lane) {
+        if (out && r < kProfRounds && lane == 0) out[128 + 3 * r + what] = __builtin_readcyclecounter();
+    }
+    __device__ __forceinline__ void flush(uint32_t wave, uint32_t lane) { if (out && lane == 0) for (int k = 0; k < 8; ++k) out[8 * wave + k] = ph[k]; }
+};
+
+// Waiting for a token.  The wave whose turn is next (or next but one) polls in a loop of five instructions; waves further away sleep
+// for most of the distance first (a round hand-off takes a few hundred cycles), so that the LDS and the issue slots stay with
+// the waves that work.
+__device__ __forceinline__ void backoff(uint32_t dist, bool off = false) {
+    if (off || dist <= 2) return;
+    if (dist > 8) __builtin_amdgcn_s_sleep(24);
+    else if (dist > 4) __builtin_amdgcn_s_sleep(8);
+    else __builtin_amdgcn_s_sleep(3);
+}
+// up to `tries` back-to-back polls of one token word for one value
+__device__ __forceinline__ bool poll_word(uint32_t addr, uint32_t want, uint32_t tries) {
+    for (uint32_t i = 0; i < tries; ++i) {
+        if (rfl(lds_peek1(addr)) == want) return true;
+    }
+    return false;
 }
 
 }  // namespace
@@ -152,12 +190,15 @@ __device__ __forceinline__ void backoff(uint32_t dist) {        // rounds until 
 // ---------------------------------------------------------------------------------------------------------------
 // encode: Codec::encode / encode_block (codec/codec.rs:34-80), Chameleon::encode_quad (chameleon.rs:88-100)
 // ---------------------------------------------------------------------------------------------------------------
+template <bool kProf>
 __global__ __launch_bounds__(kRotThreads) void chameleon_encode_rot(const uint8_t* __restrict__ in, uint64_t total, uint64_t chunk_bytes,
                                                                    uint8_t* __restrict__ out, uint64_t out_stride, uint64_t* __restrict__ sizes,
-                                                                   uint8_t* __restrict__ index, uint32_t* __restrict__ err, uint32_t tune) {
+                                                                   uint8_t* __restrict__ index, uint32_t* __restrict__ err, uint32_t tune,
+                                                                   uint64_t* __restrict__ prof) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = rfl(threadIdx.x >> 6);
     const uint64_t chunk = blockIdx.x;
+    PhaseClock<kProf> clk(blockIdx.x == 0 ? prof : nullptr);   // phases: 0 hash, 1 D wait, 2 exchange, 3 signatures, 4 O wait + commit, 5 load wait, 6 emit, 7 in-order rounds
     const uint8_t* src = in + chunk * chunk_bytes;
     const uint64_t len = (total - chunk * chunk_bytes) < chunk_bytes ? (total - chunk * chunk_bytes) : chunk_bytes;
     uint8_t* dst = out + chunk * out_stride;
@@ -166,7 +207,7 @@ __global__ __launch_bounds__(kRotThreads) void chameleon_encode_rot(const uint8_
     const uint32_t nrounds = nfull / kR;                                           // whole rounds: these rotate; the rest (< 8 blocks + a ragged one) is the epilogue
     const uint32_t lds0 = lds_addr(smem), tbl = lds0, sy = lds0 + kEncSync;
     const ZmapLds zmap{lds0 + kEncZmap};
-    const bool late_token = (tune & 1u) != 0;
+    const bool late_token = (tune & 1u) != 0, no_sleep = (tune & 2u) != 0;
 
     {   // fresh state per chunk (chameleon.rs:45-48): zero table, zero-entry map, tokens: round 0 in slow mode, nothing committed
         uint4* p = reinterpret_cast<uint4*>(smem);
@@ -293,6 +334,7 @@ __global__ __launch_bounds__(kRotThreads) void chameleon_encode_rot(const uint8_
 
     load_round(q, wave);
     for (uint32_t r = wave; r < nrounds; r += kRotWaves) {
+        clk.start();
         load_round(qn, r + kRotWaves);                                            // next round's quads: in flight for the whole iteration
 
         bool zero_entry = false;
@@ -302,25 +344,37 @@ __global__ __launch_bounds__(kRotThreads) void chameleon_encode_rot(const uint8_
             zero_entry |= val[j] == 0 && q[j] != 0;                                // needs the zero-entry map: about one quad in 64 Ki
         }
         const bool in_order_round = ballot64(zero_entry) != 0;                    // walked block by block whatever the mode
+        // (the operands are complete here, before the wait for the token: nothing of this may be scheduled into the critical section)
+        asm volatile("" : "+v"(addr[0]), "+v"(addr[1]), "+v"(addr[2]), "+v"(addr[3]), "+v"(addr[4]), "+v"(addr[5]), "+v"(addr[6]), "+v"(addr[7]),
+                          "+v"(mask[0]), "+v"(mask[1]), "+v"(mask[2]), "+v"(mask[3]), "+v"(mask[4]), "+v"(mask[5]), "+v"(mask[6]), "+v"(mask[7]),
+                          "+v"(val[0]), "+v"(val[1]), "+v"(val[2]), "+v"(val[3]), "+v"(val[4]), "+v"(val[5]), "+v"(val[6]), "+v"(val[7]));
+        const uint32_t tokaddr = lane == 0 ? sy + kSyD : sy + kSySink + 4u * lane;
 
         uint64_t sig[kR];
         uint32_t copy_mask = 0, opos = 0;
+        clk.mark(0);
+        clk.stamp(r, 0, lane);
         for (;;) {   // (re-entered after an abort)
             // ---- D chain: wait for this round's turn ----
             uint32_t slow;
             for (uint32_t spins = 0;;) {
+                if (!in_order_round && poll_word(sy + kSyD, r << 1, 16)) { slow = 0; break; }   // the common hand-off: fast token for this round
                 const u32x2 v = lds_peek2(sy + kSyD);
                 const uint32_t D = rfl(v.x), A = rfl(v.y);
                 if (__builtin_expect(A != kNone, 0)) { if (A == kPoison) wave_exit(); abort_sync(false, 0); continue; }
                 if ((D >> 1) == r) { slow = D & 1u; break; }
-                backoff(r - (D >> 1));
+                backoff(r - (D >> 1), no_sleep);
                 watchdog(spins, sy, err, lane);
             }
+            clk.mark(1);
+            clk.stamp(r, 1, lane);
             if (__builtin_expect(!slow && !in_order_round, 1)) {
                 // ---- fast round: 8 speculative exchanges, token passed behind them ----
                 __builtin_amdgcn_s_setprio(3);
-                exchange_round(ret, addr, mask, val, lane == 0 ? sy + kSyD : sy + kSySink + 4u * lane, (r + 1u) << 1, late_token);
+                exchange_round(ret, addr, mask, val, tokaddr, (r + 1u) << 1, late_token);
                 __builtin_amdgcn_s_setprio(0);
+                clk.mark(2);
+                clk.stamp(r, 2, lane);
                 uint32_t inc = 0, hits = 0, min_hits = 64;
 #pragma unroll
                 for (uint32_t j = 0; j < kR; ++j) {
@@ -334,15 +388,17 @@ __global__ __launch_bounds__(kRotThreads) void chameleon_encode_rot(const uint8_
                     for (uint32_t j = 0; j < kR; ++j) inc |= ((uint32_t)__builtin_popcountll(sig[j]) <= 4u ? 1u : 0u) << j;
                 }
                 const uint32_t sum = kR * (kSig + kBlock) - 2u * hits;
+                clk.mark(3);
                 // ---- O chain: commit ----
                 uint32_t P0, P1;
                 bool aborted = false;
                 for (uint32_t spins = 0;;) {
-                    const u32x4 v = lds_peek4(sy + kSyO);
+                    u32x4 v = lds_peek4(sy + kSyO);
+                    for (uint32_t i = 0; i < 16 && rfl(v.x) != r; ++i) v = lds_peek4(sy + kSyO);   // token and payload in one read
                     const uint32_t O = rfl(v.x), A = rfl(v.y);
                     if (O == r) { P0 = rfl(v.z); P1 = rfl(v.w); break; }
                     if (__builtin_expect(A != kNone, 0)) { if (A == kPoison) wave_exit(); abort_sync(true, r); aborted = true; break; }
-                    backoff(r - O);
+                    backoff(r - O, no_sleep);
                     watchdog(spins, sy, err, lane);
                 }
                 if (aborted) continue;
@@ -370,6 +426,7 @@ __global__ __launch_bounds__(kRotThreads) void chameleon_encode_rot(const uint8_
                     lds_poke(sy + kSyO, r + 1u);
                 }
                 copy_mask = 0;
+                clk.mark(4);
                 break;
             }
             // ---- in-order round: wait until everything before it is final, then walk the blocks with the FSM ----
@@ -380,7 +437,7 @@ __global__ __launch_bounds__(kRotThreads) void chameleon_encode_rot(const uint8_
                 const uint32_t O = rfl(v.x), A = rfl(v.y);
                 if (O == r) { P0 = rfl(v.z); P1 = rfl(v.w); break; }
                 if (A != kNone) { if (A == kPoison) wave_exit(); abort_sync(false, 0); aborted = true; break; }
-                backoff(r - O);
+                backoff(r - O, no_sleep);
                 watchdog(spins, sy, err, lane);
             }
             if (aborted) continue;
@@ -402,11 +459,13 @@ __global__ __launch_bounds__(kRotThreads) void chameleon_encode_rot(const uint8_
                 lds_poke(sy + kSyO, r + 1u);
                 lds_poke(sy + kSyD, ((r + 1u) << 1) | stay_slow);
             }
+            clk.mark(7);
             break;
         }
 
         // ---- the next round's quads must have landed before this round's stores go out behind them (memory operations retire in order) ----
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(qn[0]), "+v"(qn[1]), "+v"(qn[2]), "+v"(qn[3]), "+v"(qn[4]), "+v"(qn[5]), "+v"(qn[6]), "+v"(qn[7]) :: "memory");
+        clk.mark(5);
 
         // ---- emit: records of this round and their block-index bytes ----
         if (__builtin_expect(copy_mask == 0, 1)) {
@@ -426,7 +485,9 @@ __global__ __launch_bounds__(kRotThreads) void chameleon_encode_rot(const uint8_
         }
 #pragma unroll
         for (uint32_t j = 0; j < kR; ++j) q[j] = qn[j];
+        clk.mark(6);
     }
+    clk.flush(wave, lane);
 
     // ---- end of the chunk: every round committed (no abort can follow) ----
     for (uint32_t spins = 0;;) {
@@ -462,14 +523,17 @@ __global__ __launch_bounds__(kRotThreads) void chameleon_encode_rot(const uint8_
 // ---------------------------------------------------------------------------------------------------------------
 // decode (index-fed): Codec::decode (codec/codec.rs:82-126), Chameleon::decode_plain / decode_map (chameleon.rs:56-68)
 // ---------------------------------------------------------------------------------------------------------------
+template <bool kProf>
 __global__ __launch_bounds__(kRotThreads) void chameleon_decode_rot(const uint8_t* __restrict__ in, const uint64_t* __restrict__ offsets,
                                                                    const uint64_t* __restrict__ sizes, uint8_t* __restrict__ out,
                                                                    uint64_t out_stride, uint64_t out_total, uint32_t exact,
                                                                    const uint8_t* __restrict__ index, uint32_t* __restrict__ zmap_words,
-                                                                   uint64_t* __restrict__ produced, uint32_t* __restrict__ err, uint32_t tune) {
+                                                                   uint64_t* __restrict__ produced, uint32_t* __restrict__ err, uint32_t tune,
+                                                                   uint64_t* __restrict__ prof) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = rfl(threadIdx.x >> 6);
     const uint64_t chunk = blockIdx.x;
+    PhaseClock<kProf> clk(blockIdx.x == 0 ? prof : nullptr);   // phases: 0 stage A, 1 stage B, 2 operands, 3 D wait, 4 exchange, 5 quads, 6 Z chain, 7 stores + rotate
     const uint8_t* src = in + offsets[chunk];
     const uint8_t* idx = index + chunk * (out_stride / kBlock);                 // this chunk's slice of the block index (4-byte aligned: launcher)
     const uint64_t elen64 = sizes[chunk];
@@ -480,7 +544,7 @@ __global__ __launch_bounds__(kRotThreads) void chameleon_decode_rot(const uint8_
     const uint32_t nblk = (uint32_t)((cap + kBlock - 1) / kBlock);               // <= kRotMaxBlocks (launcher)
     const ZmapGlobal zmap{zmap_words + chunk * (kZmapBytes / 4)};
     const uint32_t lds0 = lds_addr(smem), tbl = lds0, sy = lds0 + kDecSync;
-    const bool late_token = (tune & 1u) != 0;
+    const bool late_token = (tune & 1u) != 0, no_sleep = (tune & 2u) != 0;
 
     {   // fresh dictionary, this chunk's zero-entry map, the block index into LDS
         uint4* p = reinterpret_cast<uint4*>(smem);
@@ -495,6 +559,7 @@ __global__ __launch_bounds__(kRotThreads) void chameleon_decode_rot(const uint8_
             *reinterpret_cast<uint4*>(smem + kDecSync + kSyZ) = make_uint4(0u, 0u, 0u, 0u);
             *reinterpret_cast<uint64_t*>(smem + kDecSync + kSyEnd) = ~0ull;
         }
+        if (threadIdx.x < kRotWaves) *reinterpret_cast<uint32_t*>(smem + kDecSync + kSyZdone + 4u * threadIdx.x) = 0u;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         // the map is used through L2 atomics by this work-group only (chameleon.hip)
     }
     __syncthreads();
@@ -593,8 +658,13 @@ __global__ __launch_bounds__(kRotThreads) void chameleon_decode_rot(const uint8_
 
     uint32_t addr[kR], mask[kR], val[kR], ret[kR];
     for (uint32_t x = wave; x < npr; x += kRotWaves) {
-        stage_a(x + 2 * kRotWaves, ma);
+        clk.start();
+        // (B first: what it waits for — the signatures requested one iteration ago — is older than anything issued since, so the
+        // wait does not cover a load that has just left)
         stage_b(mb, hitsb, itemb);
+        clk.mark(1);
+        stage_a(x + 2 * kRotWaves, ma);
+        clk.mark(0);
 
         // ---- C: operands of the dictionary step ----
         const uint32_t coded_mask = ((1u << mc.n) - 1u) & ~mc.copy_mask;          // records that go through the dictionary
@@ -614,17 +684,29 @@ __global__ __launch_bounds__(kRotThreads) void chameleon_decode_rot(const uint8_
             val[j] = writes ? (e << sh) : 0u;
             zacc |= (writes && e == 0 && h != 0) ? 1u : 0u;
         }
+        // (the operands are complete here, before the wait for the token: nothing of this may be scheduled into the critical section)
+        asm volatile("" : "+v"(addr[0]), "+v"(addr[1]), "+v"(addr[2]), "+v"(addr[3]), "+v"(addr[4]), "+v"(addr[5]), "+v"(addr[6]), "+v"(addr[7]),
+                          "+v"(mask[0]), "+v"(mask[1]), "+v"(mask[2]), "+v"(mask[3]), "+v"(mask[4]), "+v"(mask[5]), "+v"(mask[6]), "+v"(mask[7]),
+                          "+v"(val[0]), "+v"(val[1]), "+v"(val[2]), "+v"(val[3]), "+v"(val[4]), "+v"(val[5]), "+v"(val[6]), "+v"(val[7]));
+        const uint32_t tokaddr = lane == 0 ? sy + kSyD : sy + kSySink + 4u * lane;
+        clk.mark(2);
+        clk.stamp(x, 0, lane);
         // ---- D chain ----
         for (uint32_t spins = 0;;) {
+            if (poll_word(sy + kSyD, x, 16)) break;
             const uint32_t D = rfl(lds_peek1(sy + kSyD));
             if (D == x) break;
             if (D == kPoison) wave_exit();
-            backoff(x - D);
+            backoff(x - D, no_sleep);
             watchdog(spins, sy, err, lane);
         }
+        clk.mark(3);
+        clk.stamp(x, 1, lane);
         __builtin_amdgcn_s_setprio(3);
-        exchange_round(ret, addr, mask, val, lane == 0 ? sy + kSyD : sy + kSySink + 4u * lane, x + 1u, late_token);
+        exchange_round(ret, addr, mask, val, tokaddr, x + 1u, late_token);
         __builtin_amdgcn_s_setprio(0);
+        clk.mark(4);
+        clk.stamp(x, 2, lane);
 
         // ---- what each slot holds at this lane's turn -> quads (in place of the items) ----
 #pragma unroll
@@ -635,16 +717,18 @@ __global__ __launch_bounds__(kRotThreads) void chameleon_decode_rot(const uint8_
             zacc |= (maps && cur == 0 && h != 0) ? 2u : 0u;                       // MAP of a slot holding 0: never written, or a genuine zero entry?
             ret[j] = maps ? entry_to_quad(h, cur) : itemc[j];
         }
-        // ---- Z chain: zero-entry map in stream order (rare: stored entries are salted) ----
-        const bool zany = ballot64(zacc != 0) != 0;
-        for (uint32_t spins = 0;;) {
-            const uint32_t Z = rfl(lds_peek1(sy + kSyZ));
-            if (Z == x) break;
-            if (Z == kPoison) wave_exit();
-            backoff(x - Z);
-            watchdog(spins, sy, err, lane);
-        }
-        if (zany) {
+        clk.mark(5);
+        // ---- zero-entry map, in stream order (rare: stored entries are salted).  A round with no such quad only reports "done"; one that
+        // has any first waits until every earlier round has reported (wave w' owns the rounds = w' mod 16). ----
+        if (__builtin_expect(ballot64(zacc != 0) != 0, 0)) {
+            for (uint32_t spins = 0;;) {
+                const uint32_t wv = lane & (kRotWaves - 1u);
+                const uint32_t d = (x - wv) & (kRotWaves - 1u);                   // wave wv's last round before x is x - d
+                const uint32_t done = lds_peek1(sy + kSyZdone + 4u * wv);        // (rounds finished: last round + 1)
+                if (ballot64(d != 0 && x >= d && done < x - d + 1u) == 0) break;
+                if (rfl(lds_peek1(sy + kSyD)) == kPoison) wave_exit();
+                watchdog(spins, sy, err, lane);
+            }
 #pragma unroll
             for (uint32_t j = 0; j < kR; ++j) {
                 const bool coded = (coded_mask >> j) & 1u;
@@ -665,7 +749,8 @@ __global__ __launch_bounds__(kRotThreads) void chameleon_decode_rot(const uint8_
                 }
             }
         }
-        if (lane == 0) lds_poke(sy + kSyZ, x + 1u);
+        if (lane == 0) lds_poke(sy + kSyZdone + 4u * wave, x + 1u);
+        clk.mark(6);
 
         // ---- stores: 256 coalesced bytes per record ----
         uint8_t* base = dst + (uint64_t)x * kR * kBlock;
@@ -677,7 +762,9 @@ __global__ __launch_bounds__(kRotThreads) void chameleon_decode_rot(const uint8_
         mc = mb; mb = ma; hitsc = hitsb;
 #pragma unroll
         for (uint32_t j = 0; j < kR; ++j) itemc[j] = itemb[j];
+        clk.mark(7);
     }
+    clk.flush(wave, lane);
 
     if (bad_index && lane == 0) atomicOr(err, 8u);
     wg_barrier();
@@ -771,6 +858,55 @@ __global__ __launch_bounds__(kRotThreads) void rotor_selftest_kernel(uint32_t* _
 // host launchers
 // ---------------------------------------------------------------------------------------------------------------
 namespace {
+// DENSITY_HIP_PROF=1: per-wave, per-phase cycle accounting of work-group 0, printed to stderr after every launch (synchronises)
+constexpr size_t kProfWords = 128 + 3 * kProfRounds;
+uint64_t* rot_prof_buffer() {
+    static uint64_t* buf = nullptr;
+    if (!getenv("DENSITY_HIP_PROF")) return nullptr;
+    if (!buf && hipMalloc((void**)&buf, kProfWords * sizeof(uint64_t)) != hipSuccess) buf = nullptr;
+    if (buf) (void)hipMemset(buf, 0, kProfWords * sizeof(uint64_t));
+    return buf;
+}
+void rot_prof_report(const char* what, const char* phases, uint64_t* buf, hipStream_t stream) {
+    if (!buf) return;
+    static uint64_t h[kProfWords];
+    if (hipStreamSynchronize(stream) != hipSuccess || hipMemcpy(h, buf, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return;
+    fprintf(stderr, "[density_hip prof] %s work-group 0, kcycles per wave by phase (%s)\n", what, phases);
+    for (int w = 0; w < 16; ++w) {
+        uint64_t tot = 0;
+        for (int k = 0; k < 8; ++k) tot += h[8 * w + k];
+        fprintf(stderr, "[density_hip prof]   w%-2d", w);
+        for (int k = 0; k < 8; ++k) fprintf(stderr, " %7.1f", (double)h[8 * w + k] / 1e3);
+        fprintf(stderr, "  | total %8.1f\n", (double)tot / 1e3);
+    }
+    // D chain: hop = token seen (round r) - token seen (round r-1); critical = exchanges + token; detect = seen - max(previous token done, own arrival)
+    const uint64_t* ts = h + 128;
+    uint32_t n = 0, late = 0;
+    double hop = 0, crit = 0, det = 0, lateness = 0;
+    uint64_t hop_max = 0;
+    uint32_t hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t r = 17; r < kProfRounds; ++r) {
+        if (!ts[3 * r + 1] || !ts[3 * r + 2] || !ts[3 * (r - 1) + 1] || !ts[3 * (r - 1) + 2]) continue;
+        const uint64_t seen = ts[3 * r + 1], prev_seen = ts[3 * (r - 1) + 1], prev_done = ts[3 * (r - 1) + 2], arrive = ts[3 * r];
+        if (seen < prev_seen) continue;
+        const uint64_t hp = seen - prev_seen;
+        hop += (double)hp; crit += (double)(ts[3 * r + 2] - seen);
+        hop_max = hp > hop_max ? hp : hop_max;
+        const uint64_t ready = arrive > prev_done ? arrive : prev_done;
+        det += seen > ready ? (double)(seen - ready) : 0.0;
+        if (arrive > prev_done) { ++late; lateness += (double)(arrive - prev_done); }
+        uint32_t b = 0; for (uint64_t v = hp / 128; v && b < 7; v >>= 1) ++b;
+        ++hist[b];
+        ++n;
+    }
+    if (n) {
+        fprintf(stderr, "[density_hip prof]   D chain over %u rounds: hop %.0f (max %llu) cycles = critical section %.0f + detect %.0f; owner arrived late in %u rounds (avg lateness %.0f)\n",
+                n, hop / n, (unsigned long long)hop_max, crit / n, det / n, late, late ? lateness / late : 0.0);
+        fprintf(stderr, "[density_hip prof]   hop histogram (<128, <256, <512, <1k, <2k, <4k, <8k, more):");
+        for (int b = 0; b < 8; ++b) fprintf(stderr, " %u", hist[b]);
+        fprintf(stderr, "\n");
+    }
+}
 uint32_t rot_tune() {
     static const uint32_t t = getenv("DENSITY_HIP_TUNE") ? (uint32_t)atoi(getenv("DENSITY_HIP_TUNE")) : 0u;   // read once: bit 0 = token after answers
     return t;
@@ -783,9 +919,12 @@ bool rotor_encode_eligible(const uint8_t* d_in, uint64_t total, uint64_t chunk_b
 }
 hipError_t launch_rotor_encode(const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_out, uint64_t out_stride,
                                uint64_t* d_sizes, uint8_t* d_index, uint32_t* d_err, hipStream_t stream) {
-    hipError_t e = hipFuncSetAttribute((const void*)chameleon_encode_rot, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEncLds);
+    uint64_t* prof = rot_prof_buffer();
+    auto kernel = prof ? chameleon_encode_rot<true> : chameleon_encode_rot<false>;
+    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEncLds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(chameleon_encode_rot, dim3(n_chunks), dim3(kRotThreads), kEncLds, stream, d_in, total, chunk_bytes, d_out, out_stride, d_sizes, d_index, d_err, rot_tune());
+    hipLaunchKernelGGL(kernel, dim3(n_chunks), dim3(kRotThreads), kEncLds, stream, d_in, total, chunk_bytes, d_out, out_stride, d_sizes, d_index, d_err, rot_tune(), prof);
+    rot_prof_report("encode", "hash | D wait | exchange | signatures | O wait+commit | load wait | emit | in-order rounds", prof, stream);
     return hipGetLastError();
 }
 bool rotor_decode_eligible(const uint8_t* d_out, uint32_t n_chunks, uint64_t out_stride, uint64_t out_total, const uint8_t* d_index, const uint32_t* d_zmap) {
@@ -798,10 +937,13 @@ bool rotor_decode_eligible(const uint8_t* d_out, uint32_t n_chunks, uint64_t out
 hipError_t launch_rotor_decode(const uint8_t* d_in, const uint64_t* d_offsets, const uint64_t* d_sizes, uint32_t n_chunks, uint8_t* d_out,
                                uint64_t out_stride, uint64_t out_total, bool exact, const uint8_t* d_index, uint32_t* d_zmap,
                                uint64_t* d_produced, uint32_t* d_err, hipStream_t stream) {
-    hipError_t e = hipFuncSetAttribute((const void*)chameleon_decode_rot, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDecLds + 64);
+    uint64_t* prof = rot_prof_buffer();
+    auto kernel = prof ? chameleon_decode_rot<true> : chameleon_decode_rot<false>;
+    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDecLds + 64);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(chameleon_decode_rot, dim3(n_chunks), dim3(kRotThreads), kDecLds, stream, d_in, d_offsets, d_sizes, d_out, out_stride, out_total,
-                       exact ? 1u : 0u, d_index, d_zmap, d_produced, d_err, rot_tune());
+    hipLaunchKernelGGL(kernel, dim3(n_chunks), dim3(kRotThreads), kDecLds, stream, d_in, d_offsets, d_sizes, d_out, out_stride, out_total,
+                       exact ? 1u : 0u, d_index, d_zmap, d_produced, d_err, rot_tune(), prof);
+    rot_prof_report("decode", "stage A | stage B | operands | D wait | exchange | quads | Z chain | stores", prof, stream);
     return hipGetLastError();
 }
 hipError_t launch_rotor_selftest(uint32_t* d_fail, hipStream_t stream) {
