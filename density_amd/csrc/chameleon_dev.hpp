@@ -30,7 +30,7 @@ __device__ __forceinline__ void lds_clear(uint32_t lane) {
 // bit clear: round floats, small little-endian integers), so the zero-entry map is touched about once per 64 Ki quads on
 // any data.  slot_salt(0) == 0 keeps slot 0 / quad 0 (the reference's zero-initialised table, chameleon.rs:41) valid from
 // the start.
-__device__ __forceinline__ uint32_t slot_salt(uint32_t h) { return (__umul24(h, 0x9e5bu) ^ (h >> 5)) & 0xffffu; }   // 24-bit multiply: full rate
+__device__ __forceinline__ uint32_t slot_salt(uint32_t h) { return __umul24(h, 0x9e5bu) & 0xffffu; }   // 24-bit multiply: full rate (tests/datagen.py::salted_zero_quads mirrors it)
 __device__ __forceinline__ uint32_t stored_entry(uint32_t q, uint32_t P) { return ((P & 0xfffeu) | (q >> 31)) ^ slot_salt(P >> 16); }
 __device__ __forceinline__ uint32_t entry_to_quad(uint32_t h, uint32_t stored) {
     const uint32_t e = stored ^ slot_salt(h);
@@ -115,6 +115,7 @@ struct ZmapLds {
     __device__ __forceinline__ uint32_t test(uint32_t h) const { return zmap_test(base, h); }
     __device__ __forceinline__ void set(uint32_t h) const { zmap_set(base, h); }
     __device__ __forceinline__ uint32_t test_and_set(uint32_t h) const { return zmap_test_and_set(base, h); }
+    __device__ __forceinline__ void clear(uint32_t h) const { asm volatile("ds_and_b32 %0, %1" ::"v"(base + (h >> 5) * 4u), "v"(~(1u << (h & 31u))) : "memory"); }
 };
 struct ZmapGlobal {
     uint32_t* words;

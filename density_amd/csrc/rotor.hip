@@ -46,7 +46,7 @@ constexpr uint32_t kR = 8;                                   // blocks per round
 constexpr uint32_t kNone = 0xffffffffu;
 // sync block (bytes from its base): D line {D, A}; O line {O, A', P0, P1}; a 256-byte sink for the idle lanes of a token write;
 // 16 words "rounds whose zero-entry-map phase this wave has finished" (decoder)
-constexpr uint32_t kSyD = 0, kSyO = 16, kSyZ = 32, kSyEnd = 48, kSySink = 64, kSyZdone = 64 + 256, kSyBytes = 64 + 256 + 64;
+constexpr uint32_t kSyD = 0, kSyO = 16, kSyZ = 32, kSyEnd = 48, kSySink = 64, kSyZdone = 64 + 256, kSyWsum = 64 + 256 + 64, kSyBytes = 64 + 256 + 64 + 64;
 // encoder LDS: table | zero-entry map | sync
 constexpr uint32_t kEncZmap = kTableBytes, kEncSync = kTableBytes + kZmapBytes, kEncLds = kEncSync + kSyBytes;
 // decoder LDS: table | block-index copy | round positions | sync   (zero-entry map in global memory: ZmapGlobal)
@@ -54,7 +54,7 @@ constexpr uint32_t kRotMaxBlocks = 16384;                    // blocks per chunk
 constexpr uint32_t kDecIdx = kTableBytes, kDecPos = kDecIdx + kRotMaxBlocks, kDecSync = kDecPos + (kRotMaxBlocks / kR) * 4u,
                    kDecLds = kDecSync + kSyBytes;
 static_assert(kEncLds <= 160u * 1024u && kDecLds <= 160u * 1024u, "LDS budget");
-static_assert(kR == 8, "asm operand lists, the FSM closed form and the index word are written for 8 blocks per round");
+
 
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -77,6 +77,7 @@ __device__ __forceinline__ uint32_t lds_peek1(uint32_t addr) {
     return v;
 }
 __device__ __forceinline__ uint32_t rlane_u(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+__device__ __forceinline__ uint32_t rlane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
 __device__ __forceinline__ void lds_poke(uint32_t addr, uint32_t v) { asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
 __device__ __forceinline__ void lds_poke2(uint32_t addr, uint32_t a, uint32_t b) {
     const u32x2 v = {a, b};
@@ -110,6 +111,59 @@ __device__ __forceinline__ void exchange_round(uint32_t (&ret)[kR], const uint32
     } else {   // tuning / fall-back form: the token leaves only after the last answer is back
         asm volatile(DENSITY_ROT_XCHG8 "s_waitcnt lgkmcnt(0)\n\tds_write_b32 %32, %33" DENSITY_ROT_OPERANDS(ret, addr, mask, val, tokaddr, tokval));
     }
+}
+
+// The same with the answer returned in place of the address (one register per block less) for rounds of 8 or 16 blocks.
+#define DENSITY_ROT_X8 \
+    "ds_mskor_rtn_b32 %0, %0, %8, %16\n\t" \
+    "ds_mskor_rtn_b32 %1, %1, %9, %17\n\t" \
+    "ds_mskor_rtn_b32 %2, %2, %10, %18\n\t" \
+    "ds_mskor_rtn_b32 %3, %3, %11, %19\n\t" \
+    "ds_mskor_rtn_b32 %4, %4, %12, %20\n\t" \
+    "ds_mskor_rtn_b32 %5, %5, %13, %21\n\t" \
+    "ds_mskor_rtn_b32 %6, %6, %14, %22\n\t" \
+    "ds_mskor_rtn_b32 %7, %7, %15, %23\n\t" \
+    ""
+#define DENSITY_ROT_X8_OPS : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(ra[4]), "+v"(ra[5]), "+v"(ra[6]), "+v"(ra[7]) \
+    : "v"(mask[0]), "v"(mask[1]), "v"(mask[2]), "v"(mask[3]), "v"(mask[4]), "v"(mask[5]), "v"(mask[6]), "v"(mask[7]), "v"(val[0]), "v"(val[1]), "v"(val[2]), "v"(val[3]), "v"(val[4]), "v"(val[5]), "v"(val[6]), "v"(val[7]), "v"(tokaddr), "v"(tokval) : "memory"
+#define DENSITY_ROT_X16 \
+    "ds_mskor_rtn_b32 %0, %0, %16, %32\n\t" \
+    "ds_mskor_rtn_b32 %1, %1, %17, %33\n\t" \
+    "ds_mskor_rtn_b32 %2, %2, %18, %34\n\t" \
+    "ds_mskor_rtn_b32 %3, %3, %19, %35\n\t" \
+    "ds_mskor_rtn_b32 %4, %4, %20, %36\n\t" \
+    "ds_mskor_rtn_b32 %5, %5, %21, %37\n\t" \
+    "ds_mskor_rtn_b32 %6, %6, %22, %38\n\t" \
+    "ds_mskor_rtn_b32 %7, %7, %23, %39\n\t" \
+    "ds_mskor_rtn_b32 %8, %8, %24, %40\n\t" \
+    "ds_mskor_rtn_b32 %9, %9, %25, %41\n\t" \
+    "ds_mskor_rtn_b32 %10, %10, %26, %42\n\t" \
+    "ds_mskor_rtn_b32 %11, %11, %27, %43\n\t" \
+    "ds_mskor_rtn_b32 %12, %12, %28, %44\n\t" \
+    "ds_mskor_rtn_b32 %13, %13, %29, %45\n\t" \
+    "ds_mskor_rtn_b32 %14, %14, %30, %46\n\t" \
+    "ds_mskor_rtn_b32 %15, %15, %31, %47\n\t" \
+    ""
+#define DENSITY_ROT_X16_OPS : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(ra[4]), "+v"(ra[5]), "+v"(ra[6]), "+v"(ra[7]), "+v"(ra[8]), "+v"(ra[9]), "+v"(ra[10]), "+v"(ra[11]), "+v"(ra[12]), "+v"(ra[13]), "+v"(ra[14]), "+v"(ra[15]) \
+    : "v"(mask[0]), "v"(mask[1]), "v"(mask[2]), "v"(mask[3]), "v"(mask[4]), "v"(mask[5]), "v"(mask[6]), "v"(mask[7]), "v"(mask[8]), "v"(mask[9]), "v"(mask[10]), "v"(mask[11]), "v"(mask[12]), "v"(mask[13]), "v"(mask[14]), "v"(mask[15]), "v"(val[0]), "v"(val[1]), "v"(val[2]), "v"(val[3]), "v"(val[4]), "v"(val[5]), "v"(val[6]), "v"(val[7]), "v"(val[8]), "v"(val[9]), "v"(val[10]), "v"(val[11]), "v"(val[12]), "v"(val[13]), "v"(val[14]), "v"(val[15]), "v"(tokaddr), "v"(tokval) : "memory"
+
+template <int R>
+__device__ __forceinline__ void exchange_tied(uint32_t (&ra)[R], const uint32_t (&mask)[R], const uint32_t (&val)[R], uint32_t tokaddr, uint32_t tokval, bool token_after_answers);
+template <>
+__device__ __forceinline__ void exchange_tied<8>(uint32_t (&ra)[8], const uint32_t (&mask)[8], const uint32_t (&val)[8], uint32_t tokaddr, uint32_t tokval, bool token_after_answers) {
+    if (!token_after_answers) asm volatile(DENSITY_ROT_X8 "ds_write_b32 %24, %25\n\ts_waitcnt lgkmcnt(0)" DENSITY_ROT_X8_OPS);
+    else asm volatile(DENSITY_ROT_X8 "s_waitcnt lgkmcnt(0)\n\tds_write_b32 %24, %25" DENSITY_ROT_X8_OPS);
+}
+template <>
+__device__ __forceinline__ void exchange_tied<16>(uint32_t (&ra)[16], const uint32_t (&mask)[16], const uint32_t (&val)[16], uint32_t tokaddr, uint32_t tokval, bool token_after_answers) {
+    if (!token_after_answers) asm volatile(DENSITY_ROT_X16 "ds_write_b32 %48, %49\n\ts_waitcnt lgkmcnt(0)" DENSITY_ROT_X16_OPS);
+    else asm volatile(DENSITY_ROT_X16 "s_waitcnt lgkmcnt(0)\n\tds_write_b32 %48, %49" DENSITY_ROT_X16_OPS);
+}
+// (keeps a set of operands from being scheduled past this point, i.e. into the critical section behind the token wait)
+template <int R>
+__device__ __forceinline__ void pin_operands(uint32_t (&ra)[R], uint32_t (&mask)[R], uint32_t (&val)[R]) {
+#pragma unroll
+    for (int j = 0; j < R; ++j) asm volatile("" : "+v"(ra[j]), "+v"(mask[j]), "+v"(val[j]));
 }
 __device__ __forceinline__ uint32_t exchange_block(uint32_t addr, uint32_t mask, uint32_t val) {
     uint32_t ret;
@@ -190,11 +244,12 @@ __device__ __forceinline__ bool poll_word(uint32_t addr, uint32_t want, uint32_t
 // ---------------------------------------------------------------------------------------------------------------
 // encode: Codec::encode / encode_block (codec/codec.rs:34-80), Chameleon::encode_quad (chameleon.rs:88-100)
 // ---------------------------------------------------------------------------------------------------------------
-template <bool kProf>
-__global__ __launch_bounds__(kRotThreads) void chameleon_encode_rot(const uint8_t* __restrict__ in, uint64_t total, uint64_t chunk_bytes,
+template <int R, int W, bool kProf>
+__global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __restrict__ in, uint64_t total, uint64_t chunk_bytes,
                                                                    uint8_t* __restrict__ out, uint64_t out_stride, uint64_t* __restrict__ sizes,
                                                                    uint8_t* __restrict__ index, uint32_t* __restrict__ err, uint32_t tune,
                                                                    uint64_t* __restrict__ prof) {
+    static_assert((R == 8 || R == 16) && (W == 8 || W == 12 || W == 16), "round = 8 or 16 blocks; 8, 12 or 16 waves");
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = rfl(threadIdx.x >> 6);
     const uint64_t chunk = blockIdx.x;
@@ -204,111 +259,114 @@ __global__ __launch_bounds__(kRotThreads) void chameleon_encode_rot(const uint8_
     uint8_t* dst = out + chunk * out_stride;
     uint8_t* idx = index ? index + chunk * (chunk_bytes / kBlock) : nullptr;     // this chunk's slice of the block index
     const uint32_t nfull = (uint32_t)(len / kBlock);                              // whole blocks (the launcher bounds len)
-    const uint32_t nrounds = nfull / kR;                                           // whole rounds: these rotate; the rest (< 8 blocks + a ragged one) is the epilogue
-    const uint32_t lds0 = lds_addr(smem), tbl = lds0, sy = lds0 + kEncSync;
-    const ZmapLds zmap{lds0 + kEncZmap};
+    const uint32_t nrounds = nfull / R;                                            // whole rounds: these rotate; the rest (< R blocks + a ragged one) is the epilogue
+    // the table sits at LDS address 0 (this kernel has no static LDS): slot addresses need no base
+    const uint32_t sy = kEncSync;
+    const ZmapLds zmap{kEncZmap};
     const bool late_token = (tune & 1u) != 0, no_sleep = (tune & 2u) != 0;
 
     {   // fresh state per chunk (chameleon.rs:45-48): zero table, zero-entry map, tokens: round 0 in slow mode, nothing committed
         uint4* p = reinterpret_cast<uint4*>(smem);
         const uint4 z = make_uint4(0, 0, 0, 0);
-        for (uint32_t i = threadIdx.x; i < (kTableBytes + kZmapBytes) / 16; i += kRotThreads) p[i] = z;
+        for (uint32_t i = threadIdx.x; i < (kTableBytes + kZmapBytes) / 16; i += W * 64) p[i] = z;
         if (threadIdx.x == 0) {
             *reinterpret_cast<uint4*>(smem + kEncSync + kSyD) = make_uint4(1u, kNone, 0u, 0u);
             *reinterpret_cast<uint4*>(smem + kEncSync + kSyO) = make_uint4(0u, kNone, 0u, pack_guard(Guard{}));
+            if (lds_addr(smem) != 0 && err) atomicOr(err, kErrWatchdog);           // (cannot happen: see above)
         }
     }
     __syncthreads();
 
-    uint32_t q[kR], qn[kR];
-    auto load_round = [&](uint32_t (&d)[kR], uint32_t r) {
+    uint32_t q[R], qn[R];
+    auto load_round = [&](uint32_t (&d)[R], uint32_t r) {
         if (r < nrounds) {
-            const uint8_t* p = src + (uint64_t)r * (kR * kBlock);
+            const uint8_t* p = src + (uint64_t)r * (R * kBlock);
 #pragma unroll
-            for (uint32_t j = 0; j < kR; ++j) d[j] = *reinterpret_cast<const uint32_t*>(p + j * kBlock + 4u * lane);
+            for (uint32_t j = 0; j < R; ++j) d[j] = *reinterpret_cast<const uint32_t*>(p + j * kBlock + 4u * lane);
         }
     };
     // quad -> exchange operands {dword address, half mask, entry << 16*half} (chameleon.rs:89, chameleon_dev.hpp)
-    auto operands = [&](uint32_t qv, uint32_t& P, uint32_t& a, uint32_t& m, uint32_t& v) {
-        P = qv * kHashMul;
+    auto operands = [&](uint32_t qv, uint32_t& a, uint32_t& m, uint32_t& v) {
+        const uint32_t P = qv * kHashMul;
         const uint32_t sh = (P >> 12) & 16u;                                      // (h & 1) << 4
-        a = tbl + ((P >> 15) & 0x1fffcu);                                         // (h >> 1) << 2
+        a = (P >> 15) & 0x1fffcu;                                                 // (h >> 1) << 2
         m = 0xffffu << sh;
         v = stored_entry(qv, P) << sh;
     };
     // one record (codec.rs:39-67, io/write_buffer.rs) or raw block (codec.rs:35-37) to its place in the stream
-    auto emit_block = [&](uint8_t* rec, uint32_t qv, uint64_t s, bool raw) {
+    auto emit_block = [&](uint8_t* rec, uint32_t qv, uint64_t sg, bool raw) {
         if (raw) {
             st32u(rec + 4u * lane, qv);
         } else {
-            const uint32_t off = kSig + 4u * lane - 2u * mbcnt64(s);
-            if (lane < 2) st32u(rec + 4u * lane, lane ? (uint32_t)(s >> 32) : (uint32_t)s);     // codec.rs:24-26
-            if ((s >> lane) & 1ull) st16u(rec + off, (qv * kHashMul) >> 16); else st32u(rec + off, qv);
+            const uint32_t off = kSig + 4u * lane - 2u * mbcnt64(sg);
+            if (lane < 2) st32u(rec + 4u * lane, lane ? (uint32_t)(sg >> 32) : (uint32_t)sg);   // codec.rs:24-26
+            if ((sg >> lane) & 1ull) st16u(rec + off, (qv * kHashMul) >> 16); else st32u(rec + off, qv);
         }
     };
     // one block in order: FSM, then either a raw copy or the dictionary step with the zero-entry map (slow rounds, epilogue)
-    auto block_in_order = [&](Guard& g, uint32_t qv, uint32_t a, uint32_t m, uint32_t v, uint64_t& s, bool& raw) {
-        s = 0;
+    auto block_in_order = [&](Guard& g, uint32_t qv, uint32_t& a, uint32_t m, uint32_t v, uint64_t& sg, bool& raw) {
+        sg = 0;
         raw = g.block_is_copy();                                                  // codec.rs:35
         if (raw) { g.decay(); return; }
         const uint32_t old = exchange_block(a, m, v);
+        a = old;                                                                  // (like the fast path: the answer replaces the address)
         const bool susp = v == 0 && qv != 0;                                       // stored entry 0 outside slot 0 (entry 0 in slot 0 is the zero quad)
         const uint32_t zbit = zmap_claim_in_order(zmap, susp, (qv * kHashMul) >> 16, lane);
-        s = ballot64(((old ^ v) & m) == 0 && (!susp || zbit));                     // chameleon.rs:90-99
-        g.update((uint32_t)__builtin_popcountll(s) <= 4u);                         // codec.rs:68: 8 + 256 - 2*hits >= 256
+        sg = ballot64(((old ^ v) & m) == 0 && (!susp || zbit));                    // chameleon.rs:90-99
+        g.update((uint32_t)__builtin_popcountll(sg) <= 4u);                        // codec.rs:68: 8 + 256 - 2*hits >= 256
     };
 
-    uint32_t prod[kR], addr[kR], mask[kR], val[kR], ret[kR];
+    uint32_t ra[R], mask[R], val[R];                                              // per block: address, then (after the exchange) the answer; half mask; entry
 #pragma unroll
-    for (uint32_t j = 0; j < kR; ++j) { q[j] = 0; qn[j] = 0; prod[j] = 0; addr[j] = tbl; mask[j] = 0; val[j] = 0; ret[j] = 0; }
-    // The records of a round without raw blocks, straight-line: the 8 signatures and the 8 index bytes leave from lanes 0..7 in one
+    for (uint32_t j = 0; j < R; ++j) { q[j] = 0; qn[j] = 0; ra[j] = 0; mask[j] = 0; val[j] = 0; }
+    // The records of a round without raw blocks, straight-line: the signatures and the index bytes leave from lanes 0..R-1 in one
     // store each (lane j: record j, offsets by a DPP prefix over the record lengths); per block the MAP lanes store the 2-byte slot
     // index (the upper half of the hash product), the PLAIN lanes the quad, through an SGPR base (io/write_buffer.rs:13-27).
-    const uint32_t c_off = kSig + 4u * lane;
-    auto emit_round_coded = [&](uint32_t pos0, uint8_t* idxp, const uint64_t (&sg)[kR]) {
-        uint32_t slo = 0, shi = 0;
-#pragma unroll
-        for (uint32_t j = 0; j < kR; ++j) {
-            asm("v_writelane_b32 %0, %1, %2" : "+v"(slo) : "s"((uint32_t)sg[j]), "n"(j));
-            asm("v_writelane_b32 %0, %1, %2" : "+v"(shi) : "s"((uint32_t)(sg[j] >> 32)), "n"(j));
-        }
+    const uint32_t c_base = kSig + 2u * lane;
+    auto emit_round_coded = [&](uint32_t pos0, uint8_t* idxp, uint32_t slo, uint32_t shi) {
         const uint32_t nhv = (uint32_t)(__builtin_popcount(slo) + __builtin_popcount(shi));
         const uint32_t lenv = kSig + kBlock - 2u * nhv;
-        uint32_t incl = lenv;
+        uint32_t incl = lenv;                                                                 // prefix within a row of 16 lanes
         incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xf, 0xf, true);   // row_shr:1
         incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xf, 0xf, true);   // row_shr:2
         incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xf, 0xf, true);   // row_shr:4
-        if (lane < kR) {
+        if (R > 8) incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xf, 0xf, true);   // row_shr:8
+        if (lane < R) {
             *reinterpret_cast<u32x2_u*>(dst + (pos0 + incl - lenv)) = u32x2{slo, shi};         // codec.rs:24-26
             if (idxp) idxp[lane] = (uint8_t)nhv;
         }
         uint32_t pos = pos0;
 #pragma unroll
-        for (uint32_t j = 0; j < kR; ++j) {
-            const uint32_t off = pos + c_off - 2u * mbcnt64(sg[j]);
-            const uint64_t plain = ~sg[j];
+        for (uint32_t j = 0; j < R; ++j) {
+            const uint64_t sg = ((uint64_t)rlane_u(shi, (int)j) << 32) | rlane_u(slo, (int)j);
+            const uint64_t plain = ~sg;
+            const uint32_t off = pos + c_base + 2u * mbcnt64(plain);              // 8 + 2*lane + 2*(PLAIN lanes below) = 8 + 4*lane - 2*(MAP lanes below)
+            const uint32_t P = q[j] * kHashMul;
             asm volatile(
                 "s_mov_b64 exec, %4\n\t"
                 "global_store_short_d16_hi %0, %1, %3\n\t"
                 "s_mov_b64 exec, %5\n\t"
                 "global_store_dword %0, %2, %3\n\t"
                 "s_mov_b64 exec, -1"
-                ::"v"(off), "v"(prod[j]), "v"(q[j]), "s"(dst), "s"(sg[j]), "s"(plain) : "memory");
-            pos += kSig + kBlock - 2u * (uint32_t)__builtin_popcountll(sg[j]);
+                ::"v"(off), "v"(P), "v"(q[j]), "s"(dst), "s"(sg), "s"(plain) : "memory");
+            pos += kSig + kBlock - 2u * (uint32_t)__builtin_popcountll(sg);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
     // undo the exchanges of this wave's round, last block first: the lowest lane of a slot holds the pre-block entry, so the
-    // answers go back lane-reversed in ONE ds_write_b16 (ascending lane service order: the highest physical lane = the
-    // lowest original lane wins)
+    // answers go back lane-reversed in ONE ds_write_b16 per block (ascending lane service order: the highest physical lane =
+    // the lowest original lane wins)
     auto rollback_round = [&]() {
+        uint32_t sq[R], sr[R];                                                    // (scratch copies and a rolled loop: this path is rare, its code must not weigh on the common one)
 #pragma unroll
-        for (int j = (int)kR - 1; j >= 0; --j) {
-            uint32_t mk = mask[j];
-            asm volatile("" : "+v"(mk));                                           // (keeps this arithmetic out of the common path)
-            const uint32_t hi = mk >> 31;                                          // 1: the slot is the upper half of its dword
-            const uint32_t a16 = addr[j] + 2u * hi;
-            const uint32_t prev = hi ? (ret[j] >> 16) : (ret[j] & 0xffffu);
+        for (uint32_t j = 0; j < R; ++j) { sq[j] = q[j]; sr[j] = ra[j]; }
+#pragma nounroll
+        for (int j = (int)R - 1; j >= 0; --j) {
+            const uint32_t P = sq[j] * kHashMul;
+            const uint32_t hi = (P >> 16) & 1u;                                    // 1: the slot is the upper half of its dword
+            const uint32_t a16 = ((P >> 15) & 0x1fffcu) + 2u * hi;
+            const uint32_t prev = hi ? (sr[j] >> 16) : (sr[j] & 0xffffu);
             const uint32_t ar = bperm(63u - lane, a16), pr = bperm(63u - lane, prev);
             dict_store(ar, pr);
         }
@@ -324,7 +382,7 @@ __global__ __launch_bounds__(kRotThreads) void chameleon_encode_rot(const uint8_
             if (holding && hold_round == x) rollback_round();
             wg_barrier();
         }
-        if (wave == (a & (kRotWaves - 1u)) && lane == 0) {
+        if (wave == a % W && lane == 0) {
             lds_poke(sy + kSyD, (a << 1) | 1u);
             lds_poke(sy + kSyD + 4, kNone);
             lds_poke(sy + kSyO + 4, kNone);
@@ -333,32 +391,35 @@ __global__ __launch_bounds__(kRotThreads) void chameleon_encode_rot(const uint8_
     };
 
     load_round(q, wave);
-    for (uint32_t r = wave; r < nrounds; r += kRotWaves) {
+    for (uint32_t r = wave; r < nrounds; r += W) {
         clk.start();
-        load_round(qn, r + kRotWaves);                                            // next round's quads: in flight for the whole iteration
-
-        bool zero_entry = false;
-#pragma unroll
-        for (uint32_t j = 0; j < kR; ++j) {
-            operands(q[j], prod[j], addr[j], mask[j], val[j]);
-            zero_entry |= val[j] == 0 && q[j] != 0;                                // needs the zero-entry map: about one quad in 64 Ki
-        }
-        const bool in_order_round = ballot64(zero_entry) != 0;                    // walked block by block whatever the mode
-        // (the operands are complete here, before the wait for the token: nothing of this may be scheduled into the critical section)
-        asm volatile("" : "+v"(addr[0]), "+v"(addr[1]), "+v"(addr[2]), "+v"(addr[3]), "+v"(addr[4]), "+v"(addr[5]), "+v"(addr[6]), "+v"(addr[7]),
-                          "+v"(mask[0]), "+v"(mask[1]), "+v"(mask[2]), "+v"(mask[3]), "+v"(mask[4]), "+v"(mask[5]), "+v"(mask[6]), "+v"(mask[7]),
-                          "+v"(val[0]), "+v"(val[1]), "+v"(val[2]), "+v"(val[3]), "+v"(val[4]), "+v"(val[5]), "+v"(val[6]), "+v"(val[7]));
-        const uint32_t tokaddr = lane == 0 ? sy + kSyD : sy + kSySink + 4u * lane;
-
-        uint64_t sig[kR];
+        uint32_t slo = 0, shi = 0;                                                // lane j: the signature of block j (codec.rs:24-26)
         uint32_t copy_mask = 0, opos = 0;
+      for (;;) {   // (re-entered after an abort: the answers have replaced the addresses, so the operands are made again)
+        uint32_t zmin = 0xffffffffu;
+#pragma unroll
+        for (uint32_t j = 0; j < R; ++j) {
+            operands(q[j], ra[j], mask[j], val[j]);
+            zmin = val[j] < zmin ? val[j] : zmin;
+            __builtin_amdgcn_sched_barrier(0);                                    // block by block: short live ranges, not maximal overlap
+        }
+        bool zero_round = false;                                                  // some quad of the round needs the zero-entry map (about one in 64 Ki)
+        if (__builtin_expect(ballot64(zmin == 0) != 0, 0)) {                      // a stored entry 0: the zero quad (harmless) or one outside slot 0
+            bool zero_entry = false;
+#pragma unroll
+            for (uint32_t j = 0; j < R; ++j) zero_entry |= val[j] == 0 && q[j] != 0;
+            zero_round = ballot64(zero_entry) != 0;
+        }
+        const uint32_t tokaddr = lane == 0 ? sy + kSyD : sy + kSySink + 4u * lane;
+        pin_operands<R>(ra, mask, val);                                           // complete before the wait for the token
+
         clk.mark(0);
         clk.stamp(r, 0, lane);
-        for (;;) {   // (re-entered after an abort)
+        {
             // ---- D chain: wait for this round's turn ----
             uint32_t slow;
             for (uint32_t spins = 0;;) {
-                if (!in_order_round && poll_word(sy + kSyD, r << 1, 16)) { slow = 0; break; }   // the common hand-off: fast token for this round
+                if (poll_word(sy + kSyD, r << 1, 16)) { slow = 0; break; }         // the common hand-off: fast token for this round
                 const u32x2 v = lds_peek2(sy + kSyD);
                 const uint32_t D = rfl(v.x), A = rfl(v.y);
                 if (__builtin_expect(A != kNone, 0)) { if (A == kPoison) wave_exit(); abort_sync(false, 0); continue; }
@@ -368,26 +429,26 @@ __global__ __launch_bounds__(kRotThreads) void chameleon_encode_rot(const uint8_
             }
             clk.mark(1);
             clk.stamp(r, 1, lane);
-            if (__builtin_expect(!slow && !in_order_round, 1)) {
-                // ---- fast round: 8 speculative exchanges, token passed behind them ----
+            if (__builtin_expect(!slow, 1)) {
+                // ---- fast round: R speculative exchanges, token passed behind them ----
                 __builtin_amdgcn_s_setprio(3);
-                exchange_round(ret, addr, mask, val, tokaddr, (r + 1u) << 1, late_token);
+                exchange_tied<R>(ra, mask, val, tokaddr, (r + 1u) << 1, late_token);
                 __builtin_amdgcn_s_setprio(0);
                 clk.mark(2);
                 clk.stamp(r, 2, lane);
-                uint32_t inc = 0, hits = 0, min_hits = 64;
+                uint32_t hits = 0;
 #pragma unroll
-                for (uint32_t j = 0; j < kR; ++j) {
-                    sig[j] = ballot64(((ret[j] ^ val[j]) & mask[j]) == 0);         // chameleon.rs:90-99: MAP flag = 1 iff the slot held this quad
-                    const uint32_t nh = (uint32_t)__builtin_popcountll(sig[j]);
-                    min_hits = nh < min_hits ? nh : min_hits;
-                    hits += nh;
+                for (uint32_t j = 0; j < R; ++j) {
+                    const uint64_t sg = ballot64(((ra[j] ^ val[j]) & mask[j]) == 0);   // chameleon.rs:90-99: MAP flag = 1 iff the slot held this quad
+                    // (gfx950: an SGPR written by a VALU instruction — the compare — needs 2 wait states before a VALU instruction reads it;
+                    // the compiler inserts them for its own code, not inside an asm statement)
+                    asm("s_nop 1\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4" : "+v"(slo), "+v"(shi) : "s"((uint32_t)sg), "s"((uint32_t)(sg >> 32)), "n"(j));
+                    hits += (uint32_t)__builtin_popcountll(sg);
                 }
-                if (__builtin_expect(min_hits <= 4u, 0)) {                         // an incompressible record (codec.rs:68: 8 + 256 - 2*hits >= 256)
-#pragma unroll
-                    for (uint32_t j = 0; j < kR; ++j) inc |= ((uint32_t)__builtin_popcountll(sig[j]) <= 4u ? 1u : 0u) << j;
-                }
-                const uint32_t sum = kR * (kSig + kBlock) - 2u * hits;
+                // everything the commit needs that does not depend on the token: incompressible records (codec.rs:68: 8 + 256 - 2*hits >= 256)
+                uint32_t inc = (uint32_t)ballot64(lane < R && (uint32_t)(__builtin_popcount(slo) + __builtin_popcount(shi)) <= 4u);
+                uint32_t sum = R * (kSig + kBlock) - 2u * hits;
+                load_round(qn, r + W);                                     // next round's quads: in flight while this round commits
                 clk.mark(3);
                 // ---- O chain: commit ----
                 uint32_t P0, P1;
@@ -402,22 +463,55 @@ __global__ __launch_bounds__(kRotThreads) void chameleon_encode_rot(const uint8_
                     watchdog(spins, sy, err, lane);
                 }
                 if (aborted) continue;
+                // Zero-entry map, in stream order (this wave holds the commit token): every quad whose stored entry is 0 outside slot 0 marks
+                // its slot; its MAP flag — the slot read 0 — stands only if the slot had been marked before, i.e. really held this entry
+                // and not just never anything.  `flipped`: the marks this round set itself (taken back if the round is rolled back).
+                uint32_t flipped = 0;
+                if (__builtin_expect(zero_round, 0)) {
+                    uint32_t sq[R], sv[R];                                        // (scratch copies and a rolled loop, as in rollback_round)
+#pragma unroll
+                    for (uint32_t j = 0; j < R; ++j) { sq[j] = q[j]; sv[j] = val[j]; }
+#pragma nounroll
+                    for (uint32_t j = 0; j < R; ++j) {
+                        const uint32_t qv = sq[j];
+                        const bool susp = sv[j] == 0 && qv != 0;
+                        if (ballot64(susp) == 0) continue;
+                        const uint32_t zbit = zmap_claim_in_order(zmap, susp, (qv * kHashMul) >> 16, lane);
+                        flipped |= (susp && !zbit ? 1u : 0u) << j;
+                        const uint64_t sg = ((uint64_t)rlane(shi, j) << 32) | rlane(slo, j);
+                        const uint64_t lost = ballot64(susp && !zbit) & sg;
+                        slo = lane == j ? (uint32_t)(sg & ~lost) : slo;
+                        shi = lane == j ? (uint32_t)((sg & ~lost) >> 32) : shi;
+                        hits -= (uint32_t)__builtin_popcountll(lost);
+                    }
+                    inc = (uint32_t)ballot64(lane < R && (uint32_t)(__builtin_popcount(slo) + __builtin_popcount(shi)) <= 4u);
+                    sum = R * (kSig + kBlock) - 2u * hits;
+                }
                 // which blocks the FSM would have turned into raw copies: block j+1 iff inc[j] && prev[j] (protection_state.rs:38-47)
                 const uint32_t t = inc & ((inc << 1) | ((P1 >> 16) & 1u));
-                if (__builtin_expect((P1 & 0xffu) != 0 || (t & ((1u << (kR - 1)) - 1u)) != 0, 0)) {
+                if (__builtin_expect((P1 & 0xffu) != 0 || (t & ((1u << (R - 1)) - 1u)) != 0, 0)) {
+                    if (ballot64(flipped != 0)) {
+                        uint32_t sq[R];
+#pragma unroll
+                        for (uint32_t j = 0; j < R; ++j) sq[j] = q[j];
+#pragma nounroll
+                        for (uint32_t j = 0; j < R; ++j) {
+                            if ((flipped >> j) & 1u) zmap.clear((sq[j] * kHashMul) >> 16);
+                        }
+                    }
                     if (lane == 0) { lds_poke(sy + kSyD + 4, r); lds_poke(sy + kSyO + 4, r); }
                     abort_sync(true, r);
                     continue;
                 }
                 uint32_t g_out;
                 if (__builtin_expect((P1 & 0x1ffffu) == 0 && inc == 0, 1)) {
-                    g_out = (P1 & 0xffe1ffffu) | ((((P1 >> 17) + kR) & 15u) << 17);   // calm, start == 1: only the block counter moves
+                    g_out = (P1 & 0xffe1ffffu) | ((((P1 >> 17) + R) & 15u) << 17);    // calm, start == 1: only the block counter moves
                 } else {
                     Guard g = unpack_guard(P1);
 #pragma unroll
-                    for (uint32_t j = 0; j < kR; ++j) (void)g.block_is_copy();       // no block was a copy: bookkeeping only (:19-27)
-                    g.penalty = ((t >> (kR - 1)) & 1u) ? g.start : 0u;
-                    g.prev = (inc >> (kR - 1)) & 1u;
+                    for (uint32_t j = 0; j < R; ++j) (void)g.block_is_copy();        // no block was a copy: bookkeeping only (:19-27)
+                    g.penalty = ((t >> (R - 1)) & 1u) ? g.start : 0u;
+                    g.prev = (inc >> (R - 1)) & 1u;
                     g_out = pack_guard(g);
                 }
                 opos = P0;
@@ -444,14 +538,26 @@ __global__ __launch_bounds__(kRotThreads) void chameleon_encode_rot(const uint8_
             Guard g = unpack_guard(P1);
             uint32_t sum = 0, unrest = 0;
             copy_mask = 0;
+            {
+                uint32_t sq[R];                                                   // (scratch copy and a rolled loop, as in rollback_round)
 #pragma unroll
-            for (uint32_t j = 0; j < kR; ++j) {
-                bool raw;
-                block_in_order(g, q[j], addr[j], mask[j], val[j], sig[j], raw);
-                copy_mask |= (raw ? 1u : 0u) << j;
-                unrest |= g.prev;
-                sum += raw ? kBlock : kSig + kBlock - 2u * (uint32_t)__builtin_popcountll(sig[j]);
+                for (uint32_t j = 0; j < R; ++j) sq[j] = q[j];
+#pragma nounroll
+                for (uint32_t j = 0; j < R; ++j) {
+                    const uint32_t qv = sq[j];
+                    uint32_t a, m, v;
+                    operands(qv, a, m, v);
+                    bool raw;
+                    uint64_t sg;
+                    block_in_order(g, qv, a, m, v, sg, raw);
+                    slo = lane == j ? (uint32_t)sg : slo;
+                    shi = lane == j ? (uint32_t)(sg >> 32) : shi;
+                    copy_mask |= (raw ? 1u : 0u) << j;
+                    unrest |= g.prev;
+                    sum += raw ? kBlock : kSig + kBlock - 2u * (uint32_t)__builtin_popcountll(sg);
+                }
             }
+            load_round(qn, r + W);
             opos = P0;
             const uint32_t stay_slow = (g.penalty | copy_mask | unrest) != 0 ? 1u : 0u;   // back to speculation only after a round without an incompressible or raw block
             if (lane == 0) {
@@ -462,29 +568,33 @@ __global__ __launch_bounds__(kRotThreads) void chameleon_encode_rot(const uint8_
             clk.mark(7);
             break;
         }
+      }
 
         // ---- the next round's quads must have landed before this round's stores go out behind them (memory operations retire in order) ----
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(qn[0]), "+v"(qn[1]), "+v"(qn[2]), "+v"(qn[3]), "+v"(qn[4]), "+v"(qn[5]), "+v"(qn[6]), "+v"(qn[7]) :: "memory");
+#pragma unroll
+        for (uint32_t j = 0; j < R; ++j) asm volatile("s_waitcnt vmcnt(0)" : "+v"(qn[j]) :: "memory");
         clk.mark(5);
 
         // ---- emit: records of this round and their block-index bytes ----
         if (__builtin_expect(copy_mask == 0, 1)) {
-            emit_round_coded(opos, idx ? idx + (uint64_t)r * kR : nullptr, sig);
+            emit_round_coded(opos, idx ? idx + (uint64_t)r * R : nullptr, slo, shi);
         } else {
             uint8_t* rec = dst + opos;
-            uint64_t idxw = 0;
+            uint32_t sq[R];
 #pragma unroll
-            for (uint32_t j = 0; j < kR; ++j) {
+            for (uint32_t j = 0; j < R; ++j) sq[j] = q[j];
+#pragma nounroll
+            for (uint32_t j = 0; j < R; ++j) {
                 const bool raw = (copy_mask >> j) & 1u;
-                const uint32_t nh = (uint32_t)__builtin_popcountll(sig[j]);
-                emit_block(rec, q[j], sig[j], raw);
-                idxw |= (uint64_t)(raw ? kIdxCopy : nh) << (8u * j);
+                const uint64_t sg = ((uint64_t)rlane(shi, j) << 32) | rlane(slo, j);
+                const uint32_t nh = (uint32_t)__builtin_popcountll(sg);
+                emit_block(rec, sq[j], sg, raw);
+                if (idx && lane == 0) idx[(uint64_t)r * R + j] = (uint8_t)(raw ? kIdxCopy : nh);
                 rec += raw ? kBlock : kSig + kBlock - 2u * nh;
             }
-            if (idx && lane < kR) idx[(uint64_t)r * kR + lane] = (uint8_t)(idxw >> (8u * lane));
         }
 #pragma unroll
-        for (uint32_t j = 0; j < kR; ++j) q[j] = qn[j];
+        for (uint32_t j = 0; j < R; ++j) q[j] = qn[j];
         clk.mark(6);
     }
     clk.flush(wave, lane);
@@ -503,19 +613,19 @@ __global__ __launch_bounds__(kRotThreads) void chameleon_encode_rot(const uint8_
         const u32x4 v = lds_peek4(sy + kSyO);
         Guard g = unpack_guard(rfl(v.w));
         uint64_t opos = rfl(v.z);
-        for (uint32_t b = nrounds * kR; b < nfull; ++b) {
+        for (uint32_t b = nrounds * R; b < nfull; ++b) {
             const uint32_t qv = *reinterpret_cast<const uint32_t*>(src + (uint64_t)b * kBlock + 4u * lane);
-            uint32_t P, a, m, vv;
-            operands(qv, P, a, m, vv);
-            uint64_t s;
+            uint32_t a, m, vv;
+            operands(qv, a, m, vv);
+            uint64_t sg;
             bool raw;
-            block_in_order(g, qv, a, m, vv, s, raw);
-            emit_block(dst + opos, qv, s, raw);
-            const uint32_t nh = (uint32_t)__builtin_popcountll(s);
+            block_in_order(g, qv, a, m, vv, sg, raw);
+            emit_block(dst + opos, qv, sg, raw);
+            const uint32_t nh = (uint32_t)__builtin_popcountll(sg);
             if (idx && lane == 0) idx[b] = (uint8_t)(raw ? kIdxCopy : nh);
             opos += raw ? kBlock : kSig + kBlock - 2u * nh;
         }
-        const uint64_t end = encode_ragged_block(src, len, nfull, dst, opos, g, idx, tbl, zmap, lane);
+        const uint64_t end = encode_ragged_block(src, len, nfull, dst, opos, g, idx, 0u, zmap, lane);
         if (lane == 0) sizes[chunk] = end;
     }
 }
@@ -523,17 +633,19 @@ __global__ __launch_bounds__(kRotThreads) void chameleon_encode_rot(const uint8_
 // ---------------------------------------------------------------------------------------------------------------
 // decode (index-fed): Codec::decode (codec/codec.rs:82-126), Chameleon::decode_plain / decode_map (chameleon.rs:56-68)
 // ---------------------------------------------------------------------------------------------------------------
-template <bool kProf>
-__global__ __launch_bounds__(kRotThreads) void chameleon_decode_rot(const uint8_t* __restrict__ in, const uint64_t* __restrict__ offsets,
-                                                                   const uint64_t* __restrict__ sizes, uint8_t* __restrict__ out,
-                                                                   uint64_t out_stride, uint64_t out_total, uint32_t exact,
-                                                                   const uint8_t* __restrict__ index, uint32_t* __restrict__ zmap_words,
-                                                                   uint64_t* __restrict__ produced, uint32_t* __restrict__ err, uint32_t tune,
-                                                                   uint64_t* __restrict__ prof) {
+template <int R, int W, bool kProf>
+__global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __restrict__ in, const uint64_t* __restrict__ offsets,
+                                                              const uint64_t* __restrict__ sizes, uint8_t* __restrict__ out,
+                                                              uint64_t out_stride, uint64_t out_total, uint32_t exact,
+                                                              const uint8_t* __restrict__ index, uint32_t* __restrict__ zmap_words,
+                                                              uint64_t* __restrict__ produced, uint32_t* __restrict__ err, uint32_t tune,
+                                                              uint64_t* __restrict__ prof) {
+    static_assert((R == 8 || R == 16) && (W == 8 || W == 12 || W == 16), "round = 8 or 16 records; 8, 12 or 16 waves");
+    constexpr uint32_t kThreads = W * 64, kScanThreads = W == 16 ? 1024 : 512, kPerThread = kRotMaxBlocks / kScanThreads;   // position scan: 16 or 32 index entries per thread
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = rfl(threadIdx.x >> 6);
     const uint64_t chunk = blockIdx.x;
-    PhaseClock<kProf> clk(blockIdx.x == 0 ? prof : nullptr);   // phases: 0 stage A, 1 stage B, 2 operands, 3 D wait, 4 exchange, 5 quads, 6 Z chain, 7 stores + rotate
+    PhaseClock<kProf> clk(blockIdx.x == 0 ? prof : nullptr);   // phases: 0 stage A, 1 stage B, 2 operands, 3 D wait, 4 exchange, 5 quads, 6 zero-entry map, 7 stores + rotate
     const uint8_t* src = in + offsets[chunk];
     const uint8_t* idx = index + chunk * (out_stride / kBlock);                 // this chunk's slice of the block index (4-byte aligned: launcher)
     const uint64_t elen64 = sizes[chunk];
@@ -543,134 +655,137 @@ __global__ __launch_bounds__(kRotThreads) void chameleon_decode_rot(const uint8_
     const uint32_t elen = elen64 > 0xfff00000ull ? 0xfff00000u : (uint32_t)elen64;   // 32-bit stream offsets in the pipeline; the in-order loop finishes longer streams
     const uint32_t nblk = (uint32_t)((cap + kBlock - 1) / kBlock);               // <= kRotMaxBlocks (launcher)
     const ZmapGlobal zmap{zmap_words + chunk * (kZmapBytes / 4)};
-    const uint32_t lds0 = lds_addr(smem), tbl = lds0, sy = lds0 + kDecSync;
+    // the table sits at LDS address 0 (this kernel has no static LDS): slot addresses need no base
+    const uint32_t sy = kDecSync;
     const bool late_token = (tune & 1u) != 0, no_sleep = (tune & 2u) != 0;
 
     {   // fresh dictionary, this chunk's zero-entry map, the block index into LDS
         uint4* p = reinterpret_cast<uint4*>(smem);
         const uint4 z = make_uint4(0, 0, 0, 0);
-        for (uint32_t i = threadIdx.x; i < kTableBytes / 16; i += kRotThreads) p[i] = z;
-        for (uint32_t i = threadIdx.x; i < kZmapBytes / 16; i += kRotThreads) reinterpret_cast<uint4*>(zmap.words)[i] = z;
+        for (uint32_t i = threadIdx.x; i < kTableBytes / 16; i += kThreads) p[i] = z;
+        for (uint32_t i = threadIdx.x; i < kZmapBytes / 16; i += kThreads) reinterpret_cast<uint4*>(zmap.words)[i] = z;
         const uint32_t* iw = reinterpret_cast<const uint32_t*>(idx);
         uint32_t* lw = reinterpret_cast<uint32_t*>(smem + kDecIdx);
-        for (uint32_t i = threadIdx.x; i < kRotMaxBlocks / 4; i += kRotThreads) lw[i] = i < (nblk + 3u) / 4u ? iw[i] : 0x7f7f7f7fu;   // beyond the chunk: "ragged" = stop
+        for (uint32_t i = threadIdx.x; i < kRotMaxBlocks / 4; i += kThreads) lw[i] = i < (nblk + 3u) / 4u ? iw[i] : 0x7f7f7f7fu;   // beyond the chunk: "ragged" = stop
         if (threadIdx.x == 0) {
             *reinterpret_cast<uint4*>(smem + kDecSync + kSyD) = make_uint4(0u, kNone, 0u, 0u);
-            *reinterpret_cast<uint4*>(smem + kDecSync + kSyZ) = make_uint4(0u, 0u, 0u, 0u);
             *reinterpret_cast<uint64_t*>(smem + kDecSync + kSyEnd) = ~0ull;
+            if (lds_addr(smem) != 0) atomicOr(err, kErrWatchdog);                 // (cannot happen: see above)
         }
-        if (threadIdx.x < kRotWaves) *reinterpret_cast<uint32_t*>(smem + kDecSync + kSyZdone + 4u * threadIdx.x) = 0u;
+        if (threadIdx.x < W) *reinterpret_cast<uint32_t*>(smem + kDecSync + kSyZdone + 4u * threadIdx.x) = 0u;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         // the map is used through L2 atomics by this work-group only (chameleon.hip)
     }
     __syncthreads();
 
-    // ---- record positions of the whole chunk: one prefix sum over the index (16 consecutive entries per thread).  A record is
+    // ---- record positions of the whole chunk: one prefix sum over the index (consecutive entries per thread).  A record is
     // pipelined only if it is complete and followed by at least 2 more stream bytes (a MAP item is fetched as a dword); the first
     // one that is not (ragged block, end of the stream, end of the output, an index that disagrees with the stream length) and
     // everything behind it is finished by the in-order loop (codec.rs:102-123).
     {
-        __shared__ uint32_t wave_sums[kRotWaves];
-        const uint32_t first = threadIdx.x * 16u;
-        const uint4 ev = *reinterpret_cast<const uint4*>(smem + kDecIdx + first);
-        const uint32_t ew[4] = {ev.x, ev.y, ev.z, ev.w};
-        auto entry_at = [&](uint32_t k) -> uint32_t { return (ew[k >> 2] >> (8u * (k & 3u))) & 0xffu; };
+        uint32_t* wave_sums = reinterpret_cast<uint32_t*>(smem + kDecSync + kSyWsum);
+        const bool scans = threadIdx.x < kScanThreads;                            // (with 12 waves the first 8 do the scan)
+        const uint32_t first = threadIdx.x * kPerThread;
         auto rec_len = [&](uint32_t ent) -> uint32_t { return (ent & kIdxCopy) ? kBlock : kSig + kBlock - 2u * (ent & 0x7fu); };
         uint32_t mine = 0;
+        if (scans) {
 #pragma unroll
-        for (uint32_t k = 0; k < 16; ++k) mine += rec_len(entry_at(k));
+            for (uint32_t k = 0; k < kPerThread; ++k) mine += rec_len(smem[kDecIdx + first + k]);
+        }
         uint32_t incl = mine;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const uint32_t o = bperm(lane >= (uint32_t)d ? lane - d : lane, incl);
             if (lane >= (uint32_t)d) incl += o;
         }
-        if (lane == 63) wave_sums[wave] = incl;
+        if (lane == 63 && scans) wave_sums[wave] = incl;
         __syncthreads();
-        uint32_t pos = incl - mine;
-        for (uint32_t w = 0; w < wave; ++w) pos += wave_sums[w];
-        uint64_t stop_key = ~0ull;
+        if (scans) {
+            uint32_t pos = incl - mine;
+            for (uint32_t w = 0; w < wave; ++w) pos += wave_sums[w];
+            uint64_t stop_key = ~0ull;
 #pragma unroll
-        for (uint32_t k = 0; k < 16; ++k) {
-            const uint32_t i = first + k, ent = entry_at(k), l = rec_len(ent);
-            if ((k & 7u) == 0) *reinterpret_cast<uint32_t*>(smem + kDecPos + (i / kR) * 4u) = pos;
-            const bool stop = (ent & 0x7fu) == kIdxRagged || i >= nblk || ((uint64_t)i + 1) * kBlock > cap || pos >= elen || elen - pos < l + 2u;
-            if (stop && stop_key == ~0ull) stop_key = ((uint64_t)i << 33) | ((uint64_t)((ent & kIdxCopy) && i < nblk ? 1u : 0u) << 32) | pos;
-            pos += l;
+            for (uint32_t k = 0; k < kPerThread; ++k) {
+                const uint32_t i = first + k, ent = smem[kDecIdx + i], l = rec_len(ent);
+                if ((k & (R - 1u)) == 0) *reinterpret_cast<uint32_t*>(smem + kDecPos + (i / R) * 4u) = pos;
+                const bool stop = (ent & 0x7fu) == kIdxRagged || i >= nblk || ((uint64_t)i + 1) * kBlock > cap || pos >= elen || elen - pos < l + 2u;
+                if (stop && stop_key == ~0ull) stop_key = ((uint64_t)i << 33) | ((uint64_t)((ent & kIdxCopy) && i < nblk ? 1u : 0u) << 32) | pos;
+                pos += l;
+            }
+            if (threadIdx.x == kScanThreads - 1 && stop_key == ~0ull) stop_key = ((uint64_t)kRotMaxBlocks << 33) | pos;
+            if (stop_key != ~0ull) atomicMin(reinterpret_cast<unsigned long long*>(smem + kDecSync + kSyEnd), (unsigned long long)stop_key);
         }
-        if (threadIdx.x == kRotThreads - 1 && stop_key == ~0ull) stop_key = ((uint64_t)kRotMaxBlocks << 33) | pos;
-        if (stop_key != ~0ull) atomicMin(reinterpret_cast<unsigned long long*>(smem + kDecSync + kSyEnd), (unsigned long long)stop_key);
     }
     __syncthreads();
     const uint64_t end_key = *reinterpret_cast<const uint64_t*>(smem + kDecSync + kSyEnd);
-    const uint32_t nvalid = rfl((uint32_t)(end_key >> 33));                      // records [0, nvalid) go through the pipeline
-    const uint32_t npr = (nvalid + kR - 1) / kR;
+    const uint32_t nvalid = rfl((uint32_t)(end_key >> 33));                      // records [0, nvalid) are complete and followed by more data
+    const uint32_t npr = nvalid / R;                                              // whole rounds: these rotate; the rest (< R records + the ragged end) is the epilogue
 
-    // ---- three-stage software pipeline per wave: A(x+32) signature loads | B(x+16) item loads | C(x) dictionary + stores ----
-    // Per round in flight: lane j < 8 holds record j's position and (one 8-byte load) its signature; after stage B every lane
-    // holds its 8 items and its 8 MAP/PLAIN flags (bit j of `hits`).
-    struct Meta { uint32_t posv, cnt; u32x2 sgv; uint32_t n, copy_mask; };
-    auto stage_a = [&](uint32_t x, Meta& m) {                                    // positions of round x; signatures requested
-        m.n = 0; m.copy_mask = 0; m.posv = 0; m.cnt = 0; m.sgv = u32x2{0u, 0u};
-        if (x >= npr) return;
-        const u32x2 ent = lds_peek2(lds0 + kDecIdx + x * kR);
-        const uint32_t base = rfl(lds_peek1(lds0 + kDecPos + x * 4u));
-        const uint64_t ents = ((uint64_t)rfl(ent.y) << 32) | rfl(ent.x);
-        m.n = nvalid - x * kR < kR ? nvalid - x * kR : kR;
-        const uint32_t e = (uint32_t)(ents >> (8u * (lane & 7u))) & 0xffu;       // lane j (and its images): entry of record j
+    // ---- three-stage software pipeline per wave: A(x + 2W) signature loads | B(x + W) item loads | C(x) dictionary + stores ----
+    // Per round in flight: lane j < R holds record j's position and (one 8-byte load) its signature; after stage B every lane
+    // holds its R items and its R MAP/PLAIN flags (bit j of `hits`).  All rounds are whole, so every stage is straight-line code:
+    // the loads of a stage leave back to back and nothing waits for a store.
+    struct Meta { uint32_t posv, cnt; u32x2 sgv; uint32_t copy_mask; };
+    // (Rounds past the end are clamped to the last one instead of skipped — a few redundant loads at the end of a chunk — so that the
+    // number and order of memory operations per iteration is fixed and the compiler's waits count exactly.)
+    auto stage_a = [&](uint32_t xr, Meta& m) {                                   // positions of round x; signatures requested
+        const uint32_t x = xr < npr ? xr : npr - 1u;
+        const uint32_t e = smem[kDecIdx + x * R + (lane & (R - 1u))];             // lane j (and its images): entry of record j
+        const uint32_t base = rfl(lds_peek1(kDecPos + x * 4u));
         const uint32_t mylen = (e & kIdxCopy) ? kBlock : kSig + kBlock - 2u * (e & 0x7fu);
-        uint32_t incl = mylen;                                                    // prefix over rows of 8 lanes
+        uint32_t incl = mylen;                                                    // prefix within rows of 16 lanes
         incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xf, 0xf, true);   // row_shr:1
         incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xf, 0xf, true);   // row_shr:2
         incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xf, 0xf, true);   // row_shr:4
+        if (R > 8) incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xf, 0xf, true);   // row_shr:8
         m.posv = base + incl - mylen;
-        m.copy_mask = (uint32_t)ballot64((e & kIdxCopy) != 0 && lane < m.n);
-        if (lane < m.n && !(e & kIdxCopy)) m.sgv = *reinterpret_cast<const u32x2_u*>(src + m.posv);     // codec.rs:28-31
+        m.copy_mask = (uint32_t)ballot64((e & kIdxCopy) != 0 && lane < R);
+        m.sgv = *reinterpret_cast<const u32x2_u*>(src + ((lane < R && !(e & kIdxCopy)) ? m.posv : base));   // codec.rs:28-31 (idle lanes: any valid address)
         m.cnt = e & 0x7fu;                                                        // the entry's MAP count: checked against the signature in stage B
     };
     uint32_t bad_index = 0;
-    auto stage_b = [&](const Meta& m, uint32_t& hits, uint32_t (&item)[kR]) {   // signatures -> MAP/PLAIN flags, item loads
+    auto stage_b = [&](const Meta& m, uint32_t& hits, uint32_t (&item)[R]) {    // signatures -> MAP/PLAIN flags, item loads
         hits = 0;
 #pragma unroll
-        for (uint32_t j = 0; j < kR; ++j) {
-            item[j] = 0;
-            if (j < m.n) {
-                const uint32_t pos = rlane_u(m.posv, (int)j);
-                if ((m.copy_mask >> j) & 1u) {
-                    item[j] = ld32u(src + pos + 4u * lane);                       // codec.rs:89-91: raw block
-                } else {
-                    const uint64_t sig = ((uint64_t)rlane_u(m.sgv.y, (int)j) << 32) | rlane_u(m.sgv.x, (int)j);
-                    // the index must agree with the stream it describes: a record's MAP count is its signature's popcount
-                    bad_index |= (uint32_t)__builtin_popcountll(sig) != rlane_u(m.cnt, (int)j) ? 1u : 0u;
-                    hits |= (uint32_t)((sig >> lane) & 1ull) << j;
-                    item[j] = ld32u(src + pos + kSig + 4u * lane - 2u * mbcnt64(sig));
-                }
-            }
+        for (uint32_t j = 0; j < R; ++j) {
+            const uint32_t pos = rlane_u(m.posv, (int)j);
+            const bool raw = (m.copy_mask >> j) & 1u;                             // codec.rs:89-91: 256 raw bytes, no signature
+            const uint64_t sg = raw ? 0ull : ((uint64_t)rlane_u(m.sgv.y, (int)j) << 32) | rlane_u(m.sgv.x, (int)j);
+            // the index must agree with the stream it describes: a record's MAP count is its signature's popcount
+            bad_index |= (!raw && (uint32_t)__builtin_popcountll(sg) != rlane_u(m.cnt, (int)j)) ? 1u : 0u;
+            hits |= (uint32_t)((sg >> lane) & 1ull) << j;
+            item[j] = ld32u(src + pos + (raw ? 0u : kSig) + 4u * lane - 2u * mbcnt64(sg));
         }
     };
 
     Meta ma, mb, mc;
-    uint32_t itemb[kR], itemc[kR], hitsb = 0, hitsc = 0;
-    // prologue: B(w) needs A(w); A(w + 16) goes out behind it
-    stage_a(wave, mb);
-    stage_b(mb, hitsc, itemc);
-    mc = mb;
-    stage_a(wave + kRotWaves, mb);
+    ma.posv = mb.posv = mc.posv = 0; ma.cnt = mb.cnt = mc.cnt = 0; ma.copy_mask = mb.copy_mask = mc.copy_mask = 0;
+    ma.sgv = mb.sgv = mc.sgv = u32x2{0u, 0u};
+    uint32_t itemb[R], itemc[R], hitsb = 0, hitsc = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < R; ++j) { itemb[j] = 0; itemc[j] = 0; }
+    // prologue: B(w) needs A(w); A(w + W) goes out behind it
+    if (npr) {
+        stage_a(wave, mb);
+        stage_b(mb, hitsc, itemc);
+        mc = mb;
+        stage_a(wave + W, mb);
+    }
 
-    uint32_t addr[kR], mask[kR], val[kR], ret[kR];
-    for (uint32_t x = wave; x < npr; x += kRotWaves) {
+    uint32_t ra[R], mask[R], val[R];
+    for (uint32_t x = wave; x < npr; x += W) {
         clk.start();
         // (B first: what it waits for — the signatures requested one iteration ago — is older than anything issued since, so the
         // wait does not cover a load that has just left)
         stage_b(mb, hitsb, itemb);
         clk.mark(1);
-        stage_a(x + 2 * kRotWaves, ma);
+        stage_a(x + 2 * W, ma);
         clk.mark(0);
 
         // ---- C: operands of the dictionary step ----
-        const uint32_t coded_mask = ((1u << mc.n) - 1u) & ~mc.copy_mask;          // records that go through the dictionary
+        const uint32_t coded_mask = ((1u << R) - 1u) & ~mc.copy_mask;             // records that go through the dictionary
         uint32_t zacc = 0;
 #pragma unroll
-        for (uint32_t j = 0; j < kR; ++j) {
+        for (uint32_t j = 0; j < R; ++j) {
             const bool coded = (coded_mask >> j) & 1u;
             const bool hit = (hitsc >> j) & 1u;
             const uint32_t qv = itemc[j];
@@ -679,16 +794,13 @@ __global__ __launch_bounds__(kRotThreads) void chameleon_decode_rot(const uint8_
             const uint32_t sh = (h & 1u) << 4;
             const uint32_t e = stored_entry(qv, P);
             const bool writes = coded && !hit;                                    // PLAIN writes its entry (chameleon.rs:56-61), MAP only reads
-            addr[j] = coded ? tbl + ((h >> 1) << 2) : tbl + 4u * lane;            // raw / absent records: a harmless conflict-free read
+            ra[j] = coded ? ((h >> 1) << 2) : 4u * lane;                          // raw / absent records: a harmless conflict-free read
             mask[j] = writes ? (0xffffu << sh) : 0u;
             val[j] = writes ? (e << sh) : 0u;
             zacc |= (writes && e == 0 && h != 0) ? 1u : 0u;
         }
-        // (the operands are complete here, before the wait for the token: nothing of this may be scheduled into the critical section)
-        asm volatile("" : "+v"(addr[0]), "+v"(addr[1]), "+v"(addr[2]), "+v"(addr[3]), "+v"(addr[4]), "+v"(addr[5]), "+v"(addr[6]), "+v"(addr[7]),
-                          "+v"(mask[0]), "+v"(mask[1]), "+v"(mask[2]), "+v"(mask[3]), "+v"(mask[4]), "+v"(mask[5]), "+v"(mask[6]), "+v"(mask[7]),
-                          "+v"(val[0]), "+v"(val[1]), "+v"(val[2]), "+v"(val[3]), "+v"(val[4]), "+v"(val[5]), "+v"(val[6]), "+v"(val[7]));
         const uint32_t tokaddr = lane == 0 ? sy + kSyD : sy + kSySink + 4u * lane;
+        pin_operands<R>(ra, mask, val);                                           // complete before the wait for the token
         clk.mark(2);
         clk.stamp(x, 0, lane);
         // ---- D chain ----
@@ -703,48 +815,48 @@ __global__ __launch_bounds__(kRotThreads) void chameleon_decode_rot(const uint8_
         clk.mark(3);
         clk.stamp(x, 1, lane);
         __builtin_amdgcn_s_setprio(3);
-        exchange_round(ret, addr, mask, val, tokaddr, x + 1u, late_token);
+        exchange_tied<R>(ra, mask, val, tokaddr, x + 1u, late_token);
         __builtin_amdgcn_s_setprio(0);
         clk.mark(4);
         clk.stamp(x, 2, lane);
 
-        // ---- what each slot holds at this lane's turn -> quads (in place of the items) ----
+        // ---- what each slot holds at this lane's turn -> quads (in place of the answers) ----
 #pragma unroll
-        for (uint32_t j = 0; j < kR; ++j) {
+        for (uint32_t j = 0; j < R; ++j) {
             const bool maps = ((coded_mask & hitsc) >> j) & 1u;
             const uint32_t h = itemc[j] & 0xffffu;
-            const uint32_t cur = (ret[j] >> ((h & 1u) << 4)) & 0xffffu;
+            const uint32_t cur = (ra[j] >> ((h & 1u) << 4)) & 0xffffu;
             zacc |= (maps && cur == 0 && h != 0) ? 2u : 0u;                       // MAP of a slot holding 0: never written, or a genuine zero entry?
-            ret[j] = maps ? entry_to_quad(h, cur) : itemc[j];
+            ra[j] = maps ? entry_to_quad(h, cur) : itemc[j];
         }
         clk.mark(5);
         // ---- zero-entry map, in stream order (rare: stored entries are salted).  A round with no such quad only reports "done"; one that
-        // has any first waits until every earlier round has reported (wave w' owns the rounds = w' mod 16). ----
+        // has any first waits until every earlier round has reported (wave w' owns the rounds = w' mod W). ----
         if (__builtin_expect(ballot64(zacc != 0) != 0, 0)) {
             for (uint32_t spins = 0;;) {
-                const uint32_t wv = lane & (kRotWaves - 1u);
-                const uint32_t d = (x - wv) & (kRotWaves - 1u);                   // wave wv's last round before x is x - d
+                const uint32_t wv = lane % W;
+                const uint32_t d = (wave + W - wv) % W;                           // wave wv's last round before x is x - d
                 const uint32_t done = lds_peek1(sy + kSyZdone + 4u * wv);        // (rounds finished: last round + 1)
                 if (ballot64(d != 0 && x >= d && done < x - d + 1u) == 0) break;
                 if (rfl(lds_peek1(sy + kSyD)) == kPoison) wave_exit();
                 watchdog(spins, sy, err, lane);
             }
 #pragma unroll
-            for (uint32_t j = 0; j < kR; ++j) {
+            for (uint32_t j = 0; j < R; ++j) {
                 const bool coded = (coded_mask >> j) & 1u;
                 const bool hit = (hitsc >> j) & 1u;
                 const uint32_t qv = itemc[j];
                 const uint32_t P = qv * kHashMul;
                 const uint32_t h = hit ? (qv & 0xffffu) : (P >> 16);
                 const bool zset = coded && !hit && stored_entry(qv, P) == 0 && h != 0;
-                const bool ztest = coded && hit && h != 0 && ret[j] == entry_to_quad(h, 0);   // the slot held stored entry 0
+                const bool ztest = coded && hit && h != 0 && ra[j] == entry_to_quad(h, 0);   // the slot held stored entry 0
                 uint64_t todo = ballot64(zset || ztest);
                 while (todo) {                                                    // ascending lane == stream order
                     const uint32_t l = (uint32_t)__builtin_ctzll(todo);
                     todo &= todo - 1;
                     if (lane == l) {
                         if (zset) zmap.set(h);
-                        else if (!zmap.test(h)) ret[j] = 0;                       // chameleon.rs:64-68 on a never-written (zero) word
+                        else if (!zmap.test(h)) ra[j] = 0;                        // chameleon.rs:64-68 on a never-written (zero) word
                     }
                 }
             }
@@ -753,27 +865,34 @@ __global__ __launch_bounds__(kRotThreads) void chameleon_decode_rot(const uint8_
         clk.mark(6);
 
         // ---- stores: 256 coalesced bytes per record ----
-        uint8_t* base = dst + (uint64_t)x * kR * kBlock;
+        uint8_t* base = dst + (uint64_t)x * R * kBlock;
 #pragma unroll
-        for (uint32_t j = 0; j < kR; ++j) {
-            if (j < mc.n) *reinterpret_cast<uint32_t*>(base + j * kBlock + 4u * lane) = ret[j];
-        }
+        for (uint32_t j = 0; j < R; ++j) *reinterpret_cast<uint32_t*>(base + j * kBlock + 4u * lane) = ra[j];
         // ---- rotate the pipeline ----
         mc = mb; mb = ma; hitsc = hitsb;
 #pragma unroll
-        for (uint32_t j = 0; j < kR; ++j) itemc[j] = itemb[j];
+        for (uint32_t j = 0; j < R; ++j) itemc[j] = itemb[j];
         clk.mark(7);
     }
     clk.flush(wave, lane);
 
     if (bad_index && lane == 0) atomicOr(err, 8u);
     wg_barrier();
-    // ---- the ragged end of the stream, in order, on one wave (codec.rs:102-123) ----
+    // ---- epilogue on one wave, in order: the records of the last, partial round — one call per record, the block's raw-copy flag
+    // from the index standing in for the FSM — then the ragged end of the stream (codec.rs:102-123) ----
     if (wave == 0) {
         Guard g;
+        uint64_t ip = npr * R < nvalid ? rfl(lds_peek1(kDecPos + npr * 4u)) : (uint32_t)end_key, op = (uint64_t)npr * R * kBlock;
+        bool bad = false;
+        for (uint32_t i = npr * R; i < nvalid && !bad; ++i) {
+            const uint32_t ent = smem[kDecIdx + i];
+            const uint64_t rec_end = ip + ((ent & kIdxCopy) ? kBlock : kSig + kBlock - 2u * (ent & 0x7fu));
+            g.penalty = (ent & kIdxCopy) ? 1u : 0u; g.start = 1; g.prev = 0; g.counter = 1;
+            bad = !decode_in_order(src, rec_end, dst, cap, g, ip, op, 0u, zmap, lane) || ip != rec_end;
+        }
         g.penalty = (uint32_t)(end_key >> 32) & 1u; g.start = 1; g.prev = 0; g.counter = 1;    // the stopping block's raw-copy flag is all that is left of the FSM
-        uint64_t ip = (uint32_t)end_key, op = (uint64_t)nvalid * kBlock;
-        bool bad = !decode_in_order(src, elen64, dst, cap, g, ip, op, tbl, zmap, lane);
+        if (!bad && (ip != (uint32_t)end_key || op != (uint64_t)nvalid * kBlock)) bad = true;
+        if (!bad) bad = !decode_in_order(src, elen64, dst, cap, g, ip, op, 0u, zmap, lane);
         if (exact && !bad && op != cap) bad = true;
         if (lane == 0) {
             produced[chunk] = op;
@@ -920,10 +1039,18 @@ bool rotor_encode_eligible(const uint8_t* d_in, uint64_t total, uint64_t chunk_b
 hipError_t launch_rotor_encode(const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_out, uint64_t out_stride,
                                uint64_t* d_sizes, uint8_t* d_index, uint32_t* d_err, hipStream_t stream) {
     uint64_t* prof = rot_prof_buffer();
-    auto kernel = prof ? chameleon_encode_rot<true> : chameleon_encode_rot<false>;
+    // geometry (DENSITY_HIP_TUNE bits 2..4, 0 = default): 1 = rounds of 8 blocks on 16 waves, 2 = 16 x 12, 3 = 16 x 8 (default: the longer
+    // round amortises the hand-off, 8 waves have the registers for it), 4 = 8 x 12, 5 = 8 x 8
+    const uint32_t sel = (rot_tune() >> 2) & 7u, geo = sel == 0 ? 2u : sel == 1 ? 0u : sel == 2 ? 1u : sel == 3 ? 2u : sel == 4 ? 3u : 4u;
+    const uint32_t waves = geo == 0 ? 16 : (geo == 1 || geo == 3) ? 12 : 8;
+    auto kernel = geo == 1 ? (prof ? chameleon_encode_rot<16, 12, true> : chameleon_encode_rot<16, 12, false>)
+                : geo == 2 ? (prof ? chameleon_encode_rot<16, 8, true> : chameleon_encode_rot<16, 8, false>)
+                : geo == 3 ? (prof ? chameleon_encode_rot<8, 12, true> : chameleon_encode_rot<8, 12, false>)
+                : geo == 4 ? (prof ? chameleon_encode_rot<8, 8, true> : chameleon_encode_rot<8, 8, false>)
+                           : (prof ? chameleon_encode_rot<8, 16, true> : chameleon_encode_rot<8, 16, false>);
     hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEncLds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kernel, dim3(n_chunks), dim3(kRotThreads), kEncLds, stream, d_in, total, chunk_bytes, d_out, out_stride, d_sizes, d_index, d_err, rot_tune(), prof);
+    hipLaunchKernelGGL(kernel, dim3(n_chunks), dim3(waves * 64), kEncLds, stream, d_in, total, chunk_bytes, d_out, out_stride, d_sizes, d_index, d_err, rot_tune(), prof);
     rot_prof_report("encode", "hash | D wait | exchange | signatures | O wait+commit | load wait | emit | in-order rounds", prof, stream);
     return hipGetLastError();
 }
@@ -938,10 +1065,18 @@ hipError_t launch_rotor_decode(const uint8_t* d_in, const uint64_t* d_offsets, c
                                uint64_t out_stride, uint64_t out_total, bool exact, const uint8_t* d_index, uint32_t* d_zmap,
                                uint64_t* d_produced, uint32_t* d_err, hipStream_t stream) {
     uint64_t* prof = rot_prof_buffer();
-    auto kernel = prof ? chameleon_decode_rot<true> : chameleon_decode_rot<false>;
-    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDecLds + 64);
+    // geometry (DENSITY_HIP_TUNE bits 5..7, 0 = default): the decoder's waves carry two rounds of loads in flight, so 16 waves with rounds of 8
+    // records is its best point; 1..5 as for the encoder
+    const uint32_t sel = (rot_tune() >> 5) & 7u, geo = sel <= 1 ? 0u : sel == 2 ? 1u : sel == 3 ? 2u : sel == 4 ? 3u : 4u;
+    const uint32_t waves = geo == 0 ? 16 : (geo == 1 || geo == 3) ? 12 : 8;
+    auto kernel = geo == 1 ? (prof ? chameleon_decode_rot<16, 12, true> : chameleon_decode_rot<16, 12, false>)
+                : geo == 2 ? (prof ? chameleon_decode_rot<16, 8, true> : chameleon_decode_rot<16, 8, false>)
+                : geo == 3 ? (prof ? chameleon_decode_rot<8, 12, true> : chameleon_decode_rot<8, 12, false>)
+                : geo == 4 ? (prof ? chameleon_decode_rot<8, 8, true> : chameleon_decode_rot<8, 8, false>)
+                           : (prof ? chameleon_decode_rot<8, 16, true> : chameleon_decode_rot<8, 16, false>);
+    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDecLds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kernel, dim3(n_chunks), dim3(kRotThreads), kDecLds, stream, d_in, d_offsets, d_sizes, d_out, out_stride, out_total,
+    hipLaunchKernelGGL(kernel, dim3(n_chunks), dim3(waves * 64), kDecLds, stream, d_in, d_offsets, d_sizes, d_out, out_stride, out_total,
                        exact ? 1u : 0u, d_index, d_zmap, d_produced, d_err, rot_tune(), prof);
     rot_prof_report("decode", "stage A | stage B | operands | D wait | exchange | quads | Z chain | stores", prof, stream);
     return hipGetLastError();

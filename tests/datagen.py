@@ -99,12 +99,12 @@ def low_zero_quads(n_quads, seed=4):
 
 def salted_zero_quads(n_quads, seed=7):
     """Quads whose STORED dictionary entry is 0 outside slot 0 in the GPU table (packed entry == slot_salt(slot), see
-    density_amd/csrc/chameleon.hip): the one value that aliases a never-written slot and goes through the zero-entry map.
+    density_amd/csrc/chameleon_dev.hpp): the one value that aliases a never-written slot and goes through the zero-entry map.
     Mixed with ordinary quads and repeats so that hits, misses and overwrites of such slots all occur."""
     inv = pow(0x9D6EF916 >> 1, -1, 1 << 31)
     rng = np.random.default_rng(seed)
     hs = rng.integers(1, 1 << 16, size=40, dtype=np.uint64)
-    salt = ((hs * np.uint64(0x9E5B)) ^ (hs >> np.uint64(5))) & np.uint64(0xFFFF)
+    salt = (hs * np.uint64(0x9E5B)) & np.uint64(0xFFFF)           # chameleon_dev.hpp::slot_salt
     pfull = (hs << np.uint64(16)) | (salt & np.uint64(0xFFFE))
     special = (((pfull >> np.uint64(1)) * np.uint64(inv)) & np.uint64(0x7FFFFFFF)) | ((salt & np.uint64(1)) << np.uint64(31))
     # sanity: they hash to their slot
