@@ -6,15 +6,18 @@ resident in HBM).  `value` = uncompressed bytes processed by ALL ranks / wall ti
 (= N / (t_enc + t_dec), the round-trip throughput of SURVEY.md §8d, matching divan's BytesCount of the uncompressed
 slice in both directions, benches/density.rs:29,48).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--size BYTES] [--chunk BYTES]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--size BYTES] [--chunk BYTES] [--algo chameleon|cheetah|lion]
 
-N > 1 is launched by the driver through torch.distributed.run (one rank per GPU, RCCL); the path shards by chunks with
-no data-path collective, so scaling is weak: every rank encodes/decodes its own buffer.
+N > 1: one rank per GPU over RCCL.  Launched by the driver through torch.distributed.run, or — when WORLD_SIZE is not set —
+by this script itself, which re-executes under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N`.  The path
+shards by chunks with no data-path collective, so scaling is weak: every rank encodes/decodes its own buffer.
+`--no-gpu` is a dry mode for the CPU test of the launcher and of the distributed bookkeeping (gloo, tiny oracle-built
+containers, no timing claims).
 """
 import argparse
-import ctypes
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -25,11 +28,13 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+METRIC = "MB/s encode+decode (round-trip) per GPU + compression ratio, dickens/enwik8"
 
 
-def cpu_baseline(host, chunk, sample_bytes, algo="chameleon", reps=3):
+def cpu_baseline(host, chunk, sample_bytes, algo="chameleon", reps=3, gpu_payloads=None):
     """Times the CPU oracle (C restatement of the Rust reference, single thread like the reference's bench) on a bounded
-    sample of the same workload.  Checker/baseline only — never part of the measured GPU path."""
+    sample of the same workload.  Checker/baseline only — never part of the measured GPU path.  `gpu_payloads`: the GPU's chunk
+    streams of the same buffer; every chunk the all-cores leg encodes is compared with them (full-coverage parity at bench size)."""
     from oracle import pyoracle
     n = min(sample_bytes, host.size)
     src = np.ascontiguousarray(host[:n])
@@ -76,9 +81,114 @@ def cpu_baseline(host, chunk, sample_bytes, algo="chameleon", reps=3):
         assert np.array_equal(dec, src)
         out["all_cores"] = {"value": round(n / (t2 - t0) / 1e6, 1), "unit": "MB/s", "cores": ncpu,
                             "ratio_chunked": round(n / sum(sizes), 4), "chunk": chunk}
+        if gpu_payloads is not None:
+            bad = [i for i in range(nchunks) if bytes(encs[i][:sizes[i]]) != gpu_payloads[i]]
+            assert not bad, f"GPU chunk streams differ from the oracle: chunks {bad[:8]}"
+            out["all_cores"]["gpu_chunks_compared_bit_exact"] = nchunks
+    except AssertionError:
+        raise
     except Exception as ex:  # pragma: no cover
         out["all_cores"] = {"error": str(ex)}
     return out
+
+
+def host_api_rates(algo, host, chunk, sample_bytes):
+    """PCIe-inclusive rates of the host-pointer entry points on a bounded sample (never `value`): the reference's own symbols
+    (chameleon_encode / _decode: ONE reference stream = one work-group, include/density_hip.h section 1) and the container API."""
+    import time as _t
+    from density_amd import BY_NAME, container
+    n = min(sample_bytes, host.size)
+    src = np.ascontiguousarray(host[:n])
+    codec = BY_NAME[algo]
+    out = {"sample_bytes": int(n)}
+    enc = np.empty(codec.safe_encode_buffer_size(n), dtype=np.uint8)
+    dec = np.empty(n, dtype=np.uint8)
+    codec.encode(src, enc)                                   # warm (staging buffers, self-test)
+    t0 = _t.perf_counter(); m = codec.encode(src, enc); t1 = _t.perf_counter()
+    k = codec.decode(enc[:m], dec); t2 = _t.perf_counter()
+    assert k == n and np.array_equal(dec, src)
+    out["reference_symbols"] = {"encode_MBps": round(n / (t1 - t0) / 1e6, 1), "decode_MBps": round(n / (t2 - t1) / 1e6, 1),
+                                "round_trip_MBps": round(n / (t2 - t0) / 1e6, 1), "note": "one stream = one work-group; H2D + kernel + D2H"}
+    cont = np.empty(container.container_bound(algo, n, chunk), dtype=np.uint8)
+    container.encode(algo, src, cont, chunk)                 # warm
+    t0 = _t.perf_counter(); cn = container.encode(algo, src, cont, chunk); t1 = _t.perf_counter()
+    k = container.decode(cont[:cn], dec); t2 = _t.perf_counter()
+    assert k == n and np.array_equal(dec, src)
+    out["container"] = {"encode_MBps": round(n / (t1 - t0) / 1e6, 1), "decode_MBps": round(n / (t2 - t1) / 1e6, 1),
+                        "round_trip_MBps": round(n / (t2 - t0) / 1e6, 1), "chunk": chunk, "note": "chunked container; H2D + kernels + D2H"}
+    return out
+
+
+def size_sweep(container, algo, x, sizes, steps=5):
+    """Round-trip throughput of smaller inputs with the automatic chunk size (density_hip_auto_chunk): a chunk is one work-group, so inputs with
+    fewer chunks than CUs cannot fill the device; labelled cache-resident vs HBM-bound as SURVEY.md §8d asks."""
+    import torch
+    from density_amd import _lib
+    out = []
+    stream = torch.cuda.current_stream().cuda_stream
+    for n in sizes:
+        if n > x.numel():
+            continue
+        chunk = int(_lib.lib().density_hip_auto_chunk(n))
+        cap = container.container_bound(algo, n, chunk)
+        cont = torch.empty(cap, dtype=torch.uint8, device="cuda")
+        back = torch.empty(n, dtype=torch.uint8, device="cuda")
+        hdr = container.encode_device(algo, x.data_ptr(), n, cont.data_ptr(), cap, chunk, stream=stream)
+        assert container.decode_device(cont.data_ptr(), hdr.container_len, back.data_ptr(), n, header=hdr, stream=stream) == n and torch.equal(back, x[:n])
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(steps):
+            container.encode_device(algo, x.data_ptr(), n, cont.data_ptr(), cap, chunk, stream=stream, want_header=False)
+            container.decode_device(cont.data_ptr(), hdr.container_len, back.data_ptr(), n, header=hdr, stream=stream, sync=False)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
+        out.append({"bytes": n, "auto_chunk": chunk, "n_chunks": int(hdr.n_chunks), "round_trip_MBps": round(n / dt / 1e6, 1),
+                    "compression_ratio": round(n / hdr.container_len, 4),
+                    "residency": "HBM-bound" if 2 * n > (256 << 20) else "cache-resident (256 MiB Infinity Cache)"})
+    return out
+
+
+def self_launch(args):
+    """--gpus N without a torchrun environment: start the N ranks ourselves (one node, 127.0.0.1 rendezvous)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args, world, rank):
+    """--no-gpu: the launcher and the distributed bookkeeping on CPU tensors under gloo (tests/test_parallel_gloo.py).  Local containers
+    come from the oracle (test infrastructure); nothing is timed."""
+    import torch
+    import torch.distributed as dist
+    import datagen
+    from density_amd import parallel
+    from test_parallel_gloo import cpu_container
+    n, chunk = min(args.size, 64 << 10), 4096
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        assert dist.get_world_size() == world
+    data = datagen.mixed(n, seed=100 + rank)
+    local = torch.frombuffer(bytearray(cpu_container(data, chunk)), dtype=torch.uint8)
+    hdr, table, index, payload = parallel.parse_local(local)
+    n_gpus = 1
+    glob = {"container_len": hdr["container_len"]}
+    if world > 1:
+        lay = parallel.exchange_layout(hdr["n_chunks"], payload.numel(), n, torch.device("cpu"))
+        glob = parallel.global_layout(lay, chunk, hdr["flags"])
+        merged = parallel.concat_to_rank0(local, chunk)
+        assert (merged is not None) == (rank == 0)
+        n_gpus = dist.get_world_size()
+    if rank == 0:
+        print(json.dumps({"metric": METRIC, "value": 0.0, "unit": "MB/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+                          "dry_run": True, "scaling": "weak", "global_container_bytes": int(glob["container_len"])}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
@@ -89,12 +199,25 @@ def main():
     ap.add_argument("--size", type=int, default=1 << 30, help="bytes per GPU (default 1 GiB = BASELINE config 2)")
     ap.add_argument("--chunk", type=int, default=1 << 20)
     ap.add_argument("--cpu-sample", type=int, default=256 << 20)
-    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--host-sample", type=int, default=64 << 20, help="bytes for the PCIe-inclusive host-API rates")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline and the host-API legs")
+    ap.add_argument("--no-gpu", action="store_true", help="dry mode: launcher + distributed bookkeeping on CPU/gloo (tests)")
     ap.add_argument("--concat", action="store_true", help="also time the optional gather-to-rank-0 stitch (N > 1)")
-    ap.add_argument("--variant", type=int, default=0, help="0 = default kernels, 1 = simple one-wavefront kernels")
+    ap.add_argument("--variant", type=int, default=0, help="kernel variant bit mask (density_hip_set_kernel_variant): 0 = default")
     ap.add_argument("--algo", default="chameleon", choices=["chameleon", "cheetah", "lion"],
-                    help="chameleon is the headline workload; cheetah/lion run on the functional device kernels (use a smaller --size)")
+                    help="chameleon is the headline workload; cheetah/lion: use a smaller --size")
+    ap.add_argument("--data", default="rep-text", choices=["rep-text", "prose"],
+                    help="rep-text = BASELINE config 2 (period 1000003 B); prose = non-periodic synth-prose (configs 3/4 stand-in)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks"
+    if args.no_gpu:
+        return dry_run(args, world, rank)
 
     import torch
     import torch.distributed as dist
@@ -102,22 +225,22 @@ def main():
     from density_amd import container
     from oracle import pyoracle
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        assert dist.get_world_size() == args.gpus, "RCCL world size differs from --gpus"
     else:
         torch.cuda.set_device(0)
-    if world != args.gpus and rank == 0:
-        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    n_gpus = dist.get_world_size() if world > 1 else 1
 
     n, chunk = args.size, args.chunk
     container.set_kernel_variant(args.variant)
-    # config 2 / 5 of BASELINE.json: rep-text, per-shard seed = seed + rank
-    host = datagen.rep_text(n, seed=0x9E3779B97F4A7C15 + rank)
+    # config 2 / 5 of BASELINE.json: rep-text, per-shard seed = seed + rank; configs 3/4 stand-in: non-periodic prose
+    if args.data == "rep-text":
+        host = datagen.rep_text(n, seed=0x9E3779B97F4A7C15 + rank)
+    else:
+        host = datagen.prose(n, seed=0xD1B54A32D192ED03 + rank)
     x = torch.from_numpy(host).cuda()
     algo = args.algo
     cap = container.container_bound(algo, n, chunk)
@@ -128,7 +251,8 @@ def main():
     stream = torch.cuda.current_stream()
     s = stream.cuda_stream
 
-    # correctness before any timing: decode(encode(x)) == x, and a sample of chunk streams equals the oracle's
+    # correctness before any timing: decode(encode(x)) == x, and chunk streams equal to the oracle's (all of the CPU sample's chunks are
+    # compared in cpu_baseline; here a spread of chunks so that --no-cpu runs are checked too)
     hdr = container.encode_device(algo, x.data_ptr(), n, cont.data_ptr(), cap, chunk, stream=s, workspace=(ws.data_ptr(), ws_size))
     got = container.decode_device(cont.data_ptr(), hdr.container_len, back.data_ptr(), n, header=hdr, stream=s, workspace=(ws.data_ptr(), ws_size))
     assert got == n and torch.equal(back, x), "round trip mismatch"
@@ -137,7 +261,7 @@ def main():
     for i in sorted(set([0, hdr.n_chunks // 3, hdr.n_chunks - 1])):
         assert payloads[i] == pyoracle.encode(algo, host[i * chunk:(i + 1) * chunk]), f"chunk {i} differs from the oracle"
     E = int(hdr.container_len)
-    del raw, payloads
+    del raw
 
     def step():
         container.encode_device(algo, x.data_ptr(), n, cont.data_ptr(), cap, chunk, stream=s, workspace=(ws.data_ptr(), ws_size), want_header=False)
@@ -157,14 +281,17 @@ def main():
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    dt = time.perf_counter() - t0
+    dt_local = dt = time.perf_counter() - t0
     timings = container.last_timings()
     container.set_profiling(False)
+    per_rank_ms = [dt_local / args.steps * 1e3]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    assert os.environ.get("DENSITY_HIP_DBG", "0") != "0" or torch.equal(back, x), "round trip mismatch after timed steps"
+        all_t = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(all_t, t)
+        per_rank_ms = [float(v.item()) / args.steps * 1e3 for v in all_t]
+        dt = max(float(v.item()) for v in all_t)
+    assert torch.equal(back, x), "round trip mismatch after timed steps"
 
     # the path's only collective: all-gather of per-shard (chunks, payload bytes) -> offsets in the global container
     from density_amd import parallel
@@ -189,43 +316,49 @@ def main():
             per.setdefault(name, []).append(ms)
         avg = {k: sum(v) / len(v) for k, v in per.items()}                 # per launch
         tot = {k: sum(v) / args.steps for k, v in per.items()}            # per step
-        launches = {k: len(v) / args.steps for k, v in per.items()}       # a large encode goes out in slices: several launches per step
+        launches = {k: len(v) / args.steps for k, v in per.items()}
         # algorithmic bytes per step: encode reads N writes E, decode reads E writes N; the stitch pass
         # (layout + compact) moves no algorithmic bytes — it is overhead that lowers the whole-path fraction.
         alg = {f"{algo}_encode_chunks": n + E, f"{algo}_decode_chunks": n + E}
         dom = max(alg, key=lambda k: tot.get(k, 0.0))
-        alg_launch = alg[dom] / max(launches.get(dom, 1.0), 1.0)          # slices are equal: bytes per launch of the dominant kernel
+        alg_launch = alg[dom] / max(launches.get(dom, 1.0), 1.0)
         ach = alg_launch / (avg[dom] * 1e-3) / 1e9 if avg.get(dom) else 0.0
         # HBM traffic of that kernel from the committed PMC passes (rocprofv3 cannot run inside this process); only quoted
-        # when the profile was taken on this exact workload
+        # when the profile was taken on this exact workload and kernel generation
         traffic, traffic_src = None, None
         try:
             import glob as _glob
             cand = sorted(_glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
-            if cand and n == 1 << 30 and chunk == 1 << 20 and args.variant == 0 and algo == "chameleon":
+            if cand and n == 1 << 30 and chunk == 1 << 20 and args.variant == 0 and algo == "chameleon" and args.data == "rep-text":
                 pm = json.load(open(cand[-1]))
-                traffic = int(pm["kernels"][dom + "_pipe"]["hbm_bytes_corrected"])   # per launch, like `achieved`
-                traffic_src = os.path.relpath(cand[-1], ROOT)
+                key = dom.replace("_chunks", "")
+                match = [k for k in pm["kernels"] if key in k and pm["kernels"][k].get("default_path")]
+                if match:
+                    traffic = int(pm["kernels"][match[0]]["hbm_bytes_corrected"])   # per launch, like `achieved`
+                    traffic_src = os.path.relpath(cand[-1], ROOT)
         except Exception:
             pass
         ms_step = dt / args.steps * 1e3
         t_enc = sum(tot.get(k, 0.0) for k in (f"{algo}_encode_chunks", "layout_encode", "compact", "stitch_tail"))
         t_dec = sum(tot.get(k, 0.0) for k in ("layout_decode", f"{algo}_decode_chunks"))
+        label = "rep-text (BASELINE config 2: synthetic repeating text, period 1000003 B)" if args.data == "rep-text" else \
+                "synth-prose (non-periodic; stand-in for enwik8, BASELINE configs 3/4)"
+        residency = "HBM-bound (buffers exceed the 256 MiB Infinity Cache)" if 2 * n > (256 << 20) else "cache-resident (fits the 256 MiB Infinity Cache)"
         result = {
-            "metric": "MB/s encode+decode (round-trip) per GPU + compression ratio, dickens/enwik8",
-            "value": round(world * n * args.steps / dt / 1e6, 1),
+            "metric": METRIC,
+            "value": round(n_gpus * n * args.steps / dt / 1e6, 1),
             "unit": "MB/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
-            "config": {"workload": f"{algo} rep-text {n >> 20} MiB per GPU (BASELINE config 2: 1 GiB synthetic repeating text, "
-                                   f"period 1000003 B), device-resident container encode+decode, chunk {chunk >> 10} KiB",
+            "config": {"workload": f"{algo} {label}, {n >> 20} MiB per GPU, device-resident container encode+decode, chunk {chunk >> 10} KiB, {residency}",
                        "algorithm": algo, "bytes_per_gpu": n, "chunk_bytes": chunk, "n_chunks": int(hdr.n_chunks),
-                       "parallelism": f"chunk-sharded x{world}, no data-path collective"},
+                       "parallelism": f"chunk-sharded x{n_gpus}, no data-path collective"},
             "compression_ratio": round(n / E, 4),
             "encoded_bytes": E,
             "encode_ms": round(t_enc, 4), "decode_ms": round(t_dec, 4),
+            "per_rank_ms_per_step": [round(v, 4) for v in per_rank_ms],
             "kernel_ms": {k: round(v, 4) for k, v in tot.items()},
             "kernel_launches_per_step": {k: round(v, 2) for k, v in launches.items()},
             "whole_path_hbm_frac": round((2.0 * (n + E)) / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
@@ -236,8 +369,12 @@ def main():
             "multi_gpu": {"size_gather_ms": round(gather_ms, 3), "concat_to_rank0_ms": (round(concat_ms, 3) if concat_ms is not None else None),
                           "global_container_bytes": int(glob["container_len"])},
         }
+        if world == 1:
+            result["size_sweep"] = size_sweep(container, algo, x, [10_000_000, 100_000_000, n])
         if not args.no_cpu:
-            result["cpu_baseline"] = cpu_baseline(host, chunk, args.cpu_sample, algo)
+            nchk = (min(args.cpu_sample, n) + chunk - 1) // chunk
+            result["cpu_baseline"] = cpu_baseline(host, chunk, args.cpu_sample, algo, gpu_payloads=payloads[:nchk])
+            result["host_api"] = host_api_rates(algo, host, chunk, args.host_sample)
         print(json.dumps(result))
     if world > 1:
         dist.barrier()

@@ -38,7 +38,15 @@ inline size_t safe_size(int algo, size_t n) {
     return n + (n / b) * s + ((n % b) ? s : 0);
 }
 inline bool valid_algo(int algo) { return algo >= DENSITY_HIP_CHAMELEON && algo <= DENSITY_HIP_LION; }
-inline size_t normalise_chunk(size_t chunk) { return chunk == 0 ? (size_t)DENSITY_HIP_DEFAULT_CHUNK : chunk; }
+// chunk_size 0 = automatic: one chunk is one work-group on one CU, so an input should be cut into at least as many chunks as the device has
+// CUs (256) where that is possible without dropping below 64 KiB (small chunks restart the dictionary and cost ratio); never above the default
+// 1 MiB.  Power of two: 10 MB -> 64 KiB (156 chunks), 100 MB -> 256 KiB (382), >= 256 MiB -> 1 MiB.
+inline size_t auto_chunk(size_t n) {
+    size_t c = (size_t)DENSITY_HIP_DEFAULT_CHUNK;
+    while (c > (64u << 10) && n / c < 256) c >>= 1;
+    return c;
+}
+inline size_t normalise_chunk(size_t chunk, size_t n) { return chunk == 0 ? auto_chunk(n) : chunk; }
 inline bool valid_chunk(size_t chunk) { return chunk >= 256 && chunk % 256 == 0 && chunk <= kMaxChunk; }
 inline size_t chunk_count(size_t n, size_t chunk) { return (n + chunk - 1) / chunk; }
 inline size_t index_base(size_t n_chunks) { return align_up(sizeof(density_hip_header_t) + 4 * n_chunks, 16); }
@@ -375,13 +383,13 @@ size_t lion_safe_encode_buffer_size(size_t size) { return safe_size(DENSITY_HIP_
 
 // ---- section 2: container + device API ----
 size_t density_hip_container_bound(int algo, size_t input_size, size_t chunk_size) {
-    chunk_size = normalise_chunk(chunk_size);
+    chunk_size = normalise_chunk(chunk_size, input_size);
     if (!valid_algo(algo) || !valid_chunk(chunk_size)) return 0;
     return container_bound(algo, input_size, chunk_size);
 }
 
 size_t density_hip_encode_workspace_size(int algo, size_t input_size, size_t chunk_size) {
-    chunk_size = normalise_chunk(chunk_size);
+    chunk_size = normalise_chunk(chunk_size, input_size);
     if (!valid_algo(algo) || !valid_chunk(chunk_size)) return 0;
     return plan_encode(algo, input_size, chunk_size).total;
 }
@@ -395,7 +403,7 @@ int density_hip_encode_device(int algo, const void* d_input, size_t input_size, 
                               size_t chunk_size, void* d_workspace, size_t workspace_size, void* stream,
                               density_hip_header_t* header_out) {
     g_last_error.clear();
-    chunk_size = normalise_chunk(chunk_size);
+    chunk_size = normalise_chunk(chunk_size, input_size);
     if (!valid_algo(algo) || !valid_chunk(chunk_size) || (!d_input && input_size) || !d_output) { set_error("bad argument"); return DENSITY_HIP_ERR_ARGUMENT; }
     DeviceCtx* c = acquire_ctx();
     if (!c) return DENSITY_HIP_ERR_RUNTIME;
@@ -461,7 +469,7 @@ int density_hip_stream_decode_device(int algo, const void* d_input, size_t input
 
 size_t density_hip_encode(int algo, const uint8_t* input, size_t input_size, uint8_t* output, size_t output_size, size_t chunk_size) {
     g_last_error.clear();
-    chunk_size = normalise_chunk(chunk_size);
+    chunk_size = normalise_chunk(chunk_size, input_size);
     if (!valid_algo(algo) || !valid_chunk(chunk_size) || (!input && input_size) || !output) { set_error("bad argument"); return 0; }
     DeviceCtx* c = acquire_ctx();
     if (!c) return 0;
@@ -479,6 +487,8 @@ size_t density_hip_encode(int algo, const uint8_t* input, size_t input_size, uin
     if (e != hipSuccess) { set_error("staging (D2H)", e); return 0; }
     return (size_t)h.container_len;
 }
+
+size_t density_hip_auto_chunk(size_t input_size) { return auto_chunk(input_size); }
 
 size_t density_hip_decoded_size(const uint8_t* container, size_t container_size) {
     if (!container || container_size < sizeof(density_hip_header_t)) return 0;

@@ -106,8 +106,12 @@ typedef struct density_hip_header {
     uint64_t container_len;  /* total container length in bytes (header + table + padded payloads) */
 } density_hip_header_t;
 
-/* Upper bound of the container size for `input_size` bytes (0 if the arguments are invalid). chunk_size 0 means
- * DENSITY_HIP_DEFAULT_CHUNK. */
+/* chunk_size 0 in the calls below means density_hip_auto_chunk(input_size): a power of two between 64 KiB and DENSITY_HIP_DEFAULT_CHUNK,
+ * chosen so that the input gives every CU of the device at least one chunk where that is possible (a chunk is one work-group; small
+ * chunks restart the dictionary and cost ratio: 10 MB -> 64 KiB, 100 MB -> 256 KiB, >= 256 MiB -> 1 MiB). */
+size_t density_hip_auto_chunk(size_t input_size);
+
+/* Upper bound of the container size for `input_size` bytes (0 if the arguments are invalid). */
 size_t density_hip_container_bound(int algo, size_t input_size, size_t chunk_size);
 
 /* Host-pointer container codec (H2D, kernels, D2H). Return bytes written, 0 on failure. */

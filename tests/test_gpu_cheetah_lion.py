@@ -116,3 +116,40 @@ def test_errors_are_reported(algo):
             assert out[:m].tobytes() != data.tobytes()
         except DecodeError:
             pass
+
+
+_PROSE_100M = {}
+
+
+def synth_prose_100m():
+    """BASELINE configs 3 / 4 stand-in (enwik8 is not available): 100,000,000 bytes of non-periodic synthetic prose, SURVEY.md §8d seed."""
+    if "d" not in _PROSE_100M:
+        _PROSE_100M["d"] = datagen.prose(100_000_000, seed=0xD1B54A32D192ED03)
+    return _PROSE_100M["d"]
+
+
+@pytest.mark.parametrize("algo", ["chameleon", "cheetah", "lion"])
+def test_config34_full_coverage_parity(algo):
+    """BASELINE configs 3 and 4 at full size, at the chunk size the library ships as default: EVERY chunk stream equals the oracle's
+    stream of that chunk bit for bit, and decode(container) == input (device-resident, like the bench)."""
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    host = synth_prose_100m()
+    n, chunk = host.size, 1 << 20
+    x = torch.from_numpy(host).cuda()
+    cap = container.container_bound(algo, n, chunk)
+    cont = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    back = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    hdr = container.encode_device(algo, x.data_ptr(), n, cont.data_ptr(), cap, chunk, stream=s)
+    assert hdr.n_chunks == -(-n // chunk) and hdr.total_len == n
+    assert container.decode_device(cont.data_ptr(), hdr.container_len, back.data_ptr(), n, header=hdr, stream=s) == n
+    assert torch.equal(back, x)
+    _, payloads = container.chunk_payloads(cont[:hdr.container_len].cpu().numpy())
+
+    def check(i):
+        return payloads[i] == pyoracle.encode(algo, host[i * chunk:(i + 1) * chunk])
+
+    with ThreadPoolExecutor(os.cpu_count() or 4) as ex:
+        ok = list(ex.map(check, range(hdr.n_chunks)))
+    assert all(ok), [i for i, v in enumerate(ok) if not v][:8]

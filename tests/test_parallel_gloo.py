@@ -110,3 +110,19 @@ def test_two_rank_gather_and_concat_matches_single_process(with_index):
         mp.spawn(_worker, args=(world, os.path.join(d, "init"), total, chunk, with_index, ret), nprocs=world, join=True)
         assert ret["equal_to_single_process_container"], "stitched container differs from the one-process container"
         assert ret["round_trip"]
+
+
+def test_bench_launcher_starts_the_ranks_itself():
+    """bench.py --gpus N without a torchrun environment re-executes under torch.distributed.run with N ranks and reports the world size the
+    process group saw (dry mode: CPU tensors, gloo)."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--no-gpu", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["dry_run"] and rec["scaling"] == "weak"
