@@ -74,7 +74,8 @@ struct DeviceCtx {
     std::mutex mu;
     bool ready = false, selftest_ok = false;
     uint32_t selftest_bits = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, stitch_stream = nullptr;   // stitch_stream: the compaction of one batch of chunks beside the encoding of the next
+    hipEvent_t batch_done[8] = {}, stitch_done = nullptr;
     Buffer work, stage_in, stage_out;
     // profiling: event marks accumulated since the last density_hip_last_timings() (name == nullptr opens a call)
     std::vector<hipEvent_t> events;
@@ -98,6 +99,9 @@ DeviceCtx* acquire_ctx() {
         if (e != hipSuccess) { set_error("hipGetDeviceProperties", e); return nullptr; }
         if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) { set_error("device is not gfx950 (MI355X); this library has no other code path"); return nullptr; }
         e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stitch_stream, hipStreamNonBlocking);
+        for (int i = 0; i < 8 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->batch_done[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->stitch_done, hipEventDisableTiming);
         if (e != hipSuccess) { set_error("hipStreamCreate", e); return nullptr; }
         // kernels rely on ascending-lane service order of same-address LDS accesses: verify on this device
         uint32_t* d_fail = nullptr;
@@ -240,12 +244,44 @@ int run_encode_container(DeviceCtx* c, int algo, const uint8_t* d_in, size_t n, 
         if (e == hipSuccess) e = launch_layout_encode(d_sizes, 1, hdr, pbase, d_out, cap, d_offsets, d_err, s);
         prof.mark("layout_encode");
     } else {
-        e = codec_encode(algo, d_in, n, chunk, (uint32_t)p.n_chunks, d_slots, p.stride, d_sizes, d_index, ws + p.off_tables, d_zmap, d_err, s);
-        prof.mark(encode_kernel_name(algo));
-        if (e == hipSuccess) e = launch_layout_encode(d_sizes, (uint32_t)p.n_chunks, hdr, pbase, d_out, cap, d_offsets, d_err, s);
-        prof.mark("layout_encode");
-        if (e == hipSuccess) e = launch_compact(d_slots, p.stride, d_sizes, d_offsets, (uint32_t)p.n_chunks, d_out, d_err, s);
-        prof.mark("compact");
+        // Chunk streams go to worst-case slots; their sizes are known only afterwards (write_buffer.rs:29-31 keeps a running total: in
+        // parallel an exclusive scan), then the streams are gathered into the packed container.  Optional (kernel variant bit 3, measured, not
+        // the default): large inputs encoded in up to kStitchBatches batches of whole multiples of 256 chunks (one per CU) with the gather of
+        // batch k on a second stream beside the encoding of batch k+1.  It hides the gather but the encoder — whose dictionary chain is
+        // sensitive to load latency — slows down by as much (0.68 + 0.10 ms against 0.56 + 0.25 ms per GiB): DESIGN.md.
+        constexpr uint32_t kStitchBatches = 4;
+        const uint32_t nch = (uint32_t)p.n_chunks;
+        uint32_t per = nch, batches = 1;
+        if (algo == DENSITY_HIP_CHAMELEON && nch >= 512 && (g_variant & 8)) {
+            batches = nch / 256 < kStitchBatches ? nch / 256 : kStitchBatches;
+            per = ((nch + batches - 1) / batches + 255) / 256 * 256;
+            batches = (nch + per - 1) / per;
+        }
+        uint64_t* d_carry = d_offsets + p.n_chunks;                      // (the extra entry of the offsets array)
+        for (uint32_t k = 0; k < batches && e == hipSuccess; ++k) {
+            const uint32_t first = k * per, count = (first + per <= nch) ? per : nch - first;
+            const uint64_t in_off = (uint64_t)first * chunk;
+            e = codec_encode(algo, d_in + in_off, n - in_off < (uint64_t)count * chunk ? n - in_off : (uint64_t)count * chunk, chunk, count, d_slots + (uint64_t)first * p.stride,
+                             p.stride, d_sizes + first, d_index ? d_index + in_off / 256 : nullptr, ws + p.off_tables,
+                             d_zmap ? d_zmap + (uint64_t)first * kZmapWordsPerChunk : nullptr, d_err, s);
+            prof.mark(encode_kernel_name(algo));
+            if (e == hipSuccess) e = launch_layout_encode_batch(d_sizes, first, count, k == 0, k + 1 == batches, hdr, pbase, d_out, cap, d_offsets, d_carry, d_err, s);
+            prof.mark("layout_encode");
+            if (e != hipSuccess) break;
+            if (batches == 1) {
+                e = launch_compact(d_slots, p.stride, d_sizes, d_offsets, count, d_out, d_err, s);
+                prof.mark("compact");
+            } else {
+                e = hipEventRecord(c->batch_done[k], s);
+                if (e == hipSuccess) e = hipStreamWaitEvent(c->stitch_stream, c->batch_done[k], 0);
+                if (e == hipSuccess) e = launch_compact(d_slots + (uint64_t)first * p.stride, p.stride, d_sizes + first, d_offsets + first, count, d_out, d_err, c->stitch_stream);
+            }
+        }
+        if (e == hipSuccess && batches > 1) {                               // the caller's stream continues when the last gather is done
+            e = hipEventRecord(c->stitch_done, c->stitch_stream);
+            if (e == hipSuccess) e = hipStreamWaitEvent(s, c->stitch_done, 0);
+            prof.mark("stitch_tail");
+        }
     }
     if (e != hipSuccess) { set_error("kernel launch (encode)", e); return DENSITY_HIP_ERR_RUNTIME; }
     if (header_out) {
@@ -521,7 +557,7 @@ size_t density_hip_decode(const uint8_t* container, size_t container_size, uint8
 }
 
 void density_hip_set_profiling(int enabled) { g_profiling = enabled; }
-void density_hip_set_kernel_variant(int variant) { g_variant = variant; density::g_force_simple = (variant & 1) != 0; density::g_force_pipeline = (variant & 4) != 0; }
+void density_hip_set_kernel_variant(int variant) { g_variant = variant;   /* bit 3 (8): encode in batches with the stitch of one batch beside the encoding of the next */ density::g_force_simple = (variant & 1) != 0; density::g_force_pipeline = (variant & 4) != 0; }
 
 int density_hip_last_timings(float* milliseconds, const char** names, int capacity) {
     int dev = -1;

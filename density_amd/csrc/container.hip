@@ -81,6 +81,29 @@ __global__ __launch_bounds__(kScanThreads) void layout_encode_kernel(const uint6
     }
 }
 
+// A slice [first, first + count) of the chunks (encode in batches: api.hip): offsets continue from *carry (the end of the previous
+// batch's last payload; `base` for the first batch), the size-table entries of the slice are written, *carry moves on.  The last
+// batch writes the header.
+__global__ __launch_bounds__(kScanThreads) void layout_encode_batch_kernel(const uint64_t* __restrict__ sizes, uint32_t first, uint32_t count,
+                                                                           uint32_t is_first, uint32_t is_last, density_hip_header_t hdr, uint64_t base,
+                                                                           uint8_t* __restrict__ container, uint64_t capacity, uint64_t* __restrict__ offsets,
+                                                                           uint64_t* __restrict__ carry, uint32_t* __restrict__ err) {
+    __shared__ uint64_t end_scratch;
+    const uint64_t start = is_first ? base : align16(*carry);
+    if (threadIdx.x == 0) end_scratch = start;
+    __syncthreads();
+    layout_common<uint64_t>(sizes + first, count, start, nullptr, reinterpret_cast<uint32_t*>(container + kHeaderBytes) + first, offsets + first, &end_scratch, ~0ull, err);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        *carry = end_scratch;
+        if (is_last) {
+            hdr.container_len = end_scratch;
+            *reinterpret_cast<density_hip_header_t*>(container) = hdr;
+        }
+        if (end_scratch > capacity) atomicOr(err, 2u);
+    }
+}
+
 __global__ __launch_bounds__(kScanThreads) void layout_decode_kernel(const uint8_t* __restrict__ container, uint64_t container_size,
                                                                      uint32_t n, uint64_t base, uint64_t* __restrict__ sizes,
                                                                      uint64_t* __restrict__ offsets, uint64_t* __restrict__ end_scratch,
@@ -161,6 +184,14 @@ hipError_t launch_layout_encode(const uint64_t* d_sizes, uint32_t n_chunks, dens
     // d_offsets has n_chunks + 1 entries; the extra one is scratch for the end offset
     hipLaunchKernelGGL(layout_encode_kernel, dim3(1), dim3(kScanThreads), 0, stream, d_sizes, n_chunks, hdr, payload_base, d_container, capacity,
                        d_offsets, d_offsets + n_chunks, d_err);
+    return hipGetLastError();
+}
+
+hipError_t launch_layout_encode_batch(const uint64_t* d_sizes, uint32_t first, uint32_t count, bool is_first, bool is_last, density_hip_header_t hdr,
+                                      uint64_t payload_base, uint8_t* d_container, uint64_t capacity, uint64_t* d_offsets, uint64_t* d_carry, uint32_t* d_err,
+                                      hipStream_t stream) {
+    hipLaunchKernelGGL(layout_encode_batch_kernel, dim3(1), dim3(kScanThreads), 0, stream, d_sizes, first, count, is_first ? 1u : 0u, is_last ? 1u : 0u, hdr,
+                       payload_base, d_container, capacity, d_offsets, d_carry, d_err);
     return hipGetLastError();
 }
 

@@ -50,6 +50,10 @@ hipError_t launch_serial_decode(int algo, const uint8_t* d_in, const uint64_t* d
 // table (encode side).
 hipError_t launch_layout_encode(const uint64_t* d_sizes, uint32_t n_chunks, density_hip_header_t hdr, uint64_t payload_base, uint8_t* d_container,
                                 uint64_t capacity, uint64_t* d_offsets, uint32_t* d_err, hipStream_t stream);
+// The same for a slice of the chunks (batched encode): offsets continue from *d_carry, which is left at the slice's end.
+hipError_t launch_layout_encode_batch(const uint64_t* d_sizes, uint32_t first, uint32_t count, bool is_first, bool is_last, density_hip_header_t hdr,
+                                      uint64_t payload_base, uint8_t* d_container, uint64_t capacity, uint64_t* d_offsets, uint64_t* d_carry, uint32_t* d_err,
+                                      hipStream_t stream);
 // Decode side: reads the u32 size table of a container, produces u64 sizes + offsets, validates against container_size.
 hipError_t launch_layout_decode(const uint8_t* d_container, uint64_t container_size, uint32_t n_chunks, uint64_t payload_base,
                                 uint64_t* d_sizes, uint64_t* d_offsets, uint32_t* d_err, hipStream_t stream);
