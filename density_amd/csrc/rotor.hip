@@ -250,6 +250,8 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
                                                                    uint8_t* __restrict__ index, uint32_t* __restrict__ err, uint32_t tune,
                                                                    uint64_t* __restrict__ prof) {
     static_assert((R == 8 || R == 16) && (W == 8 || W == 12 || W == 16), "round = 8 or 16 blocks; 8, 12 or 16 waves");
+    // (rounds of 16 on 16 waves fit the 128 registers a wave then has because nothing but the exchange operands is kept across the wait for the
+    // dictionary token: the quads themselves are loaded again — from L2 — once the exchanges are out)
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = rfl(threadIdx.x >> 6);
     const uint64_t chunk = blockIdx.x;
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
     }
     __syncthreads();
 
-    uint32_t q[R], qn[R];
+    uint32_t q[R];
     auto load_round = [&](uint32_t (&d)[R], uint32_t r) {
         if (r < nrounds) {
             const uint8_t* p = src + (uint64_t)r * (R * kBlock);
@@ -318,7 +320,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
 
     uint32_t ra[R], mask[R], val[R];                                              // per block: address, then (after the exchange) the answer; half mask; entry
 #pragma unroll
-    for (uint32_t j = 0; j < R; ++j) { q[j] = 0; qn[j] = 0; ra[j] = 0; mask[j] = 0; val[j] = 0; }
+    for (uint32_t j = 0; j < R; ++j) { q[j] = 0; ra[j] = 0; mask[j] = 0; val[j] = 0; }
     // The records of a round without raw blocks, straight-line: the signatures and the index bytes leave from lanes 0..R-1 in one
     // store each (lane j: record j, offsets by a DPP prefix over the record lengths); per block the MAP lanes store the 2-byte slot
     // index (the upper half of the hash product), the PLAIN lanes the quad, through an SGPR base (io/write_buffer.rs:13-27).
@@ -448,7 +450,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
                 // everything the commit needs that does not depend on the token: incompressible records (codec.rs:68: 8 + 256 - 2*hits >= 256)
                 uint32_t inc = (uint32_t)ballot64(lane < R && (uint32_t)(__builtin_popcount(slo) + __builtin_popcount(shi)) <= 4u);
                 uint32_t sum = R * (kSig + kBlock) - 2u * hits;
-                load_round(qn, r + W);                                     // next round's quads: in flight while this round commits
+                load_round(q, r);                                          // the quads again (from L2): they are not kept across the wait for the token
                 clk.mark(3);
                 // ---- O chain: commit ----
                 uint32_t P0, P1;
@@ -535,6 +537,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
                 watchdog(spins, sy, err, lane);
             }
             if (aborted) continue;
+            load_round(q, r);                                                     // (as in the fast path: the quads are not kept across the waits)
             Guard g = unpack_guard(P1);
             uint32_t sum = 0, unrest = 0;
             copy_mask = 0;
@@ -557,7 +560,6 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
                     sum += raw ? kBlock : kSig + kBlock - 2u * (uint32_t)__builtin_popcountll(sg);
                 }
             }
-            load_round(qn, r + W);
             opos = P0;
             const uint32_t stay_slow = (g.penalty | copy_mask | unrest) != 0 ? 1u : 0u;   // back to speculation only after a round without an incompressible or raw block
             if (lane == 0) {
@@ -570,9 +572,6 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
         }
       }
 
-        // ---- the next round's quads must have landed before this round's stores go out behind them (memory operations retire in order) ----
-#pragma unroll
-        for (uint32_t j = 0; j < R; ++j) asm volatile("s_waitcnt vmcnt(0)" : "+v"(qn[j]) :: "memory");
         clk.mark(5);
 
         // ---- emit: records of this round and their block-index bytes ----
@@ -593,8 +592,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
                 rec += raw ? kBlock : kSig + kBlock - 2u * nh;
             }
         }
-#pragma unroll
-        for (uint32_t j = 0; j < R; ++j) q[j] = qn[j];
+        load_round(q, r + W);                                                     // next round's quads (their latency is this wave's slack, not the chain's)
         clk.mark(6);
     }
     clk.flush(wave, lane);
@@ -841,25 +839,32 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
                 if (rfl(lds_peek1(sy + kSyD)) == kPoison) wave_exit();
                 watchdog(spins, sy, err, lane);
             }
+            uint32_t si[R], sr[R];                                                // (scratch copies and a rolled loop: a rare path must not weigh on the common one)
 #pragma unroll
+            for (uint32_t j = 0; j < R; ++j) { si[j] = itemc[j]; sr[j] = ra[j]; }
+#pragma nounroll
             for (uint32_t j = 0; j < R; ++j) {
                 const bool coded = (coded_mask >> j) & 1u;
                 const bool hit = (hitsc >> j) & 1u;
-                const uint32_t qv = itemc[j];
+                const uint32_t qv = si[j];
                 const uint32_t P = qv * kHashMul;
                 const uint32_t h = hit ? (qv & 0xffffu) : (P >> 16);
                 const bool zset = coded && !hit && stored_entry(qv, P) == 0 && h != 0;
-                const bool ztest = coded && hit && h != 0 && ra[j] == entry_to_quad(h, 0);   // the slot held stored entry 0
+                const bool ztest = coded && hit && h != 0 && sr[j] == entry_to_quad(h, 0);   // the slot held stored entry 0
                 uint64_t todo = ballot64(zset || ztest);
+                uint32_t out = sr[j];
                 while (todo) {                                                    // ascending lane == stream order
                     const uint32_t l = (uint32_t)__builtin_ctzll(todo);
                     todo &= todo - 1;
                     if (lane == l) {
                         if (zset) zmap.set(h);
-                        else if (!zmap.test(h)) ra[j] = 0;                        // chameleon.rs:64-68 on a never-written (zero) word
+                        else if (!zmap.test(h)) out = 0;                          // chameleon.rs:64-68 on a never-written (zero) word
                     }
                 }
+                sr[j] = out;
             }
+#pragma unroll
+            for (uint32_t j = 0; j < R; ++j) ra[j] = sr[j];
         }
         if (lane == 0) lds_poke(sy + kSyZdone + 4u * wave, x + 1u);
         clk.mark(6);
@@ -1039,11 +1044,12 @@ bool rotor_encode_eligible(const uint8_t* d_in, uint64_t total, uint64_t chunk_b
 hipError_t launch_rotor_encode(const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_out, uint64_t out_stride,
                                uint64_t* d_sizes, uint8_t* d_index, uint32_t* d_err, hipStream_t stream) {
     uint64_t* prof = rot_prof_buffer();
-    // geometry (DENSITY_HIP_TUNE bits 2..4, 0 = default): 1 = rounds of 8 blocks on 16 waves, 2 = 16 x 12, 3 = 16 x 8 (default: the longer
-    // round amortises the hand-off, 8 waves have the registers for it), 4 = 8 x 12, 5 = 8 x 8
-    const uint32_t sel = (rot_tune() >> 2) & 7u, geo = sel == 0 ? 2u : sel == 1 ? 0u : sel == 2 ? 1u : sel == 3 ? 2u : sel == 4 ? 3u : 4u;
-    const uint32_t waves = geo == 0 ? 16 : (geo == 1 || geo == 3) ? 12 : 8;
-    auto kernel = geo == 1 ? (prof ? chameleon_encode_rot<16, 12, true> : chameleon_encode_rot<16, 12, false>)
+    // geometry (DENSITY_HIP_TUNE bits 2..4, 0 = default = 3): 1 = rounds of 8 blocks on 16 waves, 2 = 16 x 12, 3 = 16 x 8 (the longer round
+    // amortises the hand-off; measured best), 4 = 8 x 12, 5 = 8 x 8, 6 = 16 x 16
+    const uint32_t sel = (rot_tune() >> 2) & 7u, geo = sel == 0 ? 2u : sel == 1 ? 0u : sel == 2 ? 1u : sel == 3 ? 2u : sel == 4 ? 3u : sel == 5 ? 4u : 5u;
+    const uint32_t waves = (geo == 0 || geo == 5) ? 16 : (geo == 1 || geo == 3) ? 12 : 8;
+    auto kernel = geo == 5 ? (prof ? chameleon_encode_rot<16, 16, true> : chameleon_encode_rot<16, 16, false>)
+                : geo == 1 ? (prof ? chameleon_encode_rot<16, 12, true> : chameleon_encode_rot<16, 12, false>)
                 : geo == 2 ? (prof ? chameleon_encode_rot<16, 8, true> : chameleon_encode_rot<16, 8, false>)
                 : geo == 3 ? (prof ? chameleon_encode_rot<8, 12, true> : chameleon_encode_rot<8, 12, false>)
                 : geo == 4 ? (prof ? chameleon_encode_rot<8, 8, true> : chameleon_encode_rot<8, 8, false>)
@@ -1065,11 +1071,12 @@ hipError_t launch_rotor_decode(const uint8_t* d_in, const uint64_t* d_offsets, c
                                uint64_t out_stride, uint64_t out_total, bool exact, const uint8_t* d_index, uint32_t* d_zmap,
                                uint64_t* d_produced, uint32_t* d_err, hipStream_t stream) {
     uint64_t* prof = rot_prof_buffer();
-    // geometry (DENSITY_HIP_TUNE bits 5..7, 0 = default): the decoder's waves carry two rounds of loads in flight, so 16 waves with rounds of 8
-    // records is its best point; 1..5 as for the encoder
-    const uint32_t sel = (rot_tune() >> 5) & 7u, geo = sel <= 1 ? 0u : sel == 2 ? 1u : sel == 3 ? 2u : sel == 4 ? 3u : 4u;
-    const uint32_t waves = geo == 0 ? 16 : (geo == 1 || geo == 3) ? 12 : 8;
-    auto kernel = geo == 1 ? (prof ? chameleon_decode_rot<16, 12, true> : chameleon_decode_rot<16, 12, false>)
+    // geometry (DENSITY_HIP_TUNE bits 5..7): numbered as for the encoder; default 1 = rounds of 8 records on 16 waves (the decoder's waves carry
+    // two rounds of loads in flight: longer rounds or fewer waves leave it waiting for memory)
+    const uint32_t sel = (rot_tune() >> 5) & 7u, geo = sel <= 1 ? 0u : sel == 2 ? 1u : sel == 3 ? 2u : sel == 4 ? 3u : sel == 5 ? 4u : 5u;
+    const uint32_t waves = (geo == 0 || geo == 5) ? 16 : (geo == 1 || geo == 3) ? 12 : 8;
+    auto kernel = geo == 5 ? (prof ? chameleon_decode_rot<16, 16, true> : chameleon_decode_rot<16, 16, false>)
+                : geo == 1 ? (prof ? chameleon_decode_rot<16, 12, true> : chameleon_decode_rot<16, 12, false>)
                 : geo == 2 ? (prof ? chameleon_decode_rot<16, 8, true> : chameleon_decode_rot<16, 8, false>)
                 : geo == 3 ? (prof ? chameleon_decode_rot<8, 12, true> : chameleon_decode_rot<8, 12, false>)
                 : geo == 4 ? (prof ? chameleon_decode_rot<8, 8, true> : chameleon_decode_rot<8, 8, false>)

@@ -82,6 +82,47 @@ __global__ __launch_bounds__(1024) void hop_kernel(uint64_t* out, uint32_t round
     if (lane == 0) { out[3 * wave] = t_end - t_start; out[3 * wave + 1] = crit; out[3 * wave + 2] = acc; }
 }
 
+// Two dictionary chains by slot parity: the lanes whose slot is even exchange under token A, the odd ones under token B; the chains only
+// order exchanges among their own lanes, so wave w+1 may run chain A of its round while wave w is still in chain B of its own.
+__global__ __launch_bounds__(1024) void hop2_kernel(uint64_t* out, uint32_t rounds, uint32_t mode, uint32_t nwaves) {
+    const uint32_t lane = threadIdx.x & 63u, wave = rfl(threadIdx.x >> 6);
+    for (uint32_t i = threadIdx.x; i < kTable / 4; i += 1024) reinterpret_cast<uint32_t*>(smem)[i] = 0;
+    if (threadIdx.x == 0) { *reinterpret_cast<uint32_t*>(smem + kSync) = 0; *reinterpret_cast<uint32_t*>(smem + kSync + 16) = 0; }
+    __syncthreads();
+    if (wave >= nwaves) return;
+    uint32_t addr[8], mask[8], val[8], ret[8];
+    uint64_t par[8];
+    uint32_t seed = threadIdx.x * 2654435761u + 12345u;
+    uint64_t t_start = 0;
+    uint32_t acc = 0;
+    for (uint32_t r = wave; r < rounds; r += nwaves) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            seed = seed * 1664525u + 1013904223u;
+            uint32_t h = seed >> 16;
+            if ((mode & 8u) && (lane & 3u) == 0) h = (r * 8 + j) & 3u;
+            addr[j] = (h >> 1) << 2; mask[j] = 0xffffu << ((h & 1u) << 4); val[j] = (seed & 0xffffu) << ((h & 1u) << 4);
+            par[j] = __builtin_amdgcn_ballot_w64((h & 2u) != 0);                 // chain by a slot bit that is not the half-of-dword bit
+        }
+        if (r == wave) t_start = __builtin_readcyclecounter();
+        for (int c = 0; c < 2; ++c) {
+            const uint32_t tok = kSync + 16u * c, ta = lane == 0 ? tok : kSink + 4u * lane;
+            while (rfl(peek1(tok)) != r) {}
+            const uint32_t tv = r + 1u;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint64_t m = c ? par[j] : ~par[j];
+                asm volatile("s_mov_b64 exec, %4\n\tds_mskor_rtn_b32 %0, %1, %2, %3\n\ts_mov_b64 exec, -1" : "+v"(ret[j]) : "v"(addr[j]), "v"(mask[j]), "v"(val[j]), "s"(m) : "memory");
+            }
+            asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(ta), "v"(tv) : "memory");
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc ^= ret[j];
+    }
+    const uint64_t t_end = __builtin_readcyclecounter();
+    if (lane == 0) { out[3 * wave] = t_end - t_start; out[3 * wave + 1] = 0; out[3 * wave + 2] = acc; }
+}
+
 int main() {
     uint64_t* d;
     hipMalloc((void**)&d, 64 * 8);
@@ -103,6 +144,17 @@ int main() {
         double tot = 0, crit = 0;
         for (uint32_t w = 0; w < c.waves; ++w) { tot = h[3 * w] > tot ? h[3 * w] : tot; crit += h[3 * w + 1]; }
         printf("%-48s %7.1f cycles per round, critical section (incl. answers) %6.1f\n", c.what, tot / rounds, crit / rounds);
+    }
+    hipFuncSetAttribute((const void*)hop2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kTable + 512);
+    for (uint32_t mode : {0u, 8u}) {
+        hipMemset(d, 0, 64 * 8);
+        hipLaunchKernelGGL(hop2_kernel, dim3(1), dim3(1024), kTable + 512, 0, d, rounds, mode, 16);
+        hipDeviceSynchronize();
+        std::vector<uint64_t> h(64);
+        hipMemcpy(h.data(), d, 64 * 8, hipMemcpyDeviceToHost);
+        double tot = 0;
+        for (uint32_t w = 0; w < 16; ++w) tot = h[3 * w] > tot ? h[3 * w] : tot;
+        printf("%-48s %7.1f cycles per round\n", mode ? "16 waves, TWO chains by slot bit, text-like" : "16 waves, TWO chains by slot bit, random", tot / rounds);
     }
     return 0;
 }

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/gpu_check.sh <tag>  — GPU suite (default geometry), rotor-only suite for $TEST_TUNES, profile + bench for $BENCH_TUNES
+# usage: tools/gpu_check.sh <tag>  — GPU suite (default geometry), rotor-only suite for $TEST_TUNES, profile for $PROF_TUNES, bench for $BENCH_TUNES
 TAG=${1:-x}; shift
 mkdir -p gpurun_out/$TAG
 export TMPDIR=/tmp
@@ -7,9 +7,11 @@ timeout 900 python -m pytest tests -m gpu -x -q "$@" > gpurun_out/$TAG/pytest.lo
 for t in $TEST_TUNES; do
   DENSITY_HIP_TUNE=$t timeout 900 python -m pytest tests/test_gpu_chameleon.py -m gpu -x -q -k "rotor" > gpurun_out/$TAG/pytest_t$t.log 2>&1; echo "pytest tune $t rc=$?"; tail -2 gpurun_out/$TAG/pytest_t$t.log
 done
-for t in 0 $BENCH_TUNES; do
+for t in $PROF_TUNES; do
   DENSITY_HIP_TUNE=$t DENSITY_HIP_PROF=1 timeout 300 python bench.py --steps 1 --warmup 1 --no-cpu > gpurun_out/$TAG/prof_t$t.json 2> gpurun_out/$TAG/prof_t$t.err
-  echo "== profile tune $t"; grep "density_hip prof" gpurun_out/$TAG/prof_t$t.err | tail -30 | grep -v "  w[2-9]\|  w1[0-5]"
+  echo "== profile tune $t"; grep "density_hip prof" gpurun_out/$TAG/prof_t$t.err | tail -44 | grep -v "  w[2-9]\|  w1[0-5]"
+done
+for t in $BENCH_TUNES; do
   DENSITY_HIP_TUNE=$t timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu > gpurun_out/$TAG/bench_t$t.json 2>/dev/null
   python - <<PY
 import json
