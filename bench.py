@@ -197,7 +197,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--size", type=int, default=1 << 30, help="bytes per GPU (default 1 GiB = BASELINE config 2)")
-    ap.add_argument("--chunk", type=int, default=1 << 20)
+    ap.add_argument("--chunk", type=int, default=0, help="container chunk size; 0 = the library's automatic choice (density_hip_auto_chunk: 4 MiB at 1 GiB)")
     ap.add_argument("--cpu-sample", type=int, default=256 << 20)
     ap.add_argument("--host-sample", type=int, default=64 << 20, help="bytes for the PCIe-inclusive host-API rates")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline and the host-API legs")
@@ -234,7 +234,9 @@ def main():
         torch.cuda.set_device(0)
     n_gpus = dist.get_world_size() if world > 1 else 1
 
-    n, chunk = args.size, args.chunk
+    n = args.size
+    from density_amd import _lib
+    chunk = args.chunk or int(_lib.lib().density_hip_auto_chunk(n))
     container.set_kernel_variant(args.variant)
     # config 2 / 5 of BASELINE.json: rep-text, per-shard seed = seed + rank; configs 3/4 stand-in: non-periodic prose
     if args.data == "rep-text":
@@ -329,7 +331,7 @@ def main():
         try:
             import glob as _glob
             cand = sorted(_glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
-            if cand and n == 1 << 30 and chunk == 1 << 20 and args.variant == 0 and algo == "chameleon" and args.data == "rep-text":
+            if cand and n == 1 << 30 and chunk == 4 << 20 and args.variant == 0 and algo == "chameleon" and args.data == "rep-text":
                 pm = json.load(open(cand[-1]))
                 key = dom.replace("_chunks", "")
                 match = [k for k in pm["kernels"] if key in k and pm["kernels"][k].get("default_path")]

@@ -39,10 +39,11 @@ inline size_t safe_size(int algo, size_t n) {
 }
 inline bool valid_algo(int algo) { return algo >= DENSITY_HIP_CHAMELEON && algo <= DENSITY_HIP_LION; }
 // chunk_size 0 = automatic: one chunk is one work-group on one CU, so an input should be cut into at least as many chunks as the device has
-// CUs (256) where that is possible without dropping below 64 KiB (small chunks restart the dictionary and cost ratio); never above the default
-// 1 MiB.  Power of two: 10 MB -> 64 KiB (156 chunks), 100 MB -> 256 KiB (382), >= 256 MiB -> 1 MiB.
+// CUs (256) where that is possible without dropping below 64 KiB (small chunks restart the dictionary and cost ratio), and no finer than that
+// (every chunk start costs a table clear and a few in-order rounds): never above 4 MiB, the largest chunk the index-fed decoder takes.
+// Power of two: 10 MB -> 64 KiB (153 chunks), 100 MB -> 256 KiB (382), 256 MiB -> 1 MiB, >= 1 GiB -> 4 MiB.
 inline size_t auto_chunk(size_t n) {
-    size_t c = (size_t)DENSITY_HIP_DEFAULT_CHUNK;
+    size_t c = 4u << 20;
     while (c > (64u << 10) && n / c < 256) c >>= 1;
     return c;
 }

@@ -232,10 +232,12 @@ __device__ __forceinline__ void backoff(uint32_t dist, bool off = false) {
     else __builtin_amdgcn_s_sleep(3);
 }
 // up to `tries` back-to-back polls of one token word for one value
-__device__ __forceinline__ bool poll_word(uint32_t addr, uint32_t want, uint32_t tries) {
+__device__ __forceinline__ bool poll_word(uint32_t addr, uint32_t want, uint32_t tries, bool prio = false) {
+    if (prio) __builtin_amdgcn_s_setprio(2);
     for (uint32_t i = 0; i < tries; ++i) {
         if (rfl(lds_peek1(addr)) == want) return true;
     }
+    if (prio) __builtin_amdgcn_s_setprio(0);
     return false;
 }
 
@@ -265,7 +267,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
     // the table sits at LDS address 0 (this kernel has no static LDS): slot addresses need no base
     const uint32_t sy = kEncSync;
     const ZmapLds zmap{kEncZmap};
-    const bool late_token = (tune & 1u) != 0, no_sleep = (tune & 2u) != 0;
+    const bool late_token = (tune & 1u) != 0, no_sleep = (tune & 2u) != 0, poll_prio = (tune & 256u) != 0;
 
     {   // fresh state per chunk (chameleon.rs:45-48): zero table, zero-entry map, tokens: round 0 in slow mode, nothing committed
         uint4* p = reinterpret_cast<uint4*>(smem);
@@ -421,7 +423,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
             // ---- D chain: wait for this round's turn ----
             uint32_t slow;
             for (uint32_t spins = 0;;) {
-                if (poll_word(sy + kSyD, r << 1, 16)) { slow = 0; break; }         // the common hand-off: fast token for this round
+                if (poll_word(sy + kSyD, r << 1, 16, poll_prio)) { slow = 0; break; }         // the common hand-off: fast token for this round
                 const u32x2 v = lds_peek2(sy + kSyD);
                 const uint32_t D = rfl(v.x), A = rfl(v.y);
                 if (__builtin_expect(A != kNone, 0)) { if (A == kPoison) wave_exit(); abort_sync(false, 0); continue; }
@@ -655,7 +657,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
     const ZmapGlobal zmap{zmap_words + chunk * (kZmapBytes / 4)};
     // the table sits at LDS address 0 (this kernel has no static LDS): slot addresses need no base
     const uint32_t sy = kDecSync;
-    const bool late_token = (tune & 1u) != 0, no_sleep = (tune & 2u) != 0;
+    const bool late_token = (tune & 1u) != 0, no_sleep = (tune & 2u) != 0, poll_prio = (tune & 256u) != 0;
 
     {   // fresh dictionary, this chunk's zero-entry map, the block index into LDS
         uint4* p = reinterpret_cast<uint4*>(smem);
@@ -803,7 +805,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
         clk.stamp(x, 0, lane);
         // ---- D chain ----
         for (uint32_t spins = 0;;) {
-            if (poll_word(sy + kSyD, x, 16)) break;
+            if (poll_word(sy + kSyD, x, 16, poll_prio)) break;
             const uint32_t D = rfl(lds_peek1(sy + kSyD));
             if (D == x) break;
             if (D == kPoison) wave_exit();

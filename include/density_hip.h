@@ -106,9 +106,9 @@ typedef struct density_hip_header {
     uint64_t container_len;  /* total container length in bytes (header + table + padded payloads) */
 } density_hip_header_t;
 
-/* chunk_size 0 in the calls below means density_hip_auto_chunk(input_size): a power of two between 64 KiB and DENSITY_HIP_DEFAULT_CHUNK,
- * chosen so that the input gives every CU of the device at least one chunk where that is possible (a chunk is one work-group; small
- * chunks restart the dictionary and cost ratio: 10 MB -> 64 KiB, 100 MB -> 256 KiB, >= 256 MiB -> 1 MiB). */
+/* chunk_size 0 in the calls below means density_hip_auto_chunk(input_size): a power of two between 64 KiB and 4 MiB, the largest that
+ * still gives every CU of the device a chunk (a chunk is one work-group; small chunks restart the dictionary and cost ratio, every
+ * chunk start costs a table clear: 10 MB -> 64 KiB, 100 MB -> 256 KiB, 256 MiB -> 1 MiB, >= 1 GiB -> 4 MiB). */
 size_t density_hip_auto_chunk(size_t input_size);
 
 /* Upper bound of the container size for `input_size` bytes (0 if the arguments are invalid). */
