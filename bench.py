@@ -201,6 +201,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=256 << 20)
     ap.add_argument("--host-sample", type=int, default=64 << 20, help="bytes for the PCIe-inclusive host-API rates")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline and the host-API legs")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the size sweep (profiling runs: only the headline workload's launches)")
     ap.add_argument("--no-gpu", action="store_true", help="dry mode: launcher + distributed bookkeeping on CPU/gloo (tests)")
     ap.add_argument("--concat", action="store_true", help="also time the optional gather-to-rank-0 stitch (N > 1)")
     ap.add_argument("--variant", type=int, default=0, help="kernel variant bit mask (density_hip_set_kernel_variant): 0 = default")
@@ -371,7 +372,7 @@ def main():
             "multi_gpu": {"size_gather_ms": round(gather_ms, 3), "concat_to_rank0_ms": (round(concat_ms, 3) if concat_ms is not None else None),
                           "global_container_bytes": int(glob["container_len"])},
         }
-        if world == 1:
+        if world == 1 and not args.no_sweep:
             result["size_sweep"] = size_sweep(container, algo, x, [10_000_000, 100_000_000, n])
         if not args.no_cpu:
             nchk = (min(args.cpu_sample, n) + chunk - 1) // chunk

@@ -1,13 +1,19 @@
 #!/bin/bash
-# rocprofv3 passes behind profiles/rNN_*: kernel-trace stats, then FETCH_SIZE and WRITE_SIZE in separate counter runs.
+# rocprofv3 passes behind profiles/rNN_*: kernel-trace stats, then FETCH_SIZE and WRITE_SIZE in separate counter runs (never combined
+# with other trace domains), a counter calibration on known byte counts, and the LDS counters of the codec kernels.
 # Usage on the GPU box (from the repo root):  bash probes/profile_round.sh gpurun_out/prof
-set -e
 OUT=${1:-gpurun_out/prof}
 R=$(pwd)
 cd /tmp && export TMPDIR=/tmp
 mkdir -p $R/$OUT
 cd $R
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/stats -- python bench.py --steps 5 --warmup 1 --no-cpu > $R/$OUT/bench_stats.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/$OUT/fetch -- python bench.py --steps 2 --warmup 1 --no-cpu > $R/$OUT/bench_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/$OUT/write -- python bench.py --steps 2 --warmup 1 --no-cpu > $R/$OUT/bench_write.log 2>&1
+B="python bench.py --no-cpu --no-sweep"
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/stats -- $B --steps 5 --warmup 1 > $R/$OUT/bench_stats.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/$OUT/fetch -- $B --steps 2 --warmup 1 > $R/$OUT/bench_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/$OUT/write -- $B --steps 2 --warmup 1 > $R/$OUT/bench_write.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/$OUT/calib_fetch -- ./probes/fetch_calib > $R/$OUT/calib_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/$OUT/calib_write -- ./probes/fetch_calib > $R/$OUT/calib_write.log 2>&1
+rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_ATOMIC_RETURN SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $R/$OUT/lds -- $B --steps 2 --warmup 1 > $R/$OUT/bench_lds.log 2>&1
+DENSITY_HIP_PROF=1 $B --steps 1 --warmup 1 > $R/$OUT/phase_profile.json 2> $R/$OUT/phase_profile.txt
+python bench.py --steps 10 --warmup 3 > $R/$OUT/bench.json 2>/dev/null
 find $R/$OUT -name "*_kernel_stats.csv" -o -name "*_counter_collection.csv"
