@@ -74,7 +74,9 @@ def main():
         import torch
         from density_amd import BY_NAME, container
         x = torch.from_numpy(data).cuda()
-        stream = torch.cuda.current_stream().cuda_stream
+        tstream = torch.cuda.Stream()             # (a real stream: handle 0 would mean "the library's internal stream" to density_hip_*_device)
+        torch.cuda.set_stream(tstream)
+        stream = tstream.cuda_stream
     print(f"{'density':<34} fastest       │ slowest       │ median        │ mean          │ samples │ iters")
     for algo in args.algos.split(","):
         print(f"├─ {algo:<45} │               │               │               │         │")

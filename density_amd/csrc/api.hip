@@ -148,7 +148,13 @@ struct Profiler {
 };
 
 constexpr size_t kSerialSlots = 16384;   // concurrent chunk streams of the functional Cheetah/Lion kernels (one lane each; 12 / 28 GiB of tables when all are in use)
-inline size_t serial_slots(int algo, size_t n_chunks) { return algo == DENSITY_HIP_CHAMELEON ? 0 : (n_chunks < kSerialSlots ? n_chunks : kSerialSlots); }
+constexpr size_t kSerialTableBudget = 8ull << 30;   // ... but never more than 8 GiB of tables (the count comes from an untrusted header on decode): Cheetah 10922 streams, Lion 4681
+inline size_t serial_slots(int algo, size_t n_chunks) {
+    if (algo == DENSITY_HIP_CHAMELEON) return 0;
+    const size_t by_memory = kSerialTableBudget / serial_table_bytes(algo);
+    const size_t cap = kSerialSlots < by_memory ? kSerialSlots : by_memory;
+    return n_chunks < cap ? n_chunks : cap;
+}
 inline size_t serial_tables(int algo, size_t n_chunks) { return algo == DENSITY_HIP_CHAMELEON ? 0 : align_up(serial_slots(algo, n_chunks) * serial_table_bytes(algo), kAlign); }
 
 inline size_t zmap_bytes(int algo, size_t n_chunks) { return (algo == DENSITY_HIP_CHAMELEON && n_chunks <= kMaxPipelinedChunks) ? align_up((n_chunks ? n_chunks : 1) * kZmapWordsPerChunk * 4, kAlign) : 0; }
