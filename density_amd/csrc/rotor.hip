@@ -48,7 +48,10 @@ constexpr uint32_t kNone = 0xffffffffu;
 // 16 words "rounds whose zero-entry-map phase this wave has finished" (decoder)
 constexpr uint32_t kSyD = 0, kSyO = 16, kSyZ = 32, kSyEnd = 48, kSySink = 64, kSyZdone = 64 + 256, kSyWsum = 64 + 256 + 64, kSyBytes = 64 + 256 + 64 + 64;
 // encoder LDS: table | zero-entry map | sync
-constexpr uint32_t kEncZmap = kTableBytes, kEncSync = kTableBytes + kZmapBytes, kEncLds = kEncSync + kSyBytes;
+constexpr uint32_t kEncZmap = kTableBytes, kEncSync = kTableBytes + kZmapBytes, kEncStage = kEncSync + kSyBytes;
+// (encoder staging: two arrays of up to 16 blocks x 64 lanes for the rolled loops of the rare paths — rollback, in-order rounds, zero-entry
+// quads at commit — which exclude one another in time, so the whole work-group shares one copy)
+constexpr uint32_t kEncStageBytes = 2u * 16u * 256u, kEncLds = kEncStage + kEncStageBytes;
 // decoder LDS: table | block-index copy | round positions | sync   (zero-entry map in global memory: ZmapGlobal)
 constexpr uint32_t kRotMaxBlocks = 16384;                    // blocks per chunk the decoder keeps an index copy for (4 MiB chunks)
 constexpr uint32_t kDecIdx = kTableBytes, kDecPos = kDecIdx + kRotMaxBlocks, kDecSync = kDecPos + (kRotMaxBlocks / kR) * 4u,
@@ -146,6 +149,121 @@ __device__ __forceinline__ void exchange_round(uint32_t (&ret)[kR], const uint32
     ""
 #define DENSITY_ROT_X16_OPS : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(ra[4]), "+v"(ra[5]), "+v"(ra[6]), "+v"(ra[7]), "+v"(ra[8]), "+v"(ra[9]), "+v"(ra[10]), "+v"(ra[11]), "+v"(ra[12]), "+v"(ra[13]), "+v"(ra[14]), "+v"(ra[15]) \
     : "v"(mask[0]), "v"(mask[1]), "v"(mask[2]), "v"(mask[3]), "v"(mask[4]), "v"(mask[5]), "v"(mask[6]), "v"(mask[7]), "v"(mask[8]), "v"(mask[9]), "v"(mask[10]), "v"(mask[11]), "v"(mask[12]), "v"(mask[13]), "v"(mask[14]), "v"(mask[15]), "v"(val[0]), "v"(val[1]), "v"(val[2]), "v"(val[3]), "v"(val[4]), "v"(val[5]), "v"(val[6]), "v"(val[7]), "v"(val[8]), "v"(val[9]), "v"(val[10]), "v"(val[11]), "v"(val[12]), "v"(val[13]), "v"(val[14]), "v"(val[15]), "v"(tokaddr), "v"(tokval) : "memory"
+#define DENSITY_ROT_PF8 \
+    "global_load_dword v248, %0, off offset:0\n\t" \
+    "global_load_dword v249, %0, off offset:256\n\t" \
+    "global_load_dword v250, %0, off offset:512\n\t" \
+    "global_load_dword v251, %0, off offset:768\n\t" \
+    "global_load_dword v252, %0, off offset:1024\n\t" \
+    "global_load_dword v253, %0, off offset:1280\n\t" \
+    "global_load_dword v254, %0, off offset:1536\n\t" \
+    "global_load_dword v255, %0, off offset:1792\n\t" \
+    ""
+#define DENSITY_ROT_MV8 \
+    "v_mov_b32 %0, v248\n\t" \
+    "v_mov_b32 %1, v249\n\t" \
+    "v_mov_b32 %2, v250\n\t" \
+    "v_mov_b32 %3, v251\n\t" \
+    "v_mov_b32 %4, v252\n\t" \
+    "v_mov_b32 %5, v253\n\t" \
+    "v_mov_b32 %6, v254\n\t" \
+    "v_mov_b32 %7, v255\n\t" \
+    ""
+#define DENSITY_ROT_MV8_OUTS "=v"(q[0]), "=v"(q[1]), "=v"(q[2]), "=v"(q[3]), "=v"(q[4]), "=v"(q[5]), "=v"(q[6]), "=v"(q[7])
+#define DENSITY_ROT_STAGE8 "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255"
+#define DENSITY_ROT_PF16 \
+    "global_load_dword v240, %0, off offset:0\n\t" \
+    "global_load_dword v241, %0, off offset:256\n\t" \
+    "global_load_dword v242, %0, off offset:512\n\t" \
+    "global_load_dword v243, %0, off offset:768\n\t" \
+    "global_load_dword v244, %0, off offset:1024\n\t" \
+    "global_load_dword v245, %0, off offset:1280\n\t" \
+    "global_load_dword v246, %0, off offset:1536\n\t" \
+    "global_load_dword v247, %0, off offset:1792\n\t" \
+    "global_load_dword v248, %0, off offset:2048\n\t" \
+    "global_load_dword v249, %0, off offset:2304\n\t" \
+    "global_load_dword v250, %0, off offset:2560\n\t" \
+    "global_load_dword v251, %0, off offset:2816\n\t" \
+    "global_load_dword v252, %0, off offset:3072\n\t" \
+    "global_load_dword v253, %0, off offset:3328\n\t" \
+    "global_load_dword v254, %0, off offset:3584\n\t" \
+    "global_load_dword v255, %0, off offset:3840\n\t" \
+    ""
+#define DENSITY_ROT_MV16 \
+    "v_mov_b32 %0, v240\n\t" \
+    "v_mov_b32 %1, v241\n\t" \
+    "v_mov_b32 %2, v242\n\t" \
+    "v_mov_b32 %3, v243\n\t" \
+    "v_mov_b32 %4, v244\n\t" \
+    "v_mov_b32 %5, v245\n\t" \
+    "v_mov_b32 %6, v246\n\t" \
+    "v_mov_b32 %7, v247\n\t" \
+    "v_mov_b32 %8, v248\n\t" \
+    "v_mov_b32 %9, v249\n\t" \
+    "v_mov_b32 %10, v250\n\t" \
+    "v_mov_b32 %11, v251\n\t" \
+    "v_mov_b32 %12, v252\n\t" \
+    "v_mov_b32 %13, v253\n\t" \
+    "v_mov_b32 %14, v254\n\t" \
+    "v_mov_b32 %15, v255\n\t" \
+    ""
+#define DENSITY_ROT_MV16_OUTS "=v"(q[0]), "=v"(q[1]), "=v"(q[2]), "=v"(q[3]), "=v"(q[4]), "=v"(q[5]), "=v"(q[6]), "=v"(q[7]), "=v"(q[8]), "=v"(q[9]), "=v"(q[10]), "=v"(q[11]), "=v"(q[12]), "=v"(q[13]), "=v"(q[14]), "=v"(q[15])
+#define DENSITY_ROT_STAGE16 "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255"
+
+// element j (wave-uniform, not a compile-time constant) of a register array, for the rolled loops of the rare paths: a chain of
+// selects, so the array stays in registers (a dynamically indexed copy would live in scratch memory, and the compiler's waits for
+// its loads would also hold the common path at the top of every round)
+template <int R>
+__device__ __forceinline__ uint32_t pick(const uint32_t (&a)[R], uint32_t j) {
+    uint32_t v = a[0];
+#pragma unroll
+    for (uint32_t k = 1; k < (uint32_t)R; ++k) {
+        uint32_t jj = j;
+        asm volatile("" : "+s"(jj));                                              // (opaque: or the compiler turns the chain back into a table in scratch)
+        v = jj == k ? a[k] : v;
+    }
+    return v;
+}
+// Next round's quads, fetched by hand: R dword loads (one 256-byte block each) the compiler does not see as memory operations, so
+// it places no wait of its own between them and the stores that follow.  They land in the R highest registers of the wave
+// (v(256-R)..v255, named in the statements and declared clobbered), which the compiler, allocating upwards from v0, never reaches in
+// these kernels (tools/check_isa.py checks that no other instruction names them), so nothing can read or move them early.  (The
+// accumulation registers would be the natural staging area, but a kernel that names one has its register file split in halves.)
+// `quads_landed` waits — every load is older than the `kYounger` memory operations the
+// caller guarantees to have issued since (vmcnt counts a wave's loads and stores in order) — and reads them into `q`.
+template <int R>
+__device__ __forceinline__ void prefetch_quads(const uint8_t* p);
+template <>
+__device__ __forceinline__ void prefetch_quads<8>(const uint8_t* p) { asm volatile(DENSITY_ROT_PF8 : : "v"(p) : "memory", DENSITY_ROT_STAGE8); }
+template <>
+__device__ __forceinline__ void prefetch_quads<16>(const uint8_t* p) { asm volatile(DENSITY_ROT_PF16 : : "v"(p) : "memory", DENSITY_ROT_STAGE16); }
+template <int R, int kYounger>
+__device__ __forceinline__ void quads_landed(uint32_t (&q)[R]);
+template <>
+__device__ __forceinline__ void quads_landed<8, 8>(uint32_t (&q)[8]) { asm volatile("s_waitcnt vmcnt(8)\n\t" DENSITY_ROT_MV8 : DENSITY_ROT_MV8_OUTS : : DENSITY_ROT_STAGE8); }
+template <>
+__device__ __forceinline__ void quads_landed<8, 0>(uint32_t (&q)[8]) { asm volatile("s_waitcnt vmcnt(0)\n\t" DENSITY_ROT_MV8 : DENSITY_ROT_MV8_OUTS : : DENSITY_ROT_STAGE8); }
+template <>
+__device__ __forceinline__ void quads_landed<16, 16>(uint32_t (&q)[16]) { asm volatile("s_waitcnt vmcnt(16)\n\t" DENSITY_ROT_MV16 : DENSITY_ROT_MV16_OUTS : : DENSITY_ROT_STAGE16); }
+template <>
+__device__ __forceinline__ void quads_landed<16, 0>(uint32_t (&q)[16]) { asm volatile("s_waitcnt vmcnt(0)\n\t" DENSITY_ROT_MV16 : DENSITY_ROT_MV16_OUTS : : DENSITY_ROT_STAGE16); }
+
+#define DENSITY_ROT_X12 \
+    "ds_mskor_rtn_b32 %0, %0, %12, %24\n\t" \
+    "ds_mskor_rtn_b32 %1, %1, %13, %25\n\t" \
+    "ds_mskor_rtn_b32 %2, %2, %14, %26\n\t" \
+    "ds_mskor_rtn_b32 %3, %3, %15, %27\n\t" \
+    "ds_mskor_rtn_b32 %4, %4, %16, %28\n\t" \
+    "ds_mskor_rtn_b32 %5, %5, %17, %29\n\t" \
+    "ds_mskor_rtn_b32 %6, %6, %18, %30\n\t" \
+    "ds_mskor_rtn_b32 %7, %7, %19, %31\n\t" \
+    "ds_mskor_rtn_b32 %8, %8, %20, %32\n\t" \
+    "ds_mskor_rtn_b32 %9, %9, %21, %33\n\t" \
+    "ds_mskor_rtn_b32 %10, %10, %22, %34\n\t" \
+    "ds_mskor_rtn_b32 %11, %11, %23, %35\n\t" \
+    ""
+#define DENSITY_ROT_X12_OPS : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(ra[4]), "+v"(ra[5]), "+v"(ra[6]), "+v"(ra[7]), "+v"(ra[8]), "+v"(ra[9]), "+v"(ra[10]), "+v"(ra[11]) \
+    : "v"(mask[0]), "v"(mask[1]), "v"(mask[2]), "v"(mask[3]), "v"(mask[4]), "v"(mask[5]), "v"(mask[6]), "v"(mask[7]), "v"(mask[8]), "v"(mask[9]), "v"(mask[10]), "v"(mask[11]), "v"(val[0]), "v"(val[1]), "v"(val[2]), "v"(val[3]), "v"(val[4]), "v"(val[5]), "v"(val[6]), "v"(val[7]), "v"(val[8]), "v"(val[9]), "v"(val[10]), "v"(val[11]), "v"(tokaddr), "v"(tokval) : "memory"
 
 template <int R>
 __device__ __forceinline__ void exchange_tied(uint32_t (&ra)[R], const uint32_t (&mask)[R], const uint32_t (&val)[R], uint32_t tokaddr, uint32_t tokval, bool token_after_answers);
@@ -153,6 +271,11 @@ template <>
 __device__ __forceinline__ void exchange_tied<8>(uint32_t (&ra)[8], const uint32_t (&mask)[8], const uint32_t (&val)[8], uint32_t tokaddr, uint32_t tokval, bool token_after_answers) {
     if (!token_after_answers) asm volatile(DENSITY_ROT_X8 "ds_write_b32 %24, %25\n\ts_waitcnt lgkmcnt(0)" DENSITY_ROT_X8_OPS);
     else asm volatile(DENSITY_ROT_X8 "s_waitcnt lgkmcnt(0)\n\tds_write_b32 %24, %25" DENSITY_ROT_X8_OPS);
+}
+template <>
+__device__ __forceinline__ void exchange_tied<12>(uint32_t (&ra)[12], const uint32_t (&mask)[12], const uint32_t (&val)[12], uint32_t tokaddr, uint32_t tokval, bool token_after_answers) {
+    if (!token_after_answers) asm volatile(DENSITY_ROT_X12 "ds_write_b32 %36, %37\n\ts_waitcnt lgkmcnt(0)" DENSITY_ROT_X12_OPS);
+    else asm volatile(DENSITY_ROT_X12 "s_waitcnt lgkmcnt(0)\n\tds_write_b32 %36, %37" DENSITY_ROT_X12_OPS);
 }
 template <>
 __device__ __forceinline__ void exchange_tied<16>(uint32_t (&ra)[16], const uint32_t (&mask)[16], const uint32_t (&val)[16], uint32_t tokaddr, uint32_t tokval, bool token_after_answers) {
@@ -281,7 +404,12 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
     }
     __syncthreads();
 
-    uint32_t q[R];
+    // 8 waves have 256 registers each: the quads stay in registers across the waits and the next round's are fetched a round ahead;
+    // 12 and 16 waves load them again instead
+    constexpr bool kKeepQuads = W == 8;
+    uint32_t q[R], hp[R];                                                         // hp: the quads' hash products (kept with them)
+#pragma unroll
+    for (uint32_t j = 0; j < R; ++j) hp[j] = 0;
     auto load_round = [&](uint32_t (&d)[R], uint32_t r) {
         if (r < nrounds) {
             const uint8_t* p = src + (uint64_t)r * (R * kBlock);
@@ -290,8 +418,9 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
         }
     };
     // quad -> exchange operands {dword address, half mask, entry << 16*half} (chameleon.rs:89, chameleon_dev.hpp)
-    auto operands = [&](uint32_t qv, uint32_t& a, uint32_t& m, uint32_t& v) {
+    auto operands = [&](uint32_t qv, uint32_t& a, uint32_t& m, uint32_t& v, uint32_t* keep = nullptr) {
         const uint32_t P = qv * kHashMul;
+        if (keep) *keep = P;
         const uint32_t sh = (P >> 12) & 16u;                                      // (h & 1) << 4
         a = (P >> 15) & 0x1fffcu;                                                 // (h >> 1) << 2
         m = 0xffffu << sh;
@@ -308,6 +437,14 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
         }
     };
     // one block in order: FSM, then either a raw copy or the dictionary step with the zero-entry map (slow rounds, epilogue)
+    // a register array parked in the staging area (array 0 or 1), and element j (wave-uniform, not a compile-time constant) of it:
+    // what the rolled loops of the rare paths index instead of registers (a dynamically indexed register array would live in scratch
+    // memory, whose loads the compiler waits for at the top of every round, common path included)
+    auto park = [&](uint32_t which, const uint32_t (&a)[R]) {
+#pragma unroll
+        for (uint32_t j = 0; j < R; ++j) lds_poke(kEncStage + which * 4096u + j * 256u + 4u * lane, a[j]);
+    };
+    auto parked = [&](uint32_t which, uint32_t j) -> uint32_t { return lds_peek1(kEncStage + which * 4096u + j * 256u + 4u * lane); };
     auto block_in_order = [&](Guard& g, uint32_t qv, uint32_t& a, uint32_t m, uint32_t v, uint64_t& sg, bool& raw) {
         sg = 0;
         raw = g.block_is_copy();                                                  // codec.rs:35
@@ -345,7 +482,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
             const uint64_t sg = ((uint64_t)rlane_u(shi, (int)j) << 32) | rlane_u(slo, (int)j);
             const uint64_t plain = ~sg;
             const uint32_t off = pos + c_base + 2u * mbcnt64(plain);              // 8 + 2*lane + 2*(PLAIN lanes below) = 8 + 4*lane - 2*(MAP lanes below)
-            const uint32_t P = q[j] * kHashMul;
+            const uint32_t P = kKeepQuads ? hp[j] : q[j] * kHashMul;              // (the hash is the MAP item: chameleon.rs:92)
             asm volatile(
                 "s_mov_b64 exec, %4\n\t"
                 "global_store_short_d16_hi %0, %1, %3\n\t"
@@ -362,15 +499,13 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
     // answers go back lane-reversed in ONE ds_write_b16 per block (ascending lane service order: the highest physical lane =
     // the lowest original lane wins)
     auto rollback_round = [&]() {
-        uint32_t sq[R], sr[R];                                                    // (scratch copies and a rolled loop: this path is rare, its code must not weigh on the common one)
-#pragma unroll
-        for (uint32_t j = 0; j < R; ++j) { sq[j] = q[j]; sr[j] = ra[j]; }
+        park(0, q); park(1, ra);                                                  // (a rolled loop: this path is rare, its code must not weigh on the common one)
 #pragma nounroll
         for (int j = (int)R - 1; j >= 0; --j) {
-            const uint32_t P = sq[j] * kHashMul;
+            const uint32_t P = parked(0, (uint32_t)j) * kHashMul, srj = parked(1, (uint32_t)j);
             const uint32_t hi = (P >> 16) & 1u;                                    // 1: the slot is the upper half of its dword
             const uint32_t a16 = ((P >> 15) & 0x1fffcu) + 2u * hi;
-            const uint32_t prev = hi ? (sr[j] >> 16) : (sr[j] & 0xffffu);
+            const uint32_t prev = hi ? (srj >> 16) : (srj & 0xffffu);
             const uint32_t ar = bperm(63u - lane, a16), pr = bperm(63u - lane, prev);
             dict_store(ar, pr);
         }
@@ -394,26 +529,40 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
         wg_barrier();
     };
 
-    load_round(q, wave);
+    if (kKeepQuads) {
+        // (by hand like every later fetch: a load the compiler can see ahead of the loop would make it wait, at the top of every
+        // iteration, until all but a few of the previous round's record stores have been acknowledged)
+        if (wave < nrounds) { prefetch_quads<R>(src + (uint64_t)wave * (R * kBlock) + 4u * lane); quads_landed<R, 0>(q); }
+    } else {
+        load_round(q, wave);
+    }
     for (uint32_t r = wave; r < nrounds; r += W) {
         clk.start();
         uint32_t slo = 0, shi = 0;                                                // lane j: the signature of block j (codec.rs:24-26)
         uint32_t copy_mask = 0, opos = 0;
+        bool fetched = false;
       for (;;) {   // (re-entered after an abort: the answers have replaced the addresses, so the operands are made again)
         uint32_t zmin = 0xffffffffu;
 #pragma unroll
         for (uint32_t j = 0; j < R; ++j) {
-            operands(q[j], ra[j], mask[j], val[j]);
+            operands(q[j], ra[j], mask[j], val[j], kKeepQuads ? &hp[j] : nullptr);
             zmin = val[j] < zmin ? val[j] : zmin;
             __builtin_amdgcn_sched_barrier(0);                                    // block by block: short live ranges, not maximal overlap
         }
-        bool zero_round = false;                                                  // some quad of the round needs the zero-entry map (about one in 64 Ki)
+        // Blocks with a quad that needs the zero-entry map (about one quad in 64 Ki): found here, ahead of the waits, together with the
+        // first such block's quads, so that the commit — which holds up every later round — has next to nothing left to look up.
+        uint32_t zblocks = 0, zq = 0;
+        bool zsusp = false;
         if (__builtin_expect(ballot64(zmin == 0) != 0, 0)) {                      // a stored entry 0: the zero quad (harmless) or one outside slot 0
-            bool zero_entry = false;
 #pragma unroll
-            for (uint32_t j = 0; j < R; ++j) zero_entry |= val[j] == 0 && q[j] != 0;
-            zero_round = ballot64(zero_entry) != 0;
+            for (uint32_t j = 0; j < R; ++j) zblocks |= (ballot64(val[j] == 0 && q[j] != 0) != 0 ? 1u : 0u) << j;
+            if (zblocks) {
+                const uint32_t j0 = (uint32_t)__builtin_ctz(zblocks);
+                zq = pick<R>(q, j0);
+                zsusp = pick<R>(val, j0) == 0 && zq != 0;
+            }
         }
+        const bool zero_round = zblocks != 0;
         const uint32_t tokaddr = lane == 0 ? sy + kSyD : sy + kSySink + 4u * lane;
         pin_operands<R>(ra, mask, val);                                           // complete before the wait for the token
 
@@ -452,7 +601,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
                 // everything the commit needs that does not depend on the token: incompressible records (codec.rs:68: 8 + 256 - 2*hits >= 256)
                 uint32_t inc = (uint32_t)ballot64(lane < R && (uint32_t)(__builtin_popcount(slo) + __builtin_popcount(shi)) <= 4u);
                 uint32_t sum = R * (kSig + kBlock) - 2u * hits;
-                load_round(q, r);                                          // the quads again (from L2): they are not kept across the wait for the token
+                if (!kKeepQuads) load_round(q, r);                        // the quads again (from L2): not kept across the wait for the token
                 clk.mark(3);
                 // ---- O chain: commit ----
                 uint32_t P0, P1;
@@ -472,14 +621,11 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
                 // and not just never anything.  `flipped`: the marks this round set itself (taken back if the round is rolled back).
                 uint32_t flipped = 0;
                 if (__builtin_expect(zero_round, 0)) {
-                    uint32_t sq[R], sv[R];                                        // (scratch copies and a rolled loop, as in rollback_round)
-#pragma unroll
-                    for (uint32_t j = 0; j < R; ++j) { sq[j] = q[j]; sv[j] = val[j]; }
-#pragma nounroll
-                    for (uint32_t j = 0; j < R; ++j) {
-                        const uint32_t qv = sq[j];
-                        const bool susp = sv[j] == 0 && qv != 0;
-                        if (ballot64(susp) == 0) continue;
+                    bool first = true;
+                    for (uint32_t zb = zblocks; zb; zb &= zb - 1u, first = false) {
+                        const uint32_t j = (uint32_t)__builtin_ctz(zb);
+                        const uint32_t qv = first ? zq : pick<R>(q, j);
+                        const bool susp = first ? zsusp : (pick<R>(val, j) == 0 && qv != 0);
                         const uint32_t zbit = zmap_claim_in_order(zmap, susp, (qv * kHashMul) >> 16, lane);
                         flipped |= (susp && !zbit ? 1u : 0u) << j;
                         const uint64_t sg = ((uint64_t)rlane(shi, j) << 32) | rlane(slo, j);
@@ -495,12 +641,9 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
                 const uint32_t t = inc & ((inc << 1) | ((P1 >> 16) & 1u));
                 if (__builtin_expect((P1 & 0xffu) != 0 || (t & ((1u << (R - 1)) - 1u)) != 0, 0)) {
                     if (ballot64(flipped != 0)) {
-                        uint32_t sq[R];
-#pragma unroll
-                        for (uint32_t j = 0; j < R; ++j) sq[j] = q[j];
-#pragma nounroll
-                        for (uint32_t j = 0; j < R; ++j) {
-                            if ((flipped >> j) & 1u) zmap.clear((sq[j] * kHashMul) >> 16);
+                        for (uint32_t zb = zblocks; zb; zb &= zb - 1u) {
+                            const uint32_t j = (uint32_t)__builtin_ctz(zb);
+                            if ((flipped >> j) & 1u) zmap.clear((pick<R>(q, j) * kHashMul) >> 16);
                         }
                     }
                     if (lane == 0) { lds_poke(sy + kSyD + 4, r); lds_poke(sy + kSyO + 4, r); }
@@ -524,6 +667,10 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
                     lds_poke(sy + kSyO, r + 1u);
                 }
                 copy_mask = 0;
+                if (kKeepQuads && r + W < nrounds) {                      // next round's quads: in flight behind the commit, landed by the end of the emit
+                    prefetch_quads<R>(src + (uint64_t)(r + W) * (R * kBlock) + 4u * lane);
+                    fetched = true;
+                }
                 clk.mark(4);
                 break;
             }
@@ -539,17 +686,15 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
                 watchdog(spins, sy, err, lane);
             }
             if (aborted) continue;
-            load_round(q, r);                                                     // (as in the fast path: the quads are not kept across the waits)
+            if (!kKeepQuads) load_round(q, r);                                    // (as in the fast path: the quads are not kept across the waits)
             Guard g = unpack_guard(P1);
             uint32_t sum = 0, unrest = 0;
             copy_mask = 0;
             {
-                uint32_t sq[R];                                                   // (scratch copy and a rolled loop, as in rollback_round)
-#pragma unroll
-                for (uint32_t j = 0; j < R; ++j) sq[j] = q[j];
+                park(0, q);                                                       // (a rolled loop, as in rollback_round)
 #pragma nounroll
                 for (uint32_t j = 0; j < R; ++j) {
-                    const uint32_t qv = sq[j];
+                    const uint32_t qv = parked(0, j);
                     uint32_t a, m, v;
                     operands(qv, a, m, v);
                     bool raw;
@@ -581,20 +726,30 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
             emit_round_coded(opos, idx ? idx + (uint64_t)r * R : nullptr, slo, shi);
         } else {
             uint8_t* rec = dst + opos;
-            uint32_t sq[R];
-#pragma unroll
-            for (uint32_t j = 0; j < R; ++j) sq[j] = q[j];
 #pragma nounroll
             for (uint32_t j = 0; j < R; ++j) {
                 const bool raw = (copy_mask >> j) & 1u;
                 const uint64_t sg = ((uint64_t)rlane(shi, j) << 32) | rlane(slo, j);
                 const uint32_t nh = (uint32_t)__builtin_popcountll(sg);
-                emit_block(rec, sq[j], sg, raw);
+                emit_block(rec, pick<R>(q, j), sg, raw);
                 if (idx && lane == 0) idx[(uint64_t)r * R + j] = (uint8_t)(raw ? kIdxCopy : nh);
                 rec += raw ? kBlock : kSig + kBlock - 2u * nh;
             }
         }
-        load_round(q, r + W);                                                     // next round's quads (their latency is this wave's slack, not the chain's)
+        if (kKeepQuads) {
+            if (fetched && copy_mask == 0) {
+                // at least R stores are younger than the R loads (emit_round_coded: every record stores its MAP items, its PLAIN items or
+                // both — a store none of whose lanes is active is not counted — and the signatures go out in one more)
+                quads_landed<R, R>(q);
+            } else if (fetched) {
+                quads_landed<R, 0>(q);
+            } else if (r + W < nrounds) {                                         // (an in-order round: asked for only now)
+                prefetch_quads<R>(src + (uint64_t)(r + W) * (R * kBlock) + 4u * lane);
+                quads_landed<R, 0>(q);
+            }
+        } else {
+            load_round(q, r + W);                                                 // next round's quads (their latency is this wave's slack, not the chain's)
+        }
         clk.mark(6);
     }
     clk.flush(wave, lane);
@@ -640,7 +795,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
                                                               const uint8_t* __restrict__ index, uint32_t* __restrict__ zmap_words,
                                                               uint64_t* __restrict__ produced, uint32_t* __restrict__ err, uint32_t tune,
                                                               uint64_t* __restrict__ prof) {
-    static_assert((R == 8 || R == 16) && (W == 8 || W == 12 || W == 16), "round = 8 or 16 records; 8, 12 or 16 waves");
+    static_assert((R == 8 || R == 12 || R == 16) && (W == 8 || W == 12 || W == 16), "round = 8, 12 or 16 records; 8, 12 or 16 waves");
     constexpr uint32_t kThreads = W * 64, kScanThreads = W == 16 ? 1024 : 512, kPerThread = kRotMaxBlocks / kScanThreads;   // position scan: 16 or 32 index entries per thread
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = rfl(threadIdx.x >> 6);
@@ -706,7 +861,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
 #pragma unroll
             for (uint32_t k = 0; k < kPerThread; ++k) {
                 const uint32_t i = first + k, ent = smem[kDecIdx + i], l = rec_len(ent);
-                if ((k & (R - 1u)) == 0) *reinterpret_cast<uint32_t*>(smem + kDecPos + (i / R) * 4u) = pos;
+                if (i % R == 0) *reinterpret_cast<uint32_t*>(smem + kDecPos + (i / R) * 4u) = pos;
                 const bool stop = (ent & 0x7fu) == kIdxRagged || i >= nblk || ((uint64_t)i + 1) * kBlock > cap || pos >= elen || elen - pos < l + 2u;
                 if (stop && stop_key == ~0ull) stop_key = ((uint64_t)i << 33) | ((uint64_t)((ent & kIdxCopy) && i < nblk ? 1u : 0u) << 32) | pos;
                 pos += l;
@@ -729,7 +884,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
     // number and order of memory operations per iteration is fixed and the compiler's waits count exactly.)
     auto stage_a = [&](uint32_t xr, Meta& m) {                                   // positions of round x; signatures requested
         const uint32_t x = xr < npr ? xr : npr - 1u;
-        const uint32_t e = smem[kDecIdx + x * R + (lane & (R - 1u))];             // lane j (and its images): entry of record j
+        const uint32_t e = smem[kDecIdx + x * R + (lane < R ? lane : 0u)];        // lane j < R: entry of record j
         const uint32_t base = rfl(lds_peek1(kDecPos + x * 4u));
         const uint32_t mylen = (e & kIdxCopy) ? kBlock : kSig + kBlock - 2u * (e & 0x7fu);
         uint32_t incl = mylen;                                                    // prefix within rows of 16 lanes
@@ -797,7 +952,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
             ra[j] = coded ? ((h >> 1) << 2) : 4u * lane;                          // raw / absent records: a harmless conflict-free read
             mask[j] = writes ? (0xffffu << sh) : 0u;
             val[j] = writes ? (e << sh) : 0u;
-            zacc |= (writes && e == 0 && h != 0) ? 1u : 0u;
+            zacc |= (writes && e == 0 && h != 0) ? (1u << j) : 0u;                  // bit j: record j has a zero-entry quad in this lane
         }
         const uint32_t tokaddr = lane == 0 ? sy + kSyD : sy + kSySink + 4u * lane;
         pin_operands<R>(ra, mask, val);                                           // complete before the wait for the token
@@ -826,7 +981,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
             const bool maps = ((coded_mask & hitsc) >> j) & 1u;
             const uint32_t h = itemc[j] & 0xffffu;
             const uint32_t cur = (ra[j] >> ((h & 1u) << 4)) & 0xffffu;
-            zacc |= (maps && cur == 0 && h != 0) ? 2u : 0u;                       // MAP of a slot holding 0: never written, or a genuine zero entry?
+            zacc |= (maps && cur == 0 && h != 0) ? (1u << j) : 0u;                // MAP of a slot holding 0: never written, or a genuine zero entry?
             ra[j] = maps ? entry_to_quad(h, cur) : itemc[j];
         }
         clk.mark(5);
@@ -841,20 +996,21 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
                 if (rfl(lds_peek1(sy + kSyD)) == kPoison) wave_exit();
                 watchdog(spins, sy, err, lane);
             }
-            uint32_t si[R], sr[R];                                                // (scratch copies and a rolled loop: a rare path must not weigh on the common one)
+            // which records have such a quad, then those records one by one — usually one
+            uint32_t zblocks = 0;
 #pragma unroll
-            for (uint32_t j = 0; j < R; ++j) { si[j] = itemc[j]; sr[j] = ra[j]; }
-#pragma nounroll
-            for (uint32_t j = 0; j < R; ++j) {
+            for (uint32_t j = 0; j < R; ++j) zblocks |= (ballot64((zacc >> j) & 1u) != 0 ? 1u : 0u) << j;
+            for (uint32_t zb = zblocks; zb; zb &= zb - 1u) {
+                const uint32_t j = (uint32_t)__builtin_ctz(zb);
                 const bool coded = (coded_mask >> j) & 1u;
                 const bool hit = (hitsc >> j) & 1u;
-                const uint32_t qv = si[j];
+                const uint32_t qv = pick<R>(itemc, j), cur = pick<R>(ra, j);
                 const uint32_t P = qv * kHashMul;
                 const uint32_t h = hit ? (qv & 0xffffu) : (P >> 16);
                 const bool zset = coded && !hit && stored_entry(qv, P) == 0 && h != 0;
-                const bool ztest = coded && hit && h != 0 && sr[j] == entry_to_quad(h, 0);   // the slot held stored entry 0
+                const bool ztest = coded && hit && h != 0 && cur == entry_to_quad(h, 0);
                 uint64_t todo = ballot64(zset || ztest);
-                uint32_t out = sr[j];
+                uint32_t out = cur;
                 while (todo) {                                                    // ascending lane == stream order
                     const uint32_t l = (uint32_t)__builtin_ctzll(todo);
                     todo &= todo - 1;
@@ -863,10 +1019,13 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
                         else if (!zmap.test(h)) out = 0;                          // chameleon.rs:64-68 on a never-written (zero) word
                     }
                 }
-                sr[j] = out;
-            }
 #pragma unroll
-            for (uint32_t j = 0; j < R; ++j) ra[j] = sr[j];
+                for (uint32_t k = 0; k < R; ++k) {
+                    uint32_t jj = j;
+                    asm volatile("" : "+s"(jj));                                  // (opaque, as in pick)
+                    ra[k] = jj == k ? out : ra[k];
+                }
+            }
         }
         if (lane == 0) lds_poke(sy + kSyZdone + 4u * wave, x + 1u);
         clk.mark(6);
@@ -1077,6 +1236,15 @@ hipError_t launch_rotor_decode(const uint8_t* d_in, const uint64_t* d_offsets, c
     // two rounds of loads in flight: longer rounds or fewer waves leave it waiting for memory)
     const uint32_t sel = (rot_tune() >> 5) & 7u, geo = sel <= 1 ? 0u : sel == 2 ? 1u : sel == 3 ? 2u : sel == 4 ? 3u : sel == 5 ? 4u : 5u;
     const uint32_t waves = (geo == 0 || geo == 5) ? 16 : (geo == 1 || geo == 3) ? 12 : 8;
+    if (sel == 0 || sel == 7) {   // default: rounds of 12 records on 12 waves (168 registers each: no spills, and the shortest chain per record)
+        auto k12 = prof ? chameleon_decode_rot<12, 12, true> : chameleon_decode_rot<12, 12, false>;
+        hipError_t e12 = hipFuncSetAttribute((const void*)k12, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDecLds);
+        if (e12 != hipSuccess) return e12;
+        hipLaunchKernelGGL(k12, dim3(n_chunks), dim3(768), kDecLds, stream, d_in, d_offsets, d_sizes, d_out, out_stride, out_total,
+                           exact ? 1u : 0u, d_index, d_zmap, d_produced, d_err, rot_tune(), prof);
+        rot_prof_report("decode", "stage A | stage B | operands | D wait | exchange | quads | Z chain | stores", prof, stream);
+        return hipGetLastError();
+    }
     auto kernel = geo == 5 ? (prof ? chameleon_decode_rot<16, 16, true> : chameleon_decode_rot<16, 16, false>)
                 : geo == 1 ? (prof ? chameleon_decode_rot<16, 12, true> : chameleon_decode_rot<16, 12, false>)
                 : geo == 2 ? (prof ? chameleon_decode_rot<16, 8, true> : chameleon_decode_rot<16, 8, false>)
