@@ -330,6 +330,7 @@ struct PhaseClock<false> {
     __device__ __forceinline__ void start() {}
     __device__ __forceinline__ void mark(int) {}
     __device__ __forceinline__ void stamp(uint32_t, uint32_t, uint32_t) {}
+    __device__ __forceinline__ void note(uint32_t, uint32_t, uint32_t) {}
     __device__ __forceinline__ void flush(uint32_t, uint32_t) {}
 };
 template <>
@@ -338,9 +339,13 @@ struct PhaseClock<true> {
     __device__ __forceinline__ explicit PhaseClock(uint64_t* o) : out(o) {}
     __device__ __forceinline__ void start() { if (out) t0 = __builtin_readcyclecounter(); }
     __device__ __forceinline__ void mark(int k) { if (out) { const uint64_t t = __builtin_readcyclecounter(); ph[k] += t - t0; t0 = t; } }
-    // per-round time stamps of the D chain (rounds < kProfRounds): 0 = started polling, 1 = token seen, 2 = exchanges + token done
+    // per-round time stamps of the D chain (rounds < kProfRounds): 0 = started polling, 1 = token seen, 2 = exchanges + token done, 3 = round finished
     __device__ __forceinline__ void stamp(uint32_t r, uint32_t what, uint32_t lane) {
-        if (out && r < kProfRounds && lane == 0) out[128 + 3 * r + what] = __builtin_readcyclecounter();
+        if (out && r < kProfRounds && lane == 0) out[128 + 4 * r + what] = __builtin_readcyclecounter();
+    }
+    // a mark on a round (bit 0: it went through the zero-entry path)
+    __device__ __forceinline__ void note(uint32_t r, uint32_t v, uint32_t lane) {
+        if (out && r < kProfRounds && lane == 0) out[128 + 4 * kProfRounds + r] = v;
     }
     __device__ __forceinline__ void flush(uint32_t wave, uint32_t lane) { if (out && lane == 0) for (int k = 0; k < 8; ++k) out[8 * wave + k] = ph[k]; }
 };
@@ -390,7 +395,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
     // the table sits at LDS address 0 (this kernel has no static LDS): slot addresses need no base
     const uint32_t sy = kEncSync;
     const ZmapLds zmap{kEncZmap};
-    const bool late_token = (tune & 1u) != 0, no_sleep = (tune & 2u) != 0, poll_prio = (tune & 256u) != 0;
+    const bool late_token = (tune & 1u) != 0, no_sleep = (tune & 2u) != 0, poll_prio = (tune & 256u) != 0, edf = (tune & 512u) == 0;
 
     {   // fresh state per chunk (chameleon.rs:45-48): zero table, zero-entry map, tokens: round 0 in slow mode, nothing committed
         uint4* p = reinterpret_cast<uint4*>(smem);
@@ -538,6 +543,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
     }
     for (uint32_t r = wave; r < nrounds; r += W) {
         clk.start();
+        if (edf) __builtin_amdgcn_s_setprio(1);                                   // (see the priorities note at the exchange)
         uint32_t slo = 0, shi = 0;                                                // lane j: the signature of block j (codec.rs:24-26)
         uint32_t copy_mask = 0, opos = 0;
         bool fetched = false;
@@ -568,6 +574,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
 
         clk.mark(0);
         clk.stamp(r, 0, lane);
+        if (edf) __builtin_amdgcn_s_setprio(2);
         {
             // ---- D chain: wait for this round's turn ----
             uint32_t slow;
@@ -584,9 +591,13 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
             clk.stamp(r, 1, lane);
             if (__builtin_expect(!slow, 1)) {
                 // ---- fast round: R speculative exchanges, token passed behind them ----
+                // Priorities: the SIMD's arbiter prefers, at equal priority, the wave that was launched first, which leaves the last-launched
+                // wave of each SIMD short of issue slots and late for its turns.  So a wave's priority follows its deadline instead: 3
+                // inside the exchanges, 2 on the way to the commit and while it waits for a token, 1 while it prepares its next round, 0
+                // while it writes records out (nobody waits for those).
                 __builtin_amdgcn_s_setprio(3);
                 exchange_tied<R>(ra, mask, val, tokaddr, (r + 1u) << 1, late_token);
-                __builtin_amdgcn_s_setprio(0);
+                if (edf) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
                 clk.mark(2);
                 clk.stamp(r, 2, lane);
                 uint32_t hits = 0;
@@ -621,6 +632,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
                 // and not just never anything.  `flipped`: the marks this round set itself (taken back if the round is rolled back).
                 uint32_t flipped = 0;
                 if (__builtin_expect(zero_round, 0)) {
+                    clk.note(r, 1, lane);
                     bool first = true;
                     for (uint32_t zb = zblocks; zb; zb &= zb - 1u, first = false) {
                         const uint32_t j = (uint32_t)__builtin_ctz(zb);
@@ -667,6 +679,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
                     lds_poke(sy + kSyO, r + 1u);
                 }
                 copy_mask = 0;
+                if (edf) __builtin_amdgcn_s_setprio(0);
                 if (kKeepQuads && r + W < nrounds) {                      // next round's quads: in flight behind the commit, landed by the end of the emit
                     prefetch_quads<R>(src + (uint64_t)(r + W) * (R * kBlock) + 4u * lane);
                     fetched = true;
@@ -751,6 +764,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
             load_round(q, r + W);                                                 // next round's quads (their latency is this wave's slack, not the chain's)
         }
         clk.mark(6);
+        clk.stamp(r, 3, lane);
     }
     clk.flush(wave, lane);
 
@@ -812,7 +826,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
     const ZmapGlobal zmap{zmap_words + chunk * (kZmapBytes / 4)};
     // the table sits at LDS address 0 (this kernel has no static LDS): slot addresses need no base
     const uint32_t sy = kDecSync;
-    const bool late_token = (tune & 1u) != 0, no_sleep = (tune & 2u) != 0, poll_prio = (tune & 256u) != 0;
+    const bool late_token = (tune & 1u) != 0, no_sleep = (tune & 2u) != 0, poll_prio = (tune & 256u) != 0, edf = (tune & 512u) == 0;
 
     {   // fresh dictionary, this chunk's zero-entry map, the block index into LDS
         uint4* p = reinterpret_cast<uint4*>(smem);
@@ -929,6 +943,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
     uint32_t ra[R], mask[R], val[R];
     for (uint32_t x = wave; x < npr; x += W) {
         clk.start();
+        if (edf) __builtin_amdgcn_s_setprio(1);                                   // (priorities: see the encoder's exchange)
         // (B first: what it waits for — the signatures requested one iteration ago — is older than anything issued since, so the
         // wait does not cover a load that has just left)
         stage_b(mb, hitsb, itemb);
@@ -958,6 +973,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
         pin_operands<R>(ra, mask, val);                                           // complete before the wait for the token
         clk.mark(2);
         clk.stamp(x, 0, lane);
+        if (edf) __builtin_amdgcn_s_setprio(2);
         // ---- D chain ----
         for (uint32_t spins = 0;;) {
             if (poll_word(sy + kSyD, x, 16, poll_prio)) break;
@@ -988,6 +1004,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
         // ---- zero-entry map, in stream order (rare: stored entries are salted).  A round with no such quad only reports "done"; one that
         // has any first waits until every earlier round has reported (wave w' owns the rounds = w' mod W). ----
         if (__builtin_expect(ballot64(zacc != 0) != 0, 0)) {
+            clk.note(x, 1, lane);
             for (uint32_t spins = 0;;) {
                 const uint32_t wv = lane % W;
                 const uint32_t d = (wave + W - wv) % W;                           // wave wv's last round before x is x - d
@@ -1039,6 +1056,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
 #pragma unroll
         for (uint32_t j = 0; j < R; ++j) itemc[j] = itemb[j];
         clk.mark(7);
+        clk.stamp(x, 3, lane);
     }
     clk.flush(wave, lane);
 
@@ -1144,18 +1162,23 @@ __global__ __launch_bounds__(kRotThreads) void rotor_selftest_kernel(uint32_t* _
 // ---------------------------------------------------------------------------------------------------------------
 namespace {
 // DENSITY_HIP_PROF=1: per-wave, per-phase cycle accounting of work-group 0, printed to stderr after every launch (synchronises)
-constexpr size_t kProfWords = 128 + 3 * kProfRounds;
+constexpr size_t kProfWords = 128 + 5 * kProfRounds;
 uint64_t* rot_prof_buffer() {
     static uint64_t* buf = nullptr;
     if (!getenv("DENSITY_HIP_PROF")) return nullptr;
     if (!buf && hipMalloc((void**)&buf, kProfWords * sizeof(uint64_t)) != hipSuccess) buf = nullptr;
-    if (buf) (void)hipMemset(buf, 0, kProfWords * sizeof(uint64_t));
+    if (buf) { (void)hipDeviceSynchronize(); (void)hipMemset(buf, 0, kProfWords * sizeof(uint64_t)); (void)hipDeviceSynchronize(); }
     return buf;
 }
-void rot_prof_report(const char* what, const char* phases, uint64_t* buf, hipStream_t stream) {
+void rot_prof_report(const char* what, const char* phases, uint64_t* buf, hipStream_t stream, uint32_t waves = 8) {
     if (!buf) return;
     static uint64_t h[kProfWords];
     if (hipStreamSynchronize(stream) != hipSuccess || hipMemcpy(h, buf, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return;
+    if (const char* dump = getenv("DENSITY_HIP_PROF_DUMP")) {                     // raw buffer, for offline analysis: <prefix>.<encode|decode>.bin
+        char path[512];
+        snprintf(path, sizeof(path), "%s.%s.bin", dump, what);
+        if (FILE* f = fopen(path, "wb")) { fwrite(h, sizeof(uint64_t), kProfWords, f); fclose(f); }
+    }
     fprintf(stderr, "[density_hip prof] %s work-group 0, kcycles per wave by phase (%s)\n", what, phases);
     for (int w = 0; w < 16; ++w) {
         uint64_t tot = 0;
@@ -1171,11 +1194,11 @@ void rot_prof_report(const char* what, const char* phases, uint64_t* buf, hipStr
     uint64_t hop_max = 0;
     uint32_t hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (uint32_t r = 17; r < kProfRounds; ++r) {
-        if (!ts[3 * r + 1] || !ts[3 * r + 2] || !ts[3 * (r - 1) + 1] || !ts[3 * (r - 1) + 2]) continue;
-        const uint64_t seen = ts[3 * r + 1], prev_seen = ts[3 * (r - 1) + 1], prev_done = ts[3 * (r - 1) + 2], arrive = ts[3 * r];
+        if (!ts[4 * r + 1] || !ts[4 * r + 2] || !ts[4 * (r - 1) + 1] || !ts[4 * (r - 1) + 2]) continue;
+        const uint64_t seen = ts[4 * r + 1], prev_seen = ts[4 * (r - 1) + 1], prev_done = ts[4 * (r - 1) + 2], arrive = ts[4 * r];
         if (seen < prev_seen) continue;
         const uint64_t hp = seen - prev_seen;
-        hop += (double)hp; crit += (double)(ts[3 * r + 2] - seen);
+        hop += (double)hp; crit += (double)(ts[4 * r + 2] - seen);
         hop_max = hp > hop_max ? hp : hop_max;
         const uint64_t ready = arrive > prev_done ? arrive : prev_done;
         det += seen > ready ? (double)(seen - ready) : 0.0;
@@ -1190,6 +1213,22 @@ void rot_prof_report(const char* what, const char* phases, uint64_t* buf, hipStr
         fprintf(stderr, "[density_hip prof]   hop histogram (<128, <256, <512, <1k, <2k, <4k, <8k, more):");
         for (int b = 0; b < 8; ++b) fprintf(stderr, " %u", hist[b]);
         fprintf(stderr, "\n");
+        // why owners are late: a wave's own iteration = arrival(r) - exchanges done(r - waves), split by what its previous round was
+        const uint64_t* notes = h + 128 + 4 * kProfRounds;
+        double it_plain = 0, it_zero = 0, tail_plain = 0, tail_zero = 0;
+        uint32_t n_plain = 0, n_zero = 0, late_after_zero = 0, late_total = 0, zero_rounds = 0;
+        for (uint32_t r = 17 + waves; r < kProfRounds; ++r) {
+            if (!ts[4 * r] || !ts[4 * (r - waves) + 2] || !ts[4 * (r - waves) + 3] || !ts[4 * (r - 1) + 2]) continue;
+            const bool z = (notes[r - waves] & 1u) != 0;
+            const double it = (double)(ts[4 * r] - ts[4 * (r - waves) + 2]), tail = (double)(ts[4 * (r - waves) + 3] - ts[4 * (r - waves) + 2]);
+            if (z) { it_zero += it; tail_zero += tail; ++n_zero; } else { it_plain += it; tail_plain += tail; ++n_plain; }
+            if (ts[4 * r] > ts[4 * (r - 1) + 2]) { ++late_total; if (z) ++late_after_zero; }
+            if (notes[r] & 1u) ++zero_rounds;
+        }
+        fprintf(stderr, "[density_hip prof]   a wave between its exchanges and its next arrival: %.0f cycles (%.0f of them up to the end of the round) after a plain round (%u), "
+                        "%.0f (%.0f) after a zero-entry round (%u); %u of %u late arrivals follow a zero-entry round; %u zero-entry rounds\n",
+                n_plain ? it_plain / n_plain : 0.0, n_plain ? tail_plain / n_plain : 0.0, n_plain, n_zero ? it_zero / n_zero : 0.0, n_zero ? tail_zero / n_zero : 0.0, n_zero,
+                late_after_zero, late_total, zero_rounds);
     }
 }
 uint32_t rot_tune() {
@@ -1218,7 +1257,7 @@ hipError_t launch_rotor_encode(const uint8_t* d_in, uint64_t total, uint64_t chu
     hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEncLds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3(n_chunks), dim3(waves * 64), kEncLds, stream, d_in, total, chunk_bytes, d_out, out_stride, d_sizes, d_index, d_err, rot_tune(), prof);
-    rot_prof_report("encode", "hash | D wait | exchange | signatures | O wait+commit | load wait | emit | in-order rounds", prof, stream);
+    rot_prof_report("encode", "hash | D wait | exchange | signatures | O wait+commit | load wait | emit | in-order rounds", prof, stream, waves);
     return hipGetLastError();
 }
 bool rotor_decode_eligible(const uint8_t* d_out, uint32_t n_chunks, uint64_t out_stride, uint64_t out_total, const uint8_t* d_index, const uint32_t* d_zmap) {
@@ -1242,7 +1281,7 @@ hipError_t launch_rotor_decode(const uint8_t* d_in, const uint64_t* d_offsets, c
         if (e12 != hipSuccess) return e12;
         hipLaunchKernelGGL(k12, dim3(n_chunks), dim3(768), kDecLds, stream, d_in, d_offsets, d_sizes, d_out, out_stride, out_total,
                            exact ? 1u : 0u, d_index, d_zmap, d_produced, d_err, rot_tune(), prof);
-        rot_prof_report("decode", "stage A | stage B | operands | D wait | exchange | quads | Z chain | stores", prof, stream);
+        rot_prof_report("decode", "stage A | stage B | operands | D wait | exchange | quads | Z chain | stores", prof, stream, 12);
         return hipGetLastError();
     }
     auto kernel = geo == 5 ? (prof ? chameleon_decode_rot<16, 16, true> : chameleon_decode_rot<16, 16, false>)
@@ -1255,7 +1294,7 @@ hipError_t launch_rotor_decode(const uint8_t* d_in, const uint64_t* d_offsets, c
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3(n_chunks), dim3(waves * 64), kDecLds, stream, d_in, d_offsets, d_sizes, d_out, out_stride, out_total,
                        exact ? 1u : 0u, d_index, d_zmap, d_produced, d_err, rot_tune(), prof);
-    rot_prof_report("decode", "stage A | stage B | operands | D wait | exchange | quads | Z chain | stores", prof, stream);
+    rot_prof_report("decode", "stage A | stage B | operands | D wait | exchange | quads | Z chain | stores", prof, stream, waves);
     return hipGetLastError();
 }
 hipError_t launch_rotor_selftest(uint32_t* d_fail, hipStream_t stream) {
