@@ -2,6 +2,7 @@
 import os
 import shutil
 import subprocess
+import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
@@ -29,6 +30,13 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)
+    # the encoder's hand-issued loads rely on registers the compiler must not have used: checked in the compiled code, every build
+    check = os.path.join(os.path.dirname(HERE), "tools", "check_isa.py")
+    if os.path.exists(check):
+        r = subprocess.run([sys.executable, check], capture_output=True, text=True)
+        if r.returncode != 0:
+            os.remove(LIB)
+            raise RuntimeError("tools/check_isa.py rejected the compiled rotation encoder:\n" + r.stdout + r.stderr)
     return LIB
 
 

@@ -546,7 +546,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
         if (edf) __builtin_amdgcn_s_setprio(1);                                   // (see the priorities note at the exchange)
         uint32_t slo = 0, shi = 0;                                                // lane j: the signature of block j (codec.rs:24-26)
         uint32_t copy_mask = 0, opos = 0;
-        bool fetched = false;
+        bool fast_commit = false;
       for (;;) {   // (re-entered after an abort: the answers have replaced the addresses, so the operands are made again)
         uint32_t zmin = 0xffffffffu;
 #pragma unroll
@@ -680,10 +680,8 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
                 }
                 copy_mask = 0;
                 if (edf) __builtin_amdgcn_s_setprio(0);
-                if (kKeepQuads && r + W < nrounds) {                      // next round's quads: in flight behind the commit, landed by the end of the emit
-                    prefetch_quads<R>(src + (uint64_t)(r + W) * (R * kBlock) + 4u * lane);
-                    fetched = true;
-                }
+                fast_commit = true;
+                if (kKeepQuads && r + W < nrounds) prefetch_quads<R>(src + (uint64_t)(r + W) * (R * kBlock) + 4u * lane);   // next round's quads: in flight behind the commit, landed by the end of the emit
                 clk.mark(4);
                 break;
             }
@@ -727,6 +725,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
                 lds_poke(sy + kSyO, r + 1u);
                 lds_poke(sy + kSyD, ((r + 1u) << 1) | stay_slow);
             }
+            if (kKeepQuads && r + W < nrounds) prefetch_quads<R>(src + (uint64_t)(r + W) * (R * kBlock) + 4u * lane);   // (as behind a fast commit)
             clk.mark(7);
             break;
         }
@@ -750,15 +749,11 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
             }
         }
         if (kKeepQuads) {
-            if (fetched && copy_mask == 0) {
-                // at least R stores are younger than the R loads (emit_round_coded: every record stores its MAP items, its PLAIN items or
-                // both — a store none of whose lanes is active is not counted — and the signatures go out in one more)
-                quads_landed<R, R>(q);
-            } else if (fetched) {
-                quads_landed<R, 0>(q);
-            } else if (r + W < nrounds) {                                         // (an in-order round: asked for only now)
-                prefetch_quads<R>(src + (uint64_t)(r + W) * (R * kBlock) + 4u * lane);
-                quads_landed<R, 0>(q);
+            // (both ways out of the round have asked for the next one's quads)
+            if (r + W < nrounds) {
+                // behind a fast commit at least R stores are younger than the R loads (emit_round_coded: every record stores its MAP items,
+                // its PLAIN items or both — a store none of whose lanes is active is not counted — and the signatures go out in one more)
+                if (fast_commit) quads_landed<R, R>(q); else quads_landed<R, 0>(q);
             }
         } else {
             load_round(q, r + W);                                                 // next round's quads (their latency is this wave's slack, not the chain's)
@@ -1244,16 +1239,13 @@ bool rotor_encode_eligible(const uint8_t* d_in, uint64_t total, uint64_t chunk_b
 hipError_t launch_rotor_encode(const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_out, uint64_t out_stride,
                                uint64_t* d_sizes, uint8_t* d_index, uint32_t* d_err, hipStream_t stream) {
     uint64_t* prof = rot_prof_buffer();
-    // geometry (DENSITY_HIP_TUNE bits 2..4, 0 = default = 3): 1 = rounds of 8 blocks on 16 waves, 2 = 16 x 12, 3 = 16 x 8 (the longer round
-    // amortises the hand-off; measured best), 4 = 8 x 12, 5 = 8 x 8, 6 = 16 x 16
-    const uint32_t sel = (rot_tune() >> 2) & 7u, geo = sel == 0 ? 2u : sel == 1 ? 0u : sel == 2 ? 1u : sel == 3 ? 2u : sel == 4 ? 3u : sel == 5 ? 4u : 5u;
-    const uint32_t waves = (geo == 0 || geo == 5) ? 16 : (geo == 1 || geo == 3) ? 12 : 8;
-    auto kernel = geo == 5 ? (prof ? chameleon_encode_rot<16, 16, true> : chameleon_encode_rot<16, 16, false>)
-                : geo == 1 ? (prof ? chameleon_encode_rot<16, 12, true> : chameleon_encode_rot<16, 12, false>)
-                : geo == 2 ? (prof ? chameleon_encode_rot<16, 8, true> : chameleon_encode_rot<16, 8, false>)
-                : geo == 3 ? (prof ? chameleon_encode_rot<8, 12, true> : chameleon_encode_rot<8, 12, false>)
-                : geo == 4 ? (prof ? chameleon_encode_rot<8, 8, true> : chameleon_encode_rot<8, 8, false>)
-                           : (prof ? chameleon_encode_rot<8, 16, true> : chameleon_encode_rot<8, 16, false>);
+    // geometry (DENSITY_HIP_TUNE bits 2..4): 0 = default = rounds of 16 blocks on 8 waves (the longer round amortises the hand-off, and 8
+    // waves have the registers to keep their quads), 1 = 8 blocks on 16 waves, 2 = 16 blocks on 12 waves (as fast as the default, more code)
+    const uint32_t sel = (rot_tune() >> 2) & 7u;
+    const uint32_t waves = sel == 1 ? 16 : sel == 2 ? 12 : 8;
+    auto kernel = sel == 1 ? (prof ? chameleon_encode_rot<8, 16, true> : chameleon_encode_rot<8, 16, false>)
+                : sel == 2 ? (prof ? chameleon_encode_rot<16, 12, true> : chameleon_encode_rot<16, 12, false>)
+                           : (prof ? chameleon_encode_rot<16, 8, true> : chameleon_encode_rot<16, 8, false>);
     hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEncLds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3(n_chunks), dim3(waves * 64), kEncLds, stream, d_in, total, chunk_bytes, d_out, out_stride, d_sizes, d_index, d_err, rot_tune(), prof);
@@ -1271,25 +1263,12 @@ hipError_t launch_rotor_decode(const uint8_t* d_in, const uint64_t* d_offsets, c
                                uint64_t out_stride, uint64_t out_total, bool exact, const uint8_t* d_index, uint32_t* d_zmap,
                                uint64_t* d_produced, uint32_t* d_err, hipStream_t stream) {
     uint64_t* prof = rot_prof_buffer();
-    // geometry (DENSITY_HIP_TUNE bits 5..7): numbered as for the encoder; default 1 = rounds of 8 records on 16 waves (the decoder's waves carry
-    // two rounds of loads in flight: longer rounds or fewer waves leave it waiting for memory)
-    const uint32_t sel = (rot_tune() >> 5) & 7u, geo = sel <= 1 ? 0u : sel == 2 ? 1u : sel == 3 ? 2u : sel == 4 ? 3u : sel == 5 ? 4u : 5u;
-    const uint32_t waves = (geo == 0 || geo == 5) ? 16 : (geo == 1 || geo == 3) ? 12 : 8;
-    if (sel == 0 || sel == 7) {   // default: rounds of 12 records on 12 waves (168 registers each: no spills, and the shortest chain per record)
-        auto k12 = prof ? chameleon_decode_rot<12, 12, true> : chameleon_decode_rot<12, 12, false>;
-        hipError_t e12 = hipFuncSetAttribute((const void*)k12, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDecLds);
-        if (e12 != hipSuccess) return e12;
-        hipLaunchKernelGGL(k12, dim3(n_chunks), dim3(768), kDecLds, stream, d_in, d_offsets, d_sizes, d_out, out_stride, out_total,
-                           exact ? 1u : 0u, d_index, d_zmap, d_produced, d_err, rot_tune(), prof);
-        rot_prof_report("decode", "stage A | stage B | operands | D wait | exchange | quads | Z chain | stores", prof, stream, 12);
-        return hipGetLastError();
-    }
-    auto kernel = geo == 5 ? (prof ? chameleon_decode_rot<16, 16, true> : chameleon_decode_rot<16, 16, false>)
-                : geo == 1 ? (prof ? chameleon_decode_rot<16, 12, true> : chameleon_decode_rot<16, 12, false>)
-                : geo == 2 ? (prof ? chameleon_decode_rot<16, 8, true> : chameleon_decode_rot<16, 8, false>)
-                : geo == 3 ? (prof ? chameleon_decode_rot<8, 12, true> : chameleon_decode_rot<8, 12, false>)
-                : geo == 4 ? (prof ? chameleon_decode_rot<8, 8, true> : chameleon_decode_rot<8, 8, false>)
-                           : (prof ? chameleon_decode_rot<8, 16, true> : chameleon_decode_rot<8, 16, false>);
+    // geometry (DENSITY_HIP_TUNE bits 5..7): 0 = default = rounds of 12 records on 12 waves (168 registers each: the longest round that does
+    // not spill, i.e. the shortest chain per record), 1 = 8 records on 16 waves
+    const uint32_t sel = (rot_tune() >> 5) & 7u;
+    const uint32_t waves = sel == 1 ? 16 : 12;
+    auto kernel = sel == 1 ? (prof ? chameleon_decode_rot<8, 16, true> : chameleon_decode_rot<8, 16, false>)
+                           : (prof ? chameleon_decode_rot<12, 12, true> : chameleon_decode_rot<12, 12, false>);
     hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDecLds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3(n_chunks), dim3(waves * 64), kDecLds, stream, d_in, d_offsets, d_sizes, d_out, out_stride, out_total,
