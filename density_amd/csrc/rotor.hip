@@ -907,17 +907,24 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
         m.cnt = e & 0x7fu;                                                        // the entry's MAP count: checked against the signature in stage B
     };
     uint32_t bad_index = 0;
+    const uint32_t minus_2lane = 0u - 2u * lane;
     auto stage_b = [&](const Meta& m, uint32_t& hits, uint32_t (&item)[R]) {    // signatures -> MAP/PLAIN flags, item loads
+        // the index must agree with the stream it describes: a record's MAP count is its signature's popcount (lane j < R: record j)
+        bad_index |= (lane < R && !((m.copy_mask >> lane) & 1u) && (uint32_t)(__builtin_popcount(m.sgv.x) + __builtin_popcount(m.sgv.y)) != m.cnt) ? 1u : 0u;
         hits = 0;
 #pragma unroll
-        for (uint32_t j = 0; j < R; ++j) {
+        for (uint32_t j = 0; j < R; ++j) {                                        // (straight-line: selects, no branches)
             const uint32_t pos = rlane_u(m.posv, (int)j);
-            const bool raw = (m.copy_mask >> j) & 1u;                             // codec.rs:89-91: 256 raw bytes, no signature
-            const uint64_t sg = raw ? 0ull : ((uint64_t)rlane_u(m.sgv.y, (int)j) << 32) | rlane_u(m.sgv.x, (int)j);
-            // the index must agree with the stream it describes: a record's MAP count is its signature's popcount
-            bad_index |= (!raw && (uint32_t)__builtin_popcountll(sg) != rlane_u(m.cnt, (int)j)) ? 1u : 0u;
-            hits |= (uint32_t)((sg >> lane) & 1ull) << j;
-            item[j] = ld32u(src + pos + (raw ? 0u : kSig) + 4u * lane - 2u * mbcnt64(sg));
+            const uint32_t coded = 0u - ((~m.copy_mask >> j) & 1u);               // all ones, or 0 for 256 raw bytes without a signature (codec.rs:89-91)
+            const uint32_t slo = rlane_u(m.sgv.x, (int)j) & coded, shi = rlane_u(m.sgv.y, (int)j) & coded;
+            uint32_t bit;                                                         // this lane's flag: one select on the signature as a lane mask
+            asm("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(bit) : "s"(((uint64_t)shi << 32) | slo));
+            hits |= bit << j;
+            // this lane's item sits 4 bytes further per PLAIN lane below it and 2 per MAP lane: 4*lane - 2*(MAP lanes below)
+            const uint32_t t = __builtin_amdgcn_mbcnt_hi(shi, __builtin_amdgcn_mbcnt_lo(slo, minus_2lane));   // MAP lanes below - 2*lane
+            const uint32_t voff = (uint32_t)__mul24((int)t, -2);
+            const uint8_t* base = src + (pos + (coded & kSig));                   // (wave-uniform: the load takes it as a scalar base)
+            item[j] = ld32u(base + voff);
         }
     };
 
@@ -933,6 +940,13 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
         stage_b(mb, hitsc, itemc);
         mc = mb;
         stage_a(wave + W, mb);
+        // Everything asked for so far is waited for HERE, once, visibly to the compiler: with nothing pending at the top of the loop the
+        // waits it places inside count from the loop's own order of loads and stores (a signature load is followed by the round's 12
+        // record stores, so the next round's stage B waits for "all but the last 12"); with loads still pending from out here it would
+        // settle for the common bound of both ways in — zero — and every round would begin by waiting for its predecessor's stores.
+        asm volatile("" : : "v"(mb.sgv.x), "v"(mb.sgv.y), "v"(mb.posv), "v"(mc.sgv.x), "v"(mc.sgv.y));
+#pragma unroll
+        for (uint32_t j = 0; j < R; ++j) asm volatile("" : : "v"(itemc[j]));
     }
 
     uint32_t ra[R], mask[R], val[R];
