@@ -353,19 +353,17 @@ struct PhaseClock<true> {
 // Waiting for a token.  The wave whose turn is next (or next but one) polls in a loop of five instructions; waves further away sleep
 // for most of the distance first (a round hand-off takes a few hundred cycles), so that the LDS and the issue slots stay with
 // the waves that work.
-__device__ __forceinline__ void backoff(uint32_t dist, bool off = false) {
-    if (off || dist <= 2) return;
+__device__ __forceinline__ void backoff(uint32_t dist) {
+    if (dist <= 2) return;
     if (dist > 8) __builtin_amdgcn_s_sleep(24);
     else if (dist > 4) __builtin_amdgcn_s_sleep(8);
     else __builtin_amdgcn_s_sleep(3);
 }
 // up to `tries` back-to-back polls of one token word for one value
-__device__ __forceinline__ bool poll_word(uint32_t addr, uint32_t want, uint32_t tries, bool prio = false) {
-    if (prio) __builtin_amdgcn_s_setprio(2);
+__device__ __forceinline__ bool poll_word(uint32_t addr, uint32_t want, uint32_t tries) {
     for (uint32_t i = 0; i < tries; ++i) {
         if (rfl(lds_peek1(addr)) == want) return true;
     }
-    if (prio) __builtin_amdgcn_s_setprio(0);
     return false;
 }
 
@@ -395,7 +393,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
     // the table sits at LDS address 0 (this kernel has no static LDS): slot addresses need no base
     const uint32_t sy = kEncSync;
     const ZmapLds zmap{kEncZmap};
-    const bool late_token = (tune & 1u) != 0, no_sleep = (tune & 2u) != 0, poll_prio = (tune & 256u) != 0, edf = (tune & 512u) == 0;
+    (void)tune;                                                                   // (the launcher reads the geometry from it; the kernels have no switches left)
 
     {   // fresh state per chunk (chameleon.rs:45-48): zero table, zero-entry map, tokens: round 0 in slow mode, nothing committed
         uint4* p = reinterpret_cast<uint4*>(smem);
@@ -543,7 +541,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
     }
     for (uint32_t r = wave; r < nrounds; r += W) {
         clk.start();
-        if (edf) __builtin_amdgcn_s_setprio(1);                                   // (see the priorities note at the exchange)
+        __builtin_amdgcn_s_setprio(1);                                   // (see the priorities note at the exchange)
         uint32_t slo = 0, shi = 0;                                                // lane j: the signature of block j (codec.rs:24-26)
         uint32_t copy_mask = 0, opos = 0;
         bool fast_commit = false;
@@ -574,17 +572,17 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
 
         clk.mark(0);
         clk.stamp(r, 0, lane);
-        if (edf) __builtin_amdgcn_s_setprio(2);
+        __builtin_amdgcn_s_setprio(2);
         {
             // ---- D chain: wait for this round's turn ----
             uint32_t slow;
             for (uint32_t spins = 0;;) {
-                if (poll_word(sy + kSyD, r << 1, 16, poll_prio)) { slow = 0; break; }         // the common hand-off: fast token for this round
+                if (poll_word(sy + kSyD, r << 1, 16)) { slow = 0; break; }         // the common hand-off: fast token for this round
                 const u32x2 v = lds_peek2(sy + kSyD);
                 const uint32_t D = rfl(v.x), A = rfl(v.y);
                 if (__builtin_expect(A != kNone, 0)) { if (A == kPoison) wave_exit(); abort_sync(false, 0); continue; }
                 if ((D >> 1) == r) { slow = D & 1u; break; }
-                backoff(r - (D >> 1), no_sleep);
+                backoff(r - (D >> 1));
                 watchdog(spins, sy, err, lane);
             }
             clk.mark(1);
@@ -596,8 +594,8 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
                 // inside the exchanges, 2 on the way to the commit and while it waits for a token, 1 while it prepares its next round, 0
                 // while it writes records out (nobody waits for those).
                 __builtin_amdgcn_s_setprio(3);
-                exchange_tied<R>(ra, mask, val, tokaddr, (r + 1u) << 1, late_token);
-                if (edf) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
+                exchange_tied<R>(ra, mask, val, tokaddr, (r + 1u) << 1, false);
+                __builtin_amdgcn_s_setprio(2);
                 clk.mark(2);
                 clk.stamp(r, 2, lane);
                 uint32_t hits = 0;
@@ -612,6 +610,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
                 // everything the commit needs that does not depend on the token: incompressible records (codec.rs:68: 8 + 256 - 2*hits >= 256)
                 uint32_t inc = (uint32_t)ballot64(lane < R && (uint32_t)(__builtin_popcount(slo) + __builtin_popcount(shi)) <= 4u);
                 uint32_t sum = R * (kSig + kBlock) - 2u * hits;
+                asm volatile("" : "+s"(inc), "+s"(sum));                        // computed HERE: left to itself the compiler sinks both — and the 16 signatures they need — below the token wait, into the commit
                 if (!kKeepQuads) load_round(q, r);                        // the quads again (from L2): not kept across the wait for the token
                 clk.mark(3);
                 // ---- O chain: commit ----
@@ -623,7 +622,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
                     const uint32_t O = rfl(v.x), A = rfl(v.y);
                     if (O == r) { P0 = rfl(v.z); P1 = rfl(v.w); break; }
                     if (__builtin_expect(A != kNone, 0)) { if (A == kPoison) wave_exit(); abort_sync(true, r); aborted = true; break; }
-                    backoff(r - O, no_sleep);
+                    backoff(r - O);
                     watchdog(spins, sy, err, lane);
                 }
                 if (aborted) continue;
@@ -679,7 +678,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
                     lds_poke(sy + kSyO, r + 1u);
                 }
                 copy_mask = 0;
-                if (edf) __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_s_setprio(0);
                 fast_commit = true;
                 if (kKeepQuads && r + W < nrounds) prefetch_quads<R>(src + (uint64_t)(r + W) * (R * kBlock) + 4u * lane);   // next round's quads: in flight behind the commit, landed by the end of the emit
                 clk.mark(4);
@@ -693,7 +692,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
                 const uint32_t O = rfl(v.x), A = rfl(v.y);
                 if (O == r) { P0 = rfl(v.z); P1 = rfl(v.w); break; }
                 if (A != kNone) { if (A == kPoison) wave_exit(); abort_sync(false, 0); aborted = true; break; }
-                backoff(r - O, no_sleep);
+                backoff(r - O);
                 watchdog(spins, sy, err, lane);
             }
             if (aborted) continue;
@@ -821,7 +820,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
     const ZmapGlobal zmap{zmap_words + chunk * (kZmapBytes / 4)};
     // the table sits at LDS address 0 (this kernel has no static LDS): slot addresses need no base
     const uint32_t sy = kDecSync;
-    const bool late_token = (tune & 1u) != 0, no_sleep = (tune & 2u) != 0, poll_prio = (tune & 256u) != 0, edf = (tune & 512u) == 0;
+    (void)tune;                                                                   // (the launcher reads the geometry from it; the kernels have no switches left)
 
     {   // fresh dictionary, this chunk's zero-entry map, the block index into LDS
         uint4* p = reinterpret_cast<uint4*>(smem);
@@ -952,7 +951,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
     uint32_t ra[R], mask[R], val[R];
     for (uint32_t x = wave; x < npr; x += W) {
         clk.start();
-        if (edf) __builtin_amdgcn_s_setprio(1);                                   // (priorities: see the encoder's exchange)
+        __builtin_amdgcn_s_setprio(1);                                   // (priorities: see the encoder's exchange)
         // (B first: what it waits for — the signatures requested one iteration ago — is older than anything issued since, so the
         // wait does not cover a load that has just left)
         stage_b(mb, hitsb, itemb);
@@ -982,20 +981,20 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
         pin_operands<R>(ra, mask, val);                                           // complete before the wait for the token
         clk.mark(2);
         clk.stamp(x, 0, lane);
-        if (edf) __builtin_amdgcn_s_setprio(2);
+        __builtin_amdgcn_s_setprio(2);
         // ---- D chain ----
         for (uint32_t spins = 0;;) {
-            if (poll_word(sy + kSyD, x, 16, poll_prio)) break;
+            if (poll_word(sy + kSyD, x, 16)) break;
             const uint32_t D = rfl(lds_peek1(sy + kSyD));
             if (D == x) break;
             if (D == kPoison) wave_exit();
-            backoff(x - D, no_sleep);
+            backoff(x - D);
             watchdog(spins, sy, err, lane);
         }
         clk.mark(3);
         clk.stamp(x, 1, lane);
         __builtin_amdgcn_s_setprio(3);
-        exchange_tied<R>(ra, mask, val, tokaddr, x + 1u, late_token);
+        exchange_tied<R>(ra, mask, val, tokaddr, x + 1u, false);
         __builtin_amdgcn_s_setprio(0);
         clk.mark(4);
         clk.stamp(x, 2, lane);
