@@ -564,7 +564,7 @@ size_t density_hip_decode(const uint8_t* container, size_t container_size, uint8
 }
 
 void density_hip_set_profiling(int enabled) { g_profiling = enabled; }
-void density_hip_set_kernel_variant(int variant) { g_variant = variant;   /* bit 3 (8): encode in batches with the stitch of one batch beside the encoding of the next */ density::g_force_simple = (variant & 1) != 0; density::g_force_pipeline = (variant & 4) != 0; }
+void density_hip_set_kernel_variant(int variant) { g_variant = variant;   /* bit 3 (8): encode in batches with the stitch of one batch beside the encoding of the next */ density::g_force_simple = (variant & 1) != 0; density::g_force_pipeline = (variant & 4) != 0; density::g_force_lane_codec = (variant & 16) != 0; }
 
 int density_hip_last_timings(float* milliseconds, const char** names, int capacity) {
     int dev = -1;

@@ -37,7 +37,8 @@ hipError_t launch_rotor_selftest(uint32_t* d_fail, hipStream_t stream);
 extern bool g_force_pipeline;  // density_hip_set_kernel_variant(4): the 16-wave role pipelines of chameleon.hip instead
 extern bool g_exchange_unsafe, g_rotor_unsafe;   // start-up self-test verdicts (api.hip::acquire_ctx)
 
-// ---- serial_codec.hip (Cheetah, Lion: functional one-lane-per-stream kernels, tables in global memory) ----
+// ---- serial_codec.hip (Cheetah: one wave per chunk stream; Lion, and Cheetah as a cross-check: one lane per stream; tables in global memory) ----
+extern bool g_force_lane_codec;   // density_hip_set_kernel_variant(16)
 uint64_t serial_table_bytes(int algo);
 hipError_t launch_serial_encode(int algo, const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_out,
                                 uint64_t out_stride, uint64_t* d_sizes, uint8_t* d_tables, uint32_t n_slots, hipStream_t stream);

@@ -12,6 +12,8 @@
 
 namespace density {
 
+bool g_force_lane_codec = false;   // density_hip_set_kernel_variant(16): Cheetah on the one-lane-per-stream kernels (cross-check)
+
 namespace {
 
 struct Pair { uint32_t a, b; };
@@ -267,6 +269,380 @@ __global__ __launch_bounds__(64) void serial_decode_chunks(const uint8_t* __rest
     }
 }
 
+
+// =================================================================================================================
+// Cheetah, one WAVE per chunk stream: a record (32 quads, cheetah.rs:17-23) per step, one quad per lane.
+//
+// What is sequential in the reference is the state of the two tables.  On encode every table address is known from the
+// input alone (dictionary slot = hash of the quad, predictor slot = hash of the PREVIOUS quad, cheetah.rs:123-149), so a step
+//   1. gathers the predictor word and the dictionary pair of all 32 quads at once,
+//   2. finds, per lane, the nearest earlier lane of the record on the same predictor slot and on the same dictionary slot
+//      (exact 16-bit key match from 16 ballots per key),
+//   3. resolves the record in dependency order: a lane is ready when the lanes it follows are done, and takes the state of
+//      its slots from their registers (ds_bpermute) instead of from memory — usually one round, a chain of equal quads takes
+//      one round per link,
+//   4. stores flags / items through a prefix sum of the item lengths, and writes each touched slot back once (last lane on it).
+// The tables stay in global memory (768 KiB per stream): a step costs one gather and one scatter round trip instead of 32
+// dependent ones.  The blow-up protection FSM (codec.rs:35-37,68) runs per record on uniform values; a raw-copy block touches
+// nothing.  The ragged last block goes through the scalar code above on lane 0.
+//
+// On decode the predictor slot of a predicted quad (flag 3) is the hash of a quad that is itself looked up, so runs of
+// predicted quads are a chain of dependent reads: each round of step 1 advances every run of the record by one quad,
+// speculating that no earlier quad of the same record wrote the slot it reads; step 3 then knows the truth, and a record with a
+// mis-speculated prediction (a repeated pair of quads inside 128 bytes) is decoded again by the scalar code.
+// =================================================================================================================
+typedef unsigned long long u64a;
+__device__ __forceinline__ uint32_t tbl_load32(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void tbl_store32(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ Pair tbl_load_pair(const Pair* p) {
+    const u64a v = __hip_atomic_load(reinterpret_cast<const u64a*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return Pair{(uint32_t)v, (uint32_t)(v >> 32)};
+}
+__device__ __forceinline__ void tbl_store_pair(Pair* p, Pair v) {
+    __hip_atomic_store(reinterpret_cast<u64a*>(p), (u64a)v.a | ((u64a)v.b << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// the table stores of a step are complete (in L2, where the next step's gathers read) before anything else happens
+__device__ __forceinline__ void tbl_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// lanes 0..31: mask of the lanes whose 16-bit key equals this lane's (bit-plane ballots: exact)
+__device__ __forceinline__ uint32_t same_key_mask(uint32_t key, bool active) {
+    uint32_t eq = 0xffffffffu;
+#pragma unroll
+    for (uint32_t b = 0; b < 16; ++b) {
+        const bool bit = (key >> b) & 1u;
+        const uint32_t plane = (uint32_t)ballot64(bit && active);
+        eq &= bit ? plane : ~plane;
+    }
+    return eq & (uint32_t)ballot64(active);
+}
+// 2-bit flags of lanes 0..31 -> the 64-bit signature (io/write_signature.rs:14-17: quad k at bits 2k, 2k+1)
+__device__ __forceinline__ uint64_t spread32(uint32_t x) {
+    uint64_t v = x;
+    v = (v | (v << 16)) & 0x0000ffff0000ffffull;
+    v = (v | (v << 8)) & 0x00ff00ff00ff00ffull;
+    v = (v | (v << 4)) & 0x0f0f0f0f0f0f0f0full;
+    v = (v | (v << 2)) & 0x3333333333333333ull;
+    v = (v | (v << 1)) & 0x5555555555555555ull;
+    return v;
+}
+// exclusive prefix sum over lanes 0..31 (values of the other lanes ignored), and the total
+__device__ __forceinline__ uint32_t scan32(uint32_t v, uint32_t lane, uint32_t& total) {
+    uint32_t incl = lane < 32 ? v : 0u;
+#pragma unroll
+    for (uint32_t d = 1; d < 32; d <<= 1) {
+        const uint32_t o = bperm(lane >= d ? lane - d : lane, incl);
+        if (lane >= d) incl += o;
+    }
+    total = rfl(bperm(31u, incl));
+    return incl - (lane < 32 ? v : 0u);
+}
+
+// One record's worth of sequential table semantics, resolved across lanes.  In: per lane its predictor slot `ps`, dictionary
+// slot `ds` and the memory state of both; `op` says what the lane does once it knows its state.  Out: post-state per lane.
+struct CheetahLane {
+    uint32_t pv, da, db;        // state of my predictor word / dictionary pair when my turn comes (then: after my turn)
+    uint32_t pdirty, ddirty;    // ... differs from memory
+};
+
+__global__ __launch_bounds__(64) void cheetah_encode_wave(const uint8_t* __restrict__ in, uint64_t total, uint64_t chunk_bytes,
+                                                          uint32_t n_chunks, uint8_t* __restrict__ out, uint64_t out_stride,
+                                                          uint64_t* __restrict__ sizes, uint8_t* __restrict__ tables, uint32_t n_slots) {
+    using G = Geo<DENSITY_HIP_CHEETAH>;
+    const uint32_t slot = blockIdx.x;
+    const uint32_t lane = threadIdx.x;
+    if (slot >= n_slots) return;
+    constexpr uint64_t kTableBytes = 65536ull * (sizeof(Pair) + 4ull * G::kPredWords);
+    Tables<DENSITY_HIP_CHEETAH> t;
+    t.dict = reinterpret_cast<Pair*>(tables + slot * kTableBytes);
+    t.pred = reinterpret_cast<uint32_t*>(tables + slot * kTableBytes + 65536ull * sizeof(Pair));
+    const bool act = lane < 32;
+    for (uint64_t chunk = slot; chunk < n_chunks; chunk += n_slots) {
+        const uint8_t* src = in + chunk * chunk_bytes;
+        const uint64_t len = (total - chunk * chunk_bytes) < chunk_bytes ? (total - chunk * chunk_bytes) : chunk_bytes;
+        uint8_t* dst = out + chunk * out_stride;
+        if (chunk != slot) {                                                  // (the launcher zeroed the tables for the first chunk of a slot)
+            uint4* p = reinterpret_cast<uint4*>(tables + slot * kTableBytes);
+            const uint4 z = make_uint4(0, 0, 0, 0);
+            for (uint64_t i = lane; i < kTableBytes / 16; i += 64) p[i] = z;
+            __threadfence();
+        }
+        uint32_t last_hash = 0;
+        Guard guard;
+        uint64_t opos = 0, pos = 0;
+        uint32_t qnext = (act && G::kBlock <= len) ? ld32u(src + 4u * lane) : 0u;
+        for (; pos + G::kBlock <= len; pos += G::kBlock) {                    // whole blocks
+            const uint8_t* blk = src + pos;
+            if (guard.block_is_copy()) {                                      // codec.rs:35-37
+                if (act) st32u(dst + opos + 4u * lane, qnext);
+                qnext = (act && pos + 2 * G::kBlock <= len) ? ld32u(blk + G::kBlock + 4u * lane) : 0u;
+                opos += G::kBlock;
+                guard.decay();
+                continue;
+            }
+            // ---- 1. quads, slots, gather ----
+            const uint32_t q = qnext;
+            const uint32_t h = hash16(q);
+            const uint32_t hprev = bperm(lane ? lane - 1u : 0u, h);
+            const uint32_t ps = lane == 0 ? last_hash : hprev;               // predictor slot: hash of the previous quad (cheetah.rs:125,146)
+            CheetahLane st;
+            tbl_drain();                                                      // the previous step's table stores are in L2 (and its record stores, alas)
+            st.pv = act ? tbl_load32(t.pred + ps) : 0u;
+            const Pair e0 = act ? tbl_load_pair(t.dict + h) : Pair{0u, 0u};
+            qnext = (act && pos + 2 * G::kBlock <= len) ? ld32u(blk + G::kBlock + 4u * lane) : 0u;   // the next block's quads: in flight across this step
+            st.da = e0.a; st.db = e0.b; st.pdirty = 0; st.ddirty = 0;
+            // ---- 2. who follows whom ----
+            const uint32_t below = (1u << (lane & 31u)) - 1u;
+            const uint32_t peq = same_key_mask(ps, act), deq = same_key_mask(h, act);
+            const uint32_t pbefore = peq & below, dbefore = deq & below;
+            const uint32_t pprev = pbefore ? 31u - (uint32_t)__builtin_clz(pbefore) : 64u;   // 64: nobody
+            const uint32_t dprev = dbefore ? 31u - (uint32_t)__builtin_clz(dbefore) : 64u;
+            const bool plast = act && (peq >> (lane & 31u) >> 1) == 0, dlast = act && (deq >> (lane & 31u) >> 1) == 0;
+            // ---- 3. resolve in dependency order (cheetah.rs:123-149 per lane) ----
+            uint32_t flag = 0;
+            bool done = !act;
+            for (uint32_t round = 0; round < 32; ++round) {                   // (a chain has at most 32 links)
+                const uint32_t done_mask = (uint32_t)ballot64(done && act);
+                const bool pok = pprev == 64u || ((done_mask >> pprev) & 1u), dok = dprev == 64u || ((done_mask >> dprev) & 1u);
+                const bool ready = !done && pok && dok;
+                // the state my predecessors left (read from their registers; garbage where there is no predecessor)
+                const uint32_t fpv = bperm(pprev & 31u, st.pv), fpd = bperm(pprev & 31u, st.pdirty);
+                const uint32_t fda = bperm(dprev & 31u, st.da), fdb = bperm(dprev & 31u, st.db), fdd = bperm(dprev & 31u, st.ddirty);
+                if (ready) {
+                    if (pprev != 64u) { st.pv = fpv; st.pdirty = fpd; }
+                    if (dprev != 64u) { st.da = fda; st.db = fdb; st.ddirty = fdd; }
+                    if (st.pv == q) flag = 3;
+                    else {
+                        if (st.da == q) flag = 1;
+                        else { flag = st.db == q ? 2u : 0u; st.db = st.da; st.da = q; st.ddirty = 1; }
+                        st.pv = q; st.pdirty = 1;
+                    }
+                    done = true;
+                }
+                if (ballot64(!done) == 0) break;
+            }
+            // ---- 4. the record: signature, items (io/write_buffer.rs), tables ----
+            const uint32_t ilen = !act ? 0u : (flag == 0 ? 4u : (flag == 3 ? 0u : 2u));
+            uint32_t items;
+            const uint32_t off = scan32(ilen, lane, items);
+            uint8_t* rec = dst + opos;
+            const uint64_t sig = spread32((uint32_t)ballot64(act && (flag & 1u))) | (spread32((uint32_t)ballot64(act && (flag & 2u))) << 1);
+            if (lane < 2) st32u(rec + 4u * lane, lane ? (uint32_t)(sig >> 32) : (uint32_t)sig);   // codec.rs:24-26
+            if (ilen == 4) st32u(rec + G::kSig + off, q); else if (ilen == 2) st16u(rec + G::kSig + off, h);
+            if (plast && st.pdirty) tbl_store32(t.pred + ps, st.pv);
+            if (dlast && st.ddirty) tbl_store_pair(t.dict + h, Pair{st.da, st.db});
+            last_hash = rfl(bperm(31u, h));
+            const uint32_t rlen = G::kSig + items;
+            guard.update(rlen >= G::kBlock);                                  // codec.rs:68
+            opos += rlen;
+        }
+        tbl_drain();
+        // ---- the ragged last block: the scalar code on lane 0 (same tables; codec.rs:51-63) ----
+        if (pos < len) {
+            __threadfence();                                                  // (the scalar code reads the tables with plain loads)
+            if (lane == 0) {
+                t.last_hash = last_hash;
+                const uint32_t blen = (uint32_t)(len - pos);
+                const uint8_t* blk = src + pos;
+                if (guard.block_is_copy()) {
+                    for (uint32_t i = 0; i < blen; ++i) dst[opos + i] = blk[i];
+                    opos += blen;
+                } else {
+                    uint8_t* rec = dst + opos;
+                    uint64_t o = G::kSig, sig = 0;
+                    const uint32_t nq = blen >> 2;
+                    for (uint32_t k = 0; k < nq; ++k) {
+                        uint32_t item = 0, il = 0;
+                        const uint32_t flag = enc_quad(t, ld32u(blk + 4u * k), item, il);
+                        sig |= (uint64_t)flag << (G::kFlagBits * k);
+                        if (il == 2) st16u(rec + o, item); else if (il == 4) st32u(rec + o, item);
+                        o += il;
+                    }
+                    for (uint32_t i = 4u * nq; i < blen; ++i) rec[o++] = blk[i];
+                    store_sig<DENSITY_HIP_CHEETAH>(rec, sig);
+                    opos += o;
+                }
+            }
+            opos = ((uint64_t)rfl((uint32_t)(opos >> 32)) << 32) | rfl((uint32_t)opos);
+            __threadfence();
+        }
+        if (lane == 0) sizes[chunk] = opos;
+    }
+}
+
+
+// one coded record by the scalar code (lane 0; codec.rs:92-99,111-123 with decode_partial_unit cheetah.rs:165-185): the decoder's
+// ragged end and its answer to a mis-speculated record.  Returns "bad".
+__device__ __forceinline__ bool cheetah_record_scalar(Tables<DENSITY_HIP_CHEETAH>& t, const uint8_t* src, uint64_t elen, uint64_t& ipos,
+                                                      uint8_t* dst, uint64_t cap, uint64_t& opos, bool& done, Guard& guard) {
+    using G = Geo<DENSITY_HIP_CHEETAH>;
+    if (elen - ipos < G::kSig) return true;                                   // read_signature would panic
+    const uint64_t mark = ipos;
+    uint64_t sig = load_sig<DENSITY_HIP_CHEETAH>(src + ipos);
+    ipos += G::kSig;
+    for (uint32_t k = 0; k < G::kBlock / 4; ++k) {
+        const uint32_t flag = (uint32_t)(sig & 3u);
+        sig >>= 2;
+        const uint64_t left = elen - ipos;
+        if (flag == 0 && left < 4) {                                          // cheetah.rs:168-176: end of data
+            if (opos + left > cap) return true;
+            for (uint32_t i = 0; i < left; ++i) dst[opos + i] = src[ipos + i];
+            opos += left; ipos += left; done = true;
+            return false;
+        }
+        const uint32_t need = item_bytes(t, flag);
+        if (left < need || opos + 4 > cap) return true;
+        const uint32_t q = dec_quad(t, flag, src + ipos);
+        ipos += need;
+        st32u(dst + opos, q);
+        opos += 4;
+    }
+    guard.update(ipos - mark >= G::kBlock);                                   // codec.rs:98,122
+    return false;
+}
+__device__ __forceinline__ uint64_t bcast64(uint64_t v) { return ((uint64_t)rfl((uint32_t)(v >> 32)) << 32) | rfl((uint32_t)v); }
+
+__global__ __launch_bounds__(64) void cheetah_decode_wave(const uint8_t* __restrict__ in, const uint64_t* __restrict__ offsets,
+                                                          const uint64_t* __restrict__ sizes, uint32_t n_chunks,
+                                                          uint8_t* __restrict__ out, uint64_t out_stride, uint64_t out_total,
+                                                          uint32_t exact, uint64_t* __restrict__ produced, uint32_t* __restrict__ err,
+                                                          uint8_t* __restrict__ tables, uint32_t n_slots) {
+    using G = Geo<DENSITY_HIP_CHEETAH>;
+    const uint32_t slot = blockIdx.x;
+    const uint32_t lane = threadIdx.x;
+    if (slot >= n_slots) return;
+    constexpr uint64_t kTableBytes = 65536ull * (sizeof(Pair) + 4ull * G::kPredWords);
+    constexpr uint32_t kMaxRecord = G::kSig + G::kBlock;                      // 8 + 32 x 4
+    Tables<DENSITY_HIP_CHEETAH> t;
+    t.dict = reinterpret_cast<Pair*>(tables + slot * kTableBytes);
+    t.pred = reinterpret_cast<uint32_t*>(tables + slot * kTableBytes + 65536ull * sizeof(Pair));
+    const bool act = lane < 32;
+    const uint32_t below = (1u << (lane & 31u)) - 1u;
+    for (uint64_t chunk = slot; chunk < n_chunks; chunk += n_slots) {
+        const uint8_t* src = in + offsets[chunk];
+        const uint64_t elen = sizes[chunk];
+        uint8_t* dst = out + chunk * out_stride;
+        const uint64_t room_all = out_total - chunk * out_stride;
+        const uint64_t cap = room_all < out_stride ? room_all : out_stride;
+        if (chunk != slot) {
+            uint4* p = reinterpret_cast<uint4*>(tables + slot * kTableBytes);
+            const uint4 z = make_uint4(0, 0, 0, 0);
+            for (uint64_t i = lane; i < kTableBytes / 16; i += 64) p[i] = z;
+            __threadfence();
+        }
+        uint32_t last_hash = 0;
+        Guard guard;
+        uint64_t ipos = 0, opos = 0;
+        bool bad = false, done = false;
+        // ---- whole records / whole raw blocks with room to spare: one per step across the wave ----
+        while (elen - ipos >= kMaxRecord && cap - opos >= G::kBlock) {
+            if (guard.block_is_copy()) {                                      // codec.rs:89-91
+                if (act) st32u(dst + opos + 4u * lane, ld32u(src + ipos + 4u * lane));
+                ipos += G::kBlock; opos += G::kBlock;
+                guard.decay();                                                // (more than a block left: kMaxRecord > kBlock)
+                continue;
+            }
+            const uint8_t* rec = src + ipos;
+            const uint64_t sig = (uint64_t)ld32u(rec) | ((uint64_t)ld32u(rec + 4) << 32);   // codec.rs:28-31
+            const uint32_t flag = act ? (uint32_t)(sig >> (2u * (lane & 31u))) & 3u : 3u;
+            const uint32_t ilen = !act ? 0u : (flag == 0 ? 4u : (flag == 3 ? 0u : 2u));
+            uint32_t items;
+            const uint32_t off = scan32(ilen, lane, items);
+            uint32_t q = 0, h = 0;
+            if (ilen == 4) { q = ld32u(rec + G::kSig + off); h = hash16(q); } else if (ilen == 2) h = ld16u(rec + G::kSig + off);
+            const bool toucher = act && flag != 3;                            // touches the dictionary and writes the predictor (cheetah.rs:68-103)
+            tbl_drain();                                                      // the previous step's table stores are in L2
+            const Pair e0 = toucher ? tbl_load_pair(t.dict + h) : Pair{0u, 0u};
+            // (the stream ahead, touched early: the next steps' signature and item loads then come from L2)
+            const uint32_t ahead = (act && elen - ipos >= 3 * kMaxRecord) ? ld32u(rec + 2 * kMaxRecord - 8 + 4u * lane) : 0u;
+            // ---- runs of predicted quads: one dependent predictor read per round, every run of the record at once ----
+            bool known = !act || flag != 3;
+            for (uint32_t round = 0; round < 32; ++round) {                   // (a run has at most 32 quads)
+                const uint32_t hp = bperm(lane ? lane - 1u : 0u, h);
+                const uint32_t kpv = bperm(lane ? lane - 1u : 0u, known ? 1u : 0u);   // (unconditional: a lane masked off while the others
+                const bool kp = lane == 0 || kpv != 0;                                 //  permute reads as 0 to them)
+                if (!known && kp) {
+                    q = tbl_load32(t.pred + (lane == 0 ? last_hash : hp));    // speculation: nobody earlier in this record wrote that slot
+                    h = hash16(q);
+                    known = true;
+                }
+                if (ballot64(!known) == 0) break;
+            }
+            const uint32_t hprev = bperm(lane ? lane - 1u : 0u, h);
+            const uint32_t ps = lane == 0 ? last_hash : hprev;
+            // ---- dictionary: in dependency order among the lanes that touch it ----
+            const uint32_t touchers = (uint32_t)ballot64(toucher);
+            const uint32_t deq = same_key_mask(h, toucher);
+            const uint32_t dbefore = deq & below;
+            const uint32_t dprev = dbefore ? 31u - (uint32_t)__builtin_clz(dbefore) : 64u;
+            const bool dlast = toucher && (deq >> (lane & 31u) >> 1) == 0;
+            uint32_t da = e0.a, db = e0.b, ddirty = 0;
+            bool ddone = !toucher;
+            for (uint32_t round = 0; round < 32; ++round) {
+                const uint32_t done_mask = (uint32_t)ballot64(ddone && toucher);
+                const bool ready = !ddone && (dprev == 64u || ((done_mask >> dprev) & 1u));
+                const uint32_t fda = bperm(dprev & 31u, da), fdb = bperm(dprev & 31u, db), fdd = bperm(dprev & 31u, ddirty);
+                if (ready) {
+                    if (dprev != 64u) { da = fda; db = fdb; ddirty = fdd; }
+                    if (flag == 0) { db = da; da = q; ddirty = 1; }
+                    else if (flag == 1) q = da;
+                    else { q = db; db = da; da = q; ddirty = 1; }
+                    ddone = true;
+                }
+                if (ballot64(!ddone) == 0) break;
+            }
+            // ---- predictor: a predicted quad must see what the nearest earlier writer of its slot wrote ----
+            const uint32_t peq = same_key_mask(ps, act);
+            const uint32_t wbefore = peq & touchers & below;
+            const uint32_t wprev = wbefore ? 31u - (uint32_t)__builtin_clz(wbefore) : 64u;
+            const uint32_t wq = bperm(wprev & 31u, q);
+            const bool wrong = act && flag == 3 && wprev != 64u && wq != q;
+            if (ballot64(wrong) != 0) {
+                // mis-speculated: nothing has been written yet; the scalar code decodes this record from the tables as they stand
+                __threadfence();                                              // (it reads them with plain loads)
+                if (lane == 0) { t.last_hash = last_hash; bad = cheetah_record_scalar(t, src, elen, ipos, dst, cap, opos, done, guard); last_hash = t.last_hash; }
+                __threadfence();
+                ipos = bcast64(ipos); opos = bcast64(opos); last_hash = rfl(last_hash);
+                bad = rfl(bad ? 1u : 0u) != 0; done = rfl(done ? 1u : 0u) != 0;
+                guard.penalty = rfl(guard.penalty); guard.start = rfl(guard.start); guard.prev = rfl(guard.prev); guard.counter = rfl(guard.counter);
+                if (bad || done) break;
+                continue;
+            }
+            const bool plast = toucher && ((peq & touchers) >> (lane & 31u) >> 1) == 0;
+            if (act) st32u(dst + opos + 4u * lane, q);
+            if (plast) tbl_store32(t.pred + ps, q);
+            if (dlast && ddirty) tbl_store_pair(t.dict + h, Pair{da, db});
+            last_hash = rfl(bperm(31u, h));
+            const uint32_t rlen = G::kSig + items;
+            guard.update(rlen >= G::kBlock);                                  // codec.rs:98
+            ipos += rlen; opos += G::kBlock;
+            asm volatile("" : : "v"(ahead));
+        }
+        tbl_drain();
+        // ---- the rest (short of a whole record with room to spare): the scalar code on lane 0, codec.rs:102-123 ----
+        __threadfence();
+        if (lane == 0) {
+            t.last_hash = last_hash;
+            while (ipos < elen && !bad && !done) {
+                const uint64_t rem = elen - ipos;
+                if (guard.block_is_copy()) {
+                    const uint32_t take = rem > G::kBlock ? G::kBlock : (uint32_t)rem;
+                    if (opos + take > cap) { bad = true; break; }
+                    for (uint32_t i = 0; i < take; ++i) dst[opos + i] = src[ipos + i];
+                    ipos += take; opos += take;
+                    if (rem <= G::kBlock) break;
+                    guard.decay();
+                    continue;
+                }
+                bad = cheetah_record_scalar(t, src, elen, ipos, dst, cap, opos, done, guard);
+            }
+            if (exact && !bad && opos != cap) bad = true;
+            produced[chunk] = opos;
+            if (bad) atomicOr(err, 1u);
+        }
+        __threadfence();
+    }
+}
+
 }  // namespace
 
 uint64_t serial_table_bytes(int algo) { return 65536ull * (sizeof(Pair) + 4ull * (algo == DENSITY_HIP_LION ? 5 : 1)); }
@@ -277,7 +653,9 @@ hipError_t launch_serial_encode(int algo, const uint8_t* d_in, uint64_t total, u
     const uint32_t blocks = (n_slots + 63) / 64;
     hipError_t e = hipMemsetAsync(d_tables, 0, (size_t)n_slots * serial_table_bytes(algo), stream);
     if (e != hipSuccess) return e;
-    if (algo == DENSITY_HIP_CHEETAH)
+    if (algo == DENSITY_HIP_CHEETAH && !g_force_lane_codec)
+        hipLaunchKernelGGL(cheetah_encode_wave, dim3(n_slots), dim3(64), 0, stream, d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, n_slots);
+    else if (algo == DENSITY_HIP_CHEETAH)
         hipLaunchKernelGGL(serial_encode_chunks<DENSITY_HIP_CHEETAH>, dim3(blocks), dim3(64), 0, stream, d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, n_slots);
     else
         hipLaunchKernelGGL(serial_encode_chunks<DENSITY_HIP_LION>, dim3(blocks), dim3(64), 0, stream, d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, n_slots);
@@ -291,7 +669,9 @@ hipError_t launch_serial_decode(int algo, const uint8_t* d_in, const uint64_t* d
     const uint32_t blocks = (n_slots + 63) / 64;
     hipError_t e = hipMemsetAsync(d_tables, 0, (size_t)n_slots * serial_table_bytes(algo), stream);
     if (e != hipSuccess) return e;
-    if (algo == DENSITY_HIP_CHEETAH)
+    if (algo == DENSITY_HIP_CHEETAH && !g_force_lane_codec)
+        hipLaunchKernelGGL(cheetah_decode_wave, dim3(n_slots), dim3(64), 0, stream, d_in, d_offsets, d_sizes, n_chunks, d_out, out_stride, out_total, exact ? 1u : 0u, d_produced, d_err, d_tables, n_slots);
+    else if (algo == DENSITY_HIP_CHEETAH)
         hipLaunchKernelGGL(serial_decode_chunks<DENSITY_HIP_CHEETAH>, dim3(blocks), dim3(64), 0, stream, d_in, d_offsets, d_sizes, n_chunks, d_out, out_stride, out_total, exact ? 1u : 0u, d_produced, d_err, d_tables, n_slots);
     else
         hipLaunchKernelGGL(serial_decode_chunks<DENSITY_HIP_LION>, dim3(blocks), dim3(64), 0, stream, d_in, d_offsets, d_sizes, n_chunks, d_out, out_stride, out_total, exact ? 1u : 0u, d_produced, d_err, d_tables, n_slots);
