@@ -643,6 +643,356 @@ __global__ __launch_bounds__(64) void cheetah_decode_wave(const uint8_t* __restr
     }
 }
 
+
+// =================================================================================================================
+// Lion, one wave per chunk stream: the same scheme on records of 16 quads (lion.rs:17-27) with a 5-entry move-to-front row per
+// predictor slot (lion.rs:50-57,211-270).  Every quad reads and (unless it hits the front entry) rewrites its row, so the row is
+// what travels along a chain of lanes on the same predictor slot; the dictionary is touched only by quads no entry predicted.
+// =================================================================================================================
+struct Row5 { uint32_t n[5]; };
+__device__ __forceinline__ Row5 row_load(const uint32_t* p) {
+    Row5 r;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) r.n[i] = tbl_load32(p + i);
+    return r;
+}
+__device__ __forceinline__ void row_store(uint32_t* p, const Row5& r) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) tbl_store32(p + i, r.n[i]);
+}
+__device__ __forceinline__ Row5 row_from_lane(uint32_t src, const Row5& r) {
+    Row5 o;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) o.n[i] = bperm(src, r.n[i]);
+    return o;
+}
+// entry k (0..4) moves to the front, or q enters at the front and the last entry leaves (k == 5): lion.rs:240-262, :50-57
+__device__ __forceinline__ void row_promote(Row5& r, uint32_t k, uint32_t q) {
+#pragma unroll
+    for (int i = 4; i > 0; --i) r.n[i] = (uint32_t)i <= k ? r.n[i - 1] : r.n[i];
+    r.n[0] = q;
+}
+// 3-bit flags of lanes 0..15, one bit plane: bit i -> bit 3i
+__device__ __forceinline__ uint64_t spread16by3(uint32_t x16) {
+    uint64_t x = x16 & 0xffffu;
+    x = (x | (x << 16)) & 0x00ff0000ff0000ffull;
+    x = (x | (x << 8)) & 0xf00f00f00f00f00full;
+    x = (x | (x << 4)) & 0x30c30c30c30c30c3ull;
+    x = (x | (x << 2)) & 0x9249249249249249ull;
+    return x;
+}
+
+__global__ __launch_bounds__(64) void lion_encode_wave(const uint8_t* __restrict__ in, uint64_t total, uint64_t chunk_bytes,
+                                                       uint32_t n_chunks, uint8_t* __restrict__ out, uint64_t out_stride,
+                                                       uint64_t* __restrict__ sizes, uint8_t* __restrict__ tables, uint32_t n_slots) {
+    using G = Geo<DENSITY_HIP_LION>;
+    const uint32_t slot = blockIdx.x;
+    const uint32_t lane = threadIdx.x;
+    if (slot >= n_slots) return;
+    constexpr uint64_t kTableBytes = 65536ull * (sizeof(Pair) + 4ull * G::kPredWords);
+    Tables<DENSITY_HIP_LION> t;
+    t.dict = reinterpret_cast<Pair*>(tables + slot * kTableBytes);
+    t.pred = reinterpret_cast<uint32_t*>(tables + slot * kTableBytes + 65536ull * sizeof(Pair));
+    const bool act = lane < 16;
+    const uint32_t below = (1u << (lane & 31u)) - 1u;
+    for (uint64_t chunk = slot; chunk < n_chunks; chunk += n_slots) {
+        const uint8_t* src = in + chunk * chunk_bytes;
+        const uint64_t len = (total - chunk * chunk_bytes) < chunk_bytes ? (total - chunk * chunk_bytes) : chunk_bytes;
+        uint8_t* dst = out + chunk * out_stride;
+        if (chunk != slot) {
+            uint4* p = reinterpret_cast<uint4*>(tables + slot * kTableBytes);
+            const uint4 z = make_uint4(0, 0, 0, 0);
+            for (uint64_t i = lane; i < kTableBytes / 16; i += 64) p[i] = z;
+            __threadfence();
+        }
+        uint32_t last_hash = 0;
+        Guard guard;
+        uint64_t opos = 0, pos = 0;
+        uint32_t qnext = (act && G::kBlock <= len) ? ld32u(src + 4u * lane) : 0u;
+        for (; pos + G::kBlock <= len; pos += G::kBlock) {
+            const uint8_t* blk = src + pos;
+            if (guard.block_is_copy()) {                                      // codec.rs:35-37
+                if (act) st32u(dst + opos + 4u * lane, qnext);
+                qnext = (act && pos + 2 * G::kBlock <= len) ? ld32u(blk + G::kBlock + 4u * lane) : 0u;
+                opos += G::kBlock;
+                guard.decay();
+                continue;
+            }
+            const uint32_t q = qnext;
+            const uint32_t h = hash16(q);
+            const uint32_t hprev = bperm(lane ? lane - 1u : 0u, h);
+            const uint32_t ps = lane == 0 ? last_hash : hprev;               // lion.rs:213,268
+            tbl_drain();
+            Row5 row = act ? row_load(t.pred + 5u * ps) : Row5{{0u, 0u, 0u, 0u, 0u}};
+            const Pair e0 = act ? tbl_load_pair(t.dict + h) : Pair{0u, 0u};
+            qnext = (act && pos + 2 * G::kBlock <= len) ? ld32u(blk + G::kBlock + 4u * lane) : 0u;
+            uint32_t da = e0.a, db = e0.b, pdirty = 0, ddirty = 0;
+            const uint32_t peq = same_key_mask(ps, act), deq = same_key_mask(h, act);
+            const uint32_t pbefore = peq & below, dbefore = deq & below;
+            const uint32_t pprev = pbefore ? 31u - (uint32_t)__builtin_clz(pbefore) : 64u;
+            const uint32_t dprev = dbefore ? 31u - (uint32_t)__builtin_clz(dbefore) : 64u;
+            const bool plast = act && (peq >> (lane & 31u) >> 1) == 0, dlast = act && (deq >> (lane & 31u) >> 1) == 0;
+            uint32_t flag = 0;
+            bool done = !act;
+            for (uint32_t round = 0; round < 16; ++round) {                   // (a chain has at most 16 links)
+                const uint32_t done_mask = (uint32_t)ballot64(done && act);
+                const bool pok = pprev == 64u || ((done_mask >> pprev) & 1u), dok = dprev == 64u || ((done_mask >> dprev) & 1u);
+                const bool ready = !done && pok && dok;
+                const Row5 frow = row_from_lane(pprev & 31u, row);
+                const uint32_t fpd = bperm(pprev & 31u, pdirty);
+                const uint32_t fda = bperm(dprev & 31u, da), fdb = bperm(dprev & 31u, db), fdd = bperm(dprev & 31u, ddirty);
+                if (ready) {
+                    if (pprev != 64u) { row = frow; pdirty = fpd; }
+                    if (dprev != 64u) { da = fda; db = fdb; ddirty = fdd; }
+                    if (row.n[0] == q) flag = 1;                              // lion.rs:211-270
+                    else if (row.n[1] == q) { flag = 2; row_promote(row, 1, q); pdirty = 1; }
+                    else if (row.n[2] == q) { flag = 3; row_promote(row, 2, q); pdirty = 1; }
+                    else if (row.n[3] == q) { flag = 4; row_promote(row, 3, q); pdirty = 1; }
+                    else {
+                        if (row.n[4] == q) flag = 5;
+                        else if (da == q) flag = 6;
+                        else { flag = db == q ? 7u : 0u; db = da; da = q; ddirty = 1; }
+                        row_promote(row, 4, q); pdirty = 1;                   // shift_predictions (a hit on the last entry included)
+                    }
+                    done = true;
+                }
+                if (ballot64(!done) == 0) break;
+            }
+            const uint32_t ilen = !act ? 0u : (flag == 0 ? 4u : (flag >= 6 ? 2u : 0u));
+            uint32_t items;
+            const uint32_t off = scan32(ilen, lane, items);
+            uint8_t* rec = dst + opos;
+            const uint64_t sig = spread16by3((uint32_t)ballot64(act && (flag & 1u))) | (spread16by3((uint32_t)ballot64(act && (flag & 2u))) << 1) |
+                                 (spread16by3((uint32_t)ballot64(act && (flag & 4u))) << 2);
+            if (lane < 3) st16u(rec + 2u * lane, (uint32_t)(sig >> (16u * lane)) & 0xffffu);   // lion.rs:334-337: 6 bytes
+            if (ilen == 4) st32u(rec + G::kSig + off, q); else if (ilen == 2) st16u(rec + G::kSig + off, h);
+            if (plast && pdirty) row_store(t.pred + 5u * ps, row);
+            if (dlast && ddirty) tbl_store_pair(t.dict + h, Pair{da, db});
+            last_hash = rfl(bperm(15u, h));
+            const uint32_t rlen = G::kSig + items;
+            guard.update(rlen >= G::kBlock);
+            opos += rlen;
+        }
+        tbl_drain();
+        if (pos < len) {                                                      // the ragged last block: scalar code, lane 0
+            __threadfence();
+            if (lane == 0) {
+                t.last_hash = last_hash;
+                const uint32_t blen = (uint32_t)(len - pos);
+                const uint8_t* blk = src + pos;
+                if (guard.block_is_copy()) {
+                    for (uint32_t i = 0; i < blen; ++i) dst[opos + i] = blk[i];
+                    opos += blen;
+                } else {
+                    uint8_t* rec = dst + opos;
+                    uint64_t o = G::kSig, sig = 0;
+                    const uint32_t nq = blen >> 2;
+                    for (uint32_t k = 0; k < nq; ++k) {
+                        uint32_t item = 0, il = 0;
+                        const uint32_t flag = enc_quad(t, ld32u(blk + 4u * k), item, il);
+                        sig |= (uint64_t)flag << (G::kFlagBits * k);
+                        if (il == 2) st16u(rec + o, item); else if (il == 4) st32u(rec + o, item);
+                        o += il;
+                    }
+                    for (uint32_t i = 4u * nq; i < blen; ++i) rec[o++] = blk[i];
+                    store_sig<DENSITY_HIP_LION>(rec, sig);
+                    opos += o;
+                }
+            }
+            opos = bcast64(opos);
+            __threadfence();
+        }
+        if (lane == 0) sizes[chunk] = opos;
+    }
+}
+
+
+// one coded Lion record by the scalar code (lane 0; codec.rs:92-99,111-123, lion.rs:292-314)
+__device__ __forceinline__ bool lion_record_scalar(Tables<DENSITY_HIP_LION>& t, const uint8_t* src, uint64_t elen, uint64_t& ipos,
+                                                   uint8_t* dst, uint64_t cap, uint64_t& opos, bool& done, Guard& guard) {
+    using G = Geo<DENSITY_HIP_LION>;
+    if (elen - ipos < G::kSig) return true;
+    const uint64_t mark = ipos;
+    uint64_t sig = load_sig<DENSITY_HIP_LION>(src + ipos);
+    ipos += G::kSig;
+    for (uint32_t k = 0; k < G::kBlock / 4; ++k) {
+        const uint32_t flag = (uint32_t)(sig & 7u);
+        sig >>= 3;
+        const uint64_t left = elen - ipos;
+        if (flag == 0 && left < 4) {                                          // lion.rs:295-303: end of data
+            if (opos + left > cap) return true;
+            for (uint32_t i = 0; i < left; ++i) dst[opos + i] = src[ipos + i];
+            opos += left; ipos += left; done = true;
+            return false;
+        }
+        const uint32_t need = item_bytes(t, flag);
+        if (left < need || opos + 4 > cap) return true;
+        const uint32_t q = dec_quad(t, flag, src + ipos);
+        ipos += need;
+        st32u(dst + opos, q);
+        opos += 4;
+    }
+    guard.update(ipos - mark >= G::kBlock);
+    return false;
+}
+
+__global__ __launch_bounds__(64) void lion_decode_wave(const uint8_t* __restrict__ in, const uint64_t* __restrict__ offsets,
+                                                       const uint64_t* __restrict__ sizes, uint32_t n_chunks,
+                                                       uint8_t* __restrict__ out, uint64_t out_stride, uint64_t out_total,
+                                                       uint32_t exact, uint64_t* __restrict__ produced, uint32_t* __restrict__ err,
+                                                       uint8_t* __restrict__ tables, uint32_t n_slots) {
+    using G = Geo<DENSITY_HIP_LION>;
+    const uint32_t slot = blockIdx.x;
+    const uint32_t lane = threadIdx.x;
+    if (slot >= n_slots) return;
+    constexpr uint64_t kTableBytes = 65536ull * (sizeof(Pair) + 4ull * G::kPredWords);
+    constexpr uint32_t kMaxRecord = 8 + G::kBlock;                            // 6 + 16 x 4, and the signature is fetched as 8 bytes
+    Tables<DENSITY_HIP_LION> t;
+    t.dict = reinterpret_cast<Pair*>(tables + slot * kTableBytes);
+    t.pred = reinterpret_cast<uint32_t*>(tables + slot * kTableBytes + 65536ull * sizeof(Pair));
+    const bool act = lane < 16;
+    const uint32_t below = (1u << (lane & 31u)) - 1u;
+    for (uint64_t chunk = slot; chunk < n_chunks; chunk += n_slots) {
+        const uint8_t* src = in + offsets[chunk];
+        const uint64_t elen = sizes[chunk];
+        uint8_t* dst = out + chunk * out_stride;
+        const uint64_t room_all = out_total - chunk * out_stride;
+        const uint64_t cap = room_all < out_stride ? room_all : out_stride;
+        if (chunk != slot) {
+            uint4* p = reinterpret_cast<uint4*>(tables + slot * kTableBytes);
+            const uint4 z = make_uint4(0, 0, 0, 0);
+            for (uint64_t i = lane; i < kTableBytes / 16; i += 64) p[i] = z;
+            __threadfence();
+        }
+        uint32_t last_hash = 0;
+        Guard guard;
+        uint64_t ipos = 0, opos = 0;
+        bool bad = false, done = false;
+        while (elen - ipos >= kMaxRecord && cap - opos >= G::kBlock) {
+            if (guard.block_is_copy()) {                                      // codec.rs:89-91
+                if (act) st32u(dst + opos + 4u * lane, ld32u(src + ipos + 4u * lane));
+                ipos += G::kBlock; opos += G::kBlock;
+                guard.decay();
+                continue;
+            }
+            const uint8_t* rec = src + ipos;
+            const uint64_t sig = ((uint64_t)ld32u(rec) | ((uint64_t)ld32u(rec + 4) << 32)) & 0xffffffffffffull;   // lion.rs:340-351
+            const uint32_t flag = act ? (uint32_t)(sig >> (3u * (lane & 15u))) & 7u : 1u;
+            const uint32_t ilen = !act ? 0u : (flag == 0 ? 4u : (flag >= 6 ? 2u : 0u));
+            uint32_t items;
+            const uint32_t off = scan32(ilen, lane, items);
+            uint32_t q = 0, h = 0;
+            if (ilen == 4) { q = ld32u(rec + G::kSig + off); h = hash16(q); } else if (ilen == 2) h = ld16u(rec + G::kSig + off);
+            const bool dtouch = act && (flag == 0 || flag >= 6);              // touches the dictionary (lion.rs:85-186)
+            const bool predicted = act && flag >= 1 && flag <= 5;
+            tbl_drain();
+            const Pair e0 = dtouch ? tbl_load_pair(t.dict + h) : Pair{0u, 0u};
+            // ---- runs of predicted quads: one dependent read per round; speculation: nobody earlier in this record rewrote that row ----
+            bool known = !predicted;
+            for (uint32_t round = 0; round < 16; ++round) {
+                const uint32_t hp = bperm(lane ? lane - 1u : 0u, h);
+                const uint32_t kpv = bperm(lane ? lane - 1u : 0u, known ? 1u : 0u);
+                const bool kp = lane == 0 || kpv != 0;
+                if (!known && kp) {
+                    q = tbl_load32(t.pred + 5u * (lane == 0 ? last_hash : hp) + (flag - 1u));
+                    h = hash16(q);
+                    known = true;
+                }
+                if (ballot64(!known) == 0) break;
+            }
+            const uint32_t hprev = bperm(lane ? lane - 1u : 0u, h);
+            const uint32_t ps = lane == 0 ? last_hash : hprev;
+            Row5 row = act ? row_load(t.pred + 5u * ps) : Row5{{0u, 0u, 0u, 0u, 0u}};
+            // ---- dictionary, in dependency order among the lanes that touch it ----
+            const uint32_t deq = same_key_mask(h, dtouch);
+            const uint32_t dbefore = deq & below;
+            const uint32_t dprev = dbefore ? 31u - (uint32_t)__builtin_clz(dbefore) : 64u;
+            const bool dlast = dtouch && (deq >> (lane & 31u) >> 1) == 0;
+            uint32_t da = e0.a, db = e0.b, ddirty = 0;
+            bool ddone = !dtouch;
+            for (uint32_t round = 0; round < 16; ++round) {
+                const uint32_t done_mask = (uint32_t)ballot64(ddone && dtouch);
+                const bool ready = !ddone && (dprev == 64u || ((done_mask >> dprev) & 1u));
+                const uint32_t fda = bperm(dprev & 31u, da), fdb = bperm(dprev & 31u, db), fdd = bperm(dprev & 31u, ddirty);
+                if (ready) {
+                    if (dprev != 64u) { da = fda; db = fdb; ddirty = fdd; }
+                    if (flag == 0) { db = da; da = q; ddirty = 1; }
+                    else if (flag == 6) q = da;
+                    else { q = db; db = da; da = q; ddirty = 1; }
+                    ddone = true;
+                }
+                if (ballot64(!ddone) == 0) break;
+            }
+            // ---- predictor rows, in dependency order (every quad rewrites its row unless it hit the front entry) ----
+            const uint32_t peq = same_key_mask(ps, act);
+            const uint32_t pbefore = peq & below;
+            const uint32_t pprev = pbefore ? 31u - (uint32_t)__builtin_clz(pbefore) : 64u;
+            const bool plast = act && (peq >> (lane & 31u) >> 1) == 0;
+            uint32_t pdirty = 0;
+            bool pdone = !act, wrong = false;
+            for (uint32_t round = 0; round < 16; ++round) {
+                const uint32_t done_mask = (uint32_t)ballot64(pdone && act);
+                const bool ready = !pdone && (pprev == 64u || ((done_mask >> pprev) & 1u));
+                const Row5 frow = row_from_lane(pprev & 31u, row);
+                const uint32_t fpd = bperm(pprev & 31u, pdirty);
+                if (ready) {
+                    if (pprev != 64u) { row = frow; pdirty = fpd; }
+                    if (predicted) {
+                        uint32_t cur = row.n[0];
+#pragma unroll
+                        for (uint32_t k = 1; k < 5; ++k) cur = flag == k + 1u ? row.n[k] : cur;
+                        wrong = cur != q;                                     // the row as it really stands does not hold what the speculation read
+                        if (flag > 1) { row_promote(row, flag - 1u, q); pdirty = 1; }
+                    } else {
+                        row_promote(row, 4, q); pdirty = 1;                   // lion.rs:50-57
+                    }
+                    pdone = true;
+                }
+                if (ballot64(!pdone) == 0) break;
+            }
+            if (ballot64(wrong) != 0) {
+                __threadfence();
+                if (lane == 0) { t.last_hash = last_hash; bad = lion_record_scalar(t, src, elen, ipos, dst, cap, opos, done, guard); last_hash = t.last_hash; }
+                __threadfence();
+                ipos = bcast64(ipos); opos = bcast64(opos); last_hash = rfl(last_hash);
+                bad = rfl(bad ? 1u : 0u) != 0; done = rfl(done ? 1u : 0u) != 0;
+                guard.penalty = rfl(guard.penalty); guard.start = rfl(guard.start); guard.prev = rfl(guard.prev); guard.counter = rfl(guard.counter);
+                if (bad || done) break;
+                continue;
+            }
+            if (act) st32u(dst + opos + 4u * lane, q);
+            if (plast && pdirty) row_store(t.pred + 5u * ps, row);
+            if (dlast && ddirty) tbl_store_pair(t.dict + h, Pair{da, db});
+            last_hash = rfl(bperm(15u, h));
+            const uint32_t rlen = G::kSig + items;
+            guard.update(rlen >= G::kBlock);
+            ipos += rlen; opos += G::kBlock;
+        }
+        tbl_drain();
+        __threadfence();
+        if (lane == 0) {                                                      // the rest: scalar code, codec.rs:102-123
+            t.last_hash = last_hash;
+            while (ipos < elen && !bad && !done) {
+                const uint64_t rem = elen - ipos;
+                if (guard.block_is_copy()) {
+                    const uint32_t take = rem > G::kBlock ? G::kBlock : (uint32_t)rem;
+                    if (opos + take > cap) { bad = true; break; }
+                    for (uint32_t i = 0; i < take; ++i) dst[opos + i] = src[ipos + i];
+                    ipos += take; opos += take;
+                    if (rem <= G::kBlock) break;
+                    guard.decay();
+                    continue;
+                }
+                bad = lion_record_scalar(t, src, elen, ipos, dst, cap, opos, done, guard);
+            }
+            if (exact && !bad && opos != cap) bad = true;
+            produced[chunk] = opos;
+            if (bad) atomicOr(err, 1u);
+        }
+        __threadfence();
+    }
+}
+
 }  // namespace
 
 uint64_t serial_table_bytes(int algo) { return 65536ull * (sizeof(Pair) + 4ull * (algo == DENSITY_HIP_LION ? 5 : 1)); }
@@ -657,6 +1007,8 @@ hipError_t launch_serial_encode(int algo, const uint8_t* d_in, uint64_t total, u
         hipLaunchKernelGGL(cheetah_encode_wave, dim3(n_slots), dim3(64), 0, stream, d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, n_slots);
     else if (algo == DENSITY_HIP_CHEETAH)
         hipLaunchKernelGGL(serial_encode_chunks<DENSITY_HIP_CHEETAH>, dim3(blocks), dim3(64), 0, stream, d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, n_slots);
+    else if (!g_force_lane_codec)
+        hipLaunchKernelGGL(lion_encode_wave, dim3(n_slots), dim3(64), 0, stream, d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, n_slots);
     else
         hipLaunchKernelGGL(serial_encode_chunks<DENSITY_HIP_LION>, dim3(blocks), dim3(64), 0, stream, d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, n_slots);
     return hipGetLastError();
@@ -673,6 +1025,8 @@ hipError_t launch_serial_decode(int algo, const uint8_t* d_in, const uint64_t* d
         hipLaunchKernelGGL(cheetah_decode_wave, dim3(n_slots), dim3(64), 0, stream, d_in, d_offsets, d_sizes, n_chunks, d_out, out_stride, out_total, exact ? 1u : 0u, d_produced, d_err, d_tables, n_slots);
     else if (algo == DENSITY_HIP_CHEETAH)
         hipLaunchKernelGGL(serial_decode_chunks<DENSITY_HIP_CHEETAH>, dim3(blocks), dim3(64), 0, stream, d_in, d_offsets, d_sizes, n_chunks, d_out, out_stride, out_total, exact ? 1u : 0u, d_produced, d_err, d_tables, n_slots);
+    else if (!g_force_lane_codec)
+        hipLaunchKernelGGL(lion_decode_wave, dim3(n_slots), dim3(64), 0, stream, d_in, d_offsets, d_sizes, n_chunks, d_out, out_stride, out_total, exact ? 1u : 0u, d_produced, d_err, d_tables, n_slots);
     else
         hipLaunchKernelGGL(serial_decode_chunks<DENSITY_HIP_LION>, dim3(blocks), dim3(64), 0, stream, d_in, d_offsets, d_sizes, n_chunks, d_out, out_stride, out_total, exact ? 1u : 0u, d_produced, d_err, d_tables, n_slots);
     return hipGetLastError();
