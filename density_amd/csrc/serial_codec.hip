@@ -1,12 +1,14 @@
-// serial_codec.hip — Cheetah and Lion on the device, functional path.
+// serial_codec.hip — Cheetah and Lion on the device: tables in global memory.
 //
-// STATUS: correctness-first.  One LANE per chunk stream, the reference's scalar algorithm per lane, dictionary and
-// predictor tables in global memory (Cheetah 768 KiB, Lion 1.75 MiB per stream: cheetah.rs:25-55, lion.rs:29-72 — neither
-// fits LDS, and the predictor holds arbitrary quads, so the 16-bit packing of chameleon.hip does not apply to it).
-// Parallelism is across chunks only; memory accesses are per-lane scattered.  This exists so that every algorithm of the
-// path runs on the GPU bit-exactly behind the same C ABI; the wave-parallel, L2-resident design that replaces it is
-// described in DESIGN.md §9.  The code is written against the format, with the reference lines it
-// must agree with cited per function.
+// Dictionary and predictor tables live in a global-memory workspace (Cheetah 768 KiB, Lion 1.75 MiB per stream:
+// cheetah.rs:25-55, lion.rs:29-72 — neither fits LDS, and the predictor holds arbitrary quads, so the 16-bit packing of
+// chameleon.hip does not apply to it).  Two kernel families, bit-exact with each other and with the oracle:
+//   * one LANE per chunk stream (`serial_*_chunks`): the reference's scalar algorithm per lane.  Round 1's functional path; now
+//     the cross-check (density_hip_set_kernel_variant(16)) and, as plain device functions, the ragged ends and the re-decode of
+//     mis-speculated records of the kernels below;
+//   * one WAVE per chunk stream (`cheetah_*_wave`, `lion_*_wave`, second half of this file): a record per step, a quad per lane —
+//     the default.
+// The code is written against the format, with the reference lines it must agree with cited per function.
 #include "common.hpp"
 #include "kernels.hpp"
 

@@ -153,7 +153,9 @@ void density_hip_set_profiling(int enabled);
 int density_hip_last_timings(float* milliseconds, const char** names, int capacity);
 
 /* Test hook, bit mask: 1 = force the simple one-wavefront-per-chunk kernels, 2 = encode containers without the block index,
- * 4 = force the 16-wave role pipelines (chameleon.hip) instead of the default wave-rotation kernels (rotor.hip).
+ * 4 = force the 16-wave role pipelines (chameleon.hip) instead of the default wave-rotation kernels (rotor.hip),
+ * 8 = encode in batches with the stitch of one batch beside the encoding of the next, 16 = Cheetah / Lion on the
+ * one-lane-per-stream kernels instead of the one-wave-per-stream kernels (serial_codec.hip).
  * Payload bytes are identical in every variant. */
 void density_hip_set_kernel_variant(int variant);
 
