@@ -1,3 +1,4 @@
+"""Stream round trips of Cheetah / Lion at the edge sizes, printed one per line (a hang shows where): python tools/gpu_edge_sizes.py [cheetah|lion]"""
 import sys, os
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
 import numpy as np, datagen
