@@ -77,7 +77,7 @@ struct DeviceCtx {
     uint32_t selftest_bits = 0;
     hipStream_t stream = nullptr, stitch_stream = nullptr;   // stitch_stream: the compaction of one batch of chunks beside the encoding of the next
     hipEvent_t batch_done[8] = {}, stitch_done = nullptr;
-    Buffer work, stage_in, stage_out;
+    Buffer work, stage_in, stage_out, seg;   // seg: scratch of the segmented stream encode
     // profiling: event marks accumulated since the last density_hip_last_timings() (name == nullptr opens a call)
     std::vector<hipEvent_t> events;
     std::vector<const char*> names;
@@ -331,9 +331,108 @@ int run_decode_container(DeviceCtx* c, const uint8_t* d_in, size_t container_siz
     return DENSITY_HIP_OK;
 }
 
+// ---- whole-stream-exact Chameleon encode of ONE long stream, in parallel ----
+// The stream is cut into segments of whole rounds.  What a segment needs from its predecessors is the dictionary as they leave it
+// and the FSM state.  Speculation: no predecessor but the first has a raw-copy block (so each wrote every one of its quads, and
+// "the dictionary after segments 1..k-1" is the first segment's real final dictionary overlaid with their LAST WRITERS per slot, which
+// need no encoding to find) and every segment ends calm.  One pass: segment `first` for real (exact start) | last writers of the others
+// in parallel -> start images by a per-slot merge -> all other segments in parallel from their start images, each reporting its
+// raw-copy blocks and final FSM state.  The longest prefix whose assumptions held is final; the rest is encoded again from the exact
+// final dictionary of that prefix (incompressible input degenerates to the sequential encode: after 3 passes the remainder runs as
+// one chunk).  The output is the segments' streams concatenated byte for byte: identical to the reference's single stream.
+constexpr size_t kSegMinStream = 16u << 20;
+inline size_t seg_bytes_for(size_t n) {
+    size_t c = (n / 256) & ~(size_t)4095;                                         // about one segment per CU, whole rounds of 16 blocks
+    if (c > (4u << 20)) c = 4u << 20;
+    if (c < (256u << 10)) c = 256u << 10;
+    return c;
+}
+int run_stream_encode_segmented(DeviceCtx* c, const uint8_t* d_in, size_t n, uint8_t* d_out, hipStream_t s, size_t* size_out) {
+    const size_t C = seg_bytes_for(n), S = (n + C - 1) / C, stride = slot_stride(DENSITY_HIP_CHAMELEON, C), img = kSegImageBytes;
+    const size_t off_lw = align_up(S * stride, kAlign), off_start = off_lw + S * img, off_final = off_start + S * img, off_small = off_final + S * img;
+    hipError_t e = c->seg.ensure(off_small + S * 64 + kAlign);
+    if (e != hipSuccess) { set_error("workspace allocation (segmented stream encode)", e); return DENSITY_HIP_ERR_RUNTIME; }
+    uint8_t* base = (uint8_t*)c->seg.p;
+    uint8_t *d_stage = base, *d_lw = base + off_lw, *d_start = base + off_start, *d_final = base + off_final;
+    uint64_t* d_sizes = reinterpret_cast<uint64_t*>(base + off_small);
+    uint64_t* d_offsets = d_sizes + S;
+    uint32_t* d_gspec = reinterpret_cast<uint32_t*>(d_offsets + S);              // start FSM states of the speculating segments
+    uint32_t* d_gfinal = d_gspec + S;
+    uint32_t* d_raw = d_gfinal + S;
+    uint32_t* d_err = d_raw + S;
+    const uint32_t calm = 0x80000000u;                                             // pack_guard({0, 1, 0, 0}) = 0, speculation allowed
+    std::vector<uint32_t> h_gspec(S, calm), h_gfinal(S), h_raw(S);
+    std::vector<uint64_t> h_sizes(S), h_offsets(S);
+    e = hipMemsetAsync(d_raw, 0, (S + 1) * sizeof(uint32_t), s);                  // raw counters + error word
+    if (e == hipSuccess) e = hipMemcpyAsync(d_gspec, h_gspec.data(), S * sizeof(uint32_t), hipMemcpyHostToDevice, s);
+    // last writers of every segment that has a successor and a predecessor (whole rounds: only the last segment can be short)
+    if (e == hipSuccess && S > 2) e = launch_rotor_lastwriters(d_in + C, C, (uint32_t)(S - 2), d_lw + img, d_err, s);
+    size_t first = 0;
+    for (int pass = 0; e == hipSuccess && first < S; ++pass) {
+        const bool rest_as_one = pass >= 3;
+        // segment `first` (or, after too many passes, everything that is left as one chunk) from its exact start
+        SegArgs a;
+        a.init_images = first ? d_final + (first - 1) * img : nullptr;
+        a.init_guard = first ? d_gfinal + (first - 1) : nullptr;
+        a.final_images = d_final + first * img;
+        a.final_guard = d_gfinal + first;
+        a.raw_blocks = d_raw + first;
+        const size_t left = n - first * C;
+        e = launch_rotor_encode_seg(d_in + first * C, rest_as_one ? left : (left < C ? left : C), rest_as_one ? left : C, 1, d_stage + first * stride,
+                                    rest_as_one ? 0 : stride, d_sizes + first, d_err, a, s);
+        if (rest_as_one || first + 1 >= S) { if (rest_as_one) { /* the remainder's stream follows the final prefix directly */ } break; }
+        const size_t rest = S - first - 1;
+        // start images of first+1 ..: the exact dictionary after `first`, then the last writers of first+1, first+2, ... laid over it
+        if (e == hipSuccess) e = launch_merge_images(d_final + first * img, d_lw + (first + 1) * img, d_start + (first + 1) * img, (uint32_t)rest, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_gspec + first + 1, d_gfinal + first, sizeof(uint32_t), hipMemcpyDeviceToDevice, s);   // its successor starts from the true state
+        if (e == hipSuccess) e = hipMemsetAsync(d_raw + first + 1, 0, rest * sizeof(uint32_t), s);
+        SegArgs b;
+        b.init_images = d_start + (first + 1) * img;
+        b.init_guard = d_gspec + first + 1;
+        b.final_images = d_final + (first + 1) * img;
+        b.final_guard = d_gfinal + first + 1;
+        b.raw_blocks = d_raw + first + 1;
+        if (e == hipSuccess) e = launch_rotor_encode_seg(d_in + (first + 1) * C, n - (first + 1) * C, C, (uint32_t)rest, d_stage + (first + 1) * stride, stride,
+                                                         d_sizes + first + 1, d_err, b, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(h_gfinal.data(), d_gfinal, S * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(h_raw.data(), d_raw, S * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) break;
+        // segment first+1 started from the truth; k >= first+2 is final iff every segment first+1 .. k-1 coded all its blocks and k-1 ended calm
+        size_t k = first + 2;
+        while (k < S && h_raw[k - 1] == 0 && (h_gfinal[k - 1] & 0x7fffffffu) == 0) ++k;
+        if (getenv("DENSITY_HIP_PROF")) fprintf(stderr, "[density_hip prof] segmented stream encode: pass %d, %zu segments of %zu bytes, final up to segment %zu\n", pass, S, C, k);
+        first = k;                                                                // (== S: done)
+    }
+    uint32_t h_err = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(h_sizes.data(), d_sizes, S * sizeof(uint64_t), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(&h_err, d_err, sizeof(h_err), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { set_error("segmented stream encode", e); return DENSITY_HIP_ERR_RUNTIME; }
+    if (h_err) { set_error("stream encode: device-side watchdog"); return DENSITY_HIP_ERR_RUNTIME; }
+    // a remainder encoded as one chunk sits in the slot of its first segment; the slots behind it are unused
+    size_t used = S;
+    if (first < S && first > 0) {
+        // passes ran out at `first`: slots first .. are one stream in slot `first`
+        used = first + 1;
+    }
+    uint64_t total = 0;
+    for (size_t i = 0; i < used; ++i) { h_offsets[i] = total; total += h_sizes[i]; }
+    e = hipMemcpyAsync(d_offsets, h_offsets.data(), used * sizeof(uint64_t), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = launch_compact_bytes(d_stage, stride, d_sizes, d_offsets, (uint32_t)used, d_out, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { set_error("segmented stream encode (gather)", e); return DENSITY_HIP_ERR_RUNTIME; }
+    *size_out = (size_t)total;
+    return DENSITY_HIP_OK;
+}
+
 int run_stream_encode(DeviceCtx* c, int algo, const uint8_t* d_in, size_t n, uint8_t* d_out, size_t cap, uint8_t* ws, hipStream_t s,
                       size_t* size_out) {
     if (cap < safe_size(algo, n)) { set_error("output capacity below safe_encode_buffer_size()"); return DENSITY_HIP_ERR_CAPACITY; }
+    if (algo == DENSITY_HIP_CHAMELEON && n >= kSegMinStream && n < (1ull << 31) && (reinterpret_cast<uintptr_t>(d_in) & 3) == 0 && !(g_variant & 5) && !g_rotor_unsafe) {
+        *size_out = 0;
+        return run_stream_encode_segmented(c, d_in, n, d_out, s, size_out);
+    }
     uint64_t* d_sizes = reinterpret_cast<uint64_t*>(ws + kAlign);
     *size_out = 0;
     if (n == 0) return DENSITY_HIP_OK;

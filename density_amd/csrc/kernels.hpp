@@ -28,6 +28,25 @@ constexpr uint32_t kZmapWordsPerChunk = 2048, kMaxPipelinedChunks = 16384;
 bool rotor_encode_eligible(const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks);
 hipError_t launch_rotor_encode(const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_out, uint64_t out_stride,
                                uint64_t* d_sizes, uint8_t* d_index, uint32_t* d_err, hipStream_t stream);
+// Whole-stream-exact encoding in segments (api.hip::run_stream_encode_segmented): a chunk may start from a given dictionary image
+// (table + zero-entry map, kSegImageBytes) and FSM state instead of a fresh one, and reports where it ended.
+constexpr uint64_t kSegImageBytes = 128ull * 1024 + 8ull * 1024;
+struct SegArgs {
+    const uint8_t* init_images = nullptr;   // per chunk kSegImageBytes, or nullptr: fresh tables
+    const uint32_t* init_guard = nullptr;   // per chunk: packed FSM state (rotor.hip::pack_guard); bit 31: start in speculation (fast) mode
+    uint8_t* final_images = nullptr;        // per chunk: the dictionary image after the chunk
+    uint32_t* final_guard = nullptr;        // per chunk: the FSM state after the chunk's last whole block
+    uint32_t* raw_blocks = nullptr;         // per chunk: number of raw-copy blocks (pre-zeroed by the caller)
+};
+hipError_t launch_rotor_encode_seg(const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_out, uint64_t out_stride,
+                                   uint64_t* d_sizes, uint32_t* d_err, SegArgs seg, hipStream_t stream);
+// per chunk (whole rounds only): the dictionary image a fresh table has after every block of the chunk was coded ("last writers")
+hipError_t launch_rotor_lastwriters(const uint8_t* d_in, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_images, uint32_t* d_err, hipStream_t stream);
+// start images of chunks first+1 .. first+count: base image, then the last-writer images of chunks first+1 .. laid over it one after the other
+hipError_t launch_merge_images(const uint8_t* d_base, const uint8_t* d_lastwriters, uint8_t* d_start, uint32_t count, hipStream_t stream);
+// byte-granular gather of chunk streams (d_src + i * src_stride, sizes[i]) to d_dst + offsets[i]
+hipError_t launch_compact_bytes(const uint8_t* d_src, uint64_t src_stride, const uint64_t* d_sizes, const uint64_t* d_offsets, uint32_t n_chunks,
+                                uint8_t* d_dst, hipStream_t stream);
 bool rotor_decode_eligible(const uint8_t* d_out, uint32_t n_chunks, uint64_t out_stride, uint64_t out_total, const uint8_t* d_index, const uint32_t* d_zmap);
 hipError_t launch_rotor_decode(const uint8_t* d_in, const uint64_t* d_offsets, const uint64_t* d_sizes, uint32_t n_chunks, uint8_t* d_out,
                                uint64_t out_stride, uint64_t out_total, bool exact, const uint8_t* d_index, uint32_t* d_zmap,

@@ -375,7 +375,7 @@ __device__ __forceinline__ bool poll_word(uint32_t addr, uint32_t want, uint32_t
 template <int R, int W, bool kProf>
 __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __restrict__ in, uint64_t total, uint64_t chunk_bytes,
                                                                    uint8_t* __restrict__ out, uint64_t out_stride, uint64_t* __restrict__ sizes,
-                                                                   uint8_t* __restrict__ index, uint32_t* __restrict__ err, uint32_t tune,
+                                                                   uint8_t* __restrict__ index, uint32_t* __restrict__ err, SegArgs seg,
                                                                    uint64_t* __restrict__ prof) {
     static_assert((R == 8 || R == 16) && (W == 8 || W == 12 || W == 16), "round = 8 or 16 blocks; 8, 12 or 16 waves");
     // (rounds of 16 on 16 waves fit the 128 registers a wave then has because nothing but the exchange operands is kept across the wait for the
@@ -393,15 +393,18 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
     // the table sits at LDS address 0 (this kernel has no static LDS): slot addresses need no base
     const uint32_t sy = kEncSync;
     const ZmapLds zmap{kEncZmap};
-    (void)tune;                                                                   // (the launcher reads the geometry from it; the kernels have no switches left)
 
     {   // fresh state per chunk (chameleon.rs:45-48): zero table, zero-entry map, tokens: round 0 in slow mode, nothing committed
+        // (a segment of a longer stream — SegArgs — starts from the dictionary image and FSM state it is given instead, and in
+        // speculation mode if its predecessor ended calm)
         uint4* p = reinterpret_cast<uint4*>(smem);
         const uint4 z = make_uint4(0, 0, 0, 0);
-        for (uint32_t i = threadIdx.x; i < (kTableBytes + kZmapBytes) / 16; i += W * 64) p[i] = z;
+        const uint4* image = seg.init_images ? reinterpret_cast<const uint4*>(seg.init_images + chunk * kSegImageBytes) : nullptr;
+        for (uint32_t i = threadIdx.x; i < (kTableBytes + kZmapBytes) / 16; i += W * 64) p[i] = image ? image[i] : z;
         if (threadIdx.x == 0) {
-            *reinterpret_cast<uint4*>(smem + kEncSync + kSyD) = make_uint4(1u, kNone, 0u, 0u);
-            *reinterpret_cast<uint4*>(smem + kEncSync + kSyO) = make_uint4(0u, kNone, 0u, pack_guard(Guard{}));
+            const uint32_t g0 = seg.init_guard ? seg.init_guard[chunk] : pack_guard(Guard{});
+            *reinterpret_cast<uint4*>(smem + kEncSync + kSyD) = make_uint4((g0 >> 31) ? 0u : 1u, kNone, 0u, 0u);
+            *reinterpret_cast<uint4*>(smem + kEncSync + kSyO) = make_uint4(0u, kNone, 0u, g0 & 0x7fffffffu);
             if (lds_addr(smem) != 0 && err) atomicOr(err, kErrWatchdog);           // (cannot happen: see above)
         }
     }
@@ -718,6 +721,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
                 }
             }
             opos = P0;
+            if (seg.raw_blocks && copy_mask && lane == 0) atomicAdd(seg.raw_blocks + chunk, (uint32_t)__builtin_popcount(copy_mask));
             const uint32_t stay_slow = (g.penalty | copy_mask | unrest) != 0 ? 1u : 0u;   // back to speculation only after a round without an incompressible or raw block
             if (lane == 0) {
                 lds_poke2(sy + kSyO + 8, opos + sum, pack_guard(g));
@@ -786,11 +790,115 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
             emit_block(dst + opos, qv, sg, raw);
             const uint32_t nh = (uint32_t)__builtin_popcountll(sg);
             if (idx && lane == 0) idx[b] = (uint8_t)(raw ? kIdxCopy : nh);
+            if (seg.raw_blocks && raw && lane == 0) atomicAdd(seg.raw_blocks + chunk, 1u);
             opos += raw ? kBlock : kSig + kBlock - 2u * nh;
         }
+        if (seg.final_guard && lane == 0) seg.final_guard[chunk] = pack_guard(g) | (g.penalty == 0 ? 0x80000000u : 0u);   // (a segment that is not the stream's last ends on a whole block; bit 31: the next one may start speculating)
         const uint64_t end = encode_ragged_block(src, len, nfull, dst, opos, g, idx, 0u, zmap, lane);
         if (lane == 0) sizes[chunk] = end;
     }
+    if (seg.final_images) {                                                        // the dictionary as this chunk leaves it
+        wg_barrier();
+        uint4* image = reinterpret_cast<uint4*>(seg.final_images + chunk * kSegImageBytes);
+        const uint4* p = reinterpret_cast<const uint4*>(smem);
+        for (uint32_t i = threadIdx.x; i < (kTableBytes + kZmapBytes) / 16; i += W * 64) image[i] = p[i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Segments of one long stream (whole-stream-exact parallel encode, api.hip::run_stream_encode_segmented)
+// ---------------------------------------------------------------------------------------------------------------
+// "Last writers": the dictionary image a FRESH table has after every block of a chunk went through it (no raw-copy blocks: what
+// the segmented encode speculates for every segment but the first).  The D chain of the encoder and nothing else: rounds of 16
+// blocks rotate over 16 waves, each wave issues its round's ordered exchanges behind the token and drops the answers; zero-entry
+// quads mark their slot (the marks need no order: a stale mark under a non-zero entry is never consulted).  Whole rounds only.
+__global__ __launch_bounds__(1024) void chameleon_lastwriters_rot(const uint8_t* __restrict__ in, uint64_t chunk_bytes, uint8_t* __restrict__ images,
+                                                                   uint32_t* __restrict__ err) {
+    constexpr int R = 16, W = 16;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = rfl(threadIdx.x >> 6);
+    const uint64_t chunk = blockIdx.x;
+    const uint8_t* src = in + chunk * chunk_bytes;
+    const uint32_t nrounds = (uint32_t)(chunk_bytes / (R * kBlock));
+    const uint32_t sy = kEncSync;
+    const ZmapLds zmap{kEncZmap};
+    {
+        uint4* p = reinterpret_cast<uint4*>(smem);
+        const uint4 z = make_uint4(0, 0, 0, 0);
+        for (uint32_t i = threadIdx.x; i < (kTableBytes + kZmapBytes) / 16; i += W * 64) p[i] = z;
+        if (threadIdx.x == 0) *reinterpret_cast<uint4*>(smem + kEncSync + kSyD) = make_uint4(0u, kNone, 0u, 0u);
+    }
+    __syncthreads();
+    uint32_t q[R], ra[R], mask[R], val[R];
+    for (uint32_t r = wave; r < nrounds; r += W) {
+        const uint8_t* p = src + (uint64_t)r * (R * kBlock);
+        bool zero_entry = false;
+#pragma unroll
+        for (uint32_t j = 0; j < R; ++j) q[j] = *reinterpret_cast<const uint32_t*>(p + j * kBlock + 4u * lane);
+#pragma unroll
+        for (uint32_t j = 0; j < R; ++j) {
+            const uint32_t P = q[j] * kHashMul;
+            const uint32_t sh = (P >> 12) & 16u;
+            ra[j] = (P >> 15) & 0x1fffcu;
+            mask[j] = 0xffffu << sh;
+            val[j] = stored_entry(q[j], P) << sh;
+            zero_entry |= val[j] == 0;
+        }
+        const uint32_t tokaddr = lane == 0 ? sy + kSyD : sy + kSySink + 4u * lane;
+        pin_operands<R>(ra, mask, val);
+        for (uint32_t spins = 0;;) {
+            if (poll_word(sy + kSyD, r, 16)) break;
+            const uint32_t D = rfl(lds_peek1(sy + kSyD));
+            if (D == r) break;
+            if (D == kPoison) wave_exit();
+            backoff(r - D);
+            watchdog(spins, sy, err, lane);
+        }
+        __builtin_amdgcn_s_setprio(3);
+        exchange_tied<R>(ra, mask, val, tokaddr, r + 1u, false);
+        __builtin_amdgcn_s_setprio(0);
+        if (__builtin_expect(ballot64(zero_entry) != 0, 0)) {
+#pragma unroll
+            // (the zero quad in slot 0 included: here the mark also says "this chunk wrote the slot", which an entry of 0 alone does not;
+            // nothing ever consults slot 0's mark)
+            for (uint32_t j = 0; j < R; ++j) if (val[j] == 0) (void)zmap.test_and_set((q[j] * kHashMul) >> 16);
+        }
+    }
+    wg_barrier();
+    uint4* image = reinterpret_cast<uint4*>(images + chunk * kSegImageBytes);
+    const uint4* lp = reinterpret_cast<const uint4*>(smem);
+    for (uint32_t i = threadIdx.x; i < (kTableBytes + kZmapBytes) / 16; i += W * 64) image[i] = lp[i];
+}
+
+// Start images: slot by slot, the base image with the last-writer images of the following chunks laid over it one after the other
+// (a slot counts as written by a chunk if its entry is non-zero or its zero-entry mark is set).  One thread per slot; the output
+// marks are OR-ed into pre-zeroed words.
+__global__ __launch_bounds__(256) void merge_images_kernel(const uint8_t* __restrict__ base, const uint8_t* __restrict__ lastwriters,
+                                                           uint8_t* __restrict__ start, uint32_t count) {
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;                  // 0 .. 65535
+    uint32_t e = reinterpret_cast<const uint16_t*>(base)[slot];
+    uint32_t z = (reinterpret_cast<const uint32_t*>(base + kTableBytes)[slot >> 5] >> (slot & 31u)) & 1u;
+    for (uint32_t k = 0; k < count; ++k) {
+        uint8_t* out = start + (uint64_t)k * kSegImageBytes;
+        reinterpret_cast<uint16_t*>(out)[slot] = (uint16_t)e;
+        if (z) atomicOr(reinterpret_cast<uint32_t*>(out + kTableBytes) + (slot >> 5), 1u << (slot & 31u));
+        if (k + 1 == count) break;                                                // (the last chunk has no successor: its last writers were never computed)
+        const uint8_t* lw = lastwriters + (uint64_t)k * kSegImageBytes;
+        const uint32_t le = reinterpret_cast<const uint16_t*>(lw)[slot];
+        const uint32_t lz = (reinterpret_cast<const uint32_t*>(lw + kTableBytes)[slot >> 5] >> (slot & 31u)) & 1u;
+        if (le != 0 || lz) { e = le; z = lz; }
+    }
+}
+
+__global__ __launch_bounds__(256) void compact_bytes_kernel(const uint8_t* __restrict__ src, uint64_t src_stride, const uint64_t* __restrict__ sizes,
+                                                            const uint64_t* __restrict__ offsets, uint8_t* __restrict__ dst) {
+    const uint64_t chunk = blockIdx.y;
+    const uint64_t n = sizes[chunk];
+    const uint8_t* s = src + chunk * src_stride;
+    uint8_t* d = dst + offsets[chunk];
+    const uint64_t words = n / 4;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (uint64_t)gridDim.x * blockDim.x) st32u(d + 4 * i, ld32u(s + 4 * i));
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) d[4 * words + threadIdx.x] = s[4 * words + threadIdx.x];
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1261,7 +1369,7 @@ hipError_t launch_rotor_encode(const uint8_t* d_in, uint64_t total, uint64_t chu
                            : (prof ? chameleon_encode_rot<16, 8, true> : chameleon_encode_rot<16, 8, false>);
     hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEncLds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kernel, dim3(n_chunks), dim3(waves * 64), kEncLds, stream, d_in, total, chunk_bytes, d_out, out_stride, d_sizes, d_index, d_err, rot_tune(), prof);
+    hipLaunchKernelGGL(kernel, dim3(n_chunks), dim3(waves * 64), kEncLds, stream, d_in, total, chunk_bytes, d_out, out_stride, d_sizes, d_index, d_err, SegArgs{}, prof);
     rot_prof_report("encode", "hash | D wait | exchange | signatures | O wait+commit | load wait | emit | in-order rounds", prof, stream, waves);
     return hipGetLastError();
 }
@@ -1291,6 +1399,38 @@ hipError_t launch_rotor_decode(const uint8_t* d_in, const uint64_t* d_offsets, c
 }
 hipError_t launch_rotor_selftest(uint32_t* d_fail, hipStream_t stream) {
     hipLaunchKernelGGL(rotor_selftest_kernel, dim3(1), dim3(kRotThreads), 0, stream, d_fail, rot_tune());
+    return hipGetLastError();
+}
+
+
+hipError_t launch_rotor_encode_seg(const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_out, uint64_t out_stride,
+                                   uint64_t* d_sizes, uint32_t* d_err, SegArgs seg, hipStream_t stream) {
+    auto kernel = chameleon_encode_rot<16, 8, false>;
+    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEncLds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kernel, dim3(n_chunks), dim3(512), kEncLds, stream, d_in, total, chunk_bytes, d_out, out_stride, d_sizes, (uint8_t*)nullptr, d_err, seg, (uint64_t*)nullptr);
+    return hipGetLastError();
+}
+hipError_t launch_rotor_lastwriters(const uint8_t* d_in, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_images, uint32_t* d_err, hipStream_t stream) {
+    if (n_chunks == 0) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute((const void*)chameleon_lastwriters_rot, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEncLds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(chameleon_lastwriters_rot, dim3(n_chunks), dim3(1024), kEncLds, stream, d_in, chunk_bytes, d_images, d_err);
+    return hipGetLastError();
+}
+hipError_t launch_merge_images(const uint8_t* d_base, const uint8_t* d_lastwriters, uint8_t* d_start, uint32_t count, hipStream_t stream) {
+    if (count == 0) return hipSuccess;
+    for (uint32_t k = 0; k < count; ++k) {                                         // the marks are OR-ed in: clear them first
+        hipError_t e = hipMemsetAsync(d_start + (uint64_t)k * kSegImageBytes + kTableBytes, 0, kZmapBytes, stream);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(merge_images_kernel, dim3(65536 / 256), dim3(256), 0, stream, d_base, d_lastwriters, d_start, count);
+    return hipGetLastError();
+}
+hipError_t launch_compact_bytes(const uint8_t* d_src, uint64_t src_stride, const uint64_t* d_sizes, const uint64_t* d_offsets, uint32_t n_chunks,
+                                uint8_t* d_dst, hipStream_t stream) {
+    if (n_chunks == 0) return hipSuccess;
+    hipLaunchKernelGGL(compact_bytes_kernel, dim3(64, n_chunks), dim3(256), 0, stream, d_src, src_stride, d_sizes, d_offsets, d_dst);
     return hipGetLastError();
 }
 

@@ -292,3 +292,24 @@ def test_full_size_properties_device_resident():
     _, payloads = container.chunk_payloads(raw)
     for i in (0, 1, 117, hdr.n_chunks - 1):
         assert payloads[i] == pyoracle.encode(ALGO, host[i * chunk:(i + 1) * chunk]), i
+
+
+@pytest.mark.parametrize("kind,n", [("rep", 48 * 1024 * 1024 + 12345), ("prose", 20 * 1024 * 1024), ("patchy", 40 * 1024 * 1024 + 7), ("random", 17 * 1024 * 1024)])
+def test_long_stream_encode_in_segments_is_the_reference_stream(kind, n, kernel_variant):
+    """`chameleon_encode` of ONE long stream runs in parallel segments (api.hip::run_stream_encode_segmented) and must still be the
+    reference's single stream, byte for byte: calm text (one pass), text with incompressible patches (raw-copy blocks break the
+    speculation of the segments behind them: several passes, then the sequential remainder), random bytes (raw copies throughout)."""
+    if kernel_variant != "rotor":
+        pytest.skip("the segmented stream encode belongs to the default kernels")
+    if kind == "patchy":
+        data = datagen.by_kind("prose", n, seed=11).copy()
+        rng = np.random.default_rng(12)
+        for start in (3 << 20, (9 << 20) + 512, 21 << 20, (33 << 20) + 77 * 256):
+            data[start:start + (96 << 10)] = rng.integers(0, 256, size=96 << 10, dtype=np.uint8)
+    else:
+        data = datagen.by_kind(kind, n, seed=13)
+    want = pyoracle.encode("chameleon", data)
+    got = gpu_encode(data)
+    assert len(got) == len(want)
+    assert got == want
+    assert gpu_decode(want, n) == data.tobytes()
