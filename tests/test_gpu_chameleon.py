@@ -294,7 +294,8 @@ def test_full_size_properties_device_resident():
         assert payloads[i] == pyoracle.encode(ALGO, host[i * chunk:(i + 1) * chunk]), i
 
 
-@pytest.mark.parametrize("kind,n", [("rep", 48 * 1024 * 1024 + 12345), ("prose", 20 * 1024 * 1024), ("patchy", 40 * 1024 * 1024 + 7), ("random", 17 * 1024 * 1024)])
+@pytest.mark.parametrize("kind,n", [("rep", 48 * 1024 * 1024 + 12345), ("prose", 20 * 1024 * 1024), ("patchy", 40 * 1024 * 1024 + 7), ("random", 17 * 1024 * 1024),
+                                    ("zeros", 16 * 1024 * 1024 + 4), ("saltzero", 24 * 1024 * 1024 + 258), ("samehash", 16 * 1024 * 1024), ("zeropatch", 32 * 1024 * 1024)])
 def test_long_stream_encode_in_segments_is_the_reference_stream(kind, n, kernel_variant):
     """`chameleon_encode` of ONE long stream runs in parallel segments (api.hip::run_stream_encode_segmented) and must still be the
     reference's single stream, byte for byte: calm text (one pass), text with incompressible patches (raw-copy blocks break the
@@ -306,6 +307,15 @@ def test_long_stream_encode_in_segments_is_the_reference_stream(kind, n, kernel_
         rng = np.random.default_rng(12)
         for start in (3 << 20, (9 << 20) + 512, 21 << 20, (33 << 20) + 77 * 256):
             data[start:start + (96 << 10)] = rng.integers(0, 256, size=96 << 10, dtype=np.uint8)
+    elif kind == "zeropatch":
+        # zero quads over slot 0 and genuine zero-entry quads, overwritten and re-written across segment borders
+        data = datagen.by_kind("prose", n, seed=21).copy()
+        salted = datagen.by_kind("saltzero", 1 << 20, seed=22)
+        for i, start in enumerate(range(1 << 20, n - (2 << 20), 3 << 20)):
+            if i % 2 == 0:
+                data[start:start + (64 << 10)] = 0
+            else:
+                data[start:start + (256 << 10)] = salted[:256 << 10]
     else:
         data = datagen.by_kind(kind, n, seed=13)
     want = pyoracle.encode("chameleon", data)
