@@ -306,16 +306,26 @@ __device__ __forceinline__ void tbl_store_pair(Pair* p, Pair v) {
 // the table stores of a step are complete (in L2, where the next step's gathers read) before anything else happens
 __device__ __forceinline__ void tbl_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-// lanes 0..31: mask of the lanes whose 16-bit key equals this lane's (bit-plane ballots: exact)
-__device__ __forceinline__ uint32_t same_key_mask(uint32_t key, bool active) {
+// lanes 0..31: the lanes whose 16-bit key equals this lane's (bit-plane ballots: exact) — for two keys at once: lanes 0..31 match `k0`
+// among themselves while lanes 32..63 match copies of `k1`, one set of ballots
+__device__ __forceinline__ void same_key_masks2(uint32_t k0, bool on0, uint32_t k1, bool on1, uint32_t lane, uint32_t& eq0, uint32_t& eq1) {
+    const uint32_t k1up = bperm(lane & 31u, k1);                                  // lane 32+i: lane i's second key
+    const uint32_t on_up = bperm(lane & 31u, on1 ? 1u : 0u);
+    const bool upper = lane >= 32;
+    const uint32_t key = upper ? k1up : k0;
+    const bool on = upper ? on_up != 0 : on0;
     uint32_t eq = 0xffffffffu;
 #pragma unroll
     for (uint32_t b = 0; b < 16; ++b) {
         const bool bit = (key >> b) & 1u;
-        const uint32_t plane = (uint32_t)ballot64(bit && active);
-        eq &= bit ? plane : ~plane;
+        const uint64_t plane = ballot64(bit && on);
+        const uint32_t half = upper ? (uint32_t)(plane >> 32) : (uint32_t)plane;
+        eq &= bit ? half : ~half;
     }
-    return eq & (uint32_t)ballot64(active);
+    const uint64_t ons = ballot64(on);
+    eq &= upper ? (uint32_t)(ons >> 32) : (uint32_t)ons;
+    eq0 = eq;                                                                     // (lanes 0..31)
+    eq1 = bperm(lane | 32u, eq);                                                  // lanes 0..31 fetch their second mask from above
 }
 // 2-bit flags of lanes 0..31 -> the 64-bit signature (io/write_signature.rs:14-17: quad k at bits 2k, 2k+1)
 __device__ __forceinline__ uint64_t spread32(uint32_t x) {
@@ -327,16 +337,18 @@ __device__ __forceinline__ uint64_t spread32(uint32_t x) {
     v = (v | (v << 1)) & 0x5555555555555555ull;
     return v;
 }
-// exclusive prefix sum over lanes 0..31 (values of the other lanes ignored), and the total
+// exclusive prefix sum over lanes 0..31 (values of the other lanes ignored), and the total: DPP row shifts within the rows of 16,
+// then lane 15's sum broadcast into row 1 (a shuffle through LDS per step would cost ten times the latency)
 __device__ __forceinline__ uint32_t scan32(uint32_t v, uint32_t lane, uint32_t& total) {
-    uint32_t incl = lane < 32 ? v : 0u;
-#pragma unroll
-    for (uint32_t d = 1; d < 32; d <<= 1) {
-        const uint32_t o = bperm(lane >= d ? lane - d : lane, incl);
-        if (lane >= d) incl += o;
-    }
-    total = rfl(bperm(31u, incl));
-    return incl - (lane < 32 ? v : 0u);
+    const uint32_t mine = lane < 32 ? v : 0u;
+    uint32_t incl = mine;
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xf, 0xf, true);   // row_shr:1
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xf, 0xf, true);   // row_shr:2
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xf, 0xf, true);   // row_shr:4
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xf, 0xf, true);   // row_shr:8
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x142, 0xa, 0xf, true);   // row_bcast:15 into rows 1 and 3
+    total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 31);
+    return incl - mine;
 }
 
 // One record's worth of sequential table semantics, resolved across lanes.  In: per lane its predictor slot `ps`, dictionary
@@ -394,7 +406,8 @@ __global__ __launch_bounds__(64) void cheetah_encode_wave(const uint8_t* __restr
             st.da = e0.a; st.db = e0.b; st.pdirty = 0; st.ddirty = 0;
             // ---- 2. who follows whom ----
             const uint32_t below = (1u << (lane & 31u)) - 1u;
-            const uint32_t peq = same_key_mask(ps, act), deq = same_key_mask(h, act);
+            uint32_t peq, deq;
+            same_key_masks2(ps, act, h, act, lane, peq, deq);
             const uint32_t pbefore = peq & below, dbefore = deq & below;
             const uint32_t pprev = pbefore ? 31u - (uint32_t)__builtin_clz(pbefore) : 64u;   // 64: nobody
             const uint32_t dprev = dbefore ? 31u - (uint32_t)__builtin_clz(dbefore) : 64u;
@@ -573,7 +586,8 @@ __global__ __launch_bounds__(64) void cheetah_decode_wave(const uint8_t* __restr
             const uint32_t ps = lane == 0 ? last_hash : hprev;
             // ---- dictionary: in dependency order among the lanes that touch it ----
             const uint32_t touchers = (uint32_t)ballot64(toucher);
-            const uint32_t deq = same_key_mask(h, toucher);
+            uint32_t peq, deq;
+            same_key_masks2(ps, act, h, toucher, lane, peq, deq);
             const uint32_t dbefore = deq & below;
             const uint32_t dprev = dbefore ? 31u - (uint32_t)__builtin_clz(dbefore) : 64u;
             const bool dlast = toucher && (deq >> (lane & 31u) >> 1) == 0;
@@ -593,7 +607,6 @@ __global__ __launch_bounds__(64) void cheetah_decode_wave(const uint8_t* __restr
                 if (ballot64(!ddone) == 0) break;
             }
             // ---- predictor: a predicted quad must see what the nearest earlier writer of its slot wrote ----
-            const uint32_t peq = same_key_mask(ps, act);
             const uint32_t wbefore = peq & touchers & below;
             const uint32_t wprev = wbefore ? 31u - (uint32_t)__builtin_clz(wbefore) : 64u;
             const uint32_t wq = bperm(wprev & 31u, q);
@@ -729,7 +742,8 @@ __global__ __launch_bounds__(64) void lion_encode_wave(const uint8_t* __restrict
             const Pair e0 = act ? tbl_load_pair(t.dict + h) : Pair{0u, 0u};
             qnext = (act && pos + 2 * G::kBlock <= len) ? ld32u(blk + G::kBlock + 4u * lane) : 0u;
             uint32_t da = e0.a, db = e0.b, pdirty = 0, ddirty = 0;
-            const uint32_t peq = same_key_mask(ps, act), deq = same_key_mask(h, act);
+            uint32_t peq, deq;
+            same_key_masks2(ps, act, h, act, lane, peq, deq);
             const uint32_t pbefore = peq & below, dbefore = deq & below;
             const uint32_t pprev = pbefore ? 31u - (uint32_t)__builtin_clz(pbefore) : 64u;
             const uint32_t dprev = dbefore ? 31u - (uint32_t)__builtin_clz(dbefore) : 64u;
@@ -906,7 +920,8 @@ __global__ __launch_bounds__(64) void lion_decode_wave(const uint8_t* __restrict
             const uint32_t ps = lane == 0 ? last_hash : hprev;
             Row5 row = act ? row_load(t.pred + 5u * ps) : Row5{{0u, 0u, 0u, 0u, 0u}};
             // ---- dictionary, in dependency order among the lanes that touch it ----
-            const uint32_t deq = same_key_mask(h, dtouch);
+            uint32_t peq, deq;
+            same_key_masks2(ps, act, h, dtouch, lane, peq, deq);
             const uint32_t dbefore = deq & below;
             const uint32_t dprev = dbefore ? 31u - (uint32_t)__builtin_clz(dbefore) : 64u;
             const bool dlast = dtouch && (deq >> (lane & 31u) >> 1) == 0;
@@ -926,7 +941,6 @@ __global__ __launch_bounds__(64) void lion_decode_wave(const uint8_t* __restrict
                 if (ballot64(!ddone) == 0) break;
             }
             // ---- predictor rows, in dependency order (every quad rewrites its row unless it hit the front entry) ----
-            const uint32_t peq = same_key_mask(ps, act);
             const uint32_t pbefore = peq & below;
             const uint32_t pprev = pbefore ? 31u - (uint32_t)__builtin_clz(pbefore) : 64u;
             const bool plast = act && (peq >> (lane & 31u) >> 1) == 0;
