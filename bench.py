@@ -149,7 +149,7 @@ def size_sweep(container, algo, x, sizes, steps=5):
     for n in sizes:
         if n > x.numel():
             continue
-        chunk = int(_lib.lib().density_hip_auto_chunk(n))
+        chunk = int(_lib.lib().density_hip_auto_chunk_for({"chameleon": 0, "cheetah": 1, "lion": 2}[algo], n))
         cap = container.container_bound(algo, n, chunk)
         cont = torch.empty(cap, dtype=torch.uint8, device="cuda")
         back = torch.empty(n, dtype=torch.uint8, device="cuda")
@@ -257,7 +257,7 @@ def main():
 
     n = args.size
     from density_amd import _lib
-    chunk = args.chunk or int(_lib.lib().density_hip_auto_chunk(n))
+    chunk = args.chunk or int(_lib.lib().density_hip_auto_chunk_for({"chameleon": 0, "cheetah": 1, "lion": 2}[algo], n))
     container.set_kernel_variant(args.variant)
     # config 2 / 5 of BASELINE.json: rep-text, per-shard seed = seed + rank; configs 3/4 stand-in: non-periodic prose
     if args.data == "rep-text":

@@ -42,12 +42,16 @@ inline bool valid_algo(int algo) { return algo >= DENSITY_HIP_CHAMELEON && algo 
 // CUs (256) where that is possible without dropping below 64 KiB (small chunks restart the dictionary and cost ratio), and no finer than that
 // (every chunk start costs a table clear and a few in-order rounds): never above 4 MiB, the largest chunk the index-fed decoder takes.
 // Power of two: 10 MB -> 64 KiB (153 chunks), 100 MB -> 256 KiB (382), 256 MiB -> 1 MiB, >= 1 GiB -> 4 MiB.
-inline size_t auto_chunk(size_t n) {
-    size_t c = 4u << 20;
-    while (c > (64u << 10) && n / c < 256) c >>= 1;
+// Cheetah and Lion run one WAVE per chunk stream and are bound by memory latency per stream, not by a CU's LDS: they want eight
+// streams per CU (2048) and start from 1 MiB.
+inline size_t auto_chunk(size_t n, int algo = DENSITY_HIP_CHAMELEON) {
+    const bool lds = algo == DENSITY_HIP_CHAMELEON;
+    size_t c = lds ? (4u << 20) : (1u << 20);
+    const size_t streams = lds ? 256 : 2048;
+    while (c > (64u << 10) && n / c < streams) c >>= 1;
     return c;
 }
-inline size_t normalise_chunk(size_t chunk, size_t n) { return chunk == 0 ? auto_chunk(n) : chunk; }
+inline size_t normalise_chunk(size_t chunk, size_t n, int algo = DENSITY_HIP_CHAMELEON) { return chunk == 0 ? auto_chunk(n, algo) : chunk; }
 inline bool valid_chunk(size_t chunk) { return chunk >= 256 && chunk % 256 == 0 && chunk <= kMaxChunk; }
 inline size_t chunk_count(size_t n, size_t chunk) { return (n + chunk - 1) / chunk; }
 inline size_t index_base(size_t n_chunks) { return align_up(sizeof(density_hip_header_t) + 4 * n_chunks, 16); }
@@ -525,13 +529,13 @@ size_t lion_safe_encode_buffer_size(size_t size) { return safe_size(DENSITY_HIP_
 
 // ---- section 2: container + device API ----
 size_t density_hip_container_bound(int algo, size_t input_size, size_t chunk_size) {
-    chunk_size = normalise_chunk(chunk_size, input_size);
+    chunk_size = normalise_chunk(chunk_size, input_size, algo);
     if (!valid_algo(algo) || !valid_chunk(chunk_size)) return 0;
     return container_bound(algo, input_size, chunk_size);
 }
 
 size_t density_hip_encode_workspace_size(int algo, size_t input_size, size_t chunk_size) {
-    chunk_size = normalise_chunk(chunk_size, input_size);
+    chunk_size = normalise_chunk(chunk_size, input_size, algo);
     if (!valid_algo(algo) || !valid_chunk(chunk_size)) return 0;
     return plan_encode(algo, input_size, chunk_size).total;
 }
@@ -545,7 +549,7 @@ int density_hip_encode_device(int algo, const void* d_input, size_t input_size, 
                               size_t chunk_size, void* d_workspace, size_t workspace_size, void* stream,
                               density_hip_header_t* header_out) {
     g_last_error.clear();
-    chunk_size = normalise_chunk(chunk_size, input_size);
+    chunk_size = normalise_chunk(chunk_size, input_size, algo);
     if (!valid_algo(algo) || !valid_chunk(chunk_size) || (!d_input && input_size) || !d_output) { set_error("bad argument"); return DENSITY_HIP_ERR_ARGUMENT; }
     DeviceCtx* c = acquire_ctx();
     if (!c) return DENSITY_HIP_ERR_RUNTIME;
@@ -611,7 +615,7 @@ int density_hip_stream_decode_device(int algo, const void* d_input, size_t input
 
 size_t density_hip_encode(int algo, const uint8_t* input, size_t input_size, uint8_t* output, size_t output_size, size_t chunk_size) {
     g_last_error.clear();
-    chunk_size = normalise_chunk(chunk_size, input_size);
+    chunk_size = normalise_chunk(chunk_size, input_size, algo);
     if (!valid_algo(algo) || !valid_chunk(chunk_size) || (!input && input_size) || !output) { set_error("bad argument"); return 0; }
     DeviceCtx* c = acquire_ctx();
     if (!c) return 0;
@@ -631,6 +635,7 @@ size_t density_hip_encode(int algo, const uint8_t* input, size_t input_size, uin
 }
 
 size_t density_hip_auto_chunk(size_t input_size) { return auto_chunk(input_size); }
+size_t density_hip_auto_chunk_for(int algo, size_t input_size) { return valid_algo(algo) ? auto_chunk(input_size, algo) : 0; }
 
 size_t density_hip_decoded_size(const uint8_t* container, size_t container_size) {
     if (!container || container_size < sizeof(density_hip_header_t)) return 0;

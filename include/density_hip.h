@@ -106,10 +106,13 @@ typedef struct density_hip_header {
     uint64_t container_len;  /* total container length in bytes (header + table + padded payloads) */
 } density_hip_header_t;
 
-/* chunk_size 0 in the calls below means density_hip_auto_chunk(input_size): a power of two between 64 KiB and 4 MiB, the largest that
+/* chunk_size 0 in the calls below means density_hip_auto_chunk_for(algo, input_size); for Chameleon (density_hip_auto_chunk): a power of two between 64 KiB and 4 MiB, the largest that
  * still gives every CU of the device a chunk (a chunk is one work-group; small chunks restart the dictionary and cost ratio, every
  * chunk start costs a table clear: 10 MB -> 64 KiB, 100 MB -> 256 KiB, 256 MiB -> 1 MiB, >= 1 GiB -> 4 MiB). */
 size_t density_hip_auto_chunk(size_t input_size);
+/* The same per algorithm: Cheetah and Lion (one wave per chunk stream, memory-latency bound) take 64 KiB .. 1 MiB, the largest that
+ * still gives the device 2048 streams. */
+size_t density_hip_auto_chunk_for(int algo, size_t input_size);
 
 /* Upper bound of the container size for `input_size` bytes (0 if the arguments are invalid). */
 size_t density_hip_container_bound(int algo, size_t input_size, size_t chunk_size);
