@@ -257,7 +257,7 @@ def main():
 
     n = args.size
     from density_amd import _lib
-    chunk = args.chunk or int(_lib.lib().density_hip_auto_chunk_for({"chameleon": 0, "cheetah": 1, "lion": 2}[algo], n))
+    chunk = args.chunk or int(_lib.lib().density_hip_auto_chunk_for({"chameleon": 0, "cheetah": 1, "lion": 2}[args.algo], n))
     container.set_kernel_variant(args.variant)
     # config 2 / 5 of BASELINE.json: rep-text, per-shard seed = seed + rank; configs 3/4 stand-in: non-periodic prose
     if args.data == "rep-text":

@@ -5,12 +5,14 @@ timeout 1500 python -m pytest tests -m gpu -x -q > $T/pytest.log 2>&1; echo "pyt
 timeout 300 python __graft_entry__.py smoke > $T/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 $T/smoke.log
 timeout 900 python bench.py --steps 20 --warmup 5 > $T/bench_full.json 2> $T/bench_full.err; echo "bench rc=$?"; head -c 600 $T/bench_full.json; echo
 for a in cheetah lion; do
-  timeout 900 python bench.py --algo $a --data prose --size 100000000 --chunk 1048576 --steps 3 --warmup 1 --cpu-sample 100000000 --host-sample 16777216 --no-sweep > $T/bench_${a}_1M.json 2> $T/bench_${a}_1M.err; echo "$a 1M rc=$?"
+  timeout 900 python bench.py --algo $a --data prose --size 100000000 --chunk 1048576 --steps 3 --warmup 1 --no-sweep > $T/bench_${a}_1M.json 2> $T/bench_${a}_1M.err; echo "$a 1M rc=$?"
   timeout 900 python bench.py --algo $a --data prose --size 100000000 --chunk 65536 --steps 3 --warmup 1 --no-cpu --no-sweep > $T/bench_${a}_64K.json 2> $T/bench_${a}_64K.err; echo "$a 64K rc=$?"
+  timeout 600 python bench.py --algo $a --steps 2 --warmup 1 --no-cpu --no-sweep > $T/bench_${a}_1G_auto.json 2> $T/bench_${a}_1G_auto.err; echo "$a 1 GiB auto rc=$?"
 done
 timeout 900 python bench.py --algo chameleon --data prose --size 100000000 --steps 10 --warmup 3 --no-cpu --no-sweep > $T/bench_chameleon_prose100M.json 2>/dev/null
 timeout 900 python benches/density.py > $T/benches_density.txt 2>&1; echo "harness rc=$?"; tail -30 $T/benches_density.txt
 timeout 120 ./probes/rotor_hop > $T/rotor_hop.log 2>&1; tail -4 $T/rotor_hop.log
+for k in rep random; do timeout 200 python tools/gpu_stream_rate.py 1024 $k 2>&1 | tail -1; done > $T/stream_rate.txt; cat $T/stream_rate.txt
 python - <<'PY'
 import json, glob
 for f in sorted(glob.glob("gpurun_out/r2_final/bench_*.json")):
