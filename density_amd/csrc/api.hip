@@ -370,7 +370,12 @@ int run_stream_encode_segmented(DeviceCtx* c, const uint8_t* d_in, size_t n, uin
     e = hipMemsetAsync(d_raw, 0, (S + 1) * sizeof(uint32_t), s);                  // raw counters + error word
     if (e == hipSuccess) e = hipMemcpyAsync(d_gspec, h_gspec.data(), S * sizeof(uint32_t), hipMemcpyHostToDevice, s);
     // last writers of every segment that has a successor and a predecessor (whole rounds: only the last segment can be short)
-    if (e == hipSuccess && S > 2) e = launch_rotor_lastwriters(d_in + C, C, (uint32_t)(S - 2), d_lw + img, d_err, s);
+    // (on the context's second stream, beside the first segment's encode; joined before the first merge)
+    if (e == hipSuccess) e = hipEventRecord(c->batch_done[0], s);
+    if (e == hipSuccess) e = hipStreamWaitEvent(c->stitch_stream, c->batch_done[0], 0);
+    if (e == hipSuccess && S > 2) e = launch_rotor_lastwriters(d_in + C, C, (uint32_t)(S - 2), d_lw + img, d_err, c->stitch_stream);
+    if (e == hipSuccess) e = hipEventRecord(c->stitch_done, c->stitch_stream);
+    bool joined = false;
     size_t first = 0;
     for (int pass = 0; e == hipSuccess && first < S; ++pass) {
         const bool rest_as_one = pass >= 3;
@@ -387,6 +392,7 @@ int run_stream_encode_segmented(DeviceCtx* c, const uint8_t* d_in, size_t n, uin
         if (rest_as_one || first + 1 >= S) { if (rest_as_one) { /* the remainder's stream follows the final prefix directly */ } break; }
         const size_t rest = S - first - 1;
         // start images of first+1 ..: the exact dictionary after `first`, then the last writers of first+1, first+2, ... laid over it
+        if (e == hipSuccess && !joined) { e = hipStreamWaitEvent(s, c->stitch_done, 0); joined = true; }
         if (e == hipSuccess) e = launch_merge_images(d_final + first * img, d_lw + (first + 1) * img, d_start + (first + 1) * img, (uint32_t)rest, s);
         if (e == hipSuccess) e = hipMemcpyAsync(d_gspec + first + 1, d_gfinal + first, sizeof(uint32_t), hipMemcpyDeviceToDevice, s);   // its successor starts from the true state
         if (e == hipSuccess) e = hipMemsetAsync(d_raw + first + 1, 0, rest * sizeof(uint32_t), s);
@@ -408,6 +414,7 @@ int run_stream_encode_segmented(DeviceCtx* c, const uint8_t* d_in, size_t n, uin
         if (getenv("DENSITY_HIP_PROF")) fprintf(stderr, "[density_hip prof] segmented stream encode: pass %d, %zu segments of %zu bytes, final up to segment %zu\n", pass, S, C, k);
         first = k;                                                                // (== S: done)
     }
+    if (!joined) { hipError_t j = hipStreamWaitEvent(s, c->stitch_done, 0); if (e == hipSuccess) e = j; }
     uint32_t h_err = 0;
     if (e == hipSuccess) e = hipMemcpyAsync(h_sizes.data(), d_sizes, S * sizeof(uint64_t), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipMemcpyAsync(&h_err, d_err, sizeof(h_err), hipMemcpyDeviceToHost, s);

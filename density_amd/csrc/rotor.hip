@@ -890,15 +890,28 @@ __global__ __launch_bounds__(256) void merge_images_kernel(const uint8_t* __rest
     }
 }
 
+// 16 bytes per lane: aligned stores, unaligned loads (the streams start at any even offset of the destination); head and tail by bytes
 __global__ __launch_bounds__(256) void compact_bytes_kernel(const uint8_t* __restrict__ src, uint64_t src_stride, const uint64_t* __restrict__ sizes,
                                                             const uint64_t* __restrict__ offsets, uint8_t* __restrict__ dst) {
+    typedef uint4 uint4_u __attribute__((aligned(1)));
     const uint64_t chunk = blockIdx.y;
     const uint64_t n = sizes[chunk];
     const uint8_t* s = src + chunk * src_stride;
     uint8_t* d = dst + offsets[chunk];
-    const uint64_t words = n / 4;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (uint64_t)gridDim.x * blockDim.x) st32u(d + 4 * i, ld32u(s + 4 * i));
-    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) d[4 * words + threadIdx.x] = s[4 * words + threadIdx.x];
+    uint64_t head = (16 - (reinterpret_cast<uintptr_t>(d) & 15)) & 15;
+    if (head > n) head = n;
+    const uint64_t vecs = (n - head) / 16;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < vecs; i += (uint64_t)gridDim.x * blockDim.x)
+    {
+        const uint4_u* sp = reinterpret_cast<const uint4_u*>(s + head + 16 * i);
+        const uint4 v = {sp->x, sp->y, sp->z, sp->w};
+        *reinterpret_cast<uint4*>(d + head + 16 * i) = v;
+    }
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < head) d[threadIdx.x] = s[threadIdx.x];
+        const uint64_t tail0 = head + 16 * vecs;
+        if (tail0 + threadIdx.x < n && threadIdx.x < 16) d[tail0 + threadIdx.x] = s[tail0 + threadIdx.x];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1430,7 +1443,7 @@ hipError_t launch_merge_images(const uint8_t* d_base, const uint8_t* d_lastwrite
 hipError_t launch_compact_bytes(const uint8_t* d_src, uint64_t src_stride, const uint64_t* d_sizes, const uint64_t* d_offsets, uint32_t n_chunks,
                                 uint8_t* d_dst, hipStream_t stream) {
     if (n_chunks == 0) return hipSuccess;
-    hipLaunchKernelGGL(compact_bytes_kernel, dim3(64, n_chunks), dim3(256), 0, stream, d_src, src_stride, d_sizes, d_offsets, d_dst);
+    hipLaunchKernelGGL(compact_bytes_kernel, dim3(16, n_chunks), dim3(256), 0, stream, d_src, src_stride, d_sizes, d_offsets, d_dst);
     return hipGetLastError();
 }
 
