@@ -464,10 +464,99 @@ int run_stream_encode(DeviceCtx* c, int algo, const uint8_t* d_in, size_t n, uin
     return DENSITY_HIP_OK;
 }
 
+// ---- ONE long Chameleon reference stream decoded in parallel ----
+// stream_parse.hip finds the record boundaries of a calm stream in parallel: the block index and the stream offset of every 16384th
+// block, i.e. the description of a container whose chunks are 4 MiB segments of the one stream.  A segment's start dictionary needs
+// no speculation on decode: PLAIN quads write the dictionary whatever it holds and MAP quads never do, so it is the overlay of
+// its predecessors' last PLAIN writers — which a decode pass from an EMPTY dictionary leaves behind as its final image (its MAP quads
+// come out wrong, its writes are right; the real pass overwrites the output).  Passes: parse -> decode from empty dictionaries, final
+// images -> per-slot merge into start images -> decode from the start images.  `handled` false: not a calm stream (or too short, or
+// buffers this path does not take): the caller walks it on one work-group as before.
+constexpr size_t kSegDecodeMin = 16u << 20;
+int run_stream_decode_segmented(DeviceCtx* c, const uint8_t* d_in, size_t E, uint8_t* d_out, size_t cap, hipStream_t s, size_t* size_out, bool* handled) {
+    *handled = false;
+    constexpr uint32_t kChunkBlocks = 16384;
+    constexpr size_t kChunkBytes = (size_t)kChunkBlocks * 256, img = kSegImageBytes;
+    size_t max_blocks = E / 136 + 2;
+    if (cap / 256 + 2 < max_blocks) max_blocks = cap / 256 + 2;
+    const size_t max_chunks = (max_blocks + kChunkBlocks - 1) / kChunkBlocks + 1;
+    if (max_chunks > kMaxPipelinedChunks) return DENSITY_HIP_OK;
+    const size_t index_bytes = align_up(max_chunks * kChunkBlocks + 64, kAlign), parse_ws = align_up(stream_parse_workspace(E), kAlign);
+    const size_t off_index = parse_ws, off_lw = off_index + index_bytes, off_start = off_lw + max_chunks * img, off_zero = off_start + max_chunks * img,
+                 off_zmap = off_zero + align_up(img, kAlign), off_small = off_zmap + max_chunks * kZmapWordsPerChunk * 4;
+    hipError_t e = c->seg.ensure(off_small + (max_chunks + 2) * 32 + 256 + kAlign);
+    if (e != hipSuccess) { set_error("workspace allocation (segmented stream decode)", e); return DENSITY_HIP_ERR_RUNTIME; }
+    uint8_t* base = (uint8_t*)c->seg.p;
+    uint8_t* d_index = base + off_index;
+    uint64_t* d_chunk_offset = reinterpret_cast<uint64_t*>(base + off_small);
+    uint64_t* d_offsets = d_chunk_offset + max_chunks + 2;
+    uint64_t* d_sizes = d_offsets + max_chunks + 2;
+    uint64_t* d_produced = d_sizes + max_chunks + 2;
+    uint32_t* d_info = reinterpret_cast<uint32_t*>(d_produced + max_chunks + 2);
+    uint32_t* d_err = d_info + 16;                                                // [0] the real pass, [1] the last-writer pass (ignored)
+    e = hipMemsetAsync(d_index, 0x7f, index_bytes, s);                            // beyond the stream: "ragged" = stop
+    if (e == hipSuccess) e = hipMemsetAsync(d_chunk_offset, 0, (max_chunks + 2) * sizeof(uint64_t), s);
+    if (e == hipSuccess) e = hipMemsetAsync(d_info, 0, 18 * sizeof(uint32_t), s);
+    if (e == hipSuccess) e = launch_stream_parse(d_in, E, base, d_index, max_chunks * kChunkBlocks, d_chunk_offset, kChunkBlocks, d_info, s);
+    uint32_t info[8] = {};
+    std::vector<uint64_t> h_off(max_chunks + 2), h_offsets, h_sizes;
+    if (e == hipSuccess) e = hipMemcpyAsync(info, d_info, sizeof(info), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(h_off.data(), d_chunk_offset, (max_chunks + 2) * sizeof(uint64_t), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { set_error("segmented stream decode (parse)", e); return DENSITY_HIP_ERR_RUNTIME; }
+    const uint64_t whole = info[4], end_pos = ((uint64_t)info[6] << 32) | info[5];
+    if (getenv("DENSITY_HIP_PROF")) fprintf(stderr, "[density_hip prof] segmented stream decode: parse status %u, head %u blocks / %llu bytes, %llu whole blocks end at %llu of %zu, not calm %u\n",
+                                            info[0], info[1], (unsigned long long)(((uint64_t)info[3] << 32) | info[2]), (unsigned long long)whole, (unsigned long long)end_pos, E, info[7]);
+    const bool trace = getenv("DENSITY_HIP_PROF") != nullptr;
+    if (info[0] == 0 || info[7] != 0 || whole < 2 * kChunkBlocks || end_pos > E) { if (trace) fprintf(stderr, "[density_hip prof]   -> sequential path (not calm / short)\n"); return DENSITY_HIP_OK; }
+    const bool ragged = end_pos < E;
+    const size_t n_chunks = (whole + (ragged ? 1 : 0) + kChunkBlocks - 1) / kChunkBlocks;
+    if (n_chunks > max_chunks || (n_chunks - 1) * kChunkBytes >= cap) { if (trace) fprintf(stderr, "[density_hip prof]   -> sequential path (capacity: %zu chunks, cap %zu)\n", n_chunks, cap); return DENSITY_HIP_OK; }
+    if (ragged && whole % kChunkBlocks == 0) h_off[whole / kChunkBlocks] = end_pos;   // a ragged end that opens a chunk of its own
+    h_off[0] = 0;
+    h_offsets.resize(n_chunks); h_sizes.resize(n_chunks);
+    for (size_t k = 0; k < n_chunks; ++k) {
+        h_offsets[k] = h_off[k];
+        h_sizes[k] = (k + 1 < n_chunks ? h_off[k + 1] : (uint64_t)E) - h_off[k];
+        if (k && h_off[k] <= h_off[k - 1]) return DENSITY_HIP_OK;                     // (cannot happen; never hand the kernels a broken layout)
+    }
+    const uint64_t out_total = cap < n_chunks * kChunkBytes ? cap : n_chunks * kChunkBytes;
+    uint32_t* d_zmap = reinterpret_cast<uint32_t*>(base + off_zmap);
+    if (!rotor_decode_eligible(d_out, (uint32_t)n_chunks, kChunkBytes, out_total, d_index, d_zmap) || g_rotor_unsafe) { if (trace) fprintf(stderr, "[density_hip prof]   -> sequential path (buffers not eligible)\n"); return DENSITY_HIP_OK; }
+    e = hipMemcpyAsync(d_offsets, h_offsets.data(), n_chunks * sizeof(uint64_t), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_sizes, h_sizes.data(), n_chunks * sizeof(uint64_t), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemsetAsync(base + off_zero, 0, img, s);
+    SegArgs lw;
+    lw.final_images = base + off_lw;
+    lw.lastwriters_only = 1;
+    if (e == hipSuccess) e = launch_rotor_decode_seg(d_in, d_offsets, d_sizes, (uint32_t)n_chunks, d_out, kChunkBytes, out_total, d_index, d_zmap, d_produced, d_err + 1, lw, s);
+    if (e == hipSuccess) e = launch_merge_images(base + off_zero, base + off_lw, base + off_start, (uint32_t)n_chunks, s);
+    SegArgs real;
+    real.init_images = base + off_start;
+    if (e == hipSuccess) e = launch_rotor_decode_seg(d_in, d_offsets, d_sizes, (uint32_t)n_chunks, d_out, kChunkBytes, out_total, d_index, d_zmap, d_produced, d_err, real, s);
+    uint64_t h_last = 0;
+    uint32_t h_err = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&h_last, d_produced + (n_chunks - 1), sizeof(h_last), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(&h_err, d_err, sizeof(h_err), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { set_error("segmented stream decode", e); return DENSITY_HIP_ERR_RUNTIME; }
+    *handled = true;
+    if (trace) fprintf(stderr, "[density_hip prof]   -> %zu segments decoded in parallel, err %u\n", n_chunks, h_err);
+    if (h_err) { set_error("truncated stream or output too small"); return DENSITY_HIP_ERR_FORMAT; }
+    *size_out = (n_chunks - 1) * kChunkBytes + (size_t)h_last;
+    return DENSITY_HIP_OK;
+}
+
 int run_stream_decode(DeviceCtx* c, int algo, const uint8_t* d_in, size_t n, uint8_t* d_out, size_t cap, uint8_t* ws, hipStream_t s,
                       size_t* size_out) {
     *size_out = 0;
     if (n == 0) return DENSITY_HIP_OK;
+    if (algo == DENSITY_HIP_CHAMELEON && n >= kSegDecodeMin && n < (1ull << 31) && !(g_variant & 5) && !g_rotor_unsafe) {
+        bool handled = false;
+        const int rc = run_stream_decode_segmented(c, d_in, n, d_out, cap, s, size_out, &handled);
+        if (rc != DENSITY_HIP_OK || handled) return rc;
+        *size_out = 0;
+    }
     const DecodePlan p = plan_decode(algo, 1);
     uint32_t* d_err = reinterpret_cast<uint32_t*>(ws + p.off_err);
     uint64_t* d_sizes = reinterpret_cast<uint64_t*>(ws + p.off_sizes);

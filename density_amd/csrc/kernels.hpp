@@ -37,6 +37,8 @@ struct SegArgs {
     uint8_t* final_images = nullptr;        // per chunk: the dictionary image after the chunk
     uint32_t* final_guard = nullptr;        // per chunk: the FSM state after the chunk's last whole block
     uint32_t* raw_blocks = nullptr;         // per chunk: number of raw-copy blocks (pre-zeroed by the caller)
+    uint32_t lastwriters_only = 0;          // decoder: a pass that is run for its final dictionary alone — MAP quads are not looked up (their
+                                            // slots are mostly empty in a dictionary that starts empty, and every empty read is a zero-entry question)
 };
 hipError_t launch_rotor_encode_seg(const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_out, uint64_t out_stride,
                                    uint64_t* d_sizes, uint32_t* d_err, SegArgs seg, hipStream_t stream);
@@ -47,6 +49,10 @@ hipError_t launch_merge_images(const uint8_t* d_base, const uint8_t* d_lastwrite
 // byte-granular gather of chunk streams (d_src + i * src_stride, sizes[i]) to d_dst + offsets[i]
 hipError_t launch_compact_bytes(const uint8_t* d_src, uint64_t src_stride, const uint64_t* d_sizes, const uint64_t* d_offsets, uint32_t n_chunks,
                                 uint8_t* d_dst, hipStream_t stream);
+// the index-fed decoder on segments of one stream: start dictionaries in, final dictionaries out (SegArgs: init_images / final_images)
+hipError_t launch_rotor_decode_seg(const uint8_t* d_in, const uint64_t* d_offsets, const uint64_t* d_sizes, uint32_t n_chunks, uint8_t* d_out,
+                                   uint64_t out_stride, uint64_t out_total, const uint8_t* d_index, uint32_t* d_zmap, uint64_t* d_produced, uint32_t* d_err,
+                                   SegArgs seg, hipStream_t stream);
 bool rotor_decode_eligible(const uint8_t* d_out, uint32_t n_chunks, uint64_t out_stride, uint64_t out_total, const uint8_t* d_index, const uint32_t* d_zmap);
 hipError_t launch_rotor_decode(const uint8_t* d_in, const uint64_t* d_offsets, const uint64_t* d_sizes, uint32_t n_chunks, uint8_t* d_out,
                                uint64_t out_stride, uint64_t out_total, bool exact, const uint8_t* d_index, uint32_t* d_zmap,
@@ -64,6 +70,14 @@ hipError_t launch_serial_encode(int algo, const uint8_t* d_in, uint64_t total, u
 hipError_t launch_serial_decode(int algo, const uint8_t* d_in, const uint64_t* d_offsets, const uint64_t* d_sizes, uint32_t n_chunks,
                                 uint8_t* d_out, uint64_t out_stride, uint64_t out_total, bool exact, uint64_t* d_produced, uint32_t* d_err,
                                 uint8_t* d_tables, uint32_t n_slots, hipStream_t stream);
+
+// ---- stream_parse.hip: record boundaries of one calm Chameleon stream, in parallel ----
+// d_info (8 words): 0 status (1 = parsed), 1 first block behind the sequentially walked head, 2-3 its stream offset, 4 whole blocks of the
+// stream, 5-6 stream offset where they end (the ragged end, if any, starts there), 7 != 0: not calm (two incompressible records in a row).
+// d_index: one byte per whole block (MAP count; raw copies of the head flagged), d_chunk_offset[k]: stream offset of block k * chunk_blocks.
+uint64_t stream_parse_workspace(uint64_t E);
+hipError_t launch_stream_parse(const uint8_t* d_in, uint64_t E, uint8_t* d_ws, uint8_t* d_index, uint64_t index_cap, uint64_t* d_chunk_offset,
+                               uint32_t chunk_blocks, uint32_t* d_info, hipStream_t stream);
 
 // ---- container.hip ----
 // Exclusive scan of 16-byte-aligned chunk sizes -> payload offsets; writes the container header and the u32 size

@@ -922,7 +922,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
                                                               const uint64_t* __restrict__ sizes, uint8_t* __restrict__ out,
                                                               uint64_t out_stride, uint64_t out_total, uint32_t exact,
                                                               const uint8_t* __restrict__ index, uint32_t* __restrict__ zmap_words,
-                                                              uint64_t* __restrict__ produced, uint32_t* __restrict__ err, uint32_t tune,
+                                                              uint64_t* __restrict__ produced, uint32_t* __restrict__ err, SegArgs seg,
                                                               uint64_t* __restrict__ prof) {
     static_assert((R == 8 || R == 12 || R == 16) && (W == 8 || W == 12 || W == 16), "round = 8, 12 or 16 records; 8, 12 or 16 waves");
     constexpr uint32_t kThreads = W * 64, kScanThreads = W == 16 ? 1024 : 512, kPerThread = kRotMaxBlocks / kScanThreads;   // position scan: 16 or 32 index entries per thread
@@ -941,13 +941,14 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
     const ZmapGlobal zmap{zmap_words + chunk * (kZmapBytes / 4)};
     // the table sits at LDS address 0 (this kernel has no static LDS): slot addresses need no base
     const uint32_t sy = kDecSync;
-    (void)tune;                                                                   // (the launcher reads the geometry from it; the kernels have no switches left)
 
-    {   // fresh dictionary, this chunk's zero-entry map, the block index into LDS
+    {   // fresh dictionary, this chunk's zero-entry map, the block index into LDS (a segment of a longer stream — SegArgs — starts from
+        // the dictionary image it is given instead)
         uint4* p = reinterpret_cast<uint4*>(smem);
         const uint4 z = make_uint4(0, 0, 0, 0);
-        for (uint32_t i = threadIdx.x; i < kTableBytes / 16; i += kThreads) p[i] = z;
-        for (uint32_t i = threadIdx.x; i < kZmapBytes / 16; i += kThreads) reinterpret_cast<uint4*>(zmap.words)[i] = z;
+        const uint4* image = seg.init_images ? reinterpret_cast<const uint4*>(seg.init_images + chunk * kSegImageBytes) : nullptr;
+        for (uint32_t i = threadIdx.x; i < kTableBytes / 16; i += kThreads) p[i] = image ? image[i] : z;
+        for (uint32_t i = threadIdx.x; i < kZmapBytes / 16; i += kThreads) reinterpret_cast<uint4*>(zmap.words)[i] = image ? image[kTableBytes / 16 + i] : z;
         const uint32_t* iw = reinterpret_cast<const uint32_t*>(idx);
         uint32_t* lw = reinterpret_cast<uint32_t*>(smem + kDecIdx);
         for (uint32_t i = threadIdx.x; i < kRotMaxBlocks / 4; i += kThreads) lw[i] = i < (nblk + 3u) / 4u ? iw[i] : 0x7f7f7f7fu;   // beyond the chunk: "ragged" = stop
@@ -1082,6 +1083,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
 
         // ---- C: operands of the dictionary step ----
         const uint32_t coded_mask = ((1u << R) - 1u) & ~mc.copy_mask;             // records that go through the dictionary
+        const uint32_t map_mask = seg.lastwriters_only ? 0u : coded_mask;         // ... and whose MAP quads are looked up
         uint32_t zacc = 0;
 #pragma unroll
         for (uint32_t j = 0; j < R; ++j) {
@@ -1123,7 +1125,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
         // ---- what each slot holds at this lane's turn -> quads (in place of the answers) ----
 #pragma unroll
         for (uint32_t j = 0; j < R; ++j) {
-            const bool maps = ((coded_mask & hitsc) >> j) & 1u;
+            const bool maps = ((map_mask & hitsc) >> j) & 1u;
             const uint32_t h = itemc[j] & 0xffffu;
             const uint32_t cur = (ra[j] >> ((h & 1u) << 4)) & 0xffffu;
             zacc |= (maps && cur == 0 && h != 0) ? (1u << j) : 0u;                // MAP of a slot holding 0: never written, or a genuine zero entry?
@@ -1154,7 +1156,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
                 const uint32_t P = qv * kHashMul;
                 const uint32_t h = hit ? (qv & 0xffffu) : (P >> 16);
                 const bool zset = coded && !hit && stored_entry(qv, P) == 0 && h != 0;
-                const bool ztest = coded && hit && h != 0 && cur == entry_to_quad(h, 0);
+                const bool ztest = coded && hit && h != 0 && cur == entry_to_quad(h, 0) && !seg.lastwriters_only;
                 uint64_t todo = ballot64(zset || ztest);
                 uint32_t out = cur;
                 while (todo) {                                                    // ascending lane == stream order
@@ -1211,6 +1213,16 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
             produced[chunk] = op;
             if (bad) atomicOr(err, 1u);
         }
+    }
+    if (seg.final_images) {                                                        // the dictionary as this chunk leaves it
+        __threadfence();
+        wg_barrier();
+        uint4* image = reinterpret_cast<uint4*>(seg.final_images + chunk * kSegImageBytes);
+        const uint4* p = reinterpret_cast<const uint4*>(smem);
+        for (uint32_t i = threadIdx.x; i < kTableBytes / 16; i += kThreads) image[i] = p[i];
+        for (uint32_t i = threadIdx.x; i < kZmapBytes / 16; i += kThreads)
+            image[kTableBytes / 16 + i] = make_uint4(__hip_atomic_load(zmap.words + 4 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(zmap.words + 4 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                                                      __hip_atomic_load(zmap.words + 4 * i + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(zmap.words + 4 * i + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     }
 }
 
@@ -1406,7 +1418,7 @@ hipError_t launch_rotor_decode(const uint8_t* d_in, const uint64_t* d_offsets, c
     hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDecLds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3(n_chunks), dim3(waves * 64), kDecLds, stream, d_in, d_offsets, d_sizes, d_out, out_stride, out_total,
-                       exact ? 1u : 0u, d_index, d_zmap, d_produced, d_err, rot_tune(), prof);
+                       exact ? 1u : 0u, d_index, d_zmap, d_produced, d_err, SegArgs{}, prof);
     rot_prof_report("decode", "stage A | stage B | operands | D wait | exchange | quads | Z chain | stores", prof, stream, waves);
     return hipGetLastError();
 }
@@ -1444,6 +1456,18 @@ hipError_t launch_compact_bytes(const uint8_t* d_src, uint64_t src_stride, const
                                 uint8_t* d_dst, hipStream_t stream) {
     if (n_chunks == 0) return hipSuccess;
     hipLaunchKernelGGL(compact_bytes_kernel, dim3(16, n_chunks), dim3(256), 0, stream, d_src, src_stride, d_sizes, d_offsets, d_dst);
+    return hipGetLastError();
+}
+
+
+hipError_t launch_rotor_decode_seg(const uint8_t* d_in, const uint64_t* d_offsets, const uint64_t* d_sizes, uint32_t n_chunks, uint8_t* d_out,
+                                   uint64_t out_stride, uint64_t out_total, const uint8_t* d_index, uint32_t* d_zmap, uint64_t* d_produced, uint32_t* d_err,
+                                   SegArgs seg, hipStream_t stream) {
+    auto kernel = chameleon_decode_rot<12, 12, false>;
+    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDecLds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kernel, dim3(n_chunks), dim3(768), kDecLds, stream, d_in, d_offsets, d_sizes, d_out, out_stride, out_total, 0u, d_index, d_zmap, d_produced, d_err,
+                       seg, (uint64_t*)nullptr);
     return hipGetLastError();
 }
 

@@ -1,0 +1,215 @@
+// stream_parse.hip — record boundaries of ONE Chameleon reference stream, found in parallel (api.hip::run_stream_decode_segmented).
+//
+// A reference stream has no framing: record k+1 starts where record k ends, and a record's length is in its signature
+// (8 + 256 - 2 x MAP flags: codec.rs:28-31,92-99).  For a CALM stream — no raw-copy block, i.e. never two incompressible records in a
+// row (protection_state.rs:38-47) — every 2-byte offset p is a candidate record start with a known successor
+// p + 264 - 2*popcount(signature at p), whether or not a record really starts there.  So:
+//   head      one lane walks the first records with the real FSM until it is calm (a stream's first blocks are incompressible) -> p0, b0;
+//   windows   per window of 16 KiB behind p0, backwards over its 8192 candidates, 64 at a time (a record is 136..264 bytes, so 64
+//             consecutive candidates never depend on each other): "from candidate c the chain leaves the window at offset x of the
+//             next one after n records" — kept for the only possible entries, the first 132 candidates;
+//   groups    the tables of 256 consecutive windows composed (one lane per entry), then the groups in sequence from entry 0,
+//             then every window's entry and first block number;
+//   emit      one lane per window walks forward from its entry: MAP count of every block into the block index, stream offset of
+//             every 16384th block (the decoder's chunks), the end of the whole blocks;
+//   check     two incompressible records in a row anywhere -> the stream is not calm, the caller takes the sequential path.
+// A numpy prototype of exactly this (tools/parse_prototype.py) is checked against the FSM walk of the oracle's streams.
+#include "common.hpp"
+#include "chameleon_dev.hpp"
+#include "kernels.hpp"
+
+namespace density {
+
+namespace {
+
+constexpr uint32_t kWin = 16384, kCand = kWin / 2, kEntries = 132, kEnd = 254, kGroup = 256;
+constexpr uint32_t kHeadMaxBlocks = 4096;
+
+__device__ __forceinline__ uint64_t ld64u(const uint8_t* p) { return *reinterpret_cast<const u64_u*>(p); }
+
+// info words: 0 status (1 = calm head found), 1 b0, 2-3 p0, 4 total whole blocks, 5-6 end of the whole blocks (stream offset), 7 not calm
+__global__ void parse_head_kernel(const uint8_t* __restrict__ in, uint64_t E, uint8_t* __restrict__ index, uint64_t index_cap, uint32_t* __restrict__ info) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    Guard g;
+    uint64_t pos = 0;
+    uint32_t b = 0, status = 0;
+    while (pos < E && b < kHeadMaxBlocks && b < index_cap) {
+        if (g.block_is_copy()) {                                                  // codec.rs:89-91
+            if (pos + kBlock > E) break;                                          // (a raw tail: the sequential path's business)
+            index[b] = (uint8_t)kIdxCopy;
+            pos += kBlock;
+            g.decay();
+        } else {
+            if (pos + kSig > E) break;
+            const uint32_t pc = (uint32_t)__builtin_popcountll(ld64u(in + pos));
+            const uint32_t rl = kSig + kBlock - 2u * pc;
+            if (pos + rl > E) break;
+            index[b] = (uint8_t)pc;
+            g.update(rl >= kBlock);                                               // codec.rs:98
+            pos += rl;
+        }
+        ++b;
+        if (g.penalty == 0 && g.prev == 0 && g.start == 1 && b >= 2) { status = 1; break; }
+    }
+    info[0] = status; info[1] = b; info[2] = (uint32_t)pos; info[3] = (uint32_t)(pos >> 32);
+    info[4] = b; info[5] = (uint32_t)pos; info[6] = (uint32_t)(pos >> 32); info[7] = 0;
+}
+
+__global__ __launch_bounds__(64) void parse_windows_kernel(const uint8_t* __restrict__ in, uint64_t E, const uint32_t* __restrict__ info,
+                                                           uint8_t* __restrict__ T, uint8_t* __restrict__ C) {
+    __shared__ uint8_t ex[kCand], cn[kCand];
+    const uint32_t lane = threadIdx.x;
+    const uint64_t p0 = ((uint64_t)info[3] << 32) | info[2];
+    const uint64_t ws = p0 + (uint64_t)blockIdx.x * kWin;
+    if (info[0] == 0) return;
+    if (ws >= E) {                                                                // behind the stream: every entry ends at once
+        for (uint32_t e = lane; e < kEntries; e += 64) { T[(uint64_t)blockIdx.x * kEntries + e] = (uint8_t)kEnd; C[(uint64_t)blockIdx.x * kEntries + e] = 0; }
+        return;
+    }
+    uint64_t sig_next;
+    {
+        const uint64_t p = ws + 2ull * (kCand - 64 + lane);
+        sig_next = p + kSig <= E ? ld64u(in + p) : 0ull;
+    }
+    for (int gi = (int)(kCand / 64) - 1; gi >= 0; --gi) {
+        const uint32_t c = 64u * (uint32_t)gi + lane;
+        const uint64_t p = ws + 2ull * c;
+        const uint64_t sig = sig_next;
+        if (gi > 0) {                                                             // the next group's signatures: in flight across this step
+            const uint64_t pn = p - 128;
+            sig_next = pn + kSig <= E ? ld64u(in + pn) : 0ull;
+        }
+        const uint32_t pc = (uint32_t)__builtin_popcountll(sig);
+        const bool whole = p + kSig <= E && p + (kSig + kBlock - 2u * pc) <= E;
+        const uint32_t nxt = c + 132u - pc;                                       // in candidates: 68 .. 132 ahead
+        uint32_t e, k;
+        if (nxt >= kCand) { e = nxt - kCand; k = 1; }
+        else { e = ex[nxt]; k = 1u + cn[nxt]; }
+        ex[c] = whole ? (uint8_t)e : (uint8_t)kEnd;
+        cn[c] = whole ? (uint8_t)k : (uint8_t)0;
+        __syncthreads();
+    }
+    for (uint32_t e = lane; e < kEntries; e += 64) { T[(uint64_t)blockIdx.x * kEntries + e] = ex[e]; C[(uint64_t)blockIdx.x * kEntries + e] = cn[e]; }
+}
+
+// composition of the windows of one group: entry e of its first window -> (entry of the next group's first window, records)
+__global__ __launch_bounds__(64) void parse_groups_kernel(const uint8_t* __restrict__ T, const uint8_t* __restrict__ C, uint32_t n_windows,
+                                                          uint8_t* __restrict__ GT, uint32_t* __restrict__ GC) {
+    extern __shared__ uint8_t gsm[];
+    uint8_t* Ts = gsm;
+    uint8_t* Cs = gsm + kGroup * kEntries;
+    const uint32_t lane = threadIdx.x, g = blockIdx.x;
+    const uint32_t w0 = g * kGroup, nw = n_windows - w0 < kGroup ? n_windows - w0 : kGroup;
+    for (uint32_t i = lane; i < nw * kEntries; i += 64) { Ts[i] = T[(uint64_t)w0 * kEntries + i]; Cs[i] = C[(uint64_t)w0 * kEntries + i]; }
+    __syncthreads();
+    for (uint32_t e = lane; e < kEntries; e += 64) {
+        uint32_t x = e, n = 0;
+        for (uint32_t w = 0; w < nw && x != kEnd; ++w) { n += Cs[w * kEntries + x]; x = Ts[w * kEntries + x]; }
+        GT[g * kEntries + e] = (uint8_t)x;
+        GC[g * kEntries + e] = n;
+    }
+}
+
+// the groups in sequence from entry 0 of the first window (one lane), then nothing else needs an order
+__global__ void parse_top_kernel(const uint8_t* __restrict__ GT, const uint32_t* __restrict__ GC, uint32_t n_groups, uint32_t* __restrict__ info,
+                                 uint8_t* __restrict__ gent, uint32_t* __restrict__ gbase) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (info[0] == 0) return;
+    uint32_t x = 0, base = info[1];
+    for (uint32_t g = 0; g < n_groups; ++g) {
+        gent[g] = (uint8_t)x; gbase[g] = base;
+        if (x != kEnd) { base += GC[g * kEntries + x]; x = GT[g * kEntries + x]; }
+    }
+    info[4] = base;                                                               // whole blocks of the stream
+}
+
+__global__ __launch_bounds__(64) void parse_entries_kernel(const uint8_t* __restrict__ T, const uint8_t* __restrict__ C, uint32_t n_windows,
+                                                           const uint8_t* __restrict__ gent, const uint32_t* __restrict__ gbase,
+                                                           uint8_t* __restrict__ went, uint32_t* __restrict__ wbase) {
+    extern __shared__ uint8_t gsm[];
+    uint8_t* Ts = gsm;
+    uint8_t* Cs = gsm + kGroup * kEntries;
+    const uint32_t lane = threadIdx.x, g = blockIdx.x;
+    const uint32_t w0 = g * kGroup, nw = n_windows - w0 < kGroup ? n_windows - w0 : kGroup;
+    for (uint32_t i = lane; i < nw * kEntries; i += 64) { Ts[i] = T[(uint64_t)w0 * kEntries + i]; Cs[i] = C[(uint64_t)w0 * kEntries + i]; }
+    __syncthreads();
+    if (lane == 0) {
+        uint32_t x = gent[g], base = gbase[g];
+        for (uint32_t w = 0; w < nw; ++w) {
+            went[w0 + w] = (uint8_t)x; wbase[w0 + w] = base;
+            if (x != kEnd) { base += Cs[w * kEntries + x]; x = Ts[w * kEntries + x]; }
+        }
+    }
+}
+
+// one lane per window: forward from the window's entry — block index, chunk offsets, the end of the whole blocks
+__global__ __launch_bounds__(64) void parse_emit_kernel(const uint8_t* __restrict__ in, uint64_t E, uint32_t* __restrict__ info,
+                                                        const uint8_t* __restrict__ went, const uint32_t* __restrict__ wbase, uint32_t n_windows,
+                                                        uint8_t* __restrict__ index, uint64_t index_cap, uint64_t* __restrict__ chunk_offset, uint32_t chunk_blocks) {
+    const uint32_t w = blockIdx.x * 64 + threadIdx.x;
+    if (w >= n_windows || info[0] == 0) return;
+    uint32_t c = went[w];
+    if (c == kEnd) return;
+    const uint64_t p0 = ((uint64_t)info[3] << 32) | info[2];
+    const uint64_t ws = p0 + (uint64_t)w * kWin;
+    uint32_t b = wbase[w];
+    while (c < kCand) {
+        const uint64_t p = ws + 2ull * c;
+        uint32_t pc = 0;
+        bool whole = p + kSig <= E;
+        if (whole) { pc = (uint32_t)__builtin_popcountll(ld64u(in + p)); whole = p + (kSig + kBlock - 2u * pc) <= E; }
+        if (!whole || b >= index_cap) {                                           // the ragged end (or nothing at all) starts here
+            info[5] = (uint32_t)p; info[6] = (uint32_t)(p >> 32);
+            return;
+        }
+        index[b] = (uint8_t)pc;
+        if (b % chunk_blocks == 0) chunk_offset[b / chunk_blocks] = p;
+        ++b;
+        c += 132u - pc;
+    }
+}
+
+// two incompressible records in a row (a record of 256 bytes or more: at most 4 MAP flags): the FSM would have answered with raw copies
+__global__ __launch_bounds__(256) void parse_check_kernel(const uint8_t* __restrict__ index, uint32_t* __restrict__ info) {
+    const uint32_t total = info[4], b0 = info[1];
+    if (info[0] == 0) return;
+    const uint32_t from = b0 ? b0 - 1 : 0;
+    for (uint64_t i = from + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i + 1 < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t a = index[i], b = index[i + 1];
+        if (!(a & kIdxCopy) && !(b & kIdxCopy) && a <= 4 && b <= 4) atomicOr(info + 7, 1u);
+    }
+}
+
+}  // namespace
+
+uint64_t stream_parse_workspace(uint64_t E) {
+    const uint64_t nw = E / kWin + 2, ng = (nw + kGroup - 1) / kGroup;
+    return nw * kEntries * 2 + ng * kEntries * 5 + ng * 5 + nw * 5 + 4096;
+}
+
+hipError_t launch_stream_parse(const uint8_t* d_in, uint64_t E, uint8_t* d_ws, uint8_t* d_index, uint64_t index_cap, uint64_t* d_chunk_offset,
+                               uint32_t chunk_blocks, uint32_t* d_info, hipStream_t stream) {
+    const uint32_t nw = (uint32_t)(E / kWin + 2), ng = (nw + kGroup - 1) / kGroup;
+    uint8_t* T = d_ws;
+    uint8_t* C = T + (uint64_t)nw * kEntries;
+    uint32_t* GC = reinterpret_cast<uint32_t*>((reinterpret_cast<uintptr_t>(C + (uint64_t)nw * kEntries) + 15) & ~(uintptr_t)15);
+    uint32_t* gbase = GC + (uint64_t)ng * kEntries;
+    uint32_t* wbase = gbase + ng;
+    uint8_t* GT = reinterpret_cast<uint8_t*>(wbase + nw);
+    uint8_t* gent = GT + (uint64_t)ng * kEntries;
+    uint8_t* went = gent + ng;
+    const size_t group_lds = (size_t)kGroup * kEntries * 2;
+    hipError_t e = hipFuncSetAttribute((const void*)parse_groups_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)group_lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)parse_entries_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)group_lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(parse_head_kernel, dim3(1), dim3(64), 0, stream, d_in, E, d_index, index_cap, d_info);
+    hipLaunchKernelGGL(parse_windows_kernel, dim3(nw), dim3(64), 0, stream, d_in, E, d_info, T, C);
+    hipLaunchKernelGGL(parse_groups_kernel, dim3(ng), dim3(64), group_lds, stream, T, C, nw, GT, GC);
+    hipLaunchKernelGGL(parse_top_kernel, dim3(1), dim3(64), 0, stream, GT, GC, ng, d_info, gent, gbase);
+    hipLaunchKernelGGL(parse_entries_kernel, dim3(ng), dim3(64), group_lds, stream, T, C, nw, gent, gbase, went, wbase);
+    hipLaunchKernelGGL(parse_emit_kernel, dim3((nw + 63) / 64), dim3(64), 0, stream, d_in, E, d_info, went, wbase, nw, d_index, index_cap, d_chunk_offset, chunk_blocks);
+    hipLaunchKernelGGL(parse_check_kernel, dim3(256), dim3(256), 0, stream, d_index, d_info);
+    return hipGetLastError();
+}
+
+}  // namespace density
