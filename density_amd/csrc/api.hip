@@ -58,6 +58,7 @@ inline size_t index_base(size_t n_chunks) { return align_up(sizeof(density_hip_h
 inline size_t index_bytes(size_t total_len, bool with_index) { return with_index ? (total_len + 255) / 256 : 0; }
 inline size_t payload_base(size_t n_chunks, size_t total_len, bool with_index) { return align_up(index_base(n_chunks) + index_bytes(total_len, with_index), 16); }
 int g_variant = 0;   // density_hip_set_kernel_variant
+uint64_t g_stream_stats[4] = {0, 0, 0, 0};   // density_hip_stream_stats: long streams encoded in segments | encode passes | decoded in segments | long streams decoded sequentially
 inline bool want_index(int algo) { return algo == DENSITY_HIP_CHAMELEON && !(g_variant & 2); }
 inline size_t slot_stride(int algo, size_t chunk) { return align_up(safe_size(algo, chunk), kAlign); }
 
@@ -413,6 +414,7 @@ int run_stream_encode_segmented(DeviceCtx* c, const uint8_t* d_in, size_t n, uin
         while (k < S && h_raw[k - 1] == 0 && (h_gfinal[k - 1] & 0x7fffffffu) == 0) ++k;
         if (getenv("DENSITY_HIP_PROF")) fprintf(stderr, "[density_hip prof] segmented stream encode: pass %d, %zu segments of %zu bytes, final up to segment %zu\n", pass, S, C, k);
         first = k;                                                                // (== S: done)
+        ++g_stream_stats[1];
     }
     if (!joined) { hipError_t j = hipStreamWaitEvent(s, c->stitch_done, 0); if (e == hipSuccess) e = j; }
     uint32_t h_err = 0;
@@ -434,6 +436,7 @@ int run_stream_encode_segmented(DeviceCtx* c, const uint8_t* d_in, size_t n, uin
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) { set_error("segmented stream encode (gather)", e); return DENSITY_HIP_ERR_RUNTIME; }
     *size_out = (size_t)total;
+    ++g_stream_stats[0];
     return DENSITY_HIP_OK;
 }
 
@@ -472,7 +475,7 @@ int run_stream_encode(DeviceCtx* c, int algo, const uint8_t* d_in, size_t n, uin
 // come out wrong, its writes are right; the real pass overwrites the output).  Passes: parse -> decode from empty dictionaries, final
 // images -> per-slot merge into start images -> decode from the start images.  `handled` false: not a calm stream (or too short, or
 // buffers this path does not take): the caller walks it on one work-group as before.
-constexpr size_t kSegDecodeMin = 16u << 20;
+constexpr size_t kSegDecodeMin = 8u << 20;
 int run_stream_decode_segmented(DeviceCtx* c, const uint8_t* d_in, size_t E, uint8_t* d_out, size_t cap, hipStream_t s, size_t* size_out, bool* handled) {
     *handled = false;
     constexpr uint32_t kChunkBlocks = 16384;
@@ -541,6 +544,7 @@ int run_stream_decode_segmented(DeviceCtx* c, const uint8_t* d_in, size_t E, uin
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) { set_error("segmented stream decode", e); return DENSITY_HIP_ERR_RUNTIME; }
     *handled = true;
+    ++g_stream_stats[2];
     if (trace) fprintf(stderr, "[density_hip prof]   -> %zu segments decoded in parallel, err %u\n", n_chunks, h_err);
     if (h_err) { set_error("truncated stream or output too small"); return DENSITY_HIP_ERR_FORMAT; }
     *size_out = (n_chunks - 1) * kChunkBytes + (size_t)h_last;
@@ -556,6 +560,7 @@ int run_stream_decode(DeviceCtx* c, int algo, const uint8_t* d_in, size_t n, uin
         const int rc = run_stream_decode_segmented(c, d_in, n, d_out, cap, s, size_out, &handled);
         if (rc != DENSITY_HIP_OK || handled) return rc;
         *size_out = 0;
+        ++g_stream_stats[3];
     }
     const DecodePlan p = plan_decode(algo, 1);
     uint32_t* d_err = reinterpret_cast<uint32_t*>(ws + p.off_err);
@@ -730,6 +735,7 @@ size_t density_hip_encode(int algo, const uint8_t* input, size_t input_size, uin
     return (size_t)h.container_len;
 }
 
+void density_hip_stream_stats(uint64_t* out4) { if (out4) for (int i = 0; i < 4; ++i) out4[i] = g_stream_stats[i]; }
 size_t density_hip_auto_chunk(size_t input_size) { return auto_chunk(input_size); }
 size_t density_hip_auto_chunk_for(int algo, size_t input_size) { return valid_algo(algo) ? auto_chunk(input_size, algo) : 0; }
 

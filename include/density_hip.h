@@ -155,6 +155,11 @@ int density_hip_stream_decode_device(int algo, const void* d_input, size_t input
 void density_hip_set_profiling(int enabled);
 int density_hip_last_timings(float* milliseconds, const char** names, int capacity);
 
+/* Test hook: how the reference-shaped Chameleon stream calls of 16 MiB and more were served so far (process-wide counters):
+ * out4[0] streams encoded in parallel segments, [1] passes those encodes took (1 per stream if every speculation held),
+ * [2] streams decoded in parallel segments, [3] long streams decoded sequentially (not calm, or buffers the parallel path does not take). */
+void density_hip_stream_stats(uint64_t* out4);
+
 /* Test hook, bit mask: 1 = force the simple one-wavefront-per-chunk kernels, 2 = encode containers without the block index,
  * 4 = force the 16-wave role pipelines (chameleon.hip) instead of the default wave-rotation kernels (rotor.hip),
  * 8 = encode in batches with the stitch of one batch beside the encoding of the next, 16 = Cheetah / Lion on the

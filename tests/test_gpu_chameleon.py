@@ -299,7 +299,9 @@ def test_full_size_properties_device_resident():
 def test_long_stream_encode_in_segments_is_the_reference_stream(kind, n, kernel_variant):
     """`chameleon_encode` of ONE long stream runs in parallel segments (api.hip::run_stream_encode_segmented) and must still be the
     reference's single stream, byte for byte: calm text (one pass), text with incompressible patches (raw-copy blocks break the
-    speculation of the segments behind them: several passes, then the sequential remainder), random bytes (raw copies throughout)."""
+    speculation of the segments behind them: several passes, then the sequential remainder), random bytes (raw copies throughout).
+    `chameleon_decode` of the same stream runs in parallel segments as well when the stream is calm (stream_parse.hip), on one
+    work-group otherwise; density_hip_stream_stats says which."""
     if kernel_variant != "rotor":
         pytest.skip("the segmented stream encode belongs to the default kernels")
     if kind == "patchy":
@@ -318,8 +320,24 @@ def test_long_stream_encode_in_segments_is_the_reference_stream(kind, n, kernel_
                 data[start:start + (256 << 10)] = salted[:256 << 10]
     else:
         data = datagen.by_kind(kind, n, seed=13)
-    want = pyoracle.encode("chameleon", data)
+    import ctypes
+    from density_amd import _lib
+    def stats():
+        a = (ctypes.c_uint64 * 4)()
+        _lib.lib().density_hip_stream_stats(a)
+        return list(a)
+    want, st = pyoracle.encode_stats("chameleon", data)
+    s0 = stats()
     got = gpu_encode(data)
+    s1 = stats()
     assert len(got) == len(want)
     assert got == want
+    assert s1[0] == s0[0] + 1                                     # encoded in segments ...
+    calm = st["copy_blocks"] == 0                                 # no raw-copy block anywhere in the reference's stream
+    assert calm == (kind in ("rep", "prose", "zeros", "saltzero", "zeropatch"))
+    assert (s1[1] - s0[1] == 1) == calm, (kind, s1[1] - s0[1])    # ... in one pass iff nothing breaks the speculation
     assert gpu_decode(want, n) == data.tobytes()
+    s2 = stats()
+    # decoded in parallel iff the stream is calm (no two incompressible records in a row anywhere behind its head)
+    assert len(want) >= 8 << 20                                  # (the stream is long enough for the parallel decode to be tried)
+    assert (s2[2] - s1[2], s2[3] - s1[3]) == ((1, 0) if calm else (0, 1)), (kind, s2, s1)
