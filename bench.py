@@ -110,7 +110,7 @@ def host_api_rates(algo, host, chunk, sample_bytes):
     out["reference_symbols"] = {"encode_MBps": round(n / (t1 - t0) / 1e6, 1), "decode_MBps": round(n / (t2 - t1) / 1e6, 1),
                                 "round_trip_MBps": round(n / (t2 - t0) / 1e6, 1),
                                 "note": "ONE reference stream; H2D + kernels + D2H.  Chameleon encode of >= 16 MiB runs in parallel segments and is still the "
-                                        "reference's stream byte for byte; decode walks the stream on one work-group"}
+                                        "reference's stream byte for byte; decode of a calm stream of >= 8 MiB runs in parallel segments too"}
     if algo == "chameleon":
         # the same single stream with the buffers already on the device (density_hip_stream_encode_device): what the segments buy
         import ctypes
@@ -129,6 +129,16 @@ def host_api_rates(algo, host, chunk, sample_bytes):
         same = bytes(d_out[:size.value].cpu().numpy()) == bytes(enc[:m])
         out["reference_symbols"]["device_resident_encode_MBps"] = round(3 * n / (t1 - t0) / 1e6, 1)
         out["reference_symbols"]["device_resident_encode_is_the_same_stream"] = bool(same)
+        d_back = torch.empty(n + 64, dtype=torch.uint8, device="cuda")
+        back = ctypes.c_size_t(0)
+        dcall = lambda: lib.density_hip_stream_decode_device(0, ctypes.c_void_p(d_out.data_ptr()), size.value, ctypes.c_void_p(d_back.data_ptr()), n, None, ctypes.byref(back))
+        assert dcall() == 0
+        torch.cuda.synchronize(); t0 = _t.perf_counter()
+        for _ in range(3):
+            assert dcall() == 0
+        torch.cuda.synchronize(); t1 = _t.perf_counter()
+        out["reference_symbols"]["device_resident_decode_MBps"] = round(3 * n / (t1 - t0) / 1e6, 1)
+        out["reference_symbols"]["device_resident_decode_is_the_input"] = bool(back.value == n and torch.equal(d_back[:n], d_in))
     cont = np.empty(container.container_bound(algo, n, chunk), dtype=np.uint8)
     container.encode(algo, src, cont, chunk)                 # warm
     t0 = _t.perf_counter(); cn = container.encode(algo, src, cont, chunk); t1 = _t.perf_counter()
