@@ -341,3 +341,42 @@ def test_long_stream_encode_in_segments_is_the_reference_stream(kind, n, kernel_
     # decoded in parallel iff the stream is calm (no two incompressible records in a row anywhere behind its head)
     assert len(want) >= 8 << 20                                  # (the stream is long enough for the parallel decode to be tried)
     assert (s2[2] - s1[2], s2[3] - s1[3]) == ((1, 0) if calm else (0, 1)), (kind, s2, s1)
+
+
+def test_long_stream_decode_errors_match_the_sequential_path(kernel_variant):
+    """A long calm stream that is truncated, corrupted behind its head, or given too small an output must end like the same
+    call on the one-work-group path: the same bytes back, or DecodeError — never a crash or silence."""
+    if kernel_variant != "rotor":
+        pytest.skip("the segmented stream decode belongs to the default kernels")
+    n = 24 * 1024 * 1024 + 1000
+    data = datagen.by_kind("rep", n, seed=17)
+    enc = np.frombuffer(pyoracle.encode("chameleon", data), dtype=np.uint8)
+    out = np.zeros(n, dtype=np.uint8)
+
+    def both(stream, buf):
+        res = []
+        for variant in (0, 4):                                                    # 4: the role pipelines -> the sequential stream path
+            container.set_kernel_variant(variant)
+            try:
+                m = Chameleon.decode(stream, buf)
+                res.append(("ok", m, buf[:m].tobytes()))
+            except DecodeError:
+                res.append(("error",))
+        container.set_kernel_variant(0)
+        return res
+
+    a, b = both(enc, out)
+    assert a == b and a[0] == "ok" and a[2] == data.tobytes()
+    for cut in (1, 3, 137, 100_000):                                              # truncated
+        a, b = both(enc[:-cut].copy(), out)
+        assert a[0] == b[0], (cut, a[0], b[0])
+        if a[0] == "ok":
+            assert a[1:] == b[1:], cut
+    a, b = both(enc, np.zeros(n - 5000, dtype=np.uint8))                          # output too small
+    assert a[0] == b[0] == "error"
+    broken = enc.copy()                                                           # a signature byte flipped deep inside: the record chain derails
+    broken[9_000_001] ^= 0x5A
+    a, b = both(broken, out)
+    assert a[0] == b[0], (a[0], b[0])
+    if a[0] == "ok":
+        assert a[1:] == b[1:]
