@@ -1181,7 +1181,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
         // ---- stores: 256 coalesced bytes per record ----
         uint8_t* base = dst + (uint64_t)x * R * kBlock;
 #pragma unroll
-        for (uint32_t j = 0; j < R; ++j) *reinterpret_cast<uint32_t*>(base + j * kBlock + 4u * lane) = ra[j];
+        for (uint32_t j = 0; j < R; ++j) *reinterpret_cast<uint32_t*>(base + j * kBlock + 4u * lane) = ra[j];   // (a last-writers pass stores too: a branch here would cost stage B its exact waits)
         // ---- rotate the pipeline ----
         mc = mb; mb = ma; hitsc = hitsb;
 #pragma unroll
@@ -1445,10 +1445,9 @@ hipError_t launch_rotor_lastwriters(const uint8_t* d_in, uint64_t chunk_bytes, u
 }
 hipError_t launch_merge_images(const uint8_t* d_base, const uint8_t* d_lastwriters, uint8_t* d_start, uint32_t count, hipStream_t stream) {
     if (count == 0) return hipSuccess;
-    for (uint32_t k = 0; k < count; ++k) {                                         // the marks are OR-ed in: clear them first
-        hipError_t e = hipMemsetAsync(d_start + (uint64_t)k * kSegImageBytes + kTableBytes, 0, kZmapBytes, stream);
-        if (e != hipSuccess) return e;
-    }
+    // the marks are OR-ed in: clear them first (one strided fill)
+    hipError_t e = hipMemset2DAsync(d_start + kTableBytes, kSegImageBytes, 0, kZmapBytes, count, stream);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(merge_images_kernel, dim3(65536 / 256), dim3(256), 0, stream, d_base, d_lastwriters, d_start, count);
     return hipGetLastError();
 }

@@ -66,28 +66,36 @@ __global__ __launch_bounds__(64) void parse_windows_kernel(const uint8_t* __rest
         for (uint32_t e = lane; e < kEntries; e += 64) { T[(uint64_t)blockIdx.x * kEntries + e] = (uint8_t)kEnd; C[(uint64_t)blockIdx.x * kEntries + e] = 0; }
         return;
     }
-    uint64_t sig_next;
-    {
-        const uint64_t p = ws + 2ull * (kCand - 64 + lane);
-        sig_next = p + kSig <= E ? ld64u(in + p) : 0ull;
-    }
-    for (int gi = (int)(kCand / 64) - 1; gi >= 0; --gi) {
-        const uint32_t c = 64u * (uint32_t)gi + lane;
-        const uint64_t p = ws + 2ull * c;
-        const uint64_t sig = sig_next;
-        if (gi > 0) {                                                             // the next group's signatures: in flight across this step
-            const uint64_t pn = p - 128;
-            sig_next = pn + kSig <= E ? ld64u(in + pn) : 0ull;
+    // eight groups of signatures in flight ahead of the sweep (the loads are independent of the tables; the sweep is not)
+    constexpr int kAhead = 8;
+    uint64_t sig[kAhead], nsig[kAhead];
+    auto fetch = [&](int gi) -> uint64_t {
+        if (gi < 0) return 0ull;
+        const uint64_t p = ws + 2ull * (64u * (uint32_t)gi + lane);
+        return p + kSig <= E ? ld64u(in + p) : 0ull;
+    };
+#pragma unroll
+    for (int k = 0; k < kAhead; ++k) sig[k] = fetch((int)(kCand / 64) - 1 - k);
+    for (int g0 = (int)(kCand / 64) - 1; g0 >= 0; g0 -= kAhead) {
+#pragma unroll
+        for (int k = 0; k < kAhead; ++k) nsig[k] = fetch(g0 - kAhead - k);
+#pragma unroll
+        for (int k = 0; k < kAhead; ++k) {
+            const int gi = g0 - k;
+            const uint32_t c = 64u * (uint32_t)gi + lane;
+            const uint64_t p = ws + 2ull * c;
+            const uint32_t pc = (uint32_t)__builtin_popcountll(sig[k]);
+            const bool whole = p + kSig <= E && p + (kSig + kBlock - 2u * pc) <= E;
+            const uint32_t nxt = c + 132u - pc;                                   // in candidates: 68 .. 132 ahead
+            uint32_t e, n;
+            if (nxt >= kCand) { e = nxt - kCand; n = 1; }
+            else { e = ex[nxt]; n = 1u + cn[nxt]; }
+            ex[c] = whole ? (uint8_t)e : (uint8_t)kEnd;
+            cn[c] = whole ? (uint8_t)n : (uint8_t)0;
+            __syncthreads();
         }
-        const uint32_t pc = (uint32_t)__builtin_popcountll(sig);
-        const bool whole = p + kSig <= E && p + (kSig + kBlock - 2u * pc) <= E;
-        const uint32_t nxt = c + 132u - pc;                                       // in candidates: 68 .. 132 ahead
-        uint32_t e, k;
-        if (nxt >= kCand) { e = nxt - kCand; k = 1; }
-        else { e = ex[nxt]; k = 1u + cn[nxt]; }
-        ex[c] = whole ? (uint8_t)e : (uint8_t)kEnd;
-        cn[c] = whole ? (uint8_t)k : (uint8_t)0;
-        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kAhead; ++k) sig[k] = nsig[k];
     }
     for (uint32_t e = lane; e < kEntries; e += 64) { T[(uint64_t)blockIdx.x * kEntries + e] = ex[e]; C[(uint64_t)blockIdx.x * kEntries + e] = cn[e]; }
 }

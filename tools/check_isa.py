@@ -8,6 +8,7 @@ rotor.hip to assembly and checks, for every 8-wave encoder instance, that
   * the only instructions naming a staging register are those loads (global_load_dword vN, ..) and the moves out of them
     (v_mov_b32 vX, vN), and
   * every run of moves directly follows an s_waitcnt vmcnt(..).
+Also checked: the default decoder's stage B waits with vmcnt(12) and nothing in its round loop drains the memory queue.
 usage: python tools/check_isa.py   (exit code 1 on a violation; run by density_amd.build)"""
 import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -66,7 +67,35 @@ def main():
         g, b = check_function(m.group(1), int(m.group(2)), body)
         total += g; bad += b
         i = j
-    print(f"check_isa: {total} hand-issued loads in the 8-wave encoder instances, {bad} violation(s)")
+    # the decoder's exact waits: stage B must wait for "all but the last 12 (stores)", not for everything (a branch around the record stores,
+    # a load left pending across the loop head ... turn it into vmcnt(0) and cost 5-10 % without a test failing)
+    i = 0
+    dec = 0
+    while i < len(lines):
+        m = re.match(r"^(_ZN7density20chameleon_decode_rotILi12ELi12ELb0E\w*):", lines[i])
+        if not m:
+            i += 1
+            continue
+        j = i
+        while not lines[j].startswith(".Lfunc_end"):
+            j += 1
+        body = [l.split(";")[0].strip() for l in lines[i:j]]
+        body = [t for t in body if t and not t.startswith(".")]
+        first = next(k for k, t in enumerate(body) if t.startswith("ds_mskor_rtn_b32"))
+        window = body[max(0, first - 900):first]
+        waits = [t for t in window if t.startswith("s_waitcnt vmcnt(") and "lgkmcnt" not in t]
+        if "s_waitcnt vmcnt(12)" not in waits:
+            print(f"{m.group(1)}: stage B no longer waits with vmcnt(12): {waits}")
+            bad += 1
+        elif "s_waitcnt vmcnt(0)" in waits[waits.index("s_waitcnt vmcnt(12)"):]:
+            print(f"{m.group(1)}: a full drain (vmcnt(0)) inside the round loop: {waits}")
+            bad += 1
+        dec += 1
+        i = j
+    if not dec:
+        print("check_isa: decoder instance not found")
+        bad += 1
+    print(f"check_isa: {total} hand-issued loads in the 8-wave encoder instances, decoder waits checked, {bad} violation(s)")
     return 1 if bad or not total else 0
 
 if __name__ == "__main__":
