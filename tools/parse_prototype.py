@@ -108,11 +108,12 @@ def truth(enc,n):
             pos+=rl
         b+=1
     return idx,pos
-for kind,n in [("prose",3*1024*1024+77),("rep",5*1024*1024),("prose",1<<20)]:
-    data=datagen.by_kind(kind,n,seed=5)
-    enc=pyoracle.encode("chameleon",data)
-    r=parse(enc)
-    ti,tpos=truth(enc,n)
-    if r is None or r[0]=='fallback': print(kind,n,'->',r); continue
-    p0,b0,total,endpos,index=r
-    print(kind,n,'p0',p0,'b0',b0,'total',total,'true blocks',len(ti),'endpos',endpos,'true end of full blocks',tpos,'index equal',index==ti)
+if __name__ == '__main__':
+  for kind,n in [("prose",3*1024*1024+77),("rep",5*1024*1024),("prose",1<<20)]:
+      data=datagen.by_kind(kind,n,seed=5)
+      enc=pyoracle.encode("chameleon",data)
+      r=parse(enc)
+      ti,tpos=truth(enc,n)
+      if r is None or r[0]=='fallback': print(kind,n,'->',r); continue
+      p0,b0,total,endpos,index=r
+      print(kind,n,'p0',p0,'b0',b0,'total',total,'true blocks',len(ti),'endpos',endpos,'true end of full blocks',tpos,'index equal',index==ti)
