@@ -24,6 +24,8 @@ extern "C" {
 
 /* ------------------------------------------------------------------------------------------------------------
  * 1. Reference-compatible symbols (host pointers, single reference-format stream, bit-exact with the crate).
+ *    (One stream is one dependency chain; long Chameleon streams are still encoded — and, when they contain no
+ *    raw-copy block, decoded — in parallel segments on the device, with byte-identical results: DESIGN.md 4.7.)
  *
  *    Return value: bytes written; 0 on any failure (the reference maps Err to 0 via unwrap_or(0) and otherwise
  *    panics on a short buffer or truncated input; this library returns 0 instead and never writes past
