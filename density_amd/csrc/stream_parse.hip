@@ -5,7 +5,7 @@
 // row (protection_state.rs:38-47) — every 2-byte offset p is a candidate record start with a known successor
 // p + 264 - 2*popcount(signature at p), whether or not a record really starts there.  So:
 //   head      one lane walks the first records with the real FSM until it is calm (a stream's first blocks are incompressible) -> p0, b0;
-//   windows   per window of 16 KiB behind p0, backwards over its 8192 candidates, 64 at a time (a record is 136..264 bytes, so 64
+//   windows   per window of 8 KiB behind p0, backwards over its 4096 candidates, 64 at a time (a record is 136..264 bytes, so 64
 //             consecutive candidates never depend on each other): "from candidate c the chain leaves the window at offset x of the
 //             next one after n records" — kept for the only possible entries, the first 132 candidates;
 //   groups    the tables of 256 consecutive windows composed (one lane per entry), then the groups in sequence from entry 0,
@@ -22,7 +22,7 @@ namespace density {
 
 namespace {
 
-constexpr uint32_t kWin = 16384, kCand = kWin / 2, kEntries = 132, kEnd = 254, kGroup = 256;
+constexpr uint32_t kWin = 8192, kCand = kWin / 2, kEntries = 132, kEnd = 254, kGroup = 256;   // (8 KiB windows: 8 KiB of LDS each, 20 sweeps per CU in flight; 16 KiB and 4 KiB windows measured slower)
 constexpr uint32_t kHeadMaxBlocks = 4096;
 
 __device__ __forceinline__ uint64_t ld64u(const uint8_t* p) { return *reinterpret_cast<const u64_u*>(p); }
@@ -57,7 +57,7 @@ __global__ void parse_head_kernel(const uint8_t* __restrict__ in, uint64_t E, ui
 
 __global__ __launch_bounds__(64) void parse_windows_kernel(const uint8_t* __restrict__ in, uint64_t E, const uint32_t* __restrict__ info,
                                                            uint8_t* __restrict__ T, uint8_t* __restrict__ C) {
-    __shared__ uint8_t ex[kCand], cn[kCand];
+    __shared__ uint16_t tab[kCand];                                              // per candidate: exit (low byte), records up to it (high byte)
     const uint32_t lane = threadIdx.x;
     const uint64_t p0 = ((uint64_t)info[3] << 32) | info[2];
     const uint64_t ws = p0 + (uint64_t)blockIdx.x * kWin;
@@ -89,15 +89,14 @@ __global__ __launch_bounds__(64) void parse_windows_kernel(const uint8_t* __rest
             const uint32_t nxt = c + 132u - pc;                                   // in candidates: 68 .. 132 ahead
             uint32_t e, n;
             if (nxt >= kCand) { e = nxt - kCand; n = 1; }
-            else { e = ex[nxt]; n = 1u + cn[nxt]; }
-            ex[c] = whole ? (uint8_t)e : (uint8_t)kEnd;
-            cn[c] = whole ? (uint8_t)n : (uint8_t)0;
+            else { const uint32_t t = tab[nxt]; e = t & 0xffu; n = 1u + (t >> 8); }
+            tab[c] = whole ? (uint16_t)(e | (n << 8)) : (uint16_t)kEnd;
             __syncthreads();
         }
 #pragma unroll
         for (int k = 0; k < kAhead; ++k) sig[k] = nsig[k];
     }
-    for (uint32_t e = lane; e < kEntries; e += 64) { T[(uint64_t)blockIdx.x * kEntries + e] = ex[e]; C[(uint64_t)blockIdx.x * kEntries + e] = cn[e]; }
+    for (uint32_t e = lane; e < kEntries; e += 64) { T[(uint64_t)blockIdx.x * kEntries + e] = (uint8_t)(tab[e] & 0xffu); C[(uint64_t)blockIdx.x * kEntries + e] = (uint8_t)(tab[e] >> 8); }
 }
 
 // composition of the windows of one group: entry e of its first window -> (entry of the next group's first window, records)

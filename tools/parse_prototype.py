@@ -4,7 +4,7 @@ import sys, numpy as np
 sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
 import datagen
 from oracle import pyoracle
-W=16384; NC=W//2; END=254
+W=8192; NC=W//2; END=254
 def popc64(a): return np.array([bin(int(x)).count('1') for x in a],dtype=np.int64)
 def serial_head(enc):
     """true FSM walk until calm; returns (pos, block, index list)"""
