@@ -353,7 +353,9 @@ inline size_t seg_bytes_for(size_t n) {
     return c;
 }
 int run_stream_encode_segmented(DeviceCtx* c, const uint8_t* d_in, size_t n, uint8_t* d_out, hipStream_t s, size_t* size_out) {
-    const size_t C = seg_bytes_for(n), S = (n + C - 1) / C, stride = slot_stride(DENSITY_HIP_CHAMELEON, C), img = kSegImageBytes;
+    // the first segment runs alone, ahead of everything else: a quarter of the others' length (whole rounds)
+    const size_t C = seg_bytes_for(n), C0 = ((C / 4) + 4095) & ~(size_t)4095, S = 1 + (n - C0 + C - 1) / C, stride = slot_stride(DENSITY_HIP_CHAMELEON, C), img = kSegImageBytes;
+    auto seg_at = [&](size_t k) -> size_t { return k == 0 ? 0 : C0 + (k - 1) * C; };   // where segment k starts
     const size_t off_lw = align_up(S * stride, kAlign), off_start = off_lw + S * img, off_final = off_start + S * img, off_small = off_final + S * img;
     hipError_t e = c->seg.ensure(off_small + S * 64 + kAlign);
     if (e != hipSuccess) { set_error("workspace allocation (segmented stream encode)", e); return DENSITY_HIP_ERR_RUNTIME; }
@@ -374,7 +376,7 @@ int run_stream_encode_segmented(DeviceCtx* c, const uint8_t* d_in, size_t n, uin
     // (on the context's second stream, beside the first segment's encode; joined before the first merge)
     if (e == hipSuccess) e = hipEventRecord(c->batch_done[0], s);
     if (e == hipSuccess) e = hipStreamWaitEvent(c->stitch_stream, c->batch_done[0], 0);
-    if (e == hipSuccess && S > 2) e = launch_rotor_lastwriters(d_in + C, C, (uint32_t)(S - 2), d_lw + img, d_err, c->stitch_stream);
+    if (e == hipSuccess && S > 2) e = launch_rotor_lastwriters(d_in + C0, C, (uint32_t)(S - 2), d_lw + img, d_err, c->stitch_stream);
     if (e == hipSuccess) e = hipEventRecord(c->stitch_done, c->stitch_stream);
     bool joined = false;
     size_t first = 0;
@@ -387,8 +389,8 @@ int run_stream_encode_segmented(DeviceCtx* c, const uint8_t* d_in, size_t n, uin
         a.final_images = d_final + first * img;
         a.final_guard = d_gfinal + first;
         a.raw_blocks = d_raw + first;
-        const size_t left = n - first * C;
-        e = launch_rotor_encode_seg(d_in + first * C, rest_as_one ? left : (left < C ? left : C), rest_as_one ? left : C, 1, d_stage + first * stride,
+        const size_t left = n - seg_at(first), len1 = first == 0 ? C0 : C;
+        e = launch_rotor_encode_seg(d_in + seg_at(first), rest_as_one ? left : (left < len1 ? left : len1), rest_as_one ? left : len1, 1, d_stage + first * stride,
                                     rest_as_one ? 0 : stride, d_sizes + first, d_err, a, s);
         if (rest_as_one || first + 1 >= S) { if (rest_as_one) { /* the remainder's stream follows the final prefix directly */ } break; }
         const size_t rest = S - first - 1;
@@ -403,7 +405,7 @@ int run_stream_encode_segmented(DeviceCtx* c, const uint8_t* d_in, size_t n, uin
         b.final_images = d_final + (first + 1) * img;
         b.final_guard = d_gfinal + first + 1;
         b.raw_blocks = d_raw + first + 1;
-        if (e == hipSuccess) e = launch_rotor_encode_seg(d_in + (first + 1) * C, n - (first + 1) * C, C, (uint32_t)rest, d_stage + (first + 1) * stride, stride,
+        if (e == hipSuccess) e = launch_rotor_encode_seg(d_in + seg_at(first + 1), n - seg_at(first + 1), C, (uint32_t)rest, d_stage + (first + 1) * stride, stride,
                                                          d_sizes + first + 1, d_err, b, s);
         if (e == hipSuccess) e = hipMemcpyAsync(h_gfinal.data(), d_gfinal, S * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipMemcpyAsync(h_raw.data(), d_raw, S * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
