@@ -345,11 +345,11 @@ int run_decode_container(DeviceCtx* c, const uint8_t* d_in, size_t container_siz
 // raw-copy blocks and final FSM state.  The longest prefix whose assumptions held is final; the rest is encoded again from the exact
 // final dictionary of that prefix (incompressible input degenerates to the sequential encode: after 3 passes the remainder runs as
 // one chunk).  The output is the segments' streams concatenated byte for byte: identical to the reference's single stream.
-constexpr size_t kSegMinStream = 16u << 20;
+constexpr size_t kSegMinStream = 4u << 20;
 inline size_t seg_bytes_for(size_t n) {
     size_t c = (n / 256) & ~(size_t)4095;                                         // about one segment per CU, whole rounds of 16 blocks
     if (c > (4u << 20)) c = 4u << 20;
-    if (c < (256u << 10)) c = 256u << 10;
+    if (c < (128u << 10)) c = 128u << 10;
     return c;
 }
 int run_stream_encode_segmented(DeviceCtx* c, const uint8_t* d_in, size_t n, uint8_t* d_out, hipStream_t s, size_t* size_out) {
@@ -477,11 +477,13 @@ int run_stream_encode(DeviceCtx* c, int algo, const uint8_t* d_in, size_t n, uin
 // come out wrong, its writes are right; the real pass overwrites the output).  Passes: parse -> decode from empty dictionaries, final
 // images -> per-slot merge into start images -> decode from the start images.  `handled` false: not a calm stream (or too short, or
 // buffers this path does not take): the caller walks it on one work-group as before.
-constexpr size_t kSegDecodeMin = 8u << 20;
+constexpr size_t kSegDecodeMin = 2u << 20;
 int run_stream_decode_segmented(DeviceCtx* c, const uint8_t* d_in, size_t E, uint8_t* d_out, size_t cap, hipStream_t s, size_t* size_out, bool* handled) {
     *handled = false;
-    constexpr uint32_t kChunkBlocks = 16384;
-    constexpr size_t kChunkBytes = (size_t)kChunkBlocks * 256, img = kSegImageBytes;
+    // segments of 4 MiB of output for long streams, down to 256 KiB for short ones (about 64 segments at least)
+    uint32_t kChunkBlocks = 16384;
+    while (kChunkBlocks > 1024 && (E / 160) / kChunkBlocks < 64) kChunkBlocks >>= 1;
+    const size_t kChunkBytes = (size_t)kChunkBlocks * 256, img = kSegImageBytes;
     size_t max_blocks = E / 136 + 2;
     if (cap / 256 + 2 < max_blocks) max_blocks = cap / 256 + 2;
     const size_t max_chunks = (max_blocks + kChunkBlocks - 1) / kChunkBlocks + 1;

@@ -157,7 +157,7 @@ int density_hip_stream_decode_device(int algo, const void* d_input, size_t input
 void density_hip_set_profiling(int enabled);
 int density_hip_last_timings(float* milliseconds, const char** names, int capacity);
 
-/* Test hook: how the reference-shaped Chameleon stream calls of 16 MiB and more were served so far (process-wide counters):
+/* Test hook: how the reference-shaped Chameleon stream calls of a few MiB and more were served so far (process-wide counters):
  * out4[0] streams encoded in parallel segments, [1] passes those encodes took (1 per stream if every speculation held),
  * [2] streams decoded in parallel segments, [3] long streams decoded sequentially (not calm, or buffers the parallel path does not take). */
 void density_hip_stream_stats(uint64_t* out4);

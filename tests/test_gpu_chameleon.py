@@ -295,7 +295,8 @@ def test_full_size_properties_device_resident():
 
 
 @pytest.mark.parametrize("kind,n", [("rep", 48 * 1024 * 1024 + 12345), ("prose", 20 * 1024 * 1024), ("patchy", 40 * 1024 * 1024 + 7), ("random", 17 * 1024 * 1024),
-                                    ("zeros", 16 * 1024 * 1024 + 4), ("saltzero", 24 * 1024 * 1024 + 258), ("samehash", 16 * 1024 * 1024), ("zeropatch", 32 * 1024 * 1024)])
+                                    ("zeros", 16 * 1024 * 1024 + 4), ("saltzero", 24 * 1024 * 1024 + 258), ("samehash", 16 * 1024 * 1024), ("zeropatch", 32 * 1024 * 1024),
+                                    ("prose", 6 * 1024 * 1024 + 300), ("rep", 5 * 1024 * 1024)])
 def test_long_stream_encode_in_segments_is_the_reference_stream(kind, n, kernel_variant):
     """`chameleon_encode` of ONE long stream runs in parallel segments (api.hip::run_stream_encode_segmented) and must still be the
     reference's single stream, byte for byte: calm text (one pass), text with incompressible patches (raw-copy blocks break the
@@ -339,7 +340,7 @@ def test_long_stream_encode_in_segments_is_the_reference_stream(kind, n, kernel_
     assert gpu_decode(want, n) == data.tobytes()
     s2 = stats()
     # decoded in parallel iff the stream is calm (no two incompressible records in a row anywhere behind its head)
-    assert len(want) >= 8 << 20                                  # (the stream is long enough for the parallel decode to be tried)
+    assert len(want) >= 2 << 20                                  # (the stream is long enough for the parallel decode to be tried)
     assert (s2[2] - s1[2], s2[3] - s1[3]) == ((1, 0) if calm else (0, 1)), (kind, s2, s1)
 
 
