@@ -12,7 +12,7 @@ done
 timeout 900 python bench.py --algo chameleon --data prose --size 100000000 --steps 10 --warmup 3 --no-cpu --no-sweep > $T/bench_chameleon_prose100M.json 2>/dev/null
 timeout 900 python benches/density.py > $T/benches_density.txt 2>&1; echo "harness rc=$?"; tail -30 $T/benches_density.txt
 timeout 120 ./probes/rotor_hop > $T/rotor_hop.log 2>&1; tail -4 $T/rotor_hop.log
-for k in rep random; do timeout 200 python tools/gpu_stream_rate.py 1024 $k 2>&1 | tail -1; done > $T/stream_rate.txt; cat $T/stream_rate.txt
+for k in rep random; do timeout 200 python tools/gpu_stream_rate.py 1024 $k 2>&1 | tail -2; done > $T/stream_rate.txt; cat $T/stream_rate.txt
 python - <<'PY'
 import json, glob
 for f in sorted(glob.glob("gpurun_out/r2_final/bench_*.json")):
