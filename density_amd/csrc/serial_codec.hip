@@ -293,15 +293,18 @@ __global__ __launch_bounds__(64) void serial_decode_chunks(const uint8_t* __rest
 // speculating that no earlier quad of the same record wrote the slot it reads; step 3 then knows the truth, and a record with a
 // mis-speculated prediction (a repeated pair of quads inside 128 bytes) is decoded again by the scalar code.
 // =================================================================================================================
+// Table accesses: ONE wave ever touches a stream's tables, so nothing wider than its own CU has to agree on them — work-group scope:
+// the accesses go through this XCD's L2 instead of past it (agent scope on a chip of eight XCDs means "coherent across their
+// L2s": every gather paid the trip to memory, ~1900 cycles a step).
 typedef unsigned long long u64a;
-__device__ __forceinline__ uint32_t tbl_load32(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void tbl_store32(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t tbl_load32(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void tbl_store32(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ Pair tbl_load_pair(const Pair* p) {
-    const u64a v = __hip_atomic_load(reinterpret_cast<const u64a*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const u64a v = __hip_atomic_load(reinterpret_cast<const u64a*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     return Pair{(uint32_t)v, (uint32_t)(v >> 32)};
 }
 __device__ __forceinline__ void tbl_store_pair(Pair* p, Pair v) {
-    __hip_atomic_store(reinterpret_cast<u64a*>(p), (u64a)v.a | ((u64a)v.b << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(reinterpret_cast<u64a*>(p), (u64a)v.a | ((u64a)v.b << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 // the table stores of a step are complete (in L2, where the next step's gathers read) before anything else happens
 __device__ __forceinline__ void tbl_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
