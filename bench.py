@@ -110,7 +110,7 @@ def host_api_rates(algo, host, chunk, sample_bytes):
     out["reference_symbols"] = {"encode_MBps": round(n / (t1 - t0) / 1e6, 1), "decode_MBps": round(n / (t2 - t1) / 1e6, 1),
                                 "round_trip_MBps": round(n / (t2 - t0) / 1e6, 1),
                                 "note": "ONE reference stream; H2D + kernels + D2H.  Chameleon encode of >= 4 MiB runs in parallel segments and is still the "
-                                        "reference's stream byte for byte; decode of a calm stream of >= 2 MiB runs in parallel segments too"}
+                                        "reference's stream byte for byte; decode of >= 2 MiB runs in parallel segments too (unless it is mostly raw copies)"}
     if algo == "chameleon":
         # the same single stream with the buffers already on the device (density_hip_stream_encode_device): what the segments buy
         import ctypes

@@ -489,33 +489,56 @@ int run_stream_decode_segmented(DeviceCtx* c, const uint8_t* d_in, size_t E, uin
     const size_t max_chunks = (max_blocks + kChunkBlocks - 1) / kChunkBlocks + 1;
     if (max_chunks > kMaxPipelinedChunks) return DENSITY_HIP_OK;
     const size_t index_bytes = align_up(max_chunks * kChunkBlocks + 64, kAlign), parse_ws = align_up(stream_parse_workspace(E), kAlign);
-    const size_t off_index = parse_ws, off_lw = off_index + index_bytes, off_start = off_lw + max_chunks * img, off_zero = off_start + max_chunks * img,
-                 off_zmap = off_zero + align_up(img, kAlign), off_small = off_zmap + max_chunks * kZmapWordsPerChunk * 4;
+    const size_t pos_bytes = align_up((max_chunks * kChunkBlocks + 64) * sizeof(uint32_t), kAlign);
+    const size_t off_index = parse_ws, off_pos = off_index + index_bytes, off_lw = off_pos + pos_bytes, off_start = off_lw + max_chunks * img,
+                 off_zero = off_start + max_chunks * img, off_zmap = off_zero + align_up(img, kAlign), off_small = off_zmap + max_chunks * kZmapWordsPerChunk * 4;
     hipError_t e = c->seg.ensure(off_small + (max_chunks + 2) * 32 + 256 + kAlign);
     if (e != hipSuccess) { set_error("workspace allocation (segmented stream decode)", e); return DENSITY_HIP_ERR_RUNTIME; }
     uint8_t* base = (uint8_t*)c->seg.p;
     uint8_t* d_index = base + off_index;
+    uint32_t* d_pos32 = reinterpret_cast<uint32_t*>(base + off_pos);
     uint64_t* d_chunk_offset = reinterpret_cast<uint64_t*>(base + off_small);
     uint64_t* d_offsets = d_chunk_offset + max_chunks + 2;
     uint64_t* d_sizes = d_offsets + max_chunks + 2;
     uint64_t* d_produced = d_sizes + max_chunks + 2;
     uint32_t* d_info = reinterpret_cast<uint32_t*>(d_produced + max_chunks + 2);
     uint32_t* d_err = d_info + 16;                                                // [0] the real pass, [1] the last-writer pass (ignored)
-    e = hipMemsetAsync(d_index, 0x7f, index_bytes, s);                            // beyond the stream: "ragged" = stop
-    if (e == hipSuccess) e = hipMemsetAsync(d_chunk_offset, 0, (max_chunks + 2) * sizeof(uint64_t), s);
+    const bool trace = getenv("DENSITY_HIP_PROF") != nullptr;
+    e = hipMemsetAsync(d_chunk_offset, 0, (max_chunks + 2) * sizeof(uint64_t), s);
     if (e == hipSuccess) e = hipMemsetAsync(d_info, 0, 18 * sizeof(uint32_t), s);
-    if (e == hipSuccess) e = launch_stream_parse(d_in, E, base, d_index, max_chunks * kChunkBlocks, d_chunk_offset, kChunkBlocks, d_info, s);
+    // Parse.  A pair of incompressible records behind the head means raw copies follow: the parse is final up to that pair, the head walk
+    // (real FSM) starts over from it and takes the raw copies, the parallel parse resumes behind them — up to 16 such episodes.
     uint32_t info[8] = {};
-    std::vector<uint64_t> h_off(max_chunks + 2), h_offsets, h_sizes;
-    if (e == hipSuccess) e = hipMemcpyAsync(info, d_info, sizeof(info), hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(h_off.data(), d_chunk_offset, (max_chunks + 2) * sizeof(uint64_t), hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    uint32_t from_block = 0;
+    uint64_t from_pos = 0;
+    bool parsed = false;
+    for (int episode = 0; e == hipSuccess && episode < 16; ++episode) {
+        const uint32_t start[3] = {from_block, (uint32_t)from_pos, (uint32_t)(from_pos >> 32)};
+        e = hipMemcpyAsync(d_info + 8, start, sizeof(start), hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);                         // (`start` lives on this frame)
+        if (e == hipSuccess) e = launch_stream_parse(d_in, E, from_pos, base, d_index, max_chunks * kChunkBlocks, d_chunk_offset, kChunkBlocks, d_pos32, d_info, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(info, d_info, sizeof(info), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) break;
+        if (trace) fprintf(stderr, "[density_hip prof] segmented stream decode: parse from block %u: status %u, head to block %u, %u whole blocks, first incompressible pair at %d\n",
+                           from_block, info[0], info[1], info[4], (int)info[7]);
+        if (info[0] == 0) break;                                                  // no calm stretch within reach: the sequential path
+        if (info[7] == 0xffffffffu) { parsed = true; break; }
+        if (info[7] < from_block) break;                                          // (cannot happen)
+        uint32_t p32 = 0;
+        e = hipMemcpyAsync(&p32, d_pos32 + info[7], sizeof(p32), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        from_block = info[7]; from_pos = p32;
+    }
     if (e != hipSuccess) { set_error("segmented stream decode (parse)", e); return DENSITY_HIP_ERR_RUNTIME; }
     const uint64_t whole = info[4], end_pos = ((uint64_t)info[6] << 32) | info[5];
-    if (getenv("DENSITY_HIP_PROF")) fprintf(stderr, "[density_hip prof] segmented stream decode: parse status %u, head %u blocks / %llu bytes, %llu whole blocks end at %llu of %zu, not calm %u\n",
-                                            info[0], info[1], (unsigned long long)(((uint64_t)info[3] << 32) | info[2]), (unsigned long long)whole, (unsigned long long)end_pos, E, info[7]);
-    const bool trace = getenv("DENSITY_HIP_PROF") != nullptr;
-    if (info[0] == 0 || info[7] != 0 || whole < 2 * kChunkBlocks || end_pos > E) { if (trace) fprintf(stderr, "[density_hip prof]   -> sequential path (not calm / short)\n"); return DENSITY_HIP_OK; }
+    if (!parsed || whole < 2 * kChunkBlocks || end_pos > E) { if (trace) fprintf(stderr, "[density_hip prof]   -> sequential path (not calm enough / short)\n"); return DENSITY_HIP_OK; }
+    std::vector<uint64_t> h_off(max_chunks + 2), h_offsets, h_sizes;
+    e = hipMemcpyAsync(h_off.data(), d_chunk_offset, (max_chunks + 2) * sizeof(uint64_t), hipMemcpyDeviceToHost, s);
+    // beyond the whole blocks the index says "ragged" = stop (an episode that was started over may have written further)
+    if (e == hipSuccess) e = hipMemsetAsync(d_index + whole, 0x7f, index_bytes - whole, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { set_error("segmented stream decode (parse)", e); return DENSITY_HIP_ERR_RUNTIME; }
     const bool ragged = end_pos < E;
     const size_t n_chunks = (whole + (ragged ? 1 : 0) + kChunkBlocks - 1) / kChunkBlocks;
     if (n_chunks > max_chunks || (n_chunks - 1) * kChunkBytes >= cap) { if (trace) fprintf(stderr, "[density_hip prof]   -> sequential path (capacity: %zu chunks, cap %zu)\n", n_chunks, cap); return DENSITY_HIP_OK; }

@@ -72,12 +72,14 @@ hipError_t launch_serial_decode(int algo, const uint8_t* d_in, const uint64_t* d
                                 uint8_t* d_tables, uint32_t n_slots, hipStream_t stream);
 
 // ---- stream_parse.hip: record boundaries of one calm Chameleon stream, in parallel ----
-// d_info (8 words): 0 status (1 = parsed), 1 first block behind the sequentially walked head, 2-3 its stream offset, 4 whole blocks of the
-// stream, 5-6 stream offset where they end (the ragged end, if any, starts there), 7 != 0: not calm (two incompressible records in a row).
-// d_index: one byte per whole block (MAP count; raw copies of the head flagged), d_chunk_offset[k]: stream offset of block k * chunk_blocks.
+// d_info (16 words): 0 status (1 = a calm head was found), 1 first block behind the sequentially walked head, 2-3 its stream offset, 4 whole
+// blocks of the stream, 5-6 stream offset where they end (the ragged end, if any, starts there), 7 first block of a pair of incompressible
+// records behind the head (0xffffffff: none); in: 8 block / 9-10 stream offset the head walk starts at (0 / 0 for a whole stream; after a
+// pair at block j: j / d_pos32[j], everything before being final).  d_index: one byte per whole block (MAP count; raw copies flagged),
+// d_pos32[b]: stream offset of block b, d_chunk_offset[k]: stream offset of block k * chunk_blocks.
 uint64_t stream_parse_workspace(uint64_t E);
-hipError_t launch_stream_parse(const uint8_t* d_in, uint64_t E, uint8_t* d_ws, uint8_t* d_index, uint64_t index_cap, uint64_t* d_chunk_offset,
-                               uint32_t chunk_blocks, uint32_t* d_info, hipStream_t stream);
+hipError_t launch_stream_parse(const uint8_t* d_in, uint64_t E, uint64_t from_pos, uint8_t* d_ws, uint8_t* d_index, uint64_t index_cap, uint64_t* d_chunk_offset,
+                               uint32_t chunk_blocks, uint32_t* d_pos32, uint32_t* d_info, hipStream_t stream);
 
 // ---- container.hip ----
 // Exclusive scan of 16-byte-aligned chunk sizes -> payload offsets; writes the container header and the u32 size

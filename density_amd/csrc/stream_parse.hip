@@ -12,7 +12,8 @@
 //             then every window's entry and first block number;
 //   emit      one lane per window walks forward from its entry: MAP count of every block into the block index, stream offset of
 //             every 16384th block (the decoder's chunks), the end of the whole blocks;
-//   check     two incompressible records in a row anywhere -> the stream is not calm, the caller takes the sequential path.
+//   check     the first pair of incompressible records in a row behind the head, if any: the parse is final up to there, and the caller
+//             starts over from that block (the head walk takes the raw copies that follow with the real FSM) — or gives up.
 // A numpy prototype of exactly this (tools/parse_prototype.py) is checked against the FSM walk of the oracle's streams.
 #include "common.hpp"
 #include "chameleon_dev.hpp"
@@ -27,13 +28,20 @@ constexpr uint32_t kHeadMaxBlocks = 4096;
 
 __device__ __forceinline__ uint64_t ld64u(const uint8_t* p) { return *reinterpret_cast<const u64_u*>(p); }
 
-// info words: 0 status (1 = calm head found), 1 b0, 2-3 p0, 4 total whole blocks, 5-6 end of the whole blocks (stream offset), 7 not calm
-__global__ void parse_head_kernel(const uint8_t* __restrict__ in, uint64_t E, uint8_t* __restrict__ index, uint64_t index_cap, uint32_t* __restrict__ info) {
+// info words: 0 status (1 = calm head found), 1 b0, 2-3 p0, 4 total whole blocks, 5-6 end of the whole blocks (stream offset),
+// 7 the first block of a pair of incompressible records behind the head (0xffffffff: none — the stream is calm from the head on),
+// 8 / 9-10 in: block and stream offset the head walk starts at (everything before is final and calm)
+__global__ void parse_head_kernel(const uint8_t* __restrict__ in, uint64_t E, uint8_t* __restrict__ index, uint64_t index_cap, uint32_t* __restrict__ info,
+                                  uint32_t* __restrict__ pos32, uint64_t* __restrict__ chunk_offset, uint32_t chunk_blocks) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    Guard g;
-    uint64_t pos = 0;
-    uint32_t b = 0, status = 0;
-    while (pos < E && b < kHeadMaxBlocks && b < index_cap) {
+    Guard g;                                                                      // calm: no penalty, start 1 ...
+    uint64_t pos = ((uint64_t)info[10] << 32) | info[9];
+    uint32_t b = info[8], status = 0;
+    g.counter = b & 15u;                                                          // ... and the counter counts every block of the stream (protection_state.rs:20)
+    const uint32_t b_first = b;
+    while (pos < E && b - b_first < kHeadMaxBlocks && b < index_cap) {
+        pos32[b] = (uint32_t)pos;
+        if (b % chunk_blocks == 0) chunk_offset[b / chunk_blocks] = pos;
         if (g.block_is_copy()) {                                                  // codec.rs:89-91
             if (pos + kBlock > E) break;                                          // (a raw tail: the sequential path's business)
             index[b] = (uint8_t)kIdxCopy;
@@ -49,10 +57,10 @@ __global__ void parse_head_kernel(const uint8_t* __restrict__ in, uint64_t E, ui
             pos += rl;
         }
         ++b;
-        if (g.penalty == 0 && g.prev == 0 && g.start == 1 && b >= 2) { status = 1; break; }
+        if (g.penalty == 0 && g.prev == 0 && g.start == 1 && b - b_first >= 2) { status = 1; break; }
     }
     info[0] = status; info[1] = b; info[2] = (uint32_t)pos; info[3] = (uint32_t)(pos >> 32);
-    info[4] = b; info[5] = (uint32_t)pos; info[6] = (uint32_t)(pos >> 32); info[7] = 0;
+    info[4] = b; info[5] = (uint32_t)pos; info[6] = (uint32_t)(pos >> 32); info[7] = 0xffffffffu;
 }
 
 __global__ __launch_bounds__(64) void parse_windows_kernel(const uint8_t* __restrict__ in, uint64_t E, const uint32_t* __restrict__ info,
@@ -152,7 +160,8 @@ __global__ __launch_bounds__(64) void parse_entries_kernel(const uint8_t* __rest
 // one lane per window: forward from the window's entry — block index, chunk offsets, the end of the whole blocks
 __global__ __launch_bounds__(64) void parse_emit_kernel(const uint8_t* __restrict__ in, uint64_t E, uint32_t* __restrict__ info,
                                                         const uint8_t* __restrict__ went, const uint32_t* __restrict__ wbase, uint32_t n_windows,
-                                                        uint8_t* __restrict__ index, uint64_t index_cap, uint64_t* __restrict__ chunk_offset, uint32_t chunk_blocks) {
+                                                        uint8_t* __restrict__ index, uint64_t index_cap, uint64_t* __restrict__ chunk_offset, uint32_t chunk_blocks,
+                                                        uint32_t* __restrict__ pos32) {
     const uint32_t w = blockIdx.x * 64 + threadIdx.x;
     if (w >= n_windows || info[0] == 0) return;
     uint32_t c = went[w];
@@ -170,6 +179,7 @@ __global__ __launch_bounds__(64) void parse_emit_kernel(const uint8_t* __restric
             return;
         }
         index[b] = (uint8_t)pc;
+        pos32[b] = (uint32_t)p;
         if (b % chunk_blocks == 0) chunk_offset[b / chunk_blocks] = p;
         ++b;
         c += 132u - pc;
@@ -183,7 +193,7 @@ __global__ __launch_bounds__(256) void parse_check_kernel(const uint8_t* __restr
     const uint32_t from = b0 ? b0 - 1 : 0;
     for (uint64_t i = from + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i + 1 < total; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t a = index[i], b = index[i + 1];
-        if (!(a & kIdxCopy) && !(b & kIdxCopy) && a <= 4 && b <= 4) atomicOr(info + 7, 1u);
+        if (!(a & kIdxCopy) && !(b & kIdxCopy) && a <= 4 && b <= 4) atomicMin(info + 7, (uint32_t)i);
     }
 }
 
@@ -194,9 +204,9 @@ uint64_t stream_parse_workspace(uint64_t E) {
     return nw * kEntries * 2 + ng * kEntries * 5 + ng * 5 + nw * 5 + 4096;
 }
 
-hipError_t launch_stream_parse(const uint8_t* d_in, uint64_t E, uint8_t* d_ws, uint8_t* d_index, uint64_t index_cap, uint64_t* d_chunk_offset,
-                               uint32_t chunk_blocks, uint32_t* d_info, hipStream_t stream) {
-    const uint32_t nw = (uint32_t)(E / kWin + 2), ng = (nw + kGroup - 1) / kGroup;
+hipError_t launch_stream_parse(const uint8_t* d_in, uint64_t E, uint64_t from_pos, uint8_t* d_ws, uint8_t* d_index, uint64_t index_cap, uint64_t* d_chunk_offset,
+                               uint32_t chunk_blocks, uint32_t* d_pos32, uint32_t* d_info, hipStream_t stream) {
+    const uint32_t nw = (uint32_t)((E - from_pos) / kWin + 2), ng = (nw + kGroup - 1) / kGroup;   // (windows behind the head, which starts at or behind from_pos)
     uint8_t* T = d_ws;
     uint8_t* C = T + (uint64_t)nw * kEntries;
     uint32_t* GC = reinterpret_cast<uint32_t*>((reinterpret_cast<uintptr_t>(C + (uint64_t)nw * kEntries) + 15) & ~(uintptr_t)15);
@@ -209,12 +219,12 @@ hipError_t launch_stream_parse(const uint8_t* d_in, uint64_t E, uint8_t* d_ws, u
     hipError_t e = hipFuncSetAttribute((const void*)parse_groups_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)group_lds);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)parse_entries_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)group_lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(parse_head_kernel, dim3(1), dim3(64), 0, stream, d_in, E, d_index, index_cap, d_info);
+    hipLaunchKernelGGL(parse_head_kernel, dim3(1), dim3(64), 0, stream, d_in, E, d_index, index_cap, d_info, d_pos32, d_chunk_offset, chunk_blocks);
     hipLaunchKernelGGL(parse_windows_kernel, dim3(nw), dim3(64), 0, stream, d_in, E, d_info, T, C);
     hipLaunchKernelGGL(parse_groups_kernel, dim3(ng), dim3(64), group_lds, stream, T, C, nw, GT, GC);
     hipLaunchKernelGGL(parse_top_kernel, dim3(1), dim3(64), 0, stream, GT, GC, ng, d_info, gent, gbase);
     hipLaunchKernelGGL(parse_entries_kernel, dim3(ng), dim3(64), group_lds, stream, T, C, nw, gent, gbase, went, wbase);
-    hipLaunchKernelGGL(parse_emit_kernel, dim3((nw + 63) / 64), dim3(64), 0, stream, d_in, E, d_info, went, wbase, nw, d_index, index_cap, d_chunk_offset, chunk_blocks);
+    hipLaunchKernelGGL(parse_emit_kernel, dim3((nw + 63) / 64), dim3(64), 0, stream, d_in, E, d_info, went, wbase, nw, d_index, index_cap, d_chunk_offset, chunk_blocks, d_pos32);
     hipLaunchKernelGGL(parse_check_kernel, dim3(256), dim3(256), 0, stream, d_index, d_info);
     return hipGetLastError();
 }

@@ -24,8 +24,8 @@ extern "C" {
 
 /* ------------------------------------------------------------------------------------------------------------
  * 1. Reference-compatible symbols (host pointers, single reference-format stream, bit-exact with the crate).
- *    (One stream is one dependency chain; long Chameleon streams are still encoded — and, when they contain no
- *    raw-copy block, decoded — in parallel segments on the device, with byte-identical results: DESIGN.md 4.7.)
+ *    (One stream is one dependency chain; long Chameleon streams are still encoded and decoded in parallel segments on
+ *    the device, with byte-identical results: DESIGN.md 4.7.)
  *
  *    Return value: bytes written; 0 on any failure (the reference maps Err to 0 via unwrap_or(0) and otherwise
  *    panics on a short buffer or truncated input; this library returns 0 instead and never writes past
@@ -159,7 +159,7 @@ int density_hip_last_timings(float* milliseconds, const char** names, int capaci
 
 /* Test hook: how the reference-shaped Chameleon stream calls of a few MiB and more were served so far (process-wide counters):
  * out4[0] streams encoded in parallel segments, [1] passes those encodes took (1 per stream if every speculation held),
- * [2] streams decoded in parallel segments, [3] long streams decoded sequentially (not calm, or buffers the parallel path does not take). */
+ * [2] streams decoded in parallel segments, [3] long streams decoded sequentially (mostly raw copies, or buffers the parallel path does not take). */
 void density_hip_stream_stats(uint64_t* out4);
 
 /* Test hook, bit mask: 1 = force the simple one-wavefront-per-chunk kernels, 2 = encode containers without the block index,

@@ -339,9 +339,11 @@ def test_long_stream_encode_in_segments_is_the_reference_stream(kind, n, kernel_
     assert (s1[1] - s0[1] == 1) == calm, (kind, s1[1] - s0[1])    # ... in one pass iff nothing breaks the speculation
     assert gpu_decode(want, n) == data.tobytes()
     s2 = stats()
-    # decoded in parallel iff the stream is calm (no two incompressible records in a row anywhere behind its head)
+    # decoded in parallel unless raw copies run on and on: a few incompressible patches are walked with the real FSM, the parallel
+    # parse resumes behind each of them (stream_parse.hip); random bytes and one-slot collisions never calm down
     assert len(want) >= 2 << 20                                  # (the stream is long enough for the parallel decode to be tried)
-    assert (s2[2] - s1[2], s2[3] - s1[3]) == ((1, 0) if calm else (0, 1)), (kind, s2, s1)
+    parallel = kind not in ("random", "samehash")
+    assert (s2[2] - s1[2], s2[3] - s1[3]) == ((1, 0) if parallel else (0, 1)), (kind, s2, s1)
 
 
 def test_long_stream_decode_errors_match_the_sequential_path(kernel_variant):
