@@ -343,8 +343,8 @@ int run_decode_container(DeviceCtx* c, const uint8_t* d_in, size_t container_siz
 // need no encoding to find) and every segment ends calm.  One pass: segment `first` for real (exact start) | last writers of the others
 // in parallel -> start images by a per-slot merge -> all other segments in parallel from their start images, each reporting its
 // raw-copy blocks and final FSM state.  The longest prefix whose assumptions held is final; the rest is encoded again from the exact
-// final dictionary of that prefix (incompressible input degenerates to the sequential encode: after 3 passes the remainder runs as
-// one chunk).  The output is the segments' streams concatenated byte for byte: identical to the reference's single stream.
+// final dictionary of that prefix (incompressible input degenerates to the sequential encode: once a pass after the third makes fewer
+// than 8 segments final, the remainder runs as one chunk).  The output is the segments' streams concatenated byte for byte: identical to the reference's single stream.
 constexpr size_t kSegMinStream = 4u << 20;
 inline size_t seg_bytes_for(size_t n) {
     size_t c = (n / 256) & ~(size_t)4095;                                         // about one segment per CU, whole rounds of 16 blocks
@@ -380,8 +380,10 @@ int run_stream_encode_segmented(DeviceCtx* c, const uint8_t* d_in, size_t n, uin
     if (e == hipSuccess) e = hipEventRecord(c->stitch_done, c->stitch_stream);
     bool joined = false;
     size_t first = 0;
+    size_t advanced = S;                                                           // segments the previous pass made final
     for (int pass = 0; e == hipSuccess && first < S; ++pass) {
-        const bool rest_as_one = pass >= 3;
+        // (a pass that gets nowhere — raw copies all over — is not repeated for long: the remainder then runs as one chunk)
+        const bool rest_as_one = pass >= 16 || (pass >= 3 && advanced < 8);
         // segment `first` (or, after too many passes, everything that is left as one chunk) from its exact start
         SegArgs a;
         a.init_images = first ? d_final + (first - 1) * img : nullptr;
@@ -415,6 +417,7 @@ int run_stream_encode_segmented(DeviceCtx* c, const uint8_t* d_in, size_t n, uin
         size_t k = first + 2;
         while (k < S && h_raw[k - 1] == 0 && (h_gfinal[k - 1] & 0x7fffffffu) == 0) ++k;
         if (getenv("DENSITY_HIP_PROF")) fprintf(stderr, "[density_hip prof] segmented stream encode: pass %d, %zu segments of %zu bytes, final up to segment %zu\n", pass, S, C, k);
+        advanced = k - first;
         first = k;                                                                // (== S: done)
         ++g_stream_stats[1];
     }
