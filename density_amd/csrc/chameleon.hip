@@ -1298,7 +1298,11 @@ hipError_t launch_chameleon_encode(const uint8_t* d_in, uint64_t total, uint64_t
         auto kernel = prof ? chameleon_encode_chunks_pipe<true> : chameleon_encode_chunks_pipe<false>;
         e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytesPipe + 64);
         if (e != hipSuccess) return e;
-        const uint32_t dbg = getenv("DENSITY_HIP_DBG") ? (uint32_t)atoi(getenv("DENSITY_HIP_DBG")) : 0u;
+#ifdef DENSITY_HIP_DEBUG
+        const uint32_t dbg = getenv("DENSITY_HIP_DBG") ? (uint32_t)atoi(getenv("DENSITY_HIP_DBG")) : 0u;   // stage-idling switches: debug builds only
+#else
+        const uint32_t dbg = 0u;
+#endif
         hipLaunchKernelGGL(kernel, dim3(n_chunks), dim3(kPipeWaves * 64), kLdsBytesPipe + 64, stream, d_in, total, chunk_bytes, d_out, out_stride, d_sizes, d_index, d_zmap, dbg, prof);
         prof_report("encode", prof, stream);
     } else {
@@ -1323,7 +1327,11 @@ hipError_t launch_chameleon_decode(const uint8_t* d_in, const uint64_t* d_offset
         auto kernel = prof ? chameleon_decode_chunks_pipe<true> : chameleon_decode_chunks_pipe<false>;
         e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytesDec + 64);
         if (e != hipSuccess) return e;
-        const uint32_t dbg = getenv("DENSITY_HIP_DBG") ? (uint32_t)atoi(getenv("DENSITY_HIP_DBG")) : 0u;
+#ifdef DENSITY_HIP_DEBUG
+        const uint32_t dbg = getenv("DENSITY_HIP_DBG") ? (uint32_t)atoi(getenv("DENSITY_HIP_DBG")) : 0u;   // stage-idling switches: debug builds only
+#else
+        const uint32_t dbg = 0u;
+#endif
         hipLaunchKernelGGL(kernel, dim3(n_chunks), dim3(kDecWaves * 64), kLdsBytesDec + 64, stream, d_in, d_offsets, d_sizes, d_out, out_stride, out_total, exact ? 1u : 0u,
                            // the feeder stages the index with 4-byte DMA pieces: per-chunk slices must start 4-byte aligned
                            (d_index && (out_stride / 256) % 4 == 0 && (uintptr_t)d_index % 4 == 0) ? d_index : nullptr, d_zmap, d_produced, d_err, dbg, prof);
