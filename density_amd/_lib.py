@@ -35,6 +35,7 @@ for _a in ("chameleon", "cheetah", "lion"):
 SYMBOLS.update({
     "density_hip_auto_chunk": (_SZ, [_SZ]),
     "density_hip_stream_stats": (None, [ctypes.POINTER(ctypes.c_uint64)]),
+    "density_hip_stage_stats": (None, [ctypes.POINTER(ctypes.c_uint64)]),
     "density_hip_auto_chunk_for": (_SZ, [_I, _SZ]),
     "density_hip_container_bound": (_SZ, [_I, _SZ, _SZ]),
     "density_hip_encode": (_SZ, [_I, _VP, _SZ, _VP, _SZ, _SZ]),

@@ -165,7 +165,7 @@ inline size_t serial_tables(int algo, size_t n_chunks) { return algo == DENSITY_
 inline size_t zmap_bytes(int algo, size_t n_chunks) { return (algo == DENSITY_HIP_CHAMELEON && n_chunks <= kMaxPipelinedChunks) ? align_up((n_chunks ? n_chunks : 1) * kZmapWordsPerChunk * 4, kAlign) : 0; }
 
 struct EncodePlan {
-    size_t chunk, n_chunks, stride, off_err, off_sizes, off_offsets, off_slots, off_tables, off_zmap, total;
+    size_t chunk, n_chunks, stride, off_err, off_sizes, off_offsets, off_slots, off_tables, off_zmap, off_stage, total;
 };
 EncodePlan plan_encode(int algo, size_t n, size_t chunk) {
     EncodePlan p{};
@@ -178,7 +178,9 @@ EncodePlan plan_encode(int algo, size_t n, size_t chunk) {
     p.off_slots = p.off_offsets + align_up(8 * (p.n_chunks + 1), kAlign);
     p.off_tables = p.off_slots + (p.n_chunks > 1 ? p.n_chunks * p.stride : 0);   // one chunk encodes straight into the container
     p.off_zmap = p.off_tables + serial_tables(algo, p.n_chunks ? p.n_chunks : 1);
-    p.total = p.off_zmap + zmap_bytes(algo, p.n_chunks);
+    p.off_stage = p.off_zmap + zmap_bytes(algo, p.n_chunks);
+    // Cheetah's exchange passes (exchange_stages.hip): a dword per quad, the per-block masks, the record offsets
+    p.total = p.off_stage + (algo == DENSITY_HIP_CHEETAH && chunk % 256 == 0 ? align_up(stage_scratch_bytes(n, (uint32_t)p.n_chunks), kAlign) : 0);
     return p;
 }
 struct DecodePlan {
@@ -198,8 +200,10 @@ DecodePlan plan_decode(int algo, size_t n_chunks) {
 
 // algorithm dispatch: Chameleon has the LDS-resident pipelined kernels, Cheetah/Lion the functional one-lane-per-stream kernels
 hipError_t codec_encode(int algo, const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_out,
-                        uint64_t out_stride, uint64_t* d_sizes, uint8_t* d_index, uint8_t* d_tables, uint32_t* d_zmap, uint32_t* d_err, hipStream_t s) {
+                        uint64_t out_stride, uint64_t* d_sizes, uint8_t* d_index, uint8_t* d_tables, uint32_t* d_zmap, uint8_t* d_stage, uint32_t* d_err, hipStream_t s) {
     if (algo == DENSITY_HIP_CHAMELEON) return launch_chameleon_encode(d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_index, d_zmap, d_err, s);
+    if (d_stage && stage_encode_eligible(algo, d_in, total, chunk_bytes, n_chunks))   // Cheetah: passes of ordered LDS exchanges, the one-wave kernel for what they hand back
+        return launch_stage_encode(d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, (uint32_t)serial_slots(algo, n_chunks), d_stage, s);
     return launch_serial_encode(algo, d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, (uint32_t)serial_slots(algo, n_chunks), s);
 }
 hipError_t codec_decode(int algo, const uint8_t* d_in, const uint64_t* d_offsets, const uint64_t* d_sizes, uint32_t n_chunks, uint8_t* d_out,
@@ -251,7 +255,7 @@ int run_encode_container(DeviceCtx* c, int algo, const uint8_t* d_in, size_t n, 
     if (e != hipSuccess) { set_error("hipMemsetAsync", e); return DENSITY_HIP_ERR_RUNTIME; }
     if (p.n_chunks == 1) {
         // single chunk: its stream goes straight to its final place, no stitch pass
-        e = codec_encode(algo, d_in, n, chunk, 1, d_out + pbase, 0, d_sizes, d_index, ws + p.off_tables, d_zmap, d_err, s);
+        e = codec_encode(algo, d_in, n, chunk, 1, d_out + pbase, 0, d_sizes, d_index, ws + p.off_tables, d_zmap, p.total > p.off_stage ? ws + p.off_stage : nullptr, d_err, s);
         prof.mark(encode_kernel_name(algo));
         if (e == hipSuccess) e = launch_layout_encode(d_sizes, 1, hdr, pbase, d_out, cap, d_offsets, d_err, s);
         prof.mark("layout_encode");
@@ -275,7 +279,7 @@ int run_encode_container(DeviceCtx* c, int algo, const uint8_t* d_in, size_t n, 
             const uint64_t in_off = (uint64_t)first * chunk;
             e = codec_encode(algo, d_in + in_off, n - in_off < (uint64_t)count * chunk ? n - in_off : (uint64_t)count * chunk, chunk, count, d_slots + (uint64_t)first * p.stride,
                              p.stride, d_sizes + first, d_index ? d_index + in_off / 256 : nullptr, ws + p.off_tables,
-                             d_zmap ? d_zmap + (uint64_t)first * kZmapWordsPerChunk : nullptr, d_err, s);
+                             d_zmap ? d_zmap + (uint64_t)first * kZmapWordsPerChunk : nullptr, p.total > p.off_stage ? ws + p.off_stage : nullptr, d_err, s);
             prof.mark(encode_kernel_name(algo));
             if (e == hipSuccess) e = launch_layout_encode_batch(d_sizes, first, count, k == 0, k + 1 == batches, hdr, pbase, d_out, cap, d_offsets, d_carry, d_err, s);
             prof.mark("layout_encode");
@@ -459,7 +463,7 @@ int run_stream_encode(DeviceCtx* c, int algo, const uint8_t* d_in, size_t n, uin
     const DecodePlan sp = plan_decode(algo, 1);   // stream calls share the one-chunk decode layout
     uint32_t* d_err = reinterpret_cast<uint32_t*>(ws + sp.off_err);
     hipError_t e = hipMemsetAsync(d_err, 0, sizeof(uint32_t), s);
-    if (e == hipSuccess) e = codec_encode(algo, d_in, n, n, 1, d_out, 0, d_sizes, nullptr, ws + sp.off_tables, zmap_bytes(algo, 1) ? reinterpret_cast<uint32_t*>(ws + sp.off_zmap) : nullptr, d_err, s);
+    if (e == hipSuccess) e = codec_encode(algo, d_in, n, n, 1, d_out, 0, d_sizes, nullptr, ws + sp.off_tables, zmap_bytes(algo, 1) ? reinterpret_cast<uint32_t*>(ws + sp.off_zmap) : nullptr, nullptr, d_err, s);
     prof.mark(encode_kernel_name(algo));
     uint64_t h_size = 0;
     uint32_t h_err = 0;
@@ -765,6 +769,7 @@ size_t density_hip_encode(int algo, const uint8_t* input, size_t input_size, uin
     return (size_t)h.container_len;
 }
 
+void density_hip_stage_stats(uint64_t* out2) { if (out2) { out2[0] = density::g_stage_stats[0]; out2[1] = density::g_stage_stats[1]; } }
 void density_hip_stream_stats(uint64_t* out4) { if (out4) for (int i = 0; i < 4; ++i) out4[i] = g_stream_stats[i]; }
 size_t density_hip_auto_chunk(size_t input_size) { return auto_chunk(input_size); }
 size_t density_hip_auto_chunk_for(int algo, size_t input_size) { return valid_algo(algo) ? auto_chunk(input_size, algo) : 0; }
@@ -800,7 +805,7 @@ size_t density_hip_decode(const uint8_t* container, size_t container_size, uint8
 }
 
 void density_hip_set_profiling(int enabled) { g_profiling = enabled; }
-void density_hip_set_kernel_variant(int variant) { g_variant = variant;   /* bit 3 (8): encode in batches with the stitch of one batch beside the encoding of the next */ density::g_force_simple = (variant & 1) != 0; density::g_force_pipeline = (variant & 4) != 0; density::g_force_lane_codec = (variant & 16) != 0; }
+void density_hip_set_kernel_variant(int variant) { g_variant = variant;   /* bit 3 (8): encode in batches with the stitch of one batch beside the encoding of the next */ density::g_force_simple = (variant & 1) != 0; density::g_force_pipeline = (variant & 4) != 0; density::g_force_lane_codec = (variant & 16) != 0; density::g_force_wave_codec = (variant & 32) != 0; density::g_stage_audit = (variant & 64) != 0; }
 
 int density_hip_last_timings(float* milliseconds, const char** names, int capacity) {
     int dev = -1;

@@ -363,7 +363,12 @@ struct CheetahLane {
 
 __global__ __launch_bounds__(64) void cheetah_encode_wave(const uint8_t* __restrict__ in, uint64_t total, uint64_t chunk_bytes,
                                                           uint32_t n_chunks, uint8_t* __restrict__ out, uint64_t out_stride,
-                                                          uint64_t* __restrict__ sizes, uint8_t* __restrict__ tables, uint32_t n_slots) {
+                                                          uint64_t* __restrict__ sizes, uint8_t* __restrict__ tables, uint32_t n_slots,
+                                                          const uint32_t* __restrict__ only, uint32_t* __restrict__ head_state, uint32_t head_bytes) {
+    // `only` (nullable): encode just the chunks it marks — the ones exchange_stages.hip hands back (raw copies, a ragged end).
+    // `head_state` (nullable): encode just the first head_bytes of every chunk — where a cold dictionary makes records incompressible and
+    // the blow-up protection copies blocks — and leave the tables (one slot per chunk) and four words per chunk behind: stream bytes so far,
+    // last_hash, FSM (bit 0 penalty running, bit 1 last record incompressible), 1 = not a chunk for the exchange passes (too short, ragged)
     using G = Geo<DENSITY_HIP_CHEETAH>;
     const uint32_t slot = blockIdx.x;
     const uint32_t lane = threadIdx.x;
@@ -377,7 +382,12 @@ __global__ __launch_bounds__(64) void cheetah_encode_wave(const uint8_t* __restr
         const uint8_t* src = in + chunk * chunk_bytes;
         const uint64_t len = (total - chunk * chunk_bytes) < chunk_bytes ? (total - chunk * chunk_bytes) : chunk_bytes;
         uint8_t* dst = out + chunk * out_stride;
-        if (chunk != slot) {                                                  // (the launcher zeroed the tables for the first chunk of a slot)
+        if (only && !only[chunk]) continue;
+        if (head_state && (len % 4096u != 0 || len < 4ull * head_bytes)) {
+            if (lane == 0) head_state[4 * chunk + 3] = 1u;
+            continue;
+        }
+        if (chunk != slot || only || head_state) {                                          // (the launcher zeroed the tables for the first chunk of a slot — not when it filters)
             uint4* p = reinterpret_cast<uint4*>(tables + slot * kTableBytes);
             const uint4 z = make_uint4(0, 0, 0, 0);
             for (uint64_t i = lane; i < kTableBytes / 16; i += 64) p[i] = z;
@@ -387,7 +397,8 @@ __global__ __launch_bounds__(64) void cheetah_encode_wave(const uint8_t* __restr
         Guard guard;
         uint64_t opos = 0, pos = 0;
         uint32_t qnext = (act && G::kBlock <= len) ? ld32u(src + 4u * lane) : 0u;
-        for (; pos + G::kBlock <= len; pos += G::kBlock) {                    // whole blocks
+        const uint64_t run = head_state ? head_bytes : len;
+        for (; pos + G::kBlock <= run; pos += G::kBlock) {                    // whole blocks
             const uint8_t* blk = src + pos;
             if (guard.block_is_copy()) {                                      // codec.rs:35-37
                 if (act) st32u(dst + opos + 4u * lane, qnext);
@@ -454,6 +465,15 @@ __global__ __launch_bounds__(64) void cheetah_encode_wave(const uint8_t* __restr
             opos += rlen;
         }
         tbl_drain();
+        if (head_state) {
+            if (lane == 0) {
+                head_state[4 * chunk + 0] = (uint32_t)opos;
+                head_state[4 * chunk + 1] = last_hash;
+                head_state[4 * chunk + 2] = (guard.penalty ? 1u : 0u) | (guard.prev ? 2u : 0u);
+                head_state[4 * chunk + 3] = 0u;
+            }
+            continue;
+        }
         // ---- the ragged last block: the scalar code on lane 0 (same tables; codec.rs:51-63) ----
         if (pos < len) {
             __threadfence();                                                  // (the scalar code reads the tables with plain loads)
@@ -1023,13 +1043,28 @@ hipError_t launch_serial_encode(int algo, const uint8_t* d_in, uint64_t total, u
     hipError_t e = hipMemsetAsync(d_tables, 0, (size_t)n_slots * serial_table_bytes(algo), stream);
     if (e != hipSuccess) return e;
     if (algo == DENSITY_HIP_CHEETAH && !g_force_lane_codec)
-        hipLaunchKernelGGL(cheetah_encode_wave, dim3(n_slots), dim3(64), 0, stream, d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, n_slots);
+        hipLaunchKernelGGL(cheetah_encode_wave, dim3(n_slots), dim3(64), 0, stream, d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, n_slots, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0u);
     else if (algo == DENSITY_HIP_CHEETAH)
         hipLaunchKernelGGL(serial_encode_chunks<DENSITY_HIP_CHEETAH>, dim3(blocks), dim3(64), 0, stream, d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, n_slots);
     else if (!g_force_lane_codec)
         hipLaunchKernelGGL(lion_encode_wave, dim3(n_slots), dim3(64), 0, stream, d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, n_slots);
     else
         hipLaunchKernelGGL(serial_encode_chunks<DENSITY_HIP_LION>, dim3(blocks), dim3(64), 0, stream, d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, n_slots);
+    return hipGetLastError();
+}
+
+hipError_t launch_cheetah_encode_only(const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_out, uint64_t out_stride,
+                                      uint64_t* d_sizes, uint8_t* d_tables, uint32_t n_slots, const uint32_t* d_only, hipStream_t stream) {
+    if (n_chunks == 0) return hipSuccess;
+    hipLaunchKernelGGL(cheetah_encode_wave, dim3(n_slots), dim3(64), 0, stream, d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, n_slots, d_only,
+                       (uint32_t*)nullptr, 0u);
+    return hipGetLastError();
+}
+hipError_t launch_cheetah_encode_heads(const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_out, uint64_t out_stride,
+                                       uint8_t* d_tables, uint32_t* d_head_state, uint32_t head_bytes, hipStream_t stream) {
+    if (n_chunks == 0) return hipSuccess;
+    hipLaunchKernelGGL(cheetah_encode_wave, dim3(n_chunks), dim3(64), 0, stream, d_in, total, chunk_bytes, n_chunks, d_out, out_stride, (uint64_t*)nullptr, d_tables, n_chunks,
+                       (const uint32_t*)nullptr, d_head_state, head_bytes);
     return hipGetLastError();
 }
 

@@ -161,11 +161,16 @@ int density_hip_last_timings(float* milliseconds, const char** names, int capaci
  * out4[0] streams encoded in parallel segments, [1] passes those encodes took (1 per stream if every speculation held),
  * [2] streams decoded in parallel segments, [3] long streams decoded sequentially (mostly raw copies, or buffers the parallel path does not take). */
 void density_hip_stream_stats(uint64_t* out4);
+/* ... and of Cheetah container encodes under kernel variant bit 64: out2[0] chunks that went through the exchange passes, [1] how many
+ * of them were handed back to the in-order kernel (raw-copy blocks, a ragged end). */
+void density_hip_stage_stats(uint64_t* out2);
 
 /* Test hook, bit mask: 1 = force the simple one-wavefront-per-chunk kernels, 2 = encode containers without the block index,
  * 4 = force the 16-wave role pipelines (chameleon.hip) instead of the default wave-rotation kernels (rotor.hip),
  * 8 = encode in batches with the stitch of one batch beside the encoding of the next, 16 = Cheetah / Lion on the
- * one-lane-per-stream kernels instead of the one-wave-per-stream kernels (serial_codec.hip).
+ * one-lane-per-stream kernels instead of the one-wave-per-stream kernels (serial_codec.hip), 32 = Cheetah containers on the
+ * one-wave-per-stream encoder instead of the exchange passes (exchange_stages.hip), 64 = count the chunks the exchange passes
+ * keep / hand back (density_hip_stage_stats; reads the verdicts back, so the encode call synchronises).
  * Payload bytes are identical in every variant. */
 void density_hip_set_kernel_variant(int variant);
 

@@ -1,5 +1,6 @@
-"""GPU parity tests for Cheetah and Lion (density_amd/csrc/serial_codec.hip) through the same C ABI, bit-exact against the CPU
-oracle: every test runs on the one-wave-per-stream kernels (default) and on the one-lane-per-stream kernels (kernel variant 16)."""
+"""GPU parity tests for Cheetah and Lion (density_amd/csrc/serial_codec.hip, exchange_stages.hip) through the same C ABI, bit-exact
+against the CPU oracle: every test runs on the default kernels (one wave per stream; Cheetah containers encode in passes of ordered
+LDS exchanges), on the one-lane-per-stream kernels (kernel variant 16) and — Cheetah — with the exchange passes off (variant 32)."""
 import hashlib
 import json
 import os
@@ -15,11 +16,14 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 KAT = json.load(open(os.path.join(HERE, "golden", "kat.json")))
 ALGOS = ["cheetah", "lion"]
-VARIANTS = {"wave": 0, "lane": 16}
+VARIANTS = {"default": 0, "lane": 16, "wave": 32}
 
 
 @pytest.fixture(autouse=True, params=list(VARIANTS))
 def kernel_variant(request):
+    params = getattr(getattr(request.node, "callspec", None), "params", {})
+    if request.param == "wave" and params.get("algo", "cheetah") != "cheetah":
+        pytest.skip("variant 32 only changes Cheetah's encoder")
     container.set_kernel_variant(VARIANTS[request.param])
     yield request.param
     container.set_kernel_variant(0)
@@ -138,7 +142,7 @@ def synth_prose_100m():
 
 @pytest.mark.parametrize("algo", ["chameleon", "cheetah", "lion"])
 def test_config34_full_coverage_parity(algo, kernel_variant):
-    if kernel_variant != "wave":
+    if kernel_variant != "default":
         pytest.skip("full-size configs run on the default kernels")
     """BASELINE configs 3 and 4 at full size, at the chunk size the library ships as default: EVERY chunk stream equals the oracle's
     stream of that chunk bit for bit, and decode(container) == input (device-resident, like the bench)."""
@@ -189,3 +193,66 @@ def test_repeated_pairs_inside_a_record(algo):
     want = pyoracle.encode(algo, data)
     assert gpu_encode(algo, data) == want
     assert gpu_decode(algo, want, data.size) == data.tobytes()
+
+
+def stage_stats():
+    import ctypes
+    from density_amd import _lib
+    a = (ctypes.c_uint64 * 2)()
+    _lib.lib().density_hip_stage_stats(a)
+    return list(a)
+
+
+@pytest.mark.parametrize("kind", ["prose", "rep", "zeros", "lowzero", "mixed", "random", "samehash", "binaryish"])
+@pytest.mark.parametrize("chunk", [65536, 262144])
+def test_cheetah_exchange_passes_match_oracle(kind, chunk, kernel_variant):
+    """Cheetah containers at chunk sizes the exchange passes take (64 KiB and up, whole 4 KiB trips): text (the cold-dictionary head of
+    every chunk in order, raw copies and all, the rest in passes), data whose records meet the blow-up protection later on (those
+    chunks are handed back to the in-order kernel), zero quads against empty tables, one-slot pile-ups, a short ragged last chunk —
+    every chunk stream == the oracle's, decode == input; and the passes keep every chunk of calm data."""
+    n = 5 * chunk + 3 * 4096 + 1001
+    data = datagen.by_kind(kind, n, seed=chunk + 7)
+    cont = np.zeros(container.container_bound("cheetah", n, chunk), dtype=np.uint8)
+    if kernel_variant == "default":
+        container.set_kernel_variant(64)                          # audit: count the chunks kept / handed back
+    s0 = stage_stats()
+    cn = container.encode("cheetah", data, cont, chunk)
+    s1 = stage_stats()
+    hdr, payloads = container.chunk_payloads(cont[:cn])
+    assert hdr.n_chunks == 6
+    copies = 0
+    for i, p in enumerate(payloads):
+        want, st = pyoracle.encode_stats("cheetah", data[i * chunk:(i + 1) * chunk])
+        assert p == want, (kind, chunk, i)
+        copies += st["copy_blocks"]
+    if kernel_variant == "default":
+        assert s1[0] - s0[0] == hdr.n_chunks
+        back_to_in_order = s1[1] - s0[1]
+        assert 1 <= back_to_in_order <= hdr.n_chunks               # the short ragged chunk always
+        if kind in ("prose", "rep", "zeros", "lowzero"):
+            assert back_to_in_order == 1                          # raw copies (if any) only while the dictionary is cold: the head's
+        if kind == "random":
+            assert copies > 0 and back_to_in_order == hdr.n_chunks
+    back = np.zeros(n, dtype=np.uint8)
+    assert container.decode(cont[:cn], back) == n
+    assert np.array_equal(back, data)
+
+
+def test_cheetah_exchange_passes_repeats_inside_a_block(kernel_variant):
+    """the same slot many times within one 64-quad exchange, predicted quads rewriting their prediction, chains through A and B"""
+    rng = np.random.default_rng(17)
+    words = rng.integers(0, 2**32, size=9, dtype=np.uint32)
+    words[0] = 0
+    data = words[rng.integers(0, 9, size=3 * 32768)].view(np.uint8)
+    chunk = 131072
+    cont = np.zeros(container.container_bound("cheetah", data.size, chunk), dtype=np.uint8)
+    if kernel_variant == "default":
+        container.set_kernel_variant(64)
+    s0 = stage_stats()
+    cn = container.encode("cheetah", data, cont, chunk)
+    s1 = stage_stats()
+    _, payloads = container.chunk_payloads(cont[:cn])
+    for i, p in enumerate(payloads):
+        assert p == pyoracle.encode("cheetah", data[i * chunk:(i + 1) * chunk]), i
+    if kernel_variant == "default":
+        assert (s1[0] - s0[0], s1[1] - s0[1]) == (len(payloads), 0)
