@@ -79,8 +79,8 @@ __global__ __launch_bounds__(64) void exchange_stage(const uint8_t* __restrict__
     const uint32_t half = blockIdx.x & 1u;
     const uint64_t base = chunk * chunk_bytes;
     const uint64_t len = (total - base) < chunk_bytes ? (total - base) : chunk_bytes;
-    if (head_state[4 * chunk + 3]) return;                                        // too short or ragged: the one-wave kernel takes it whole
-    const uint32_t nb = (uint32_t)(len >> 8);                                     // a multiple of kAhead
+    if (head_state[8 * chunk + 3]) return;                                        // too short: the one-wave kernel takes it whole
+    const uint32_t nb = (uint32_t)(len / kTrip) * kAhead;                         // whole trips; a ragged end is the in-order kernel's again
     const uint64_t gb0 = base >> 8;
     {
         // the table as the head left it (serial_codec.hip: 64 Ki {a, b} pairs, then 64 Ki predictions, per chunk): this half of the slots
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(64) void exchange_stage(const uint8_t* __restrict__
     const uint32_t sink = lds0 + kTable + lane * 4u;
     const uint32_t ones = 0xffffffffu;
 
-    const uint32_t last_hash = head_state[4 * chunk + 1];                         // cheetah.rs:146 as the head left it (its last block may be a raw copy)
+    const uint32_t last_hash = head_state[8 * chunk + 1];                         // cheetah.rs:146 as the head left it (its last block may be a raw copy)
     uint32_t qn[kAhead], pn[kAhead], vn[kAhead];
 #pragma unroll
     for (uint32_t j = 0; j < kAhead; ++j) {
@@ -164,6 +164,19 @@ __global__ __launch_bounds__(64) void exchange_stage(const uint8_t* __restrict__
             }
         }
     }
+    if (len % kTrip) {                                                             // a ragged end follows: the table goes back where it came from
+        __syncthreads();
+        uint8_t* mine_tb = const_cast<uint8_t*>(tables) + chunk * kChunkTables;
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(stage_lds);
+        if (KEY_PREV) {
+            uint4* dst = reinterpret_cast<uint4*>(mine_tb + 65536ull * 8 + (uint64_t)half * kTable);
+            const uint4* p = reinterpret_cast<const uint4*>(stage_lds);
+            for (uint32_t i = lane; i < kTable / 16; i += 64) dst[i] = p[i];
+        } else {
+            uint32_t* dst = reinterpret_cast<uint32_t*>(mine_tb) + (uint64_t)half * kHalfSlots * 2 + (OWN_VALUE ? 0 : 1);
+            for (uint32_t k = lane; k < kHalfSlots; k += 64) dst[2 * k] = w[k];
+        }
+    }
 }
 
 // record sizes of a 64-quad block (two records) from the cumulative masks: predicted quads cost nothing, MAP_A / MAP_B two bytes,
@@ -186,20 +199,21 @@ __device__ __forceinline__ uint32_t record_bytes(const BlockMasks& m, uint32_t r
 constexpr uint32_t kLayoutThreads = 256;
 __global__ __launch_bounds__(kLayoutThreads) void stage_record_layout(uint64_t total, uint64_t chunk_bytes, const uint64_t* __restrict__ done,
                                                                       uint64_t blocks_total, const uint32_t* __restrict__ head_state,
-                                                                      uint32_t* __restrict__ rec_off, uint64_t* __restrict__ sizes,
-                                                                      uint32_t* __restrict__ redo) {
+                                                                      const uint8_t* __restrict__ in, uint32_t* __restrict__ rec_off,
+                                                                      uint64_t* __restrict__ sizes, uint32_t* __restrict__ redo,
+                                                                      uint32_t* __restrict__ tail_state) {
     __shared__ uint32_t s_sum[kLayoutThreads], s_first[kLayoutThreads], s_last[kLayoutThreads];
     const uint32_t t = threadIdx.x;
     const uint64_t chunk = blockIdx.x;
     const uint64_t base = chunk * chunk_bytes;
     const uint64_t len = (total - base) < chunk_bytes ? (total - base) : chunk_bytes;
-    if (head_state[4 * chunk + 3]) { if (t == 0) redo[chunk] = 1u; return; }      // (uniform)
-    const uint32_t nb = (uint32_t)(len >> 8);
+    if (head_state[8 * chunk + 3]) { if (t == 0) { redo[chunk] = 1u; tail_state[8 * chunk + 6] = 0u; } return; }   // (uniform)
+    const uint32_t nb = (uint32_t)(len / kTrip) * kAhead;
     const uint64_t gb0 = base >> 8;
     const uint32_t rest = nb - kHeadBlocks;
     const uint32_t per = (rest + kLayoutThreads - 1) / kLayoutThreads;
     const uint32_t b0 = kHeadBlocks + (t * per < rest ? t * per : rest), b1 = b0 + per < nb ? b0 + per : nb;
-    const uint32_t head_fsm = head_state[4 * chunk + 2];
+    const uint32_t head_fsm = head_state[8 * chunk + 2];
     uint32_t sum = 0, first = 0, last = 0, pair = 0;
     for (uint32_t b = b0; b < b1; ++b) {
         const BlockMasks m = block_masks(done, blocks_total, gb0 + b);
@@ -214,7 +228,7 @@ __global__ __launch_bounds__(kLayoutThreads) void stage_record_layout(uint64_t t
     }
     s_sum[t] = sum; s_first[t] = first; s_last[t] = last;
     __syncthreads();
-    uint32_t off = head_state[4 * chunk + 0];                                      // the head's records are in place
+    uint32_t off = head_state[8 * chunk + 0];                                      // the head's records are in place
     for (uint32_t i = 0; i < t; ++i) off += s_sum[i];
     if (b0 < b1) pair |= s_first[t] & (t ? s_last[t - 1] : (head_fsm >> 1) & 1u);   // (threads with blocks are contiguous from 0, each full but the last)
     if (t == 0) pair |= head_fsm & 1u;                                             // the head ended inside a penalty: its copies are not over
@@ -231,6 +245,28 @@ __global__ __launch_bounds__(kLayoutThreads) void stage_record_layout(uint64_t t
         // see them — the whole chunk is done again by the in-order kernel, which also writes its size
         redo[chunk] = any_pair ? 1u : 0u;
         if (!any_pair) sizes[chunk] = off;
+        // a ragged end: the in-order kernel goes on from here — where the passes stopped, with the FSM as the calm blocks in between
+        // leave it (protection_state.rs:19-27: the counter runs, penalty_start halves every 16 blocks; no penalty was started)
+        const bool ragged = !any_pair && (len % kTrip) != 0;
+        uint32_t* ts = tail_state + 8 * chunk;
+        ts[6] = ragged ? 1u : 0u;
+        if (ragged) {
+            uint32_t start = head_state[8 * chunk + 4], counter = head_state[8 * chunk + 5];
+            for (uint32_t r = 2 * kHeadBlocks; r < 2 * nb; ++r) {
+                if (start == 1) { counter += 2 * nb - r; break; }                  // (only the counter's low four bits matter from here on)
+                if ((counter & 0xfu) == 0) start >>= 1;
+                ++counter;
+            }
+            // (thread 255 owns the last blocks, or none: the last record's verdict is the last one anybody saw)
+            uint32_t prev = last;
+            if (b0 >= b1) for (uint32_t i = kLayoutThreads - 1; i-- > 0;) if (s_sum[i]) { prev = s_last[i]; break; }
+            ts[0] = nb * 256u;
+            ts[1] = off;
+            ts[2] = hash16(reinterpret_cast<const uint32_t*>(in + base)[nb * 64u - 1]);   // cheetah.rs:146
+            ts[3] = prev;
+            ts[4] = start;
+            ts[5] = counter;
+        }
     }
 }
 
@@ -256,7 +292,10 @@ __global__ __launch_bounds__(kEmitWaves * 64) void stage_emit_records(const uint
     const uint64_t gb = (uint64_t)blockIdx.x * kEmitWaves + (threadIdx.x >> 6);
     if (gb * 256 + 256 > total) return;                                           // (a ragged end belongs to a chunk that is done again)
     const uint64_t chunk = (gb * 256) / chunk_bytes;
-    if (redo[chunk] || gb - chunk * (chunk_bytes >> 8) < kHeadBlocks) return;
+    const uint64_t base = chunk * chunk_bytes;
+    const uint64_t len = (total - base) < chunk_bytes ? (total - base) : chunk_bytes;
+    const uint64_t bw = gb - chunk * (chunk_bytes >> 8);
+    if (redo[chunk] || bw < kHeadBlocks || bw >= (len / kTrip) * kAhead) return;  // (the head and a ragged end are the in-order kernel's)
     const BlockMasks m = block_masks(done, blocks_total, gb);
     const uint32_t q = reinterpret_cast<const uint32_t*>(in)[gb * 64 + lane];
     const uint32_t r = lane >> 5, k = lane & 31u;
@@ -288,7 +327,7 @@ bool stage_encode_eligible(int algo, const uint8_t* d_in, uint64_t total, uint64
 // vals (a dword per quad) | done masks (3 stages x 2 halves x a qword per 64-quad block) | record offsets | per-chunk verdicts
 uint64_t stage_scratch_bytes(uint64_t total, uint32_t n_chunks) {
     const uint64_t blocks = (total + 255) / 256;
-    return ((total + 255) & ~255ull) + blocks * (6 * 8 + 2 * 4) + (((uint64_t)n_chunks * (4 + 16) + 255) & ~255ull) + 256;
+    return ((total + 255) & ~255ull) + blocks * (6 * 8 + 2 * 4) + (((uint64_t)n_chunks * (4 + 32 + 32) + 255) & ~255ull) + 256;
 }
 
 hipError_t launch_stage_encode(const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_out, uint64_t out_stride,
@@ -299,6 +338,7 @@ hipError_t launch_stage_encode(const uint8_t* d_in, uint64_t total, uint64_t chu
     uint32_t* rec_off = reinterpret_cast<uint32_t*>(done + 6 * blocks);
     uint32_t* redo = rec_off + 2 * blocks;
     uint32_t* head_state = redo + n_chunks;
+    uint32_t* tail_state = head_state + 8 * (size_t)n_chunks;
     auto stage_p = exchange_stage<true, true, false>, stage_a = exchange_stage<false, true, true>, stage_b = exchange_stage<false, false, false>;
     hipError_t e = hipFuncSetAttribute((const void*)stage_p, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStageLds);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)stage_a, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStageLds);
@@ -313,10 +353,11 @@ hipError_t launch_stage_encode(const uint8_t* d_in, uint64_t total, uint64_t chu
     hipLaunchKernelGGL(stage_p, grid, wave, kStageLds, stream, d_in, total, chunk_bytes, (const uint64_t*)nullptr, done, vals, blocks, tb, hs);
     hipLaunchKernelGGL(stage_a, grid, wave, kStageLds, stream, d_in, total, chunk_bytes, (const uint64_t*)done, done + 2 * blocks, vals, blocks, tb, hs);
     hipLaunchKernelGGL(stage_b, grid, wave, kStageLds, stream, d_in, total, chunk_bytes, (const uint64_t*)(done + 2 * blocks), done + 4 * blocks, vals, blocks, tb, hs);
-    hipLaunchKernelGGL(stage_record_layout, dim3(n_chunks), dim3(kLayoutThreads), 0, stream, total, chunk_bytes, (const uint64_t*)done, blocks, hs, rec_off, d_sizes, redo);
+    hipLaunchKernelGGL(stage_record_layout, dim3(n_chunks), dim3(kLayoutThreads), 0, stream, total, chunk_bytes, (const uint64_t*)done, blocks, hs, d_in, rec_off, d_sizes, redo, tail_state);
     hipLaunchKernelGGL(stage_emit_records, dim3((uint32_t)((blocks + kEmitWaves - 1) / kEmitWaves)), dim3(kEmitWaves * 64), 0, stream, d_in, total, chunk_bytes,
                        (const uint64_t*)done, blocks, (const uint32_t*)rec_off, (const uint32_t*)redo, d_out, out_stride);
     e = hipGetLastError();
+    if (e == hipSuccess) e = launch_cheetah_encode_tails(d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, tail_state, stream);
     if (e != hipSuccess) return e;
     if (g_stage_audit) {                                                           // tests and profiles: how many chunks the passes kept
         std::vector<uint32_t> verdicts(n_chunks);

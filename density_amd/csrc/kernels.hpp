@@ -75,9 +75,13 @@ hipError_t launch_serial_decode(int algo, const uint8_t* d_in, const uint64_t* d
 hipError_t launch_cheetah_encode_only(const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_out, uint64_t out_stride,
                                       uint64_t* d_sizes, uint8_t* d_tables, uint32_t n_slots, const uint32_t* d_only, hipStream_t stream);
 
-// ... and just the first head_bytes of every chunk, tables (one slot per chunk: n_chunks x serial_table_bytes) and d_head_state (4 words per chunk) left behind
+// ... and just the first head_bytes of every chunk, tables (one slot per chunk: n_chunks x serial_table_bytes) and d_head_state (8 words per chunk) left behind
 hipError_t launch_cheetah_encode_heads(const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_out, uint64_t out_stride,
                                        uint8_t* d_tables, uint32_t* d_head_state, uint32_t head_bytes, hipStream_t stream);
+
+// ... and just the ragged end of the chunks d_tail_state marks (8 words per chunk), from the tables the passes wrote back
+hipError_t launch_cheetah_encode_tails(const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_out, uint64_t out_stride,
+                                       uint64_t* d_sizes, uint8_t* d_tables, const uint32_t* d_tail_state, hipStream_t stream);
 
 // ---- exchange_stages.hip (Cheetah encode, the default: three passes of ordered LDS exchanges per chunk, then a size scan and the records) ----
 extern bool g_force_wave_codec;   // density_hip_set_kernel_variant(32): the one-wave-per-stream Cheetah encoder instead

@@ -364,11 +364,16 @@ struct CheetahLane {
 __global__ __launch_bounds__(64) void cheetah_encode_wave(const uint8_t* __restrict__ in, uint64_t total, uint64_t chunk_bytes,
                                                           uint32_t n_chunks, uint8_t* __restrict__ out, uint64_t out_stride,
                                                           uint64_t* __restrict__ sizes, uint8_t* __restrict__ tables, uint32_t n_slots,
-                                                          const uint32_t* __restrict__ only, uint32_t* __restrict__ head_state, uint32_t head_bytes) {
+                                                          const uint32_t* __restrict__ only, uint32_t* __restrict__ head_state, uint32_t head_bytes,
+                                                          const uint32_t* __restrict__ tail_state) {
     // `only` (nullable): encode just the chunks it marks — the ones exchange_stages.hip hands back (raw copies, a ragged end).
     // `head_state` (nullable): encode just the first head_bytes of every chunk — where a cold dictionary makes records incompressible and
     // the blow-up protection copies blocks — and leave the tables (one slot per chunk) and four words per chunk behind: stream bytes so far,
-    // last_hash, FSM (bit 0 penalty running, bit 1 last record incompressible), 1 = not a chunk for the exchange passes (too short, ragged)
+    // last_hash, FSM (bit 0 penalty running, bit 1 last record incompressible), 1 = not a chunk for the exchange passes (too short), and the
+    // FSM's penalty_start and block counter.
+    // `tail_state` (nullable): encode just the ragged end of the chunks it marks, from where the passes stopped — eight words per chunk:
+    // input offset, stream bytes so far, last_hash, last record incompressible, penalty_start, counter, 1 = there is an end to do; the
+    // tables (one slot per chunk) are as the passes left them
     using G = Geo<DENSITY_HIP_CHEETAH>;
     const uint32_t slot = blockIdx.x;
     const uint32_t lane = threadIdx.x;
@@ -383,11 +388,12 @@ __global__ __launch_bounds__(64) void cheetah_encode_wave(const uint8_t* __restr
         const uint64_t len = (total - chunk * chunk_bytes) < chunk_bytes ? (total - chunk * chunk_bytes) : chunk_bytes;
         uint8_t* dst = out + chunk * out_stride;
         if (only && !only[chunk]) continue;
-        if (head_state && (len % 4096u != 0 || len < 4ull * head_bytes)) {
-            if (lane == 0) head_state[4 * chunk + 3] = 1u;
+        if (tail_state && !tail_state[8 * chunk + 6]) continue;
+        if (head_state && len < 4ull * head_bytes) {
+            if (lane == 0) head_state[8 * chunk + 3] = 1u;
             continue;
         }
-        if (chunk != slot || only || head_state) {                                          // (the launcher zeroed the tables for the first chunk of a slot — not when it filters)
+        if ((chunk != slot || only || head_state) && !tail_state) {                                          // (the launcher zeroed the tables for the first chunk of a slot — not when it filters)
             uint4* p = reinterpret_cast<uint4*>(tables + slot * kTableBytes);
             const uint4 z = make_uint4(0, 0, 0, 0);
             for (uint64_t i = lane; i < kTableBytes / 16; i += 64) p[i] = z;
@@ -396,7 +402,12 @@ __global__ __launch_bounds__(64) void cheetah_encode_wave(const uint8_t* __restr
         uint32_t last_hash = 0;
         Guard guard;
         uint64_t opos = 0, pos = 0;
-        uint32_t qnext = (act && G::kBlock <= len) ? ld32u(src + 4u * lane) : 0u;
+        if (tail_state) {
+            const uint32_t* ts = tail_state + 8 * chunk;
+            pos = ts[0]; opos = ts[1]; last_hash = ts[2];
+            guard.prev = ts[3]; guard.start = ts[4]; guard.counter = ts[5];
+        }
+        uint32_t qnext = (act && pos + G::kBlock <= len) ? ld32u(src + pos + 4u * lane) : 0u;
         const uint64_t run = head_state ? head_bytes : len;
         for (; pos + G::kBlock <= run; pos += G::kBlock) {                    // whole blocks
             const uint8_t* blk = src + pos;
@@ -467,10 +478,12 @@ __global__ __launch_bounds__(64) void cheetah_encode_wave(const uint8_t* __restr
         tbl_drain();
         if (head_state) {
             if (lane == 0) {
-                head_state[4 * chunk + 0] = (uint32_t)opos;
-                head_state[4 * chunk + 1] = last_hash;
-                head_state[4 * chunk + 2] = (guard.penalty ? 1u : 0u) | (guard.prev ? 2u : 0u);
-                head_state[4 * chunk + 3] = 0u;
+                head_state[8 * chunk + 0] = (uint32_t)opos;
+                head_state[8 * chunk + 1] = last_hash;
+                head_state[8 * chunk + 2] = (guard.penalty ? 1u : 0u) | (guard.prev ? 2u : 0u);
+                head_state[8 * chunk + 3] = 0u;
+                head_state[8 * chunk + 4] = guard.start;
+                head_state[8 * chunk + 5] = guard.counter;
             }
             continue;
         }
@@ -1043,7 +1056,7 @@ hipError_t launch_serial_encode(int algo, const uint8_t* d_in, uint64_t total, u
     hipError_t e = hipMemsetAsync(d_tables, 0, (size_t)n_slots * serial_table_bytes(algo), stream);
     if (e != hipSuccess) return e;
     if (algo == DENSITY_HIP_CHEETAH && !g_force_lane_codec)
-        hipLaunchKernelGGL(cheetah_encode_wave, dim3(n_slots), dim3(64), 0, stream, d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, n_slots, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0u);
+        hipLaunchKernelGGL(cheetah_encode_wave, dim3(n_slots), dim3(64), 0, stream, d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, n_slots, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (const uint32_t*)nullptr);
     else if (algo == DENSITY_HIP_CHEETAH)
         hipLaunchKernelGGL(serial_encode_chunks<DENSITY_HIP_CHEETAH>, dim3(blocks), dim3(64), 0, stream, d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, n_slots);
     else if (!g_force_lane_codec)
@@ -1057,14 +1070,21 @@ hipError_t launch_cheetah_encode_only(const uint8_t* d_in, uint64_t total, uint6
                                       uint64_t* d_sizes, uint8_t* d_tables, uint32_t n_slots, const uint32_t* d_only, hipStream_t stream) {
     if (n_chunks == 0) return hipSuccess;
     hipLaunchKernelGGL(cheetah_encode_wave, dim3(n_slots), dim3(64), 0, stream, d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, n_slots, d_only,
-                       (uint32_t*)nullptr, 0u);
+                       (uint32_t*)nullptr, 0u, (const uint32_t*)nullptr);
     return hipGetLastError();
 }
 hipError_t launch_cheetah_encode_heads(const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_out, uint64_t out_stride,
                                        uint8_t* d_tables, uint32_t* d_head_state, uint32_t head_bytes, hipStream_t stream) {
     if (n_chunks == 0) return hipSuccess;
     hipLaunchKernelGGL(cheetah_encode_wave, dim3(n_chunks), dim3(64), 0, stream, d_in, total, chunk_bytes, n_chunks, d_out, out_stride, (uint64_t*)nullptr, d_tables, n_chunks,
-                       (const uint32_t*)nullptr, d_head_state, head_bytes);
+                       (const uint32_t*)nullptr, d_head_state, head_bytes, (const uint32_t*)nullptr);
+    return hipGetLastError();
+}
+hipError_t launch_cheetah_encode_tails(const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_out, uint64_t out_stride,
+                                       uint64_t* d_sizes, uint8_t* d_tables, const uint32_t* d_tail_state, hipStream_t stream) {
+    if (n_chunks == 0) return hipSuccess;
+    hipLaunchKernelGGL(cheetah_encode_wave, dim3(n_chunks), dim3(64), 0, stream, d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, n_chunks,
+                       (const uint32_t*)nullptr, (uint32_t*)nullptr, 0u, d_tail_state);
     return hipGetLastError();
 }
 

@@ -256,3 +256,27 @@ def test_cheetah_exchange_passes_repeats_inside_a_block(kernel_variant):
         assert p == pyoracle.encode("cheetah", data[i * chunk:(i + 1) * chunk]), i
     if kernel_variant == "default":
         assert (s1[0] - s0[0], s1[1] - s0[1]) == (len(payloads), 0)
+
+
+@pytest.mark.parametrize("kind", ["prose", "rep", "mixed", "zeros"])
+@pytest.mark.parametrize("ragged", [70 * 1024 + 1001, 64 * 1024 + 4096 - 1, 100 * 1024 + 128, 65536 + 2])
+def test_cheetah_exchange_passes_ragged_end(kind, ragged, kernel_variant):
+    """A last chunk that is not whole 4 KiB trips: the passes take its whole trips, write their tables back, and the in-order kernel goes
+    on from there (blow-up protection counters advanced over the calm blocks in between) — no chunk is handed back for calm data."""
+    chunk = 131072
+    n = 2 * chunk + ragged
+    data = datagen.by_kind(kind, n, seed=ragged)
+    cont = np.zeros(container.container_bound("cheetah", n, chunk), dtype=np.uint8)
+    if kernel_variant == "default":
+        container.set_kernel_variant(64)
+    s0 = stage_stats()
+    cn = container.encode("cheetah", data, cont, chunk)
+    s1 = stage_stats()
+    _, payloads = container.chunk_payloads(cont[:cn])
+    for i, p in enumerate(payloads):
+        assert p == pyoracle.encode("cheetah", data[i * chunk:(i + 1) * chunk]), (kind, ragged, i)
+    if kernel_variant == "default" and kind != "mixed":
+        assert (s1[0] - s0[0], s1[1] - s0[1]) == (3, 0)
+    back = np.zeros(n, dtype=np.uint8)
+    assert container.decode(cont[:cn], back) == n
+    assert np.array_equal(back, data)
