@@ -179,8 +179,8 @@ EncodePlan plan_encode(int algo, size_t n, size_t chunk) {
     p.off_tables = p.off_slots + (p.n_chunks > 1 ? p.n_chunks * p.stride : 0);   // one chunk encodes straight into the container
     p.off_zmap = p.off_tables + serial_tables(algo, p.n_chunks ? p.n_chunks : 1);
     p.off_stage = p.off_zmap + zmap_bytes(algo, p.n_chunks);
-    // Cheetah's exchange passes (exchange_stages.hip): a dword per quad, the per-block masks, the record offsets
-    p.total = p.off_stage + (algo == DENSITY_HIP_CHEETAH && chunk % 256 == 0 ? align_up(stage_scratch_bytes(n, (uint32_t)p.n_chunks), kAlign) : 0);
+    // the exchange passes of Cheetah / Lion (exchange_stages.hip): a dword per quad, the per-block masks, the record offsets
+    p.total = p.off_stage + (algo != DENSITY_HIP_CHAMELEON && chunk % 4096 == 0 ? align_up(stage_scratch_bytes(algo, n, (uint32_t)p.n_chunks), kAlign) : 0);
     return p;
 }
 struct DecodePlan {
@@ -202,8 +202,8 @@ DecodePlan plan_decode(int algo, size_t n_chunks) {
 hipError_t codec_encode(int algo, const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_out,
                         uint64_t out_stride, uint64_t* d_sizes, uint8_t* d_index, uint8_t* d_tables, uint32_t* d_zmap, uint8_t* d_stage, uint32_t* d_err, hipStream_t s) {
     if (algo == DENSITY_HIP_CHAMELEON) return launch_chameleon_encode(d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_index, d_zmap, d_err, s);
-    if (d_stage && stage_encode_eligible(algo, d_in, total, chunk_bytes, n_chunks))   // Cheetah: passes of ordered LDS exchanges, the one-wave kernel for what they hand back
-        return launch_stage_encode(d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, (uint32_t)serial_slots(algo, n_chunks), d_stage, s);
+    if (d_stage && stage_encode_eligible(algo, d_in, total, chunk_bytes, n_chunks))   // Cheetah / Lion: passes of ordered LDS exchanges, the one-wave kernels for what they hand back
+        return launch_stage_encode(algo, d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, (uint32_t)serial_slots(algo, n_chunks), d_stage, s);
     return launch_serial_encode(algo, d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, (uint32_t)serial_slots(algo, n_chunks), s);
 }
 hipError_t codec_decode(int algo, const uint8_t* d_in, const uint64_t* d_offsets, const uint64_t* d_sizes, uint32_t n_chunks, uint8_t* d_out,

@@ -1,24 +1,33 @@
-// exchange_stages.hip — Cheetah ENCODING as passes of ordered LDS exchanges (gfx950).
+// exchange_stages.hip — Cheetah and Lion container ENCODING as passes of ordered LDS exchanges (gfx950).
 //
-// The reference walks a chunk quad by quad through three tables (cheetah.rs:123-149).  Every one of those table steps is an
-// unconditional EXCHANGE once it is known which quads take part:
+// The reference walks a chunk quad by quad through three tables (cheetah.rs:123-149) or seven (lion.rs:211-270).  Every one of those
+// table steps is an unconditional EXCHANGE once it is known which quads take part:
 //
-//   P   old = xchg(pred[h(q[i-1])], q[i])   every quad;             predicted <=> old == q[i]   (a hit rewrites what is there)
-//   A   old = xchg(a[h(q[i])], q[i])        the quads P missed;     MAP_A     <=> old == q[i]
-//   B   old = xchg(b[h(q[i])], old_A)       the quads A missed too; MAP_B     <=> old == q[i]   (cheetah.rs:140-141: b = a, a = quad)
+//   Cheetah  P   old = xchg(pred[h(q[i-1])], q[i])   every quad;             predicted <=> old == q[i]   (a hit rewrites what is there)
+//            A   old = xchg(a[h(q[i])], q[i])        the quads P missed;     MAP_A     <=> old == q[i]
+//            B   old = xchg(b[h(q[i])], old_A)       the quads A missed too; MAP_B     <=> old == q[i]   (cheetah.rs:140-141: b = a, a = quad)
+//   Lion     P0..P4: the five-deep move-to-front list per predictor slot (lion.rs:50-57, 240-262) is a chain of five such exchanges —
+//            level k takes in what level k-1 displaced and the chain stops where it finds the quad — then A and B as above.
 //
 // so a stage can run over the WHOLE chunk before the next one starts, and a stage is "one table, the taking-part quads in stream
 // order": what ds_mskor_rtn_b32 does for 64 quads in one instruction (ascending-lane service order, verified at start-up —
 // rotor.hip::rotor_selftest_kernel; with a full mask it is an exchange).  A table of 64 Ki dwords does not fit the LDS, a half does:
 // one work-group per (chunk, half of the slots) streams the chunk and exchanges the quads whose slot falls in its half, the others
-// exchange into a sink word of their own.  Three launches, 2 x n_chunks work-groups each, no table in global memory, no dependent
-// memory round trip per record; then the record sizes are scanned per chunk and the records written by as many waves as there are
-// 256-byte blocks.  (tools/exchange_stage_model.py restates this in Python; tests/test_exchange_stage_model.py checks it against the
-// oracle, Lion's seven-stage form included.)
+// exchange into a sink word of their own.  Three / seven launches, 2 x n_chunks work-groups each, no dependent memory round trip per
+// record; then the record sizes are scanned per chunk and the records written by as many waves as there are 256-byte blocks.
+// (tools/exchange_stage_model.py restates this in Python; tests/test_exchange_stage_model.py checks it against the oracle.)
 //
-// What the passes cannot know is the blow-up protection (codec.rs:35-37): a raw-copy block takes its quads out of every table.
-// They run as if there were none; the size scan sees whether two incompressible records ever meet (protection_state.rs:38-47), and
-// such a chunk — and a ragged last chunk — is encoded by the one-wave-per-stream kernel of serial_codec.hip instead (`only` filter).
+// What the passes cannot know is the blow-up protection (codec.rs:35-37): a raw-copy block takes its quads out of every table, and
+// whether a block is copied depends on the sizes of the records before it.  Raw copies cluster where the dictionary is cold — the
+// first KiBs of every chunk — so:
+//   * the HEAD of every chunk is encoded in order by the one-wave kernel of serial_codec.hip — at least 16 KiB (Cheetah) / 48 KiB (Lion),
+//     and on to the first 4 KiB boundary where no block has been copied for 16 / 32 KiB (a chunk too short for that, or still restless
+//     at its middle, is simply finished there; the numbers: no late raw copy in 100 MB of prose and 64 MB of repetitive text) — which leaves its tables in global memory; the stages load their half of their table
+//     from there instead of starting from zeros;
+//   * behind the head the passes run as if no block were copied; the size scan sees whether two incompressible records ever meet
+//     (protection_state.rs:38-47) — such a chunk is done again, whole, by the in-order kernel (`only` filter);
+//   * a RAGGED END (a chunk that is not whole 4 KiB trips) goes back to the in-order kernel as well, but only the end: the stages
+//     write their tables back, the size scan advances the FSM counters over the calm blocks, the wave resumes from there.
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -38,11 +47,18 @@ constexpr uint32_t kTable = kHalfSlots * 4;              // 128 KiB of dwords
 constexpr uint32_t kStageLds = kTable + 64 * 4;          // + a sink word per lane for the quads of the other half / of earlier stages
 constexpr uint32_t kBatch = 8;                           // blocks of 64 quads per exchange batch (one asm statement)
 constexpr uint32_t kAhead = 2 * kBatch;                  // blocks per loop trip = blocks in flight from memory
-constexpr uint32_t kTrip = kAhead * 256;                    // bytes per loop trip: chunks are whole trips (a ragged one is handed back)
-constexpr uint32_t kHeadBytes = 4 * kTrip;               // the in-order head of every chunk (cold dictionary: incompressible records, raw copies)
-constexpr uint32_t kHeadBlocks = kHeadBytes / 256;
-constexpr uint64_t kChunkTables = 65536ull * 12;         // serial_codec.hip: per chunk 64 Ki {a, b} pairs, then 64 Ki predictions
-constexpr uint32_t kRec = 128;                           // cheetah.rs:188-196: 32 quads per signature
+constexpr uint32_t kTrip = kAhead * 256;                 // bytes per loop trip: the passes cover whole trips
+
+// per algorithm: stages, record geometry (cheetah.rs:17-23,188-196; lion.rs:17-27,317-325), the in-order head, the table slot of serial_codec.hip
+template <int ALGO> struct StageGeo;
+template <> struct StageGeo<DENSITY_HIP_CHEETAH> {
+    static constexpr uint32_t kStages = 3, kRecQuads = 32, kSig = 8, kRec = 128, kHeadBytes = 4 * kTrip, kHeadCalm = 4 * kTrip;
+    static constexpr uint64_t kChunkTables = 65536ull * (8 + 4);
+};
+template <> struct StageGeo<DENSITY_HIP_LION> {
+    static constexpr uint32_t kStages = 7, kRecQuads = 16, kSig = 6, kRec = 64, kHeadBytes = 12 * kTrip, kHeadCalm = 8 * kTrip;
+    static constexpr uint64_t kChunkTables = 65536ull * (8 + 20);
+};
 
 __device__ __forceinline__ uint32_t hash16(uint32_t q) { return (q * kHashMul) >> 16; }
 
@@ -63,39 +79,36 @@ __device__ __forceinline__ uint32_t hash16(uint32_t q) { return (q * kHashMul) >
           "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(ones)                       \
         : "memory")
 
+// where a stage's table lives in the chunk's table slot of serial_codec.hip (64 Ki {a, b} pairs, then 64 Ki x 1 or 5 predictions):
+// byte offset of slot 0's word and the stride from slot to slot
+struct StagePlace { uint64_t chunk_tables; uint32_t offset, stride; };
+
 // One stage over one chunk for one half of the slots.
-//   KEY_PREV   the slot is the hash of the quad BEFORE (P) / of the quad itself (A, B)
-//   OWN_VALUE  the value exchanged in is the quad (P, A) / what the previous stage displaced (B: vals[])
-//   KEEP_OLD   the displaced value is kept in vals[] for the next stage (A)
+//   KEY_PREV    the slot is the hash of the quad BEFORE (the predictor levels) / of the quad itself (A, B)
+//   OWN_VALUE   the value exchanged in is the quad (first predictor level, A) / what the previous stage displaced (vals[])
+//   KEEP_OLD    the displaced value is kept in vals[] for the next stage
+//   HAS_BEFORE  not the first stage: the quads an earlier stage settled take no part
 // done_prev / done_out: per 64-quad block of the whole input and per half, "quad settled by this stage or an earlier one"
-// (cumulative; a reader ORs the two halves).  Quads settled earlier take no part.
-template <bool KEY_PREV, bool OWN_VALUE, bool KEEP_OLD>
+// (cumulative; a reader ORs the two halves).
+template <bool KEY_PREV, bool OWN_VALUE, bool KEEP_OLD, bool HAS_BEFORE>
 __global__ __launch_bounds__(64) void exchange_stage(const uint8_t* __restrict__ in, uint64_t total, uint64_t chunk_bytes,
                                                      const uint64_t* __restrict__ done_prev, uint64_t* __restrict__ done_out,
-                                                     uint32_t* __restrict__ vals, uint64_t blocks_total, const uint8_t* __restrict__ tables,
-                                                     const uint32_t* __restrict__ head_state) {
+                                                     uint32_t* __restrict__ vals, uint64_t blocks_total, uint8_t* __restrict__ tables,
+                                                     const uint32_t* __restrict__ head_state, StagePlace place) {
     const uint32_t lane = threadIdx.x;
     const uint64_t chunk = blockIdx.x >> 1;
     const uint32_t half = blockIdx.x & 1u;
     const uint64_t base = chunk * chunk_bytes;
     const uint64_t len = (total - base) < chunk_bytes ? (total - base) : chunk_bytes;
-    if (head_state[8 * chunk + 3]) return;                                        // too short: the one-wave kernel takes it whole
+    if (head_state[8 * chunk + 3]) return;                                        // short or restless: the one-wave kernel has finished it
     const uint32_t nb = (uint32_t)(len / kTrip) * kAhead;                         // whole trips; a ragged end is the in-order kernel's again
     const uint64_t gb0 = base >> 8;
+    uint8_t* mine_tb = tables + chunk * place.chunk_tables + place.offset + (uint64_t)half * kHalfSlots * place.stride;
     {
-        // the table as the head left it (serial_codec.hip: 64 Ki {a, b} pairs, then 64 Ki predictions, per chunk): this half of the slots
-        const uint8_t* mine_tb = tables + chunk * kChunkTables;
+        // the table as the head left it: this half of the slots
         uint32_t* w = reinterpret_cast<uint32_t*>(stage_lds);
-        if (KEY_PREV) {
-            const uint4* src = reinterpret_cast<const uint4*>(mine_tb + 65536ull * 8 + (uint64_t)half * kTable);
-            uint4* p = reinterpret_cast<uint4*>(stage_lds);
 #pragma unroll 8
-            for (uint32_t i = lane; i < kTable / 16; i += 64) p[i] = src[i];
-        } else {
-            const uint2* src = reinterpret_cast<const uint2*>(mine_tb) + (uint64_t)half * kHalfSlots;
-#pragma unroll 8
-            for (uint32_t k = lane; k < kHalfSlots; k += 64) { const uint2 e = src[k]; w[k] = OWN_VALUE ? e.x : e.y; }
-        }
+        for (uint32_t k = lane; k < kHalfSlots; k += 64) w[k] = *reinterpret_cast<const uint32_t*>(mine_tb + (uint64_t)k * place.stride);
         w[kHalfSlots + lane] = 0u;                                                // the sinks
         __syncthreads();
     }
@@ -107,27 +120,28 @@ __global__ __launch_bounds__(64) void exchange_stage(const uint8_t* __restrict__
     const uint32_t lds0 = lds_addr(stage_lds);
     const uint32_t sink = lds0 + kTable + lane * 4u;
     const uint32_t ones = 0xffffffffu;
+    const uint32_t hb = head_state[8 * chunk + 6] >> 8;                           // blocks of the in-order head (whole trips)
 
-    const uint32_t last_hash = head_state[8 * chunk + 1];                         // cheetah.rs:146 as the head left it (its last block may be a raw copy)
+    const uint32_t last_hash = head_state[8 * chunk + 1];                         // cheetah.rs:146 / lion.rs:268 as the head left it (its last block may be a raw copy)
     uint32_t qn[kAhead], pn[kAhead], vn[kAhead];
 #pragma unroll
     for (uint32_t j = 0; j < kAhead; ++j) {
-        const uint32_t i = (kHeadBlocks + j) * 64u + lane;
+        const uint32_t i = (hb + j) * 64u + lane;
         qn[j] = q32[i];
         pn[j] = KEY_PREV ? q32[i - 1] : 0u;
         vn[j] = !OWN_VALUE ? v32[i] : 0u;
     }
-    for (uint32_t g = kHeadBlocks; g < nb; g += kAhead) {
+    for (uint32_t g = hb; g < nb; g += kAhead) {
         uint32_t q[kAhead], key[kAhead], val[kAhead];
         uint64_t before[kAhead];
 #pragma unroll
         for (uint32_t j = 0; j < kAhead; ++j) {
             q[j] = qn[j];
             val[j] = OWN_VALUE ? qn[j] : vn[j];
-            // slot: cheetah.rs:125 (the predictor is addressed by the previous quad's hash) / :131
+            // slot: cheetah.rs:125 / lion.rs:213 (the predictor is addressed by the previous quad's hash), cheetah.rs:131 / lion.rs:245
             key[j] = KEY_PREV ? hash16(pn[j]) : hash16(qn[j]);
         }
-        if (KEY_PREV && g == kHeadBlocks && lane == 0) key[0] = last_hash;
+        if (KEY_PREV && g == hb && lane == 0) key[0] = last_hash;
         {                                                                          // the next trip's quads: in flight across this one
             const uint32_t gn = g + kAhead < nb ? g + kAhead : g;                  // (the last trip loads itself again: no branch, nothing out of bounds)
 #pragma unroll
@@ -139,7 +153,7 @@ __global__ __launch_bounds__(64) void exchange_stage(const uint8_t* __restrict__
             }
         }
 #pragma unroll
-        for (uint32_t j = 0; j < kAhead; ++j) before[j] = KEY_PREV ? 0ull : (before0[g + j] | before1[g + j]);   // (P is the first stage)
+        for (uint32_t j = 0; j < kAhead; ++j) before[j] = HAS_BEFORE ? (before0[g + j] | before1[g + j]) : 0ull;
 #pragma unroll
         for (uint32_t s = 0; s < kAhead; s += kBatch) {
             uint32_t addr[kBatch], put[kBatch], old[kBatch];
@@ -166,60 +180,62 @@ __global__ __launch_bounds__(64) void exchange_stage(const uint8_t* __restrict__
     }
     if (len % kTrip) {                                                             // a ragged end follows: the table goes back where it came from
         __syncthreads();
-        uint8_t* mine_tb = const_cast<uint8_t*>(tables) + chunk * kChunkTables;
         const uint32_t* w = reinterpret_cast<const uint32_t*>(stage_lds);
-        if (KEY_PREV) {
-            uint4* dst = reinterpret_cast<uint4*>(mine_tb + 65536ull * 8 + (uint64_t)half * kTable);
-            const uint4* p = reinterpret_cast<const uint4*>(stage_lds);
-            for (uint32_t i = lane; i < kTable / 16; i += 64) dst[i] = p[i];
-        } else {
-            uint32_t* dst = reinterpret_cast<uint32_t*>(mine_tb) + (uint64_t)half * kHalfSlots * 2 + (OWN_VALUE ? 0 : 1);
-            for (uint32_t k = lane; k < kHalfSlots; k += 64) dst[2 * k] = w[k];
-        }
+        for (uint32_t k = lane; k < kHalfSlots; k += 64) *reinterpret_cast<uint32_t*>(mine_tb + (uint64_t)k * place.stride) = w[k];
     }
 }
 
-// record sizes of a 64-quad block (two records) from the cumulative masks: predicted quads cost nothing, MAP_A / MAP_B two bytes,
-// plain quads four (cheetah.rs:123-149), behind an 8-byte signature
-struct BlockMasks { uint64_t p, a, b; };
-__device__ __forceinline__ BlockMasks block_masks(const uint64_t* __restrict__ done, uint64_t blocks_total, uint64_t gb) {
-    BlockMasks m;
-    m.p = done[gb] | done[blocks_total + gb];
-    m.a = done[2 * blocks_total + gb] | done[3 * blocks_total + gb];
-    m.b = done[4 * blocks_total + gb] | done[5 * blocks_total + gb];
-    return m;
-}
-__device__ __forceinline__ uint32_t record_bytes(const BlockMasks& m, uint32_t r) {
-    const uint32_t p = (uint32_t)(m.p >> (32 * r)), b = (uint32_t)(m.b >> (32 * r));
-    const uint32_t plain = 32u - (uint32_t)__builtin_popcount(b), maps = (uint32_t)__builtin_popcount(b) - (uint32_t)__builtin_popcount(p);
-    return 8u + 4u * plain + 2u * maps;
-}
+// The settled-by masks of a 64-quad block, one per stage, cumulative: predicted = through the last predictor level, coded = through
+// MAP_B.  Predicted quads cost nothing, MAP_A / MAP_B two bytes, plain quads four.
+template <int ALGO>
+struct BlockMasks {
+    uint64_t m[StageGeo<ALGO>::kStages];
+    __device__ __forceinline__ void load(const uint64_t* __restrict__ done, uint64_t blocks_total, uint64_t gb) {
+#pragma unroll
+        for (uint32_t s = 0; s < StageGeo<ALGO>::kStages; ++s) m[s] = done[(2 * s) * blocks_total + gb] | done[(2 * s + 1) * blocks_total + gb];
+    }
+    __device__ __forceinline__ uint64_t predicted() const { return m[StageGeo<ALGO>::kStages - 3]; }
+    __device__ __forceinline__ uint64_t coded() const { return m[StageGeo<ALGO>::kStages - 1]; }   // everything but the plain quads
+    __device__ __forceinline__ uint32_t record_bytes(uint32_t r) const {                            // record r of the block
+        constexpr uint32_t Q = StageGeo<ALGO>::kRecQuads;
+        constexpr uint32_t mask = Q == 32 ? 0xffffffffu : 0xffffu;
+        const uint32_t p = (uint32_t)(predicted() >> (Q * r)) & mask, c = (uint32_t)(coded() >> (Q * r)) & mask;
+        const uint32_t plain = Q - (uint32_t)__builtin_popcount(c), maps = (uint32_t)__builtin_popcount(c) - (uint32_t)__builtin_popcount(p);
+        return StageGeo<ALGO>::kSig + 4u * plain + 2u * maps;
+    }
+};
 
-// per chunk: record offsets (exclusive scan of the record sizes), the stream length, and whether the passes' assumption held
+// per chunk: record offsets (exclusive scan of the record sizes), the stream length, whether the passes' assumption held, and where a
+// ragged end resumes
 constexpr uint32_t kLayoutThreads = 256;
+template <int ALGO>
 __global__ __launch_bounds__(kLayoutThreads) void stage_record_layout(uint64_t total, uint64_t chunk_bytes, const uint64_t* __restrict__ done,
                                                                       uint64_t blocks_total, const uint32_t* __restrict__ head_state,
                                                                       const uint8_t* __restrict__ in, uint32_t* __restrict__ rec_off,
                                                                       uint64_t* __restrict__ sizes, uint32_t* __restrict__ redo,
                                                                       uint32_t* __restrict__ tail_state) {
+    using G = StageGeo<ALGO>;
+    constexpr uint32_t kRecs = 64 / G::kRecQuads;
     __shared__ uint32_t s_sum[kLayoutThreads], s_first[kLayoutThreads], s_last[kLayoutThreads];
     const uint32_t t = threadIdx.x;
     const uint64_t chunk = blockIdx.x;
     const uint64_t base = chunk * chunk_bytes;
     const uint64_t len = (total - base) < chunk_bytes ? (total - base) : chunk_bytes;
-    if (head_state[8 * chunk + 3]) { if (t == 0) { redo[chunk] = 1u; tail_state[8 * chunk + 6] = 0u; } return; }   // (uniform)
+    if (head_state[8 * chunk + 3]) { if (t == 0) { redo[chunk] = 0u; tail_state[8 * chunk + 6] = 0u; } return; }   // finished by the head kernel (uniform)
     const uint32_t nb = (uint32_t)(len / kTrip) * kAhead;
     const uint64_t gb0 = base >> 8;
-    const uint32_t rest = nb - kHeadBlocks;
+    const uint32_t head_blocks = head_state[8 * chunk + 6] >> 8;
+    const uint32_t rest = nb - head_blocks;
     const uint32_t per = (rest + kLayoutThreads - 1) / kLayoutThreads;
-    const uint32_t b0 = kHeadBlocks + (t * per < rest ? t * per : rest), b1 = b0 + per < nb ? b0 + per : nb;
+    const uint32_t b0 = head_blocks + (t * per < rest ? t * per : rest), b1 = b0 + per < nb ? b0 + per : nb;
     const uint32_t head_fsm = head_state[8 * chunk + 2];
     uint32_t sum = 0, first = 0, last = 0, pair = 0;
     for (uint32_t b = b0; b < b1; ++b) {
-        const BlockMasks m = block_masks(done, blocks_total, gb0 + b);
-        for (uint32_t r = 0; r < 2; ++r) {
-            const uint32_t bytes = record_bytes(m, r);
-            const uint32_t inc = bytes >= kRec ? 1u : 0u;                         // codec.rs:68
+        BlockMasks<ALGO> m;
+        m.load(done, blocks_total, gb0 + b);
+        for (uint32_t r = 0; r < kRecs; ++r) {
+            const uint32_t bytes = m.record_bytes(r);
+            const uint32_t inc = bytes >= G::kRec ? 1u : 0u;                      // codec.rs:68
             if (b == b0 && r == 0) first = inc;
             else pair |= inc & last;
             last = inc;
@@ -233,10 +249,11 @@ __global__ __launch_bounds__(kLayoutThreads) void stage_record_layout(uint64_t t
     if (b0 < b1) pair |= s_first[t] & (t ? s_last[t - 1] : (head_fsm >> 1) & 1u);   // (threads with blocks are contiguous from 0, each full but the last)
     if (t == 0) pair |= head_fsm & 1u;                                             // the head ended inside a penalty: its copies are not over
     for (uint32_t b = b0; b < b1; ++b) {
-        const BlockMasks m = block_masks(done, blocks_total, gb0 + b);
-        for (uint32_t r = 0; r < 2; ++r) {
-            rec_off[(gb0 + b) * 2 + r] = off;
-            off += record_bytes(m, r);
+        BlockMasks<ALGO> m;
+        m.load(done, blocks_total, gb0 + b);
+        for (uint32_t r = 0; r < kRecs; ++r) {
+            rec_off[(gb0 + b) * kRecs + r] = off;
+            off += m.record_bytes(r);
         }
     }
     const int any_pair = __syncthreads_or((int)pair);
@@ -252,8 +269,8 @@ __global__ __launch_bounds__(kLayoutThreads) void stage_record_layout(uint64_t t
         ts[6] = ragged ? 1u : 0u;
         if (ragged) {
             uint32_t start = head_state[8 * chunk + 4], counter = head_state[8 * chunk + 5];
-            for (uint32_t r = 2 * kHeadBlocks; r < 2 * nb; ++r) {
-                if (start == 1) { counter += 2 * nb - r; break; }                  // (only the counter's low four bits matter from here on)
+            for (uint32_t r = kRecs * head_blocks; r < kRecs * nb; ++r) {
+                if (start == 1) { counter += kRecs * nb - r; break; }              // (only the counter's low four bits matter from here on)
                 if ((counter & 0xfu) == 0) start >>= 1;
                 ++counter;
             }
@@ -262,7 +279,7 @@ __global__ __launch_bounds__(kLayoutThreads) void stage_record_layout(uint64_t t
             if (b0 >= b1) for (uint32_t i = kLayoutThreads - 1; i-- > 0;) if (s_sum[i]) { prev = s_last[i]; break; }
             ts[0] = nb * 256u;
             ts[1] = off;
-            ts[2] = hash16(reinterpret_cast<const uint32_t*>(in + base)[nb * 64u - 1]);   // cheetah.rs:146
+            ts[2] = hash16(reinterpret_cast<const uint32_t*>(in + base)[nb * 64u - 1]);   // cheetah.rs:146 / lion.rs:268
             ts[3] = prev;
             ts[4] = start;
             ts[5] = counter;
@@ -270,8 +287,8 @@ __global__ __launch_bounds__(kLayoutThreads) void stage_record_layout(uint64_t t
     }
 }
 
-// 2-bit flags of 32 quads -> the 64-bit signature (io/write_signature.rs:14-17: quad k at bits 2k, 2k+1)
-__device__ __forceinline__ uint64_t spread_bits(uint32_t x) {
+// one flag bit plane of a record -> its place in the signature (io/write_signature.rs:14-17: quad k at bits 2k.. / 3k..)
+__device__ __forceinline__ uint64_t spread_by2(uint32_t x) {
     uint64_t v = x;
     v = (v | (v << 16)) & 0x0000ffff0000ffffull;
     v = (v | (v << 8)) & 0x00ff00ff00ff00ffull;
@@ -280,84 +297,111 @@ __device__ __forceinline__ uint64_t spread_bits(uint32_t x) {
     v = (v | (v << 1)) & 0x5555555555555555ull;
     return v;
 }
+__device__ __forceinline__ uint64_t spread_by3(uint32_t x16) {
+    uint64_t x = x16 & 0xffffu;
+    x = (x | (x << 16)) & 0x00ff0000ff0000ffull;
+    x = (x | (x << 8)) & 0xf00f00f00f00f00full;
+    x = (x | (x << 4)) & 0x30c30c30c30c30c3ull;
+    x = (x | (x << 2)) & 0x9249249249249249ull;
+    return x;
+}
 
-// the records: one wave per 64-quad block (two records), a quad per lane
+// the records: one wave per 64-quad block (two Cheetah records, four Lion records), a quad per lane
 constexpr uint32_t kEmitWaves = 4;
+template <int ALGO>
 __global__ __launch_bounds__(kEmitWaves * 64) void stage_emit_records(const uint8_t* __restrict__ in, uint64_t total, uint64_t chunk_bytes,
                                                                        const uint64_t* __restrict__ done, uint64_t blocks_total,
                                                                        const uint32_t* __restrict__ rec_off, const uint32_t* __restrict__ redo,
-                                                                       uint8_t* __restrict__ out, uint64_t out_stride) {
-    // (the records of a chunk's first kHeadBlocks are the in-order kernel's)
+                                                                       const uint32_t* __restrict__ head_state, uint8_t* __restrict__ out, uint64_t out_stride) {
+    using G = StageGeo<ALGO>;
+    constexpr uint32_t Q = G::kRecQuads, kRecs = 64 / Q;
+    constexpr uint32_t rec_mask = Q == 32 ? 0xffffffffu : 0xffffu;
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t gb = (uint64_t)blockIdx.x * kEmitWaves + (threadIdx.x >> 6);
-    if (gb * 256 + 256 > total) return;                                           // (a ragged end belongs to a chunk that is done again)
+    if (gb * 256 + 256 > total) return;
     const uint64_t chunk = (gb * 256) / chunk_bytes;
     const uint64_t base = chunk * chunk_bytes;
     const uint64_t len = (total - base) < chunk_bytes ? (total - base) : chunk_bytes;
     const uint64_t bw = gb - chunk * (chunk_bytes >> 8);
-    if (redo[chunk] || bw < kHeadBlocks || bw >= (len / kTrip) * kAhead) return;  // (the head and a ragged end are the in-order kernel's)
-    const BlockMasks m = block_masks(done, blocks_total, gb);
+    if (redo[chunk] || head_state[8 * chunk + 3] || bw < (head_state[8 * chunk + 6] >> 8) || bw >= (len / kTrip) * kAhead) return;   // (the head and a ragged end are the in-order kernel's)
+    BlockMasks<ALGO> m;
+    m.load(done, blocks_total, gb);
     const uint32_t q = reinterpret_cast<const uint32_t*>(in)[gb * 64 + lane];
-    const uint32_t r = lane >> 5, k = lane & 31u;
-    const uint32_t p = (uint32_t)(m.p >> (32 * r)), a = (uint32_t)(m.a >> (32 * r)), b = (uint32_t)(m.b >> (32 * r));
+    const uint32_t r = lane / Q, k = lane % Q;
+    // the stage that settled my quad = the number of stages that had not yet (the masks are cumulative); kStages: nobody, a plain quad
+    uint32_t stage = 0;
+#pragma unroll
+    for (uint32_t s = 0; s < G::kStages; ++s) stage += ((m.m[s] >> lane) & 1ull) ? 0u : 1u;
+    // flags: cheetah.rs:17-23 (predicted 3, MAP_A 1, MAP_B 2, plain 0), lion.rs:17-27 (predictions 1..5, MAP_A 6, MAP_B 7, plain 0)
+    const uint32_t flag = ALGO == DENSITY_HIP_CHEETAH ? (stage == 0 ? 3u : stage == 1 ? 1u : stage == 2 ? 2u : 0u) : (stage < G::kStages ? stage + 1u : 0u);
+    const uint32_t p = (uint32_t)(m.predicted() >> (Q * r)) & rec_mask, c = (uint32_t)(m.coded() >> (Q * r)) & rec_mask;
     const uint32_t below = (1u << k) - 1u;
     // bytes of the items before mine in my record: four per plain quad, two per MAP quad
-    const uint32_t before = 4u * (uint32_t)__builtin_popcount(~b & below) + 2u * (uint32_t)__builtin_popcount(b & ~p & below);
-    uint8_t* rec = out + chunk * out_stride + rec_off[gb * 2 + r];
-    uint8_t* at = rec + 8u + before;
-    const bool plain = !((b >> k) & 1u), predicted = (p >> k) & 1u;
-    if (plain) st32u(at, q);                                                      // cheetah.rs:136-139
-    else if (!predicted) st16u(at, hash16(q));                                    // :132-135
+    const uint32_t before = 4u * (uint32_t)__builtin_popcount(~c & below) + 2u * (uint32_t)__builtin_popcount(c & ~p & below);
+    uint8_t* rec = out + chunk * out_stride + rec_off[gb * kRecs + r];
+    uint8_t* at = rec + G::kSig + before;
+    const bool plain = !((c >> k) & 1u), predicted = (p >> k) & 1u;
+    if (plain) st32u(at, q);                                                      // cheetah.rs:136-139, lion.rs:250-253
+    else if (!predicted) st16u(at, hash16(q));                                    // cheetah.rs:132-135, lion.rs:246-249
+    const uint64_t plane0 = ballot64(flag & 1u), plane1 = ballot64(flag & 2u), plane2 = ballot64(flag & 4u);
     if (k == 0) {
-        // flags (cheetah.rs:17-23): predicted 3, MAP_A 1, MAP_B 2, plain 0 -> bit 0 = predicted | MAP_A, bit 1 = predicted | MAP_B
-        const uint32_t bit0 = p | (a & ~p), bit1 = p | (b & ~a);
-        const uint64_t sig = spread_bits(bit0) | (spread_bits(bit1) << 1);
-        st32u(rec, (uint32_t)sig);
-        st32u(rec + 4, (uint32_t)(sig >> 32));
+        const uint32_t f0 = (uint32_t)(plane0 >> (Q * r)) & rec_mask, f1 = (uint32_t)(plane1 >> (Q * r)) & rec_mask, f2 = (uint32_t)(plane2 >> (Q * r)) & rec_mask;
+        if (ALGO == DENSITY_HIP_CHEETAH) {
+            const uint64_t sig = spread_by2(f0) | (spread_by2(f1) << 1);
+            st32u(rec, (uint32_t)sig);
+            st32u(rec + 4, (uint32_t)(sig >> 32));
+        } else {
+            const uint64_t sig = spread_by3(f0) | (spread_by3(f1) << 1) | (spread_by3(f2) << 2);   // lion.rs:334-337: six bytes
+            st32u(rec, (uint32_t)sig);
+            st16u(rec + 4, (uint32_t)(sig >> 32) & 0xffffu);
+        }
     }
 }
 
-}  // namespace
-
-bool stage_encode_eligible(int algo, const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks) {
-    return algo == DENSITY_HIP_CHEETAH && !g_force_lane_codec && !g_force_wave_codec && !g_exchange_unsafe && n_chunks != 0 &&
-           (uintptr_t)d_in % 4 == 0 && chunk_bytes % kTrip == 0 && chunk_bytes >= 4 * kHeadBytes && chunk_bytes < (1ull << 31) &&
-           (uint64_t)n_chunks * kChunkTables <= (8ull << 30);                     // (a table slot per chunk: api.hip::kSerialTableBudget)
-}
-// vals (a dword per quad) | done masks (3 stages x 2 halves x a qword per 64-quad block) | record offsets | per-chunk verdicts
-uint64_t stage_scratch_bytes(uint64_t total, uint32_t n_chunks) {
-    const uint64_t blocks = (total + 255) / 256;
-    return ((total + 255) & ~255ull) + blocks * (6 * 8 + 2 * 4) + (((uint64_t)n_chunks * (4 + 32 + 32) + 255) & ~255ull) + 256;
-}
-
-hipError_t launch_stage_encode(const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_out, uint64_t out_stride,
-                               uint64_t* d_sizes, uint8_t* d_tables, uint32_t n_slots, uint8_t* d_scratch, hipStream_t stream) {
+template <int ALGO>
+hipError_t run_stages(const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_out, uint64_t out_stride,
+                      uint64_t* d_sizes, uint8_t* d_tables, uint32_t n_slots, uint8_t* d_scratch, hipStream_t stream) {
+    using G = StageGeo<ALGO>;
+    constexpr uint32_t kRecs = 64 / G::kRecQuads;
     const uint64_t blocks = (total + 255) / 256;
     uint32_t* vals = reinterpret_cast<uint32_t*>(d_scratch);
     uint64_t* done = reinterpret_cast<uint64_t*>(d_scratch + ((total + 255) & ~255ull));
-    uint32_t* rec_off = reinterpret_cast<uint32_t*>(done + 6 * blocks);
-    uint32_t* redo = rec_off + 2 * blocks;
+    uint32_t* rec_off = reinterpret_cast<uint32_t*>(done + 2 * G::kStages * blocks);
+    uint32_t* redo = rec_off + kRecs * blocks;
     uint32_t* head_state = redo + n_chunks;
     uint32_t* tail_state = head_state + 8 * (size_t)n_chunks;
-    auto stage_p = exchange_stage<true, true, false>, stage_a = exchange_stage<false, true, true>, stage_b = exchange_stage<false, false, false>;
-    hipError_t e = hipFuncSetAttribute((const void*)stage_p, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStageLds);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)stage_a, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStageLds);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)stage_b, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStageLds);
-    if (e != hipSuccess) return e;
     // the head of every chunk in order (a wave per chunk, its tables left in d_tables), then the passes from those tables
-    e = launch_cheetah_encode_heads(d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_tables, head_state, kHeadBytes, stream);
+    hipError_t e = launch_wave_encode_heads(ALGO, d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, head_state, G::kHeadBytes, G::kHeadCalm, stream);
     if (e != hipSuccess) return e;
+    auto first = ALGO == DENSITY_HIP_CHEETAH ? exchange_stage<true, true, false, false> : exchange_stage<true, true, true, false>;
+    auto level = exchange_stage<true, false, true, true>, last_level = exchange_stage<true, false, false, true>;
+    auto stage_a = exchange_stage<false, true, true, true>, stage_b = exchange_stage<false, false, false, true>;
+    for (const void* k : {(const void*)first, (const void*)level, (const void*)last_level, (const void*)stage_a, (const void*)stage_b}) {
+        e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStageLds);
+        if (e != hipSuccess) return e;
+    }
     const dim3 grid(2 * n_chunks), wave(64);
-    const uint8_t* tb = d_tables;
     const uint32_t* hs = head_state;
-    hipLaunchKernelGGL(stage_p, grid, wave, kStageLds, stream, d_in, total, chunk_bytes, (const uint64_t*)nullptr, done, vals, blocks, tb, hs);
-    hipLaunchKernelGGL(stage_a, grid, wave, kStageLds, stream, d_in, total, chunk_bytes, (const uint64_t*)done, done + 2 * blocks, vals, blocks, tb, hs);
-    hipLaunchKernelGGL(stage_b, grid, wave, kStageLds, stream, d_in, total, chunk_bytes, (const uint64_t*)(done + 2 * blocks), done + 4 * blocks, vals, blocks, tb, hs);
-    hipLaunchKernelGGL(stage_record_layout, dim3(n_chunks), dim3(kLayoutThreads), 0, stream, total, chunk_bytes, (const uint64_t*)done, blocks, hs, d_in, rec_off, d_sizes, redo, tail_state);
-    hipLaunchKernelGGL(stage_emit_records, dim3((uint32_t)((blocks + kEmitWaves - 1) / kEmitWaves)), dim3(kEmitWaves * 64), 0, stream, d_in, total, chunk_bytes,
-                       (const uint64_t*)done, blocks, (const uint32_t*)rec_off, (const uint32_t*)redo, d_out, out_stride);
+    const uint32_t levels = G::kStages - 2;                                        // predictor levels: 1 (Cheetah), 5 (Lion: 20 bytes a slot)
+    const uint32_t pred_stride = 4 * levels;
+    uint32_t s = 0;
+    for (uint32_t l = 0; l < levels; ++l, ++s) {
+        const StagePlace place{G::kChunkTables, (uint32_t)(65536u * 8u + 4u * l), pred_stride};
+        auto kernel = l == 0 ? first : (l + 1 < levels ? level : last_level);
+        hipLaunchKernelGGL(kernel, grid, wave, kStageLds, stream, d_in, total, chunk_bytes, (const uint64_t*)(done + 2 * (s ? s - 1 : 0) * blocks), done + 2 * s * blocks, vals,
+                           blocks, d_tables, hs, place);
+    }
+    for (uint32_t ab = 0; ab < 2; ++ab, ++s) {
+        const StagePlace place{G::kChunkTables, 4u * ab, 8u};
+        hipLaunchKernelGGL(ab == 0 ? stage_a : stage_b, grid, wave, kStageLds, stream, d_in, total, chunk_bytes, (const uint64_t*)(done + 2 * (s - 1) * blocks), done + 2 * s * blocks,
+                           vals, blocks, d_tables, hs, place);
+    }
+    hipLaunchKernelGGL(stage_record_layout<ALGO>, dim3(n_chunks), dim3(kLayoutThreads), 0, stream, total, chunk_bytes, (const uint64_t*)done, blocks, hs, d_in, rec_off, d_sizes,
+                       redo, tail_state);
+    hipLaunchKernelGGL(stage_emit_records<ALGO>, dim3((uint32_t)((blocks + kEmitWaves - 1) / kEmitWaves)), dim3(kEmitWaves * 64), 0, stream, d_in, total, chunk_bytes,
+                       (const uint64_t*)done, blocks, (const uint32_t*)rec_off, (const uint32_t*)redo, hs, d_out, out_stride);
     e = hipGetLastError();
-    if (e == hipSuccess) e = launch_cheetah_encode_tails(d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, tail_state, stream);
+    if (e == hipSuccess) e = launch_wave_encode_tails(ALGO, d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, tail_state, stream);
     if (e != hipSuccess) return e;
     if (g_stage_audit) {                                                           // tests and profiles: how many chunks the passes kept
         std::vector<uint32_t> verdicts(n_chunks);
@@ -367,8 +411,32 @@ hipError_t launch_stage_encode(const uint8_t* d_in, uint64_t total, uint64_t chu
         g_stage_stats[0] += n_chunks;
         for (uint32_t v : verdicts) g_stage_stats[1] += v ? 1 : 0;
     }
-    // chunks whose records met the blow-up protection, and a ragged last chunk: in order, on their own tables
-    return launch_cheetah_encode_only(d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, n_slots, redo, stream);
+    // chunks whose records met the blow-up protection behind the head after all: in order, on their own tables
+    return launch_wave_encode_only(ALGO, d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, n_slots, redo, stream);
+}
+
+}  // namespace
+
+bool stage_encode_eligible(int algo, const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks) {
+    if (algo != DENSITY_HIP_CHEETAH && algo != DENSITY_HIP_LION) return false;
+    const uint64_t head = algo == DENSITY_HIP_CHEETAH ? StageGeo<DENSITY_HIP_CHEETAH>::kHeadBytes : StageGeo<DENSITY_HIP_LION>::kHeadBytes;
+    const uint64_t slot = algo == DENSITY_HIP_CHEETAH ? StageGeo<DENSITY_HIP_CHEETAH>::kChunkTables : StageGeo<DENSITY_HIP_LION>::kChunkTables;
+    return !g_force_lane_codec && !g_force_wave_codec && !g_exchange_unsafe && n_chunks != 0 && (uintptr_t)d_in % 4 == 0 && chunk_bytes % kTrip == 0 &&
+           chunk_bytes >= 4 * head && chunk_bytes < (1ull << 31) && total >= 4 * head &&
+           (uint64_t)n_chunks * slot <= (8ull << 30);                             // (a table slot per chunk: api.hip::kSerialTableBudget)
+}
+// vals (a dword per quad) | done masks (stages x 2 halves x a qword per 64-quad block) | record offsets | per-chunk verdicts, head and tail states
+uint64_t stage_scratch_bytes(int algo, uint64_t total, uint32_t n_chunks) {
+    const uint64_t blocks = (total + 255) / 256;
+    const uint64_t stages = algo == DENSITY_HIP_CHEETAH ? StageGeo<DENSITY_HIP_CHEETAH>::kStages : StageGeo<DENSITY_HIP_LION>::kStages;
+    const uint64_t recs = algo == DENSITY_HIP_CHEETAH ? 2 : 4;
+    return ((total + 255) & ~255ull) + blocks * (stages * 2 * 8 + recs * 4) + (((uint64_t)n_chunks * (4 + 32 + 32) + 255) & ~255ull) + 256;
+}
+
+hipError_t launch_stage_encode(int algo, const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_out, uint64_t out_stride,
+                               uint64_t* d_sizes, uint8_t* d_tables, uint32_t n_slots, uint8_t* d_scratch, hipStream_t stream) {
+    return algo == DENSITY_HIP_CHEETAH ? run_stages<DENSITY_HIP_CHEETAH>(d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, n_slots, d_scratch, stream)
+                                       : run_stages<DENSITY_HIP_LION>(d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, n_slots, d_scratch, stream);
 }
 
 }  // namespace density

@@ -71,25 +71,24 @@ hipError_t launch_serial_decode(int algo, const uint8_t* d_in, const uint64_t* d
                                 uint8_t* d_out, uint64_t out_stride, uint64_t out_total, bool exact, uint64_t* d_produced, uint32_t* d_err,
                                 uint8_t* d_tables, uint32_t n_slots, hipStream_t stream);
 
-// Cheetah on the one-wave kernel for the chunks d_only marks (the wave clears its tables itself)
-hipError_t launch_cheetah_encode_only(const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_out, uint64_t out_stride,
-                                      uint64_t* d_sizes, uint8_t* d_tables, uint32_t n_slots, const uint32_t* d_only, hipStream_t stream);
+// The one-wave kernels (Cheetah, Lion) in the service of exchange_stages.hip: the chunks d_only marks, whole (the wave clears its tables itself);
+// just the head of every chunk (head_bytes and more, until the blow-up protection is quiet; short or restless chunks are finished), tables (one slot per chunk: n_chunks x serial_table_bytes) and d_head_state (8 words per chunk) left
+// behind; just the ragged end of the chunks d_tail_state marks (8 words per chunk), from the tables the passes wrote back
+hipError_t launch_wave_encode_only(int algo, const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_out, uint64_t out_stride,
+                                   uint64_t* d_sizes, uint8_t* d_tables, uint32_t n_slots, const uint32_t* d_only, hipStream_t stream);
+hipError_t launch_wave_encode_heads(int algo, const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_out, uint64_t out_stride,
+                                    uint64_t* d_sizes, uint8_t* d_tables, uint32_t* d_head_state, uint32_t head_bytes, uint32_t head_calm, hipStream_t stream);
+hipError_t launch_wave_encode_tails(int algo, const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_out, uint64_t out_stride,
+                                    uint64_t* d_sizes, uint8_t* d_tables, const uint32_t* d_tail_state, hipStream_t stream);
 
-// ... and just the first head_bytes of every chunk, tables (one slot per chunk: n_chunks x serial_table_bytes) and d_head_state (8 words per chunk) left behind
-hipError_t launch_cheetah_encode_heads(const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_out, uint64_t out_stride,
-                                       uint8_t* d_tables, uint32_t* d_head_state, uint32_t head_bytes, hipStream_t stream);
-
-// ... and just the ragged end of the chunks d_tail_state marks (8 words per chunk), from the tables the passes wrote back
-hipError_t launch_cheetah_encode_tails(const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_out, uint64_t out_stride,
-                                       uint64_t* d_sizes, uint8_t* d_tables, const uint32_t* d_tail_state, hipStream_t stream);
-
-// ---- exchange_stages.hip (Cheetah encode, the default: three passes of ordered LDS exchanges per chunk, then a size scan and the records) ----
-extern bool g_force_wave_codec;   // density_hip_set_kernel_variant(32): the one-wave-per-stream Cheetah encoder instead
+// ---- exchange_stages.hip (Cheetah / Lion container encode, the default: three / seven passes of ordered LDS exchanges per chunk, then a size scan
+// and the records) ----
+extern bool g_force_wave_codec;   // density_hip_set_kernel_variant(32): the one-wave-per-stream encoders instead
 extern bool g_stage_audit;        // density_hip_set_kernel_variant(64): count chunks kept / handed back (synchronises)
 extern uint64_t g_stage_stats[2];
 bool stage_encode_eligible(int algo, const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks);
-uint64_t stage_scratch_bytes(uint64_t total, uint32_t n_chunks);
-hipError_t launch_stage_encode(const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_out, uint64_t out_stride,
+uint64_t stage_scratch_bytes(int algo, uint64_t total, uint32_t n_chunks);
+hipError_t launch_stage_encode(int algo, const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_out, uint64_t out_stride,
                                uint64_t* d_sizes, uint8_t* d_tables, uint32_t n_slots, uint8_t* d_scratch, hipStream_t stream);
 
 // ---- stream_parse.hip: record boundaries of one calm Chameleon stream, in parallel ----

@@ -365,12 +365,13 @@ __global__ __launch_bounds__(64) void cheetah_encode_wave(const uint8_t* __restr
                                                           uint32_t n_chunks, uint8_t* __restrict__ out, uint64_t out_stride,
                                                           uint64_t* __restrict__ sizes, uint8_t* __restrict__ tables, uint32_t n_slots,
                                                           const uint32_t* __restrict__ only, uint32_t* __restrict__ head_state, uint32_t head_bytes,
-                                                          const uint32_t* __restrict__ tail_state) {
+                                                          uint32_t head_calm, const uint32_t* __restrict__ tail_state) {
     // `only` (nullable): encode just the chunks it marks — the ones exchange_stages.hip hands back (raw copies, a ragged end).
-    // `head_state` (nullable): encode just the first head_bytes of every chunk — where a cold dictionary makes records incompressible and
-    // the blow-up protection copies blocks — and leave the tables (one slot per chunk) and four words per chunk behind: stream bytes so far,
-    // last_hash, FSM (bit 0 penalty running, bit 1 last record incompressible), 1 = not a chunk for the exchange passes (too short), and the
-    // FSM's penalty_start and block counter.
+    // `head_state` (nullable): encode just the head of every chunk — at least head_bytes, and on until the blow-up protection has been
+    // quiet for head_calm bytes: a cold dictionary makes records incompressible and blocks get copied — and leave the tables (one slot per
+    // chunk) and eight words per chunk behind: stream bytes so far, last_hash, FSM (bit 0 penalty running, bit 1 last record
+    // incompressible), 0 = the passes take over / 2 = the chunk was finished here (short, or never calm), the FSM's penalty_start and
+    // block counter, the input offset where the passes take over.
     // `tail_state` (nullable): encode just the ragged end of the chunks it marks, from where the passes stopped — eight words per chunk:
     // input offset, stream bytes so far, last_hash, last record incompressible, penalty_start, counter, 1 = there is an end to do; the
     // tables (one slot per chunk) are as the passes left them
@@ -389,10 +390,6 @@ __global__ __launch_bounds__(64) void cheetah_encode_wave(const uint8_t* __restr
         uint8_t* dst = out + chunk * out_stride;
         if (only && !only[chunk]) continue;
         if (tail_state && !tail_state[8 * chunk + 6]) continue;
-        if (head_state && len < 4ull * head_bytes) {
-            if (lane == 0) head_state[8 * chunk + 3] = 1u;
-            continue;
-        }
         if ((chunk != slot || only || head_state) && !tail_state) {                                          // (the launcher zeroed the tables for the first chunk of a slot — not when it filters)
             uint4* p = reinterpret_cast<uint4*>(tables + slot * kTableBytes);
             const uint4 z = make_uint4(0, 0, 0, 0);
@@ -408,10 +405,18 @@ __global__ __launch_bounds__(64) void cheetah_encode_wave(const uint8_t* __restr
             guard.prev = ts[3]; guard.start = ts[4]; guard.counter = ts[5];
         }
         uint32_t qnext = (act && pos + G::kBlock <= len) ? ld32u(src + pos + 4u * lane) : 0u;
-        const uint64_t run = head_state ? head_bytes : len;
-        for (; pos + G::kBlock <= run; pos += G::kBlock) {                    // whole blocks
+        // head mode: hand over to the exchange passes at the first 4 KiB boundary behind head_bytes where the blow-up protection has been quiet
+        // for kHeadCalm bytes; a chunk that is too short for that, or has not calmed down by its middle, is simply finished here
+        bool may_hand_over = head_state && len >= 4ull * head_bytes, handed_over = false;
+        uint64_t last_copy_end = 0;
+        for (; pos + G::kBlock <= len; pos += G::kBlock) {                    // whole blocks
+            if (may_hand_over && pos >= head_bytes && (pos & 4095u) == 0) {
+                if (pos >= last_copy_end + head_calm && guard.penalty == 0) { handed_over = true; break; }
+                if (pos >= len / 2) may_hand_over = false;
+            }
             const uint8_t* blk = src + pos;
             if (guard.block_is_copy()) {                                      // codec.rs:35-37
+                last_copy_end = pos + G::kBlock;
                 if (act) st32u(dst + opos + 4u * lane, qnext);
                 qnext = (act && pos + 2 * G::kBlock <= len) ? ld32u(blk + G::kBlock + 4u * lane) : 0u;
                 opos += G::kBlock;
@@ -481,11 +486,12 @@ __global__ __launch_bounds__(64) void cheetah_encode_wave(const uint8_t* __restr
                 head_state[8 * chunk + 0] = (uint32_t)opos;
                 head_state[8 * chunk + 1] = last_hash;
                 head_state[8 * chunk + 2] = (guard.penalty ? 1u : 0u) | (guard.prev ? 2u : 0u);
-                head_state[8 * chunk + 3] = 0u;
+                head_state[8 * chunk + 3] = handed_over ? 0u : 2u;             // 2: the chunk is finished, nothing for the passes
                 head_state[8 * chunk + 4] = guard.start;
                 head_state[8 * chunk + 5] = guard.counter;
+                head_state[8 * chunk + 6] = (uint32_t)pos;                    // where the passes take over
             }
-            continue;
+            if (handed_over) continue;
         }
         // ---- the ragged last block: the scalar code on lane 0 (same tables; codec.rs:51-63) ----
         if (pos < len) {
@@ -735,7 +741,11 @@ __device__ __forceinline__ uint64_t spread16by3(uint32_t x16) {
 
 __global__ __launch_bounds__(64) void lion_encode_wave(const uint8_t* __restrict__ in, uint64_t total, uint64_t chunk_bytes,
                                                        uint32_t n_chunks, uint8_t* __restrict__ out, uint64_t out_stride,
-                                                       uint64_t* __restrict__ sizes, uint8_t* __restrict__ tables, uint32_t n_slots) {
+                                                       uint64_t* __restrict__ sizes, uint8_t* __restrict__ tables, uint32_t n_slots,
+                                                       const uint32_t* __restrict__ only, uint32_t* __restrict__ head_state, uint32_t head_bytes,
+                                                       uint32_t head_calm, const uint32_t* __restrict__ tail_state) {
+    // only / head_state / tail_state: as cheetah_encode_wave (the chunks handed back by, the heads before and the ragged ends behind the
+    // exchange passes of exchange_stages.hip)
     using G = Geo<DENSITY_HIP_LION>;
     const uint32_t slot = blockIdx.x;
     const uint32_t lane = threadIdx.x;
@@ -750,7 +760,9 @@ __global__ __launch_bounds__(64) void lion_encode_wave(const uint8_t* __restrict
         const uint8_t* src = in + chunk * chunk_bytes;
         const uint64_t len = (total - chunk * chunk_bytes) < chunk_bytes ? (total - chunk * chunk_bytes) : chunk_bytes;
         uint8_t* dst = out + chunk * out_stride;
-        if (chunk != slot) {
+        if (only && !only[chunk]) continue;
+        if (tail_state && !tail_state[8 * chunk + 6]) continue;
+        if ((chunk != slot || only || head_state) && !tail_state) {
             uint4* p = reinterpret_cast<uint4*>(tables + slot * kTableBytes);
             const uint4 z = make_uint4(0, 0, 0, 0);
             for (uint64_t i = lane; i < kTableBytes / 16; i += 64) p[i] = z;
@@ -759,10 +771,22 @@ __global__ __launch_bounds__(64) void lion_encode_wave(const uint8_t* __restrict
         uint32_t last_hash = 0;
         Guard guard;
         uint64_t opos = 0, pos = 0;
-        uint32_t qnext = (act && G::kBlock <= len) ? ld32u(src + 4u * lane) : 0u;
+        if (tail_state) {
+            const uint32_t* ts = tail_state + 8 * chunk;
+            pos = ts[0]; opos = ts[1]; last_hash = ts[2];
+            guard.prev = ts[3]; guard.start = ts[4]; guard.counter = ts[5];
+        }
+        uint32_t qnext = (act && pos + G::kBlock <= len) ? ld32u(src + pos + 4u * lane) : 0u;
+        bool may_hand_over = head_state && len >= 4ull * head_bytes, handed_over = false;   // (as cheetah_encode_wave)
+        uint64_t last_copy_end = 0;
         for (; pos + G::kBlock <= len; pos += G::kBlock) {
+            if (may_hand_over && pos >= head_bytes && (pos & 4095u) == 0) {
+                if (pos >= last_copy_end + head_calm && guard.penalty == 0) { handed_over = true; break; }
+                if (pos >= len / 2) may_hand_over = false;
+            }
             const uint8_t* blk = src + pos;
             if (guard.block_is_copy()) {                                      // codec.rs:35-37
+                last_copy_end = pos + G::kBlock;
                 if (act) st32u(dst + opos + 4u * lane, qnext);
                 qnext = (act && pos + 2 * G::kBlock <= len) ? ld32u(blk + G::kBlock + 4u * lane) : 0u;
                 opos += G::kBlock;
@@ -826,6 +850,18 @@ __global__ __launch_bounds__(64) void lion_encode_wave(const uint8_t* __restrict
             opos += rlen;
         }
         tbl_drain();
+        if (head_state) {
+            if (lane == 0) {
+                head_state[8 * chunk + 0] = (uint32_t)opos;
+                head_state[8 * chunk + 1] = last_hash;
+                head_state[8 * chunk + 2] = (guard.penalty ? 1u : 0u) | (guard.prev ? 2u : 0u);
+                head_state[8 * chunk + 3] = handed_over ? 0u : 2u;             // 2: the chunk is finished, nothing for the passes
+                head_state[8 * chunk + 4] = guard.start;
+                head_state[8 * chunk + 5] = guard.counter;
+                head_state[8 * chunk + 6] = (uint32_t)pos;                    // where the passes take over
+            }
+            if (handed_over) continue;
+        }
         if (pos < len) {                                                      // the ragged last block: scalar code, lane 0
             __threadfence();
             if (lane == 0) {
@@ -1056,35 +1092,40 @@ hipError_t launch_serial_encode(int algo, const uint8_t* d_in, uint64_t total, u
     hipError_t e = hipMemsetAsync(d_tables, 0, (size_t)n_slots * serial_table_bytes(algo), stream);
     if (e != hipSuccess) return e;
     if (algo == DENSITY_HIP_CHEETAH && !g_force_lane_codec)
-        hipLaunchKernelGGL(cheetah_encode_wave, dim3(n_slots), dim3(64), 0, stream, d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, n_slots, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (const uint32_t*)nullptr);
+        hipLaunchKernelGGL(cheetah_encode_wave, dim3(n_slots), dim3(64), 0, stream, d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, n_slots, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0u, 0u, (const uint32_t*)nullptr);
     else if (algo == DENSITY_HIP_CHEETAH)
         hipLaunchKernelGGL(serial_encode_chunks<DENSITY_HIP_CHEETAH>, dim3(blocks), dim3(64), 0, stream, d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, n_slots);
     else if (!g_force_lane_codec)
-        hipLaunchKernelGGL(lion_encode_wave, dim3(n_slots), dim3(64), 0, stream, d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, n_slots);
+        hipLaunchKernelGGL(lion_encode_wave, dim3(n_slots), dim3(64), 0, stream, d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, n_slots,
+                           (const uint32_t*)nullptr, (uint32_t*)nullptr, 0u, 0u, (const uint32_t*)nullptr);
     else
         hipLaunchKernelGGL(serial_encode_chunks<DENSITY_HIP_LION>, dim3(blocks), dim3(64), 0, stream, d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, n_slots);
     return hipGetLastError();
 }
 
-hipError_t launch_cheetah_encode_only(const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_out, uint64_t out_stride,
-                                      uint64_t* d_sizes, uint8_t* d_tables, uint32_t n_slots, const uint32_t* d_only, hipStream_t stream) {
+// the one-wave kernels in the service of exchange_stages.hip: the chunks d_only marks, whole (the wave clears its tables itself)
+hipError_t launch_wave_encode_only(int algo, const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_out, uint64_t out_stride,
+                                   uint64_t* d_sizes, uint8_t* d_tables, uint32_t n_slots, const uint32_t* d_only, hipStream_t stream) {
     if (n_chunks == 0) return hipSuccess;
-    hipLaunchKernelGGL(cheetah_encode_wave, dim3(n_slots), dim3(64), 0, stream, d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, n_slots, d_only,
-                       (uint32_t*)nullptr, 0u, (const uint32_t*)nullptr);
+    auto kernel = algo == DENSITY_HIP_CHEETAH ? cheetah_encode_wave : lion_encode_wave;
+    hipLaunchKernelGGL(kernel, dim3(n_slots), dim3(64), 0, stream, d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, n_slots, d_only,
+                       (uint32_t*)nullptr, 0u, 0u, (const uint32_t*)nullptr);
     return hipGetLastError();
 }
-hipError_t launch_cheetah_encode_heads(const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_out, uint64_t out_stride,
-                                       uint8_t* d_tables, uint32_t* d_head_state, uint32_t head_bytes, hipStream_t stream) {
+hipError_t launch_wave_encode_heads(int algo, const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_out, uint64_t out_stride,
+                                    uint64_t* d_sizes, uint8_t* d_tables, uint32_t* d_head_state, uint32_t head_bytes, uint32_t head_calm, hipStream_t stream) {
     if (n_chunks == 0) return hipSuccess;
-    hipLaunchKernelGGL(cheetah_encode_wave, dim3(n_chunks), dim3(64), 0, stream, d_in, total, chunk_bytes, n_chunks, d_out, out_stride, (uint64_t*)nullptr, d_tables, n_chunks,
-                       (const uint32_t*)nullptr, d_head_state, head_bytes, (const uint32_t*)nullptr);
+    auto kernel = algo == DENSITY_HIP_CHEETAH ? cheetah_encode_wave : lion_encode_wave;
+    hipLaunchKernelGGL(kernel, dim3(n_chunks), dim3(64), 0, stream, d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, n_chunks,
+                       (const uint32_t*)nullptr, d_head_state, head_bytes, head_calm, (const uint32_t*)nullptr);
     return hipGetLastError();
 }
-hipError_t launch_cheetah_encode_tails(const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_out, uint64_t out_stride,
-                                       uint64_t* d_sizes, uint8_t* d_tables, const uint32_t* d_tail_state, hipStream_t stream) {
+hipError_t launch_wave_encode_tails(int algo, const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_out, uint64_t out_stride,
+                                    uint64_t* d_sizes, uint8_t* d_tables, const uint32_t* d_tail_state, hipStream_t stream) {
     if (n_chunks == 0) return hipSuccess;
-    hipLaunchKernelGGL(cheetah_encode_wave, dim3(n_chunks), dim3(64), 0, stream, d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, n_chunks,
-                       (const uint32_t*)nullptr, (uint32_t*)nullptr, 0u, d_tail_state);
+    auto kernel = algo == DENSITY_HIP_CHEETAH ? cheetah_encode_wave : lion_encode_wave;
+    hipLaunchKernelGGL(kernel, dim3(n_chunks), dim3(64), 0, stream, d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, n_chunks,
+                       (const uint32_t*)nullptr, (uint32_t*)nullptr, 0u, 0u, d_tail_state);
     return hipGetLastError();
 }
 
