@@ -421,8 +421,11 @@ bool stage_encode_eligible(int algo, const uint8_t* d_in, uint64_t total, uint64
     if (algo != DENSITY_HIP_CHEETAH && algo != DENSITY_HIP_LION) return false;
     const uint64_t head = algo == DENSITY_HIP_CHEETAH ? StageGeo<DENSITY_HIP_CHEETAH>::kHeadBytes : StageGeo<DENSITY_HIP_LION>::kHeadBytes;
     const uint64_t slot = algo == DENSITY_HIP_CHEETAH ? StageGeo<DENSITY_HIP_CHEETAH>::kChunkTables : StageGeo<DENSITY_HIP_LION>::kChunkTables;
-    return !g_force_lane_codec && !g_force_wave_codec && !g_exchange_unsafe && n_chunks != 0 && (uintptr_t)d_in % 4 == 0 && chunk_bytes % kTrip == 0 &&
-           chunk_bytes >= 4 * head && chunk_bytes < (1ull << 31) && total >= 4 * head &&
+    // The passes cost time in proportion to the input (one wave per CU at a time: the LDS holds one half table), the one-wave kernels in
+    // proportion to the CHUNK while there are CUs for more waves: measured cross-over near 1000 (Cheetah) / 500 (Lion) chunks.
+    const uint32_t most = algo == DENSITY_HIP_CHEETAH ? 768u : 384u;
+    return !g_force_lane_codec && !g_force_wave_codec && !g_exchange_unsafe && n_chunks != 0 && n_chunks <= most && (uintptr_t)d_in % 4 == 0 &&
+           chunk_bytes % kTrip == 0 && chunk_bytes >= 4 * head && chunk_bytes < (1ull << 31) && total >= 4 * head &&
            (uint64_t)n_chunks * slot <= (8ull << 30);                             // (a table slot per chunk: api.hip::kSerialTableBudget)
 }
 // vals (a dword per quad) | done masks (stages x 2 halves x a qword per 64-quad block) | record offsets | per-chunk verdicts, head and tail states
