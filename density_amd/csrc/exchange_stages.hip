@@ -88,12 +88,12 @@ struct StagePlace { uint64_t chunk_tables; uint32_t offset, stride; };
 //   OWN_VALUE   the value exchanged in is the quad (first predictor level, A) / what the previous stage displaced (vals[])
 //   KEEP_OLD    the displaced value is kept in vals[] for the next stage
 //   HAS_BEFORE  not the first stage: the quads an earlier stage settled take no part
-// done_prev / done_out: per 64-quad block of the whole input and per half, "quad settled by this stage or an earlier one"
-// (cumulative; a reader ORs the two halves).
+// done_prev / done_out: per 64-quad block of the whole input four dwords — lanes 0..31 of half 0, of half 1, lanes 32..63 of half 0, of
+// half 1 — "quad settled by this stage or an earlier one" (cumulative; a reader ORs the two halves: one 8-byte load per lane).
 template <bool KEY_PREV, bool OWN_VALUE, bool KEEP_OLD, bool HAS_BEFORE>
 __global__ __launch_bounds__(64) void exchange_stage(const uint8_t* __restrict__ in, uint64_t total, uint64_t chunk_bytes,
-                                                     const uint64_t* __restrict__ done_prev, uint64_t* __restrict__ done_out,
-                                                     uint32_t* __restrict__ vals, uint64_t blocks_total, uint8_t* __restrict__ tables,
+                                                     const uint32_t* __restrict__ done_prev, uint32_t* __restrict__ done_out,
+                                                     uint32_t* __restrict__ vals, uint8_t* __restrict__ tables,
                                                      const uint32_t* __restrict__ head_state, StagePlace place) {
     const uint32_t lane = threadIdx.x;
     const uint64_t chunk = blockIdx.x >> 1;
@@ -114,9 +114,8 @@ __global__ __launch_bounds__(64) void exchange_stage(const uint8_t* __restrict__
     }
     const uint32_t* __restrict__ q32 = reinterpret_cast<const uint32_t*>(in + base);
     uint32_t* __restrict__ v32 = vals + gb0 * 64;
-    const uint64_t* __restrict__ before0 = done_prev + gb0;
-    const uint64_t* __restrict__ before1 = done_prev + blocks_total + gb0;
-    uint64_t* __restrict__ mine = done_out + (uint64_t)half * blocks_total + gb0;
+    const uint2* __restrict__ before2 = reinterpret_cast<const uint2*>(done_prev + gb0 * 4) + (lane >> 5);   // + 2 per block
+    uint32_t* __restrict__ mine = done_out + gb0 * 4 + half;                                                 // + 4 per block, + 2 for the upper lanes
     const uint32_t lds0 = lds_addr(stage_lds);
     const uint32_t sink = lds0 + kTable + lane * 4u;
     const uint32_t ones = 0xffffffffu;
@@ -124,20 +123,23 @@ __global__ __launch_bounds__(64) void exchange_stage(const uint8_t* __restrict__
 
     const uint32_t last_hash = head_state[8 * chunk + 1];                         // cheetah.rs:146 / lion.rs:268 as the head left it (its last block may be a raw copy)
     uint32_t qn[kAhead], pn[kAhead], vn[kAhead];
+    uint2 bn[kAhead];
 #pragma unroll
     for (uint32_t j = 0; j < kAhead; ++j) {
         const uint32_t i = (hb + j) * 64u + lane;
         qn[j] = q32[i];
         pn[j] = KEY_PREV ? q32[i - 1] : 0u;
         vn[j] = !OWN_VALUE ? v32[i] : 0u;
+        bn[j] = HAS_BEFORE ? before2[(hb + j) * 2u] : make_uint2(0u, 0u);
     }
     for (uint32_t g = hb; g < nb; g += kAhead) {
         uint32_t q[kAhead], key[kAhead], val[kAhead];
-        uint64_t before[kAhead];
+        bool before[kAhead];
 #pragma unroll
         for (uint32_t j = 0; j < kAhead; ++j) {
             q[j] = qn[j];
             val[j] = OWN_VALUE ? qn[j] : vn[j];
+            before[j] = HAS_BEFORE && (((bn[j].x | bn[j].y) >> (lane & 31u)) & 1u);
             // slot: cheetah.rs:125 / lion.rs:213 (the predictor is addressed by the previous quad's hash), cheetah.rs:131 / lion.rs:245
             key[j] = KEY_PREV ? hash16(pn[j]) : hash16(qn[j]);
         }
@@ -150,18 +152,16 @@ __global__ __launch_bounds__(64) void exchange_stage(const uint8_t* __restrict__
                 qn[j] = q32[i];
                 if (KEY_PREV) pn[j] = q32[i - 1];
                 if (!OWN_VALUE) vn[j] = v32[i];
+                if (HAS_BEFORE) bn[j] = before2[(gn + j) * 2u];
             }
         }
 #pragma unroll
-        for (uint32_t j = 0; j < kAhead; ++j) before[j] = HAS_BEFORE ? (before0[g + j] | before1[g + j]) : 0ull;
-#pragma unroll
         for (uint32_t s = 0; s < kAhead; s += kBatch) {
             uint32_t addr[kBatch], put[kBatch], old[kBatch];
-            uint64_t hits[kBatch];
             bool part[kBatch];
 #pragma unroll
             for (uint32_t j = 0; j < kBatch; ++j) {
-                part[j] = !((before[s + j] >> lane) & 1ull) && (key[s + j] >> 15) == half;
+                part[j] = !before[s + j] && (key[s + j] >> 15) == half;
                 addr[j] = part[j] ? lds0 + (key[s + j] & (kHalfSlots - 1u)) * 4u : sink;
                 put[j] = val[s + j];
             }
@@ -169,12 +169,9 @@ __global__ __launch_bounds__(64) void exchange_stage(const uint8_t* __restrict__
 #pragma unroll
             for (uint32_t j = 0; j < kBatch; ++j) {
                 const bool hit = part[j] && old[j] == q[s + j];
-                hits[j] = ballot64(hit) | before[s + j];
+                const uint64_t settled = ballot64(hit || before[s + j]);
                 if (KEEP_OLD && part[j] && !hit) v32[(g + s + j) * 64u + lane] = old[j];
-            }
-            if (lane == 0) {
-#pragma unroll
-                for (uint32_t j = 0; j < kBatch; ++j) mine[g + s + j] = hits[j];
+                if (lane < 2) mine[(g + s + j) * 4u + lane * 2u] = lane ? (uint32_t)(settled >> 32) : (uint32_t)settled;
             }
         }
     }
@@ -190,9 +187,12 @@ __global__ __launch_bounds__(64) void exchange_stage(const uint8_t* __restrict__
 template <int ALGO>
 struct BlockMasks {
     uint64_t m[StageGeo<ALGO>::kStages];
-    __device__ __forceinline__ void load(const uint64_t* __restrict__ done, uint64_t blocks_total, uint64_t gb) {
+    __device__ __forceinline__ void load(const uint32_t* __restrict__ done, uint64_t blocks_total, uint64_t gb) {
 #pragma unroll
-        for (uint32_t s = 0; s < StageGeo<ALGO>::kStages; ++s) m[s] = done[(2 * s) * blocks_total + gb] | done[(2 * s + 1) * blocks_total + gb];
+        for (uint32_t s = 0; s < StageGeo<ALGO>::kStages; ++s) {
+            const uint4 w = *reinterpret_cast<const uint4*>(done + (s * blocks_total + gb) * 4);   // lanes 0..31: halves 0, 1; lanes 32..63: halves 0, 1
+            m[s] = (uint64_t)(w.x | w.y) | ((uint64_t)(w.z | w.w) << 32);
+        }
     }
     __device__ __forceinline__ uint64_t predicted() const { return m[StageGeo<ALGO>::kStages - 3]; }
     __device__ __forceinline__ uint64_t coded() const { return m[StageGeo<ALGO>::kStages - 1]; }   // everything but the plain quads
@@ -209,7 +209,7 @@ struct BlockMasks {
 // ragged end resumes
 constexpr uint32_t kLayoutThreads = 256;
 template <int ALGO>
-__global__ __launch_bounds__(kLayoutThreads) void stage_record_layout(uint64_t total, uint64_t chunk_bytes, const uint64_t* __restrict__ done,
+__global__ __launch_bounds__(kLayoutThreads) void stage_record_layout(uint64_t total, uint64_t chunk_bytes, const uint32_t* __restrict__ done,
                                                                       uint64_t blocks_total, const uint32_t* __restrict__ head_state,
                                                                       const uint8_t* __restrict__ in, uint32_t* __restrict__ rec_off,
                                                                       uint64_t* __restrict__ sizes, uint32_t* __restrict__ redo,
@@ -310,7 +310,7 @@ __device__ __forceinline__ uint64_t spread_by3(uint32_t x16) {
 constexpr uint32_t kEmitWaves = 4;
 template <int ALGO>
 __global__ __launch_bounds__(kEmitWaves * 64) void stage_emit_records(const uint8_t* __restrict__ in, uint64_t total, uint64_t chunk_bytes,
-                                                                       const uint64_t* __restrict__ done, uint64_t blocks_total,
+                                                                       const uint32_t* __restrict__ done, uint64_t blocks_total,
                                                                        const uint32_t* __restrict__ rec_off, const uint32_t* __restrict__ redo,
                                                                        const uint32_t* __restrict__ head_state, uint8_t* __restrict__ out, uint64_t out_stride) {
     using G = StageGeo<ALGO>;
@@ -365,8 +365,8 @@ hipError_t run_stages(const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes,
     constexpr uint32_t kRecs = 64 / G::kRecQuads;
     const uint64_t blocks = (total + 255) / 256;
     uint32_t* vals = reinterpret_cast<uint32_t*>(d_scratch);
-    uint64_t* done = reinterpret_cast<uint64_t*>(d_scratch + ((total + 255) & ~255ull));
-    uint32_t* rec_off = reinterpret_cast<uint32_t*>(done + 2 * G::kStages * blocks);
+    uint32_t* done = reinterpret_cast<uint32_t*>(d_scratch + ((total + 255) & ~255ull));   // per stage: four dwords per block
+    uint32_t* rec_off = done + 4 * G::kStages * blocks;
     uint32_t* redo = rec_off + kRecs * blocks;
     uint32_t* head_state = redo + n_chunks;
     uint32_t* tail_state = head_state + 8 * (size_t)n_chunks;
@@ -388,18 +388,18 @@ hipError_t run_stages(const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes,
     for (uint32_t l = 0; l < levels; ++l, ++s) {
         const StagePlace place{G::kChunkTables, (uint32_t)(65536u * 8u + 4u * l), pred_stride};
         auto kernel = l == 0 ? first : (l + 1 < levels ? level : last_level);
-        hipLaunchKernelGGL(kernel, grid, wave, kStageLds, stream, d_in, total, chunk_bytes, (const uint64_t*)(done + 2 * (s ? s - 1 : 0) * blocks), done + 2 * s * blocks, vals,
-                           blocks, d_tables, hs, place);
+        hipLaunchKernelGGL(kernel, grid, wave, kStageLds, stream, d_in, total, chunk_bytes, (const uint32_t*)(done + 4 * (s ? s - 1 : 0) * blocks), done + 4 * s * blocks, vals,
+                           d_tables, hs, place);
     }
     for (uint32_t ab = 0; ab < 2; ++ab, ++s) {
         const StagePlace place{G::kChunkTables, 4u * ab, 8u};
-        hipLaunchKernelGGL(ab == 0 ? stage_a : stage_b, grid, wave, kStageLds, stream, d_in, total, chunk_bytes, (const uint64_t*)(done + 2 * (s - 1) * blocks), done + 2 * s * blocks,
-                           vals, blocks, d_tables, hs, place);
+        hipLaunchKernelGGL(ab == 0 ? stage_a : stage_b, grid, wave, kStageLds, stream, d_in, total, chunk_bytes, (const uint32_t*)(done + 4 * (s - 1) * blocks), done + 4 * s * blocks,
+                           vals, d_tables, hs, place);
     }
-    hipLaunchKernelGGL(stage_record_layout<ALGO>, dim3(n_chunks), dim3(kLayoutThreads), 0, stream, total, chunk_bytes, (const uint64_t*)done, blocks, hs, d_in, rec_off, d_sizes,
+    hipLaunchKernelGGL(stage_record_layout<ALGO>, dim3(n_chunks), dim3(kLayoutThreads), 0, stream, total, chunk_bytes, (const uint32_t*)done, blocks, hs, d_in, rec_off, d_sizes,
                        redo, tail_state);
     hipLaunchKernelGGL(stage_emit_records<ALGO>, dim3((uint32_t)((blocks + kEmitWaves - 1) / kEmitWaves)), dim3(kEmitWaves * 64), 0, stream, d_in, total, chunk_bytes,
-                       (const uint64_t*)done, blocks, (const uint32_t*)rec_off, (const uint32_t*)redo, hs, d_out, out_stride);
+                       (const uint32_t*)done, blocks, (const uint32_t*)rec_off, (const uint32_t*)redo, hs, d_out, out_stride);
     e = hipGetLastError();
     if (e == hipSuccess) e = launch_wave_encode_tails(ALGO, d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, tail_state, stream);
     if (e != hipSuccess) return e;
