@@ -203,7 +203,7 @@ hipError_t codec_encode(int algo, const uint8_t* d_in, uint64_t total, uint64_t 
                         uint64_t out_stride, uint64_t* d_sizes, uint8_t* d_index, uint8_t* d_tables, uint32_t* d_zmap, uint8_t* d_stage, uint32_t* d_err, hipStream_t s) {
     if (algo == DENSITY_HIP_CHAMELEON) return launch_chameleon_encode(d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_index, d_zmap, d_err, s);
     if (d_stage && stage_encode_eligible(algo, d_in, total, chunk_bytes, n_chunks))   // Cheetah / Lion: passes of ordered LDS exchanges, the one-wave kernels for what they hand back
-        return launch_stage_encode(algo, d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, (uint32_t)serial_slots(algo, n_chunks), d_stage, s);
+        return launch_stage_encode(algo, d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, (uint32_t)serial_slots(algo, n_chunks), d_stage, d_err, s);
     return launch_serial_encode(algo, d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, (uint32_t)serial_slots(algo, n_chunks), s);
 }
 hipError_t codec_decode(int algo, const uint8_t* d_in, const uint64_t* d_offsets, const uint64_t* d_sizes, uint32_t n_chunks, uint8_t* d_out,

@@ -44,10 +44,12 @@ namespace {
 
 constexpr uint32_t kHalfSlots = 32768;                   // slots per work-group
 constexpr uint32_t kTable = kHalfSlots * 4;              // 128 KiB of dwords
-constexpr uint32_t kStageLds = kTable + 64 * 4;          // + a sink word per lane for the quads of the other half / of earlier stages
-constexpr uint32_t kBatch = 8;                           // blocks of 64 quads per exchange batch (one asm statement)
-constexpr uint32_t kAhead = 2 * kBatch;                  // blocks per loop trip = blocks in flight from memory
-constexpr uint32_t kTrip = kAhead * 256;                 // bytes per loop trip: the passes cover whole trips
+constexpr uint32_t kAhead = 16;                          // blocks of 64 quads per trip: one statement of 16 exchanges, and what a wave has in flight from memory
+constexpr uint32_t kTrip = kAhead * 256;                 // bytes per trip: the passes cover whole trips
+constexpr uint32_t kStageWaves = 8;                      // waves of a stage work-group, taking the trips in rotation
+constexpr uint32_t kSpinLimit = 1u << 22, kPoison = 0xfffffffeu, kErrWatchdog = 16u;   // (as rotor.hip)
+// LDS: the half table | a sink word per lane (the quads of the other half / of earlier stages; the token store of lanes 1..63) | the token
+constexpr uint32_t stage_lds_bytes(uint32_t waves) { return kTable + waves * 64 * 4 + 16; }
 
 // per algorithm: stages, record geometry (cheetah.rs:17-23,188-196; lion.rs:17-27,317-325), the in-order head, the table slot of serial_codec.hip
 template <int ALGO> struct StageGeo;
@@ -62,40 +64,55 @@ template <> struct StageGeo<DENSITY_HIP_LION> {
 
 __device__ __forceinline__ uint32_t hash16(uint32_t q) { return (q * kHashMul) >> 16; }
 
-// eight ordered exchanges back to back, answers valid at the end of the statement
-#define DENSITY_STAGE_XCHG8(o, a, v, ones)                                                                                        \
+// The critical section of a trip: sixteen ordered exchanges (the answer comes back in the address register), the token for the next
+// trip written right behind them (the LDS takes a wave's instructions in order: whoever sees the token queues up behind these
+// exchanges — rotor.hip's hand-off, self-tested at start-up), then the answers.
+#define DENSITY_STAGE_X16_TOKEN(ra, v, ones, tokaddr, tokval)                                                                     \
     asm volatile(                                                                                                                 \
-        "ds_mskor_rtn_b32 %0, %8, %24, %16\n\t"                                                                                   \
-        "ds_mskor_rtn_b32 %1, %9, %24, %17\n\t"                                                                                   \
-        "ds_mskor_rtn_b32 %2, %10, %24, %18\n\t"                                                                                  \
-        "ds_mskor_rtn_b32 %3, %11, %24, %19\n\t"                                                                                  \
-        "ds_mskor_rtn_b32 %4, %12, %24, %20\n\t"                                                                                  \
-        "ds_mskor_rtn_b32 %5, %13, %24, %21\n\t"                                                                                  \
-        "ds_mskor_rtn_b32 %6, %14, %24, %22\n\t"                                                                                  \
-        "ds_mskor_rtn_b32 %7, %15, %24, %23\n\t"                                                                                  \
+        "ds_mskor_rtn_b32 %0, %0, %32, %16\n\t"                                                                                   \
+        "ds_mskor_rtn_b32 %1, %1, %32, %17\n\t"                                                                                   \
+        "ds_mskor_rtn_b32 %2, %2, %32, %18\n\t"                                                                                   \
+        "ds_mskor_rtn_b32 %3, %3, %32, %19\n\t"                                                                                   \
+        "ds_mskor_rtn_b32 %4, %4, %32, %20\n\t"                                                                                   \
+        "ds_mskor_rtn_b32 %5, %5, %32, %21\n\t"                                                                                   \
+        "ds_mskor_rtn_b32 %6, %6, %32, %22\n\t"                                                                                   \
+        "ds_mskor_rtn_b32 %7, %7, %32, %23\n\t"                                                                                   \
+        "ds_mskor_rtn_b32 %8, %8, %32, %24\n\t"                                                                                   \
+        "ds_mskor_rtn_b32 %9, %9, %32, %25\n\t"                                                                                   \
+        "ds_mskor_rtn_b32 %10, %10, %32, %26\n\t"                                                                                 \
+        "ds_mskor_rtn_b32 %11, %11, %32, %27\n\t"                                                                                 \
+        "ds_mskor_rtn_b32 %12, %12, %32, %28\n\t"                                                                                 \
+        "ds_mskor_rtn_b32 %13, %13, %32, %29\n\t"                                                                                 \
+        "ds_mskor_rtn_b32 %14, %14, %32, %30\n\t"                                                                                 \
+        "ds_mskor_rtn_b32 %15, %15, %32, %31\n\t"                                                                                 \
+        "ds_write_b32 %33, %34\n\t"                                                                                               \
         "s_waitcnt lgkmcnt(0)"                                                                                                    \
-        : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7])                  \
-        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]),                                 \
-          "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(ones)                       \
+        : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(ra[4]), "+v"(ra[5]), "+v"(ra[6]), "+v"(ra[7]),                 \
+          "+v"(ra[8]), "+v"(ra[9]), "+v"(ra[10]), "+v"(ra[11]), "+v"(ra[12]), "+v"(ra[13]), "+v"(ra[14]), "+v"(ra[15])            \
+        : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]),                                 \
+          "v"(v[8]), "v"(v[9]), "v"(v[10]), "v"(v[11]), "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]),                           \
+          "v"(ones), "v"(tokaddr), "v"(tokval)                                                                                    \
         : "memory")
 
 // where a stage's table lives in the chunk's table slot of serial_codec.hip (64 Ki {a, b} pairs, then 64 Ki x 1 or 5 predictions):
 // byte offset of slot 0's word and the stride from slot to slot
 struct StagePlace { uint64_t chunk_tables; uint32_t offset, stride; };
 
-// One stage over one chunk for one half of the slots.
+// One stage over one chunk for one half of the slots: a work-group of W waves that take the trips of 16 blocks in rotation — loads,
+// hashes, ballots and stores of one wave beside the exchanges of another; the exchanges themselves in stream order behind the token.
 //   KEY_PREV    the slot is the hash of the quad BEFORE (the predictor levels) / of the quad itself (A, B)
 //   OWN_VALUE   the value exchanged in is the quad (first predictor level, A) / what the previous stage displaced (vals[])
 //   KEEP_OLD    the displaced value is kept in vals[] for the next stage
 //   HAS_BEFORE  not the first stage: the quads an earlier stage settled take no part
 // done_prev / done_out: per 64-quad block of the whole input four dwords — lanes 0..31 of half 0, of half 1, lanes 32..63 of half 0, of
 // half 1 — "quad settled by this stage or an earlier one" (cumulative; a reader ORs the two halves: one 8-byte load per lane).
-template <bool KEY_PREV, bool OWN_VALUE, bool KEEP_OLD, bool HAS_BEFORE>
-__global__ __launch_bounds__(64) void exchange_stage(const uint8_t* __restrict__ in, uint64_t total, uint64_t chunk_bytes,
-                                                     const uint32_t* __restrict__ done_prev, uint32_t* __restrict__ done_out,
-                                                     uint32_t* __restrict__ vals, uint8_t* __restrict__ tables,
-                                                     const uint32_t* __restrict__ head_state, StagePlace place) {
-    const uint32_t lane = threadIdx.x;
+template <bool KEY_PREV, bool OWN_VALUE, bool KEEP_OLD, bool HAS_BEFORE, uint32_t W>
+__global__ __launch_bounds__(W * 64) void exchange_stage(const uint8_t* __restrict__ in, uint64_t total, uint64_t chunk_bytes,
+                                                         const uint32_t* __restrict__ done_prev, uint32_t* __restrict__ done_out,
+                                                         uint32_t* __restrict__ vals, uint8_t* __restrict__ tables,
+                                                         const uint32_t* __restrict__ head_state, StagePlace place, uint32_t* __restrict__ fault) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = rfl(threadIdx.x >> 6);
     const uint64_t chunk = blockIdx.x >> 1;
     const uint32_t half = blockIdx.x & 1u;
     const uint64_t base = chunk * chunk_bytes;
@@ -104,12 +121,13 @@ __global__ __launch_bounds__(64) void exchange_stage(const uint8_t* __restrict__
     const uint32_t nb = (uint32_t)(len / kTrip) * kAhead;                         // whole trips; a ragged end is the in-order kernel's again
     const uint64_t gb0 = base >> 8;
     uint8_t* mine_tb = tables + chunk * place.chunk_tables + place.offset + (uint64_t)half * kHalfSlots * place.stride;
+    uint32_t* w = reinterpret_cast<uint32_t*>(stage_lds);
     {
         // the table as the head left it: this half of the slots
-        uint32_t* w = reinterpret_cast<uint32_t*>(stage_lds);
 #pragma unroll 8
-        for (uint32_t k = lane; k < kHalfSlots; k += 64) w[k] = *reinterpret_cast<const uint32_t*>(mine_tb + (uint64_t)k * place.stride);
-        w[kHalfSlots + lane] = 0u;                                                // the sinks
+        for (uint32_t k = threadIdx.x; k < kHalfSlots; k += W * 64) w[k] = *reinterpret_cast<const uint32_t*>(mine_tb + (uint64_t)k * place.stride);
+        w[kHalfSlots + threadIdx.x] = 0u;                                         // the sinks
+        if (threadIdx.x == 0) w[kHalfSlots + W * 64] = 0u;                        // the token: the trip whose exchanges go next
         __syncthreads();
     }
     const uint32_t* __restrict__ q32 = reinterpret_cast<const uint32_t*>(in + base);
@@ -117,68 +135,86 @@ __global__ __launch_bounds__(64) void exchange_stage(const uint8_t* __restrict__
     const uint2* __restrict__ before2 = reinterpret_cast<const uint2*>(done_prev + gb0 * 4) + (lane >> 5);   // + 2 per block
     uint32_t* __restrict__ mine = done_out + gb0 * 4 + half;                                                 // + 4 per block, + 2 for the upper lanes
     const uint32_t lds0 = lds_addr(stage_lds);
-    const uint32_t sink = lds0 + kTable + lane * 4u;
+    const uint32_t sink = lds0 + kTable + threadIdx.x * 4u;
+    const uint32_t token = lds0 + kTable + W * 256u;
     const uint32_t ones = 0xffffffffu;
     const uint32_t hb = head_state[8 * chunk + 6] >> 8;                           // blocks of the in-order head (whole trips)
-
+    const uint32_t trips = (nb - hb) / kAhead;
     const uint32_t last_hash = head_state[8 * chunk + 1];                         // cheetah.rs:146 / lion.rs:268 as the head left it (its last block may be a raw copy)
-    uint32_t qn[kAhead], pn[kAhead], vn[kAhead];
-    uint2 bn[kAhead];
-#pragma unroll
-    for (uint32_t j = 0; j < kAhead; ++j) {
-        const uint32_t i = (hb + j) * 64u + lane;
-        qn[j] = q32[i];
-        pn[j] = KEY_PREV ? q32[i - 1] : 0u;
-        vn[j] = !OWN_VALUE ? v32[i] : 0u;
-        bn[j] = HAS_BEFORE ? before2[(hb + j) * 2u] : make_uint2(0u, 0u);
-    }
-    for (uint32_t g = hb; g < nb; g += kAhead) {
-        uint32_t q[kAhead], key[kAhead], val[kAhead];
-        bool before[kAhead];
+
+    if (wave < trips) {
+        uint32_t qn[kAhead], pn[kAhead], vn[kAhead];
+        uint2 bn[kAhead];
 #pragma unroll
         for (uint32_t j = 0; j < kAhead; ++j) {
-            q[j] = qn[j];
-            val[j] = OWN_VALUE ? qn[j] : vn[j];
-            before[j] = HAS_BEFORE && (((bn[j].x | bn[j].y) >> (lane & 31u)) & 1u);
-            // slot: cheetah.rs:125 / lion.rs:213 (the predictor is addressed by the previous quad's hash), cheetah.rs:131 / lion.rs:245
-            key[j] = KEY_PREV ? hash16(pn[j]) : hash16(qn[j]);
+            const uint32_t i = (hb + wave * kAhead + j) * 64u + lane;
+            qn[j] = q32[i];
+            pn[j] = KEY_PREV ? q32[i - 1] : 0u;
+            vn[j] = !OWN_VALUE ? v32[i] : 0u;
+            bn[j] = HAS_BEFORE ? before2[(hb + wave * kAhead + j) * 2u] : make_uint2(0u, 0u);
         }
-        if (KEY_PREV && g == hb && lane == 0) key[0] = last_hash;
-        {                                                                          // the next trip's quads: in flight across this one
-            const uint32_t gn = g + kAhead < nb ? g + kAhead : g;                  // (the last trip loads itself again: no branch, nothing out of bounds)
+        for (uint32_t t = wave; t < trips; t += W) {
+            const uint32_t g = hb + t * kAhead;
+            uint32_t q[kAhead], key[kAhead], val[kAhead];
+            bool before[kAhead];
 #pragma unroll
             for (uint32_t j = 0; j < kAhead; ++j) {
-                const uint32_t i = (gn + j) * 64u + lane;
-                qn[j] = q32[i];
-                if (KEY_PREV) pn[j] = q32[i - 1];
-                if (!OWN_VALUE) vn[j] = v32[i];
-                if (HAS_BEFORE) bn[j] = before2[(gn + j) * 2u];
+                q[j] = qn[j];
+                val[j] = OWN_VALUE ? qn[j] : vn[j];
+                before[j] = HAS_BEFORE && (((bn[j].x | bn[j].y) >> (lane & 31u)) & 1u);
+                // slot: cheetah.rs:125 / lion.rs:213 (the predictor is addressed by the previous quad's hash), cheetah.rs:131 / lion.rs:245
+                key[j] = KEY_PREV ? hash16(pn[j]) : hash16(qn[j]);
             }
-        }
+            if (KEY_PREV && t == 0 && lane == 0) key[0] = last_hash;
+            {                                                                      // this wave's next trip: in flight across this one
+                const uint32_t gn = hb + (t + W < trips ? t + W : t) * kAhead;     // (its last trip loads itself again: no branch, nothing out of bounds)
 #pragma unroll
-        for (uint32_t s = 0; s < kAhead; s += kBatch) {
-            uint32_t addr[kBatch], put[kBatch], old[kBatch];
-            bool part[kBatch];
-#pragma unroll
-            for (uint32_t j = 0; j < kBatch; ++j) {
-                part[j] = !before[s + j] && (key[s + j] >> 15) == half;
-                addr[j] = part[j] ? lds0 + (key[s + j] & (kHalfSlots - 1u)) * 4u : sink;
-                put[j] = val[s + j];
+                for (uint32_t j = 0; j < kAhead; ++j) {
+                    const uint32_t i = (gn + j) * 64u + lane;
+                    qn[j] = q32[i];
+                    if (KEY_PREV) pn[j] = q32[i - 1];
+                    if (!OWN_VALUE) vn[j] = v32[i];
+                    if (HAS_BEFORE) bn[j] = before2[(gn + j) * 2u];
+                }
             }
-            DENSITY_STAGE_XCHG8(old, addr, put, ones);
+            uint32_t ra[kAhead];                                                   // slot address in, what the slot held out
+            bool part[kAhead];
 #pragma unroll
-            for (uint32_t j = 0; j < kBatch; ++j) {
-                const bool hit = part[j] && old[j] == q[s + j];
-                const uint64_t settled = ballot64(hit || before[s + j]);
-                if (KEEP_OLD && part[j] && !hit) v32[(g + s + j) * 64u + lane] = old[j];
-                if (lane < 2) mine[(g + s + j) * 4u + lane * 2u] = lane ? (uint32_t)(settled >> 32) : (uint32_t)settled;
+            for (uint32_t j = 0; j < kAhead; ++j) {
+                part[j] = !before[j] && (key[j] >> 15) == half;
+                ra[j] = part[j] ? lds0 + (key[j] & (kHalfSlots - 1u)) * 4u : sink;
+            }
+            if (W > 1) {                                                           // my turn: every earlier trip's exchanges are queued
+                bool poisoned = false;
+                for (uint32_t spins = 0;; ++spins) {
+                    uint32_t seen;
+                    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(seen) : "v"(token) : "memory");
+                    seen = rfl(seen);
+                    if (seen == t) break;
+                    if (seen == kPoison || spins > kSpinLimit) {
+                        if (seen != kPoison && lane == 0) { atomicOr(fault, kErrWatchdog); w[kHalfSlots + W * 64] = kPoison; }
+                        poisoned = true;
+                        break;
+                    }
+                }
+                if (poisoned) break;
+            }
+            {
+                const uint32_t tokaddr = lane == 0 ? token : sink, tokval = t + 1u;
+                DENSITY_STAGE_X16_TOKEN(ra, val, ones, tokaddr, tokval);
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < kAhead; ++j) {
+                const bool hit = part[j] && ra[j] == q[j];
+                const uint64_t settled = ballot64(hit || before[j]);
+                if (KEEP_OLD && part[j] && !hit) v32[(g + j) * 64u + lane] = ra[j];
+                if (lane < 2) mine[(g + j) * 4u + lane * 2u] = lane ? (uint32_t)(settled >> 32) : (uint32_t)settled;
             }
         }
     }
     if (len % kTrip) {                                                             // a ragged end follows: the table goes back where it came from
         __syncthreads();
-        const uint32_t* w = reinterpret_cast<const uint32_t*>(stage_lds);
-        for (uint32_t k = lane; k < kHalfSlots; k += 64) *reinterpret_cast<uint32_t*>(mine_tb + (uint64_t)k * place.stride) = w[k];
+        for (uint32_t k = threadIdx.x; k < kHalfSlots; k += W * 64) *reinterpret_cast<uint32_t*>(mine_tb + (uint64_t)k * place.stride) = w[k];
     }
 }
 
@@ -360,7 +396,7 @@ __global__ __launch_bounds__(kEmitWaves * 64) void stage_emit_records(const uint
 
 template <int ALGO>
 hipError_t run_stages(const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_out, uint64_t out_stride,
-                      uint64_t* d_sizes, uint8_t* d_tables, uint32_t n_slots, uint8_t* d_scratch, hipStream_t stream) {
+                      uint64_t* d_sizes, uint8_t* d_tables, uint32_t n_slots, uint8_t* d_scratch, uint32_t* d_err, hipStream_t stream) {
     using G = StageGeo<ALGO>;
     constexpr uint32_t kRecs = 64 / G::kRecQuads;
     const uint64_t blocks = (total + 255) / 256;
@@ -373,14 +409,16 @@ hipError_t run_stages(const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes,
     // the head of every chunk in order (a wave per chunk, its tables left in d_tables), then the passes from those tables
     hipError_t e = launch_wave_encode_heads(ALGO, d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, head_state, G::kHeadBytes, G::kHeadCalm, stream);
     if (e != hipSuccess) return e;
-    auto first = ALGO == DENSITY_HIP_CHEETAH ? exchange_stage<true, true, false, false> : exchange_stage<true, true, true, false>;
-    auto level = exchange_stage<true, false, true, true>, last_level = exchange_stage<true, false, false, true>;
-    auto stage_a = exchange_stage<false, true, true, true>, stage_b = exchange_stage<false, false, false, true>;
+    constexpr uint32_t W = kStageWaves;
+    auto first = ALGO == DENSITY_HIP_CHEETAH ? exchange_stage<true, true, false, false, W> : exchange_stage<true, true, true, false, W>;
+    auto level = exchange_stage<true, false, true, true, W>, last_level = exchange_stage<true, false, false, true, W>;
+    auto stage_a = exchange_stage<false, true, true, true, W>, stage_b = exchange_stage<false, false, false, true, W>;
+    constexpr uint32_t kStageLds = stage_lds_bytes(W);
     for (const void* k : {(const void*)first, (const void*)level, (const void*)last_level, (const void*)stage_a, (const void*)stage_b}) {
         e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStageLds);
         if (e != hipSuccess) return e;
     }
-    const dim3 grid(2 * n_chunks), wave(64);
+    const dim3 grid(2 * n_chunks), wave(W * 64);
     const uint32_t* hs = head_state;
     const uint32_t levels = G::kStages - 2;                                        // predictor levels: 1 (Cheetah), 5 (Lion: 20 bytes a slot)
     const uint32_t pred_stride = 4 * levels;
@@ -389,12 +427,12 @@ hipError_t run_stages(const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes,
         const StagePlace place{G::kChunkTables, (uint32_t)(65536u * 8u + 4u * l), pred_stride};
         auto kernel = l == 0 ? first : (l + 1 < levels ? level : last_level);
         hipLaunchKernelGGL(kernel, grid, wave, kStageLds, stream, d_in, total, chunk_bytes, (const uint32_t*)(done + 4 * (s ? s - 1 : 0) * blocks), done + 4 * s * blocks, vals,
-                           d_tables, hs, place);
+                           d_tables, hs, place, d_err);
     }
     for (uint32_t ab = 0; ab < 2; ++ab, ++s) {
         const StagePlace place{G::kChunkTables, 4u * ab, 8u};
         hipLaunchKernelGGL(ab == 0 ? stage_a : stage_b, grid, wave, kStageLds, stream, d_in, total, chunk_bytes, (const uint32_t*)(done + 4 * (s - 1) * blocks), done + 4 * s * blocks,
-                           vals, d_tables, hs, place);
+                           vals, d_tables, hs, place, d_err);
     }
     hipLaunchKernelGGL(stage_record_layout<ALGO>, dim3(n_chunks), dim3(kLayoutThreads), 0, stream, total, chunk_bytes, (const uint32_t*)done, blocks, hs, d_in, rec_off, d_sizes,
                        redo, tail_state);
@@ -424,7 +462,7 @@ bool stage_encode_eligible(int algo, const uint8_t* d_in, uint64_t total, uint64
     // The passes cost time in proportion to the input (one wave per CU at a time: the LDS holds one half table), the one-wave kernels in
     // proportion to the CHUNK while there are CUs for more waves: measured cross-over near 1000 (Cheetah) / 500 (Lion) chunks.
     const uint32_t most = algo == DENSITY_HIP_CHEETAH ? 768u : 384u;
-    return !g_force_lane_codec && !g_force_wave_codec && !g_exchange_unsafe && n_chunks != 0 && n_chunks <= most && (uintptr_t)d_in % 4 == 0 &&
+    return !g_force_lane_codec && !g_force_wave_codec && !g_rotor_unsafe && n_chunks != 0 && n_chunks <= most && (uintptr_t)d_in % 4 == 0 &&
            chunk_bytes % kTrip == 0 && chunk_bytes >= 4 * head && chunk_bytes < (1ull << 31) && total >= 4 * head &&
            (uint64_t)n_chunks * slot <= (8ull << 30);                             // (a table slot per chunk: api.hip::kSerialTableBudget)
 }
@@ -437,9 +475,9 @@ uint64_t stage_scratch_bytes(int algo, uint64_t total, uint32_t n_chunks) {
 }
 
 hipError_t launch_stage_encode(int algo, const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_out, uint64_t out_stride,
-                               uint64_t* d_sizes, uint8_t* d_tables, uint32_t n_slots, uint8_t* d_scratch, hipStream_t stream) {
-    return algo == DENSITY_HIP_CHEETAH ? run_stages<DENSITY_HIP_CHEETAH>(d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, n_slots, d_scratch, stream)
-                                       : run_stages<DENSITY_HIP_LION>(d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, n_slots, d_scratch, stream);
+                               uint64_t* d_sizes, uint8_t* d_tables, uint32_t n_slots, uint8_t* d_scratch, uint32_t* d_err, hipStream_t stream) {
+    return algo == DENSITY_HIP_CHEETAH ? run_stages<DENSITY_HIP_CHEETAH>(d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, n_slots, d_scratch, d_err, stream)
+                                       : run_stages<DENSITY_HIP_LION>(d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, n_slots, d_scratch, d_err, stream);
 }
 
 }  // namespace density

@@ -89,7 +89,7 @@ extern uint64_t g_stage_stats[2];
 bool stage_encode_eligible(int algo, const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks);
 uint64_t stage_scratch_bytes(int algo, uint64_t total, uint32_t n_chunks);
 hipError_t launch_stage_encode(int algo, const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_out, uint64_t out_stride,
-                               uint64_t* d_sizes, uint8_t* d_tables, uint32_t n_slots, uint8_t* d_scratch, hipStream_t stream);
+                               uint64_t* d_sizes, uint8_t* d_tables, uint32_t n_slots, uint8_t* d_scratch, uint32_t* d_err, hipStream_t stream);
 
 // ---- stream_parse.hip: record boundaries of one calm Chameleon stream, in parallel ----
 // d_info (16 words): 0 status (1 = a calm head was found), 1 first block behind the sequentially walked head, 2-3 its stream offset, 4 whole
