@@ -31,6 +31,7 @@
 #include "common.hpp"
 #include "kernels.hpp"
 
+#include <cstdlib>
 #include <vector>
 
 namespace density {
@@ -459,9 +460,11 @@ bool stage_encode_eligible(int algo, const uint8_t* d_in, uint64_t total, uint64
     if (algo != DENSITY_HIP_CHEETAH && algo != DENSITY_HIP_LION) return false;
     const uint64_t head = algo == DENSITY_HIP_CHEETAH ? StageGeo<DENSITY_HIP_CHEETAH>::kHeadBytes : StageGeo<DENSITY_HIP_LION>::kHeadBytes;
     const uint64_t slot = algo == DENSITY_HIP_CHEETAH ? StageGeo<DENSITY_HIP_CHEETAH>::kChunkTables : StageGeo<DENSITY_HIP_LION>::kChunkTables;
-    // The passes cost time in proportion to the input (one wave per CU at a time: the LDS holds one half table), the one-wave kernels in
-    // proportion to the CHUNK while there are CUs for more waves: measured cross-over near 1000 (Cheetah) / 500 (Lion) chunks.
-    const uint32_t most = algo == DENSITY_HIP_CHEETAH ? 768u : 384u;
+    // The passes cost time in proportion to the input (one work-group per CU at a time: the LDS holds one half table), the one-wave kernels
+    // in proportion to the CHUNK while there are CUs for more waves.  Measured on 1 GiB in 2048 chunks of 512 KiB: Cheetah 6.8 ms in passes
+    // against 13.1 on the one-wave kernel, Lion (seven stages, 48 KiB heads) 29.9 against 20.3; on 100 MB in 96 chunks 0.9 / 3.4 against 11.4 / 24.2.
+    static const uint32_t most_override = getenv("DENSITY_HIP_STAGE_MOST") ? (uint32_t)atoi(getenv("DENSITY_HIP_STAGE_MOST")) : 0u;   // (tuning runs)
+    const uint32_t most = most_override ? most_override : algo == DENSITY_HIP_CHEETAH ? 4096u : 384u;
     return !g_force_lane_codec && !g_force_wave_codec && !g_rotor_unsafe && n_chunks != 0 && n_chunks <= most && (uintptr_t)d_in % 4 == 0 &&
            chunk_bytes % kTrip == 0 && chunk_bytes >= 4 * head && chunk_bytes < (1ull << 31) && total >= 4 * head &&
            (uint64_t)n_chunks * slot <= (8ull << 30);                             // (a table slot per chunk: api.hip::kSerialTableBudget)
