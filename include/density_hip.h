@@ -130,6 +130,9 @@ size_t density_hip_decoded_size(const uint8_t* container, size_t container_size)
  * hipStream_t (NULL = the library's internal stream).  Work is enqueued on `stream`.
  *   - workspace: pass a device buffer of at least density_hip_{encode,decode}_workspace_size() bytes, or NULL to
  *     use the library's per-device cached workspace (then calls on different streams must not overlap).
+ *     The encode workspace holds a worst-case slot per chunk (about 1.06 x the input) and, for Cheetah / Lion, a table slot per
+ *     concurrent chunk stream (768 KiB / 1.75 MiB, at most 8 GiB) plus the scratch of the exchange passes (a dword per quad and
+ *     the per-block masks: about 1.25 / 1.5 x the input).
  *   - header_out / decoded_size_out: optional HOST pointers; when non-NULL the call synchronises `stream` and
  *     fills them (and then also reports kernel-detected format errors).  When NULL the call is fully asynchronous.
  * Returns DENSITY_HIP_OK or an error code. */
