@@ -463,7 +463,13 @@ int run_stream_encode(DeviceCtx* c, int algo, const uint8_t* d_in, size_t n, uin
     const DecodePlan sp = plan_decode(algo, 1);   // stream calls share the one-chunk decode layout
     uint32_t* d_err = reinterpret_cast<uint32_t*>(ws + sp.off_err);
     hipError_t e = hipMemsetAsync(d_err, 0, sizeof(uint32_t), s);
-    if (e == hipSuccess) e = codec_encode(algo, d_in, n, n, 1, d_out, 0, d_sizes, nullptr, ws + sp.off_tables, zmap_bytes(algo, 1) ? reinterpret_cast<uint32_t*>(ws + sp.off_zmap) : nullptr, nullptr, d_err, s);
+    // a long Cheetah / Lion stream is ONE chunk for the exchange passes (exchange_stages.hip): their scratch comes from the context
+    uint8_t* d_stage = nullptr;
+    if (e == hipSuccess && algo != DENSITY_HIP_CHAMELEON && stage_encode_eligible(algo, d_in, n, n, 1)) {
+        e = c->seg.ensure(stage_scratch_bytes(algo, n, 1) + kAlign);
+        d_stage = (uint8_t*)c->seg.p;
+    }
+    if (e == hipSuccess) e = codec_encode(algo, d_in, n, n, 1, d_out, 0, d_sizes, nullptr, ws + sp.off_tables, zmap_bytes(algo, 1) ? reinterpret_cast<uint32_t*>(ws + sp.off_zmap) : nullptr, d_stage, d_err, s);
     prof.mark(encode_kernel_name(algo));
     uint64_t h_size = 0;
     uint32_t h_err = 0;

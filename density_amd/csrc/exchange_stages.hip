@@ -465,8 +465,9 @@ bool stage_encode_eligible(int algo, const uint8_t* d_in, uint64_t total, uint64
     // against 13.1 on the one-wave kernel, Lion (seven stages, 48 KiB heads) 29.9 against 20.3; on 100 MB in 96 chunks 0.9 / 3.4 against 11.4 / 24.2.
     static const uint32_t most_override = getenv("DENSITY_HIP_STAGE_MOST") ? (uint32_t)atoi(getenv("DENSITY_HIP_STAGE_MOST")) : 0u;   // (tuning runs)
     const uint32_t most = most_override ? most_override : algo == DENSITY_HIP_CHEETAH ? 4096u : 384u;
+    // (chunk bases must be whole 256-byte blocks; ONE chunk — a reference stream — may have any length: its ragged end is the in-order kernel's)
     return !g_force_lane_codec && !g_force_wave_codec && !g_rotor_unsafe && n_chunks != 0 && n_chunks <= most && (uintptr_t)d_in % 4 == 0 &&
-           chunk_bytes % kTrip == 0 && chunk_bytes >= 4 * head && chunk_bytes < (1ull << 31) && total >= 4 * head &&
+           (n_chunks == 1 || chunk_bytes % kTrip == 0) && chunk_bytes >= 4 * head && chunk_bytes < (1ull << 31) && total >= 4 * head &&
            (uint64_t)n_chunks * slot <= (8ull << 30);                             // (a table slot per chunk: api.hip::kSerialTableBudget)
 }
 // vals (a dword per quad) | done masks (stages x 2 halves x a qword per 64-quad block) | record offsets | per-chunk verdicts, head and tail states

@@ -280,3 +280,23 @@ def test_exchange_passes_ragged_end(algo, kind, ragged, kernel_variant):
     back = np.zeros(n, dtype=np.uint8)
     assert container.decode(cont[:cn], back) == n
     assert np.array_equal(back, data)
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("kind,n", [("prose", 3_000_003), ("rep", 2_500_000), ("mixed", 1_200_001)])
+def test_long_stream_encode_in_exchange_passes(algo, kind, n, kernel_variant):
+    """The reference symbols `cheetah_encode` / `lion_encode` on one long stream: the whole stream is one chunk for the exchange passes
+    (in-order head, stages over the whole trips, the ragged end in order again) — byte for byte the reference's stream."""
+    data = datagen.by_kind(kind, n, seed=n)
+    want = pyoracle.encode(algo, data)
+    if kernel_variant == "default":
+        container.set_kernel_variant(64)
+    s0 = stage_stats()
+    got = gpu_encode(algo, data)
+    s1 = stage_stats()
+    assert len(got) == len(want) and got == want
+    if kernel_variant == "default":
+        assert s1[0] - s0[0] == 1                                  # one chunk through the passes ...
+        if kind != "mixed":
+            assert s1[1] - s0[1] == 0                              # ... and kept
+    assert gpu_decode(algo, want, n) == data.tobytes()
