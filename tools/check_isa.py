@@ -8,7 +8,8 @@ rotor.hip to assembly and checks, for every 8-wave encoder instance, that
   * the only instructions naming a staging register are those loads (global_load_dword vN, ..) and the moves out of them
     (v_mov_b32 vX, vN), and
   * every run of moves directly follows an s_waitcnt vmcnt(..).
-Also checked: the default decoder's stage B waits with vmcnt(12) and nothing in its round loop drains the memory queue.
+Also checked: the default decoder's stage B waits with vmcnt(12) and nothing in its round loop drains the memory queue; the
+exchange stage kernels of exchange_stages.hip fit their 256 registers without scratch memory.
 usage: python tools/check_isa.py   (exit code 1 on a violation; run by density_amd.build)"""
 import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -95,7 +96,23 @@ def main():
     if not dec:
         print("check_isa: decoder instance not found")
         bad += 1
-    print(f"check_isa: {total} hand-issued loads in the 8-wave encoder instances, decoder waits checked, {bad} violation(s)")
+    # exchange_stages.hip: eight waves of a stage work-group share a CU, two per SIMD — 256 registers each.  A stage kernel that needs
+    # more spills to scratch memory inside the token's critical path without a test failing.
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "stages.s")
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", out,
+                        os.path.join(ROOT, "density_amd", "csrc", "exchange_stages.hip")], check=True, stderr=subprocess.DEVNULL)
+        text = open(out).read()
+    stages = 0
+    for m in re.finditer(r"\.name:\s+(\S*exchange_stage\S*)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)\n(?:.*\n)*?\s+\.vgpr_spill_count:\s+(\d+)", text):
+        stages += 1
+        if int(m.group(2)) or int(m.group(4)) or int(m.group(3)) > 256:
+            print(f"{m.group(1)}: scratch {m.group(2)} bytes, {m.group(3)} registers, {m.group(4)} spilled")
+            bad += 1
+    if not stages:
+        print("check_isa: no exchange stage kernels found")
+        bad += 1
+    print(f"check_isa: {total} hand-issued loads in the 8-wave encoder instances, decoder waits checked, {stages} exchange stage kernels without scratch, {bad} violation(s)")
     return 1 if bad or not total else 0
 
 if __name__ == "__main__":
