@@ -63,3 +63,16 @@ def test_in_order_head_then_passes(kind, n, handed_back):
         assert got == want
     if kind == "prose":
         assert st["copy_blocks"] > 0                              # ... all of them inside the head
+
+
+@pytest.mark.parametrize("kind,n", [("prose", 160 * 1024), ("rep", 128 * 1024), ("zeros", 64 * 1024)])
+def test_lion_in_order_head_then_passes(kind, n):
+    """The same hand-over for Lion: seven tables (the prediction row level by level) seeded from an in-order head of 48 KiB."""
+    data = datagen.by_kind(kind, n, seed=29)
+    want, st = pyoracle.encode_stats("lion", data)
+    got = model.encode_head_then_passes("lion", bytes(data), 48 * 1024)
+    if got is not None:
+        assert got == want
+    else:
+        assert st["copy_blocks"] > 0
+    assert model.encode_head_then_passes("cheetah", bytes(data), 16 * 1024) in (None, pyoracle.encode("cheetah", data))

@@ -50,19 +50,19 @@ def cheetah_flags(q, last_hash=0, tables=(None, None, None)):
     return flags, h
 
 
-def lion_flags(q):
+def lion_flags(q, last_hash=0, tables=(None,) * 7):
     h = hashes(q)
-    prev = np.concatenate(([0], h[:-1])).astype(np.uint32)
+    prev = np.concatenate(([last_hash], h[:-1])).astype(np.uint32)
     left = np.ones(len(q), dtype=bool)
     flags = np.zeros(len(q), dtype=np.uint8)
     carry = q
     for level in range(5):                                             # the list: level k takes what level k-1 displaced
-        carry_old, hit = stage(prev, carry, left, q)
+        carry_old, hit = stage(prev, carry, left, q, tables[level])
         flags[hit] = level + 1
         left = left & ~hit
         carry = carry_old
-    old_a, map_a = stage(h, q, left, q)
-    _, map_b = stage(h, old_a, left & ~map_a, q)
+    old_a, map_a = stage(h, q, left, q, tables[5])
+    _, map_b = stage(h, old_a, left & ~map_a, q, tables[6])
     flags[map_a] = 6
     flags[map_b] = 7
     return flags, h
@@ -160,6 +160,76 @@ def cheetah_encode_head_then_passes(data, head_bytes):
     flags, h = cheetah_flags(q, last_hash, tables)
     body, sizes = assemble("cheetah", rest, flags, h)
     inc = [prev_inc] + [s >= 128 for s in sizes]
+    if any(a and b for a, b in zip(inc, inc[1:])):
+        return None
+    return head + body
+
+
+def lion_head_in_order(data, head_bytes):
+    """As cheetah_head_in_order for Lion (lion.rs:211-270): -> (stream, tables N0..N4/A/B, last_hash, penalty running, last record incompressible)."""
+    q = np.frombuffer(data[:head_bytes], dtype="<u4")
+    N = [np.zeros(65536, dtype=np.uint32) for _ in range(5)]
+    A = np.zeros(65536, dtype=np.uint32); B = A.copy()
+    out = bytearray()
+    penalty, start, prev_inc, counter, last_hash = 0, 1, False, 0, 0
+    for r in range(len(q) // 16):
+        if (counter & 0xF) == 0 and start > 1:
+            start >>= 1
+        counter += 1
+        block = q[16 * r: 16 * r + 16]
+        if penalty > 0:
+            out += block.tobytes()
+            penalty -= 1
+            if penalty == 0:
+                start += 1
+            continue
+        sig, items = 0, bytearray()
+        for k, x in enumerate(block):
+            x = int(x)
+            hx = (x * M & 0xFFFFFFFF) >> 16
+            row = [int(n[last_hash]) for n in N]
+            if x in row:
+                depth = row.index(x)
+                f = depth + 1
+            else:
+                depth = 4                                               # shift_predictions: everything moves down, the last entry falls out
+                if A[hx] == x:
+                    f = 6
+                    items += hx.to_bytes(2, "little")
+                else:
+                    if B[hx] == x:
+                        f = 7
+                        items += hx.to_bytes(2, "little")
+                    else:
+                        f = 0
+                        items += x.to_bytes(4, "little")
+                    B[hx] = A[hx]
+                    A[hx] = x
+            for i in range(depth, 0, -1):                               # move to front (lion.rs:50-57, 240-262)
+                N[i][last_hash] = row[i - 1]
+            N[0][last_hash] = x
+            last_hash = hx
+            sig |= f << (3 * k)
+        out += sig.to_bytes(6, "little") + items
+        inc = 6 + len(items) >= 64
+        if inc and prev_inc:
+            penalty = start
+        prev_inc = inc
+    return bytes(out), tuple(N) + (A, B), last_hash, penalty > 0, prev_inc
+
+
+def encode_head_then_passes(algo, data, head_bytes):
+    """-> the chunk's stream, or None where the passes must hand the chunk back (the head ends inside a penalty, or two incompressible
+    records meet behind it)."""
+    head_fn, flags_fn, rec = (cheetah_head_in_order, cheetah_flags, 128) if algo == "cheetah" else (lion_head_in_order, lion_flags, 64)
+    head, tables, last_hash, in_penalty, prev_inc = head_fn(data, head_bytes)
+    if in_penalty:
+        return None
+    rest = data[head_bytes:]
+    q = np.frombuffer(rest, dtype="<u4")
+    flags, h = flags_fn(q, last_hash, tables)
+    body, sizes = assemble(algo, rest, flags, h)
+    inc = [prev_inc] + [s >= rec for s in sizes]
     if any(a and b for a, b in zip(inc, inc[1:])):
         return None
     return head + body
