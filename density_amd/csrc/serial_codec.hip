@@ -406,13 +406,13 @@ __global__ __launch_bounds__(64) void cheetah_encode_wave(const uint8_t* __restr
         }
         uint32_t qnext = (act && pos + G::kBlock <= len) ? ld32u(src + pos + 4u * lane) : 0u;
         // head mode: hand over to the exchange passes at the first 4 KiB boundary behind head_bytes where the blow-up protection has been quiet
-        // for kHeadCalm bytes; a chunk that is too short for that, or has not calmed down by its middle, is simply finished here
+        // for head_calm bytes; a chunk that is too short for that, or has not calmed down within four times head_bytes (or by its middle), is simply finished here
         bool may_hand_over = head_state && len >= 4ull * head_bytes, handed_over = false;
         uint64_t last_copy_end = 0;
         for (; pos + G::kBlock <= len; pos += G::kBlock) {                    // whole blocks
             if (may_hand_over && pos >= head_bytes && (pos & 4095u) == 0) {
                 if (pos >= last_copy_end + head_calm && guard.penalty == 0) { handed_over = true; break; }
-                if (pos >= len / 2) may_hand_over = false;
+                if (pos >= 4ull * head_bytes || pos >= len / 2) may_hand_over = false;   // raw copies this far in are not the cold start's: no hand-over
             }
             const uint8_t* blk = src + pos;
             if (guard.block_is_copy()) {                                      // codec.rs:35-37
@@ -782,7 +782,7 @@ __global__ __launch_bounds__(64) void lion_encode_wave(const uint8_t* __restrict
         for (; pos + G::kBlock <= len; pos += G::kBlock) {
             if (may_hand_over && pos >= head_bytes && (pos & 4095u) == 0) {
                 if (pos >= last_copy_end + head_calm && guard.penalty == 0) { handed_over = true; break; }
-                if (pos >= len / 2) may_hand_over = false;
+                if (pos >= 4ull * head_bytes || pos >= len / 2) may_hand_over = false;   // raw copies this far in are not the cold start's: no hand-over
             }
             const uint8_t* blk = src + pos;
             if (guard.block_is_copy()) {                                      // codec.rs:35-37
