@@ -22,7 +22,7 @@
 // first KiBs of every chunk — so:
 //   * the HEAD of every chunk is encoded in order by the one-wave kernel of serial_codec.hip — at least 16 KiB (Cheetah) / 48 KiB (Lion),
 //     and on to the first 4 KiB boundary where no block has been copied for 16 / 32 KiB (a chunk too short for that, or still restless
-//     at its middle, is simply finished there; the numbers: no late raw copy in 100 MB of prose and 64 MB of repetitive text) — which leaves its tables in global memory; the stages load their half of their table
+//     four heads in, is simply finished there; the numbers: no late raw copy in 100 MB of prose and 64 MB of repetitive text) — which leaves its tables in global memory; the stages load their half of their table
 //     from there instead of starting from zeros;
 //   * behind the head the passes run as if no block were copied; the size scan sees whether two incompressible records ever meet
 //     (protection_state.rs:38-47) — such a chunk is done again, whole, by the in-order kernel (`only` filter);
