@@ -232,6 +232,7 @@ def main():
     ap.add_argument("--host-sample", type=int, default=64 << 20, help="bytes for the PCIe-inclusive host-API rates")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline and the host-API legs")
     ap.add_argument("--no-sweep", action="store_true", help="skip the size sweep (profiling runs: only the headline workload's launches)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the other_configs legs (configs 3/4, strict stream): only the headline workload")
     ap.add_argument("--no-gpu", action="store_true", help="dry mode: launcher + distributed bookkeeping on CPU/gloo (tests)")
     ap.add_argument("--concat", action="store_true", help="also time the optional gather-to-rank-0 stitch (N > 1)")
     ap.add_argument("--variant", type=int, default=0, help="kernel variant bit mask (density_hip_set_kernel_variant): 0 = default")
@@ -256,14 +257,19 @@ def main():
     from density_amd import container
     from oracle import pyoracle
 
-    if world > 1:
+    # One rank per GPU over RCCL whenever a launcher set the rendezvous up — including a world of ONE (WORLD_SIZE=1 in the environment:
+    # the whole process-group branch — init, the size all-gather, the optional concat — then runs on a single GPU, which is how
+    # tests/test_gpu_rccl.py exercises it on the 1-GPU box); a plain `python bench.py` is a single process without a group.
+    use_pg = world > 1 or (os.environ.get("WORLD_SIZE") == "1" and "MASTER_PORT" in os.environ)
+    if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         assert dist.get_world_size() == args.gpus, "RCCL world size differs from --gpus"
     else:
         torch.cuda.set_device(0)
-    n_gpus = dist.get_world_size() if world > 1 else 1
+    n_gpus = dist.get_world_size() if use_pg else 1
 
     n = args.size
     from density_amd import _lib
@@ -305,20 +311,20 @@ def main():
     torch.cuda.synchronize()
     container.set_profiling(True)      # HIP events around every kernel, on the launch stream, inside the timed region
     container.last_timings()           # drain
-    if world > 1:
+    if use_pg:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_pg:
         dist.barrier()
     dt_local = dt = time.perf_counter() - t0
     timings = container.last_timings()
     container.set_profiling(False)
     per_rank_ms = [dt_local / args.steps * 1e3]
-    if world > 1:
+    if use_pg:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         all_t = [torch.empty_like(t) for _ in range(world)]
         dist.all_gather(all_t, t)
@@ -329,18 +335,29 @@ def main():
     # the path's only collective: all-gather of per-shard (chunks, payload bytes) -> offsets in the global container
     from density_amd import parallel
     hdr_l, table_l, index_l, payload_l = parallel.parse_local(cont[:E])
-    if world > 1:
+    if use_pg:
         torch.cuda.synchronize(); tg0 = time.perf_counter()
         lay = parallel.exchange_layout(hdr_l["n_chunks"], payload_l.numel(), n, x.device)
         torch.cuda.synchronize(); gather_ms = (time.perf_counter() - tg0) * 1e3
         glob = parallel.global_layout(lay, chunk, hdr_l["flags"])
     else:
         gather_ms, glob = 0.0, {"container_len": E, "n_chunks": int(hdr.n_chunks), "total_len": n}
-    concat_ms = None
-    if world > 1 and args.concat:
+    concat_ms, concat_checked = None, None
+    if use_pg and args.concat:
         torch.cuda.synchronize(); dist.barrier(); tc0 = time.perf_counter()
         merged = parallel.concat_to_rank0(cont[:E], chunk)
         torch.cuda.synchronize(); dist.barrier(); concat_ms = (time.perf_counter() - tc0) * 1e3
+        if rank == 0:
+            # the stitched global container decodes on this GPU to the ranks' inputs one after the other; with one rank it IS the local container
+            assert merged.numel() == glob["container_len"]
+            if n_gpus == 1:
+                assert torch.equal(merged, cont[:E]), "world-size-1 concat differs from the local container"
+            mh = container.parse_header(bytes(merged[:32].cpu().numpy()))
+            gback = torch.empty(int(mh.total_len), dtype=torch.uint8, device="cuda")
+            assert container.decode_device(merged.data_ptr(), merged.numel(), gback.data_ptr(), gback.numel(), header=mh, stream=s) == mh.total_len
+            assert torch.equal(gback[:n], x), "rank 0's part of the stitched container does not decode to its input"
+            concat_checked = True
+            del gback
         del merged
 
     if rank == 0:
@@ -399,17 +416,18 @@ def main():
                          "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": int(alg_launch), "kernel_avg_ms": round(avg[dom], 4),
                          "launches_per_step": round(launches.get(dom, 1.0), 2)},
-            "multi_gpu": {"size_gather_ms": round(gather_ms, 3), "concat_to_rank0_ms": (round(concat_ms, 3) if concat_ms is not None else None),
+            "multi_gpu": {"process_group": ("nccl (RCCL)" if use_pg else None), "size_gather_ms": round(gather_ms, 3),
+                          "concat_to_rank0_ms": (round(concat_ms, 3) if concat_ms is not None else None), "concat_decodes_to_input": concat_checked,
                           "global_container_bytes": int(glob["container_len"])},
         }
-        if world == 1 and not args.no_sweep:
+        if n_gpus == 1 and not args.no_sweep:
             result["size_sweep"] = size_sweep(container, algo, x, [10_000_000, 100_000_000, n])
         if not args.no_cpu:
             nchk = (min(args.cpu_sample, n) + chunk - 1) // chunk
             result["cpu_baseline"] = cpu_baseline(host, chunk, args.cpu_sample, algo, gpu_payloads=payloads[:nchk])
             result["host_api"] = host_api_rates(algo, host, chunk, args.host_sample)
         print(json.dumps(result))
-    if world > 1:
+    if use_pg:
         dist.barrier()
         dist.destroy_process_group()
 

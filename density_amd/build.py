@@ -33,7 +33,7 @@ def build(force=False, verbose=False):
     # the encoder's hand-issued loads rely on registers the compiler must not have used: checked in the compiled code, every build
     check = os.path.join(os.path.dirname(HERE), "tools", "check_isa.py")
     if os.path.exists(check):
-        r = subprocess.run([sys.executable, check], capture_output=True, text=True)
+        r = subprocess.run([sys.executable, check, LIB], capture_output=True, text=True)
         if r.returncode != 0:
             os.remove(LIB)
             raise RuntimeError("tools/check_isa.py rejected the compiled rotation encoder:\n" + r.stdout + r.stderr)

@@ -180,7 +180,10 @@ EncodePlan plan_encode(int algo, size_t n, size_t chunk) {
     p.off_zmap = p.off_tables + serial_tables(algo, p.n_chunks ? p.n_chunks : 1);
     p.off_stage = p.off_zmap + zmap_bytes(algo, p.n_chunks);
     // the exchange passes of Cheetah / Lion (exchange_stages.hip): a dword per quad, the per-block masks, the record offsets
-    p.total = p.off_stage + (algo != DENSITY_HIP_CHAMELEON && chunk % 4096 == 0 ? align_up(stage_scratch_bytes(algo, n, (uint32_t)p.n_chunks), kAlign) : 0);
+    // — only where the passes will run: every condition of stage_encode_eligible but the input pointer's alignment is known here (chunk count
+    // limits, head size, table budget, forced variants), and a caller sizing its own workspace should not pay 1.25-1.5 x the input for nothing
+    const bool passes = algo != DENSITY_HIP_CHAMELEON && p.n_chunks <= 0xffffffffull && stage_encode_eligible(algo, nullptr, n, chunk, (uint32_t)p.n_chunks);
+    p.total = p.off_stage + (passes ? align_up(stage_scratch_bytes(algo, n, (uint32_t)p.n_chunks), kAlign) : 0);
     return p;
 }
 struct DecodePlan {
@@ -546,6 +549,9 @@ int run_stream_decode_segmented(DeviceCtx* c, const uint8_t* d_in, size_t E, uin
     if (e != hipSuccess) { set_error("segmented stream decode (parse)", e); return DENSITY_HIP_ERR_RUNTIME; }
     const uint64_t whole = info[4], end_pos = ((uint64_t)info[6] << 32) | info[5];
     if (!parsed || whole < 2 * kChunkBlocks || end_pos > E) { if (trace) fprintf(stderr, "[density_hip prof]   -> sequential path (not calm enough / short)\n"); return DENSITY_HIP_OK; }
+    // `whole` comes from the (untrusted) stream, the index was sized from the OUTPUT capacity: a stream that holds more blocks than the
+    // output has room for is the sequential path's to refuse (a format error), before anything is sized or filled with it
+    if (whole > max_chunks * kChunkBlocks || whole > index_bytes) { if (trace) fprintf(stderr, "[density_hip prof]   -> sequential path (stream longer than the output: %llu blocks)\n", (unsigned long long)whole); return DENSITY_HIP_OK; }
     std::vector<uint64_t> h_off(max_chunks + 2), h_offsets, h_sizes;
     e = hipMemcpyAsync(h_off.data(), d_chunk_offset, (max_chunks + 2) * sizeof(uint64_t), hipMemcpyDeviceToHost, s);
     // beyond the whole blocks the index says "ragged" = stop (an episode that was started over may have written further)

@@ -161,7 +161,9 @@ __device__ __forceinline__ void resolve_groups(bool active, uint32_t lane, uint3
 // reference would panic (truncated stream, output too small).
 template <typename Zmap>
 __device__ __forceinline__ bool decode_in_order(const uint8_t* __restrict__ src, uint64_t elen, uint8_t* __restrict__ dst, uint64_t cap,
-                                                Guard& guard, uint64_t& ipos, uint64_t& opos, uint32_t tbl, Zmap zmap, uint32_t lane) {
+                                                Guard& guard, uint64_t& ipos, uint64_t& opos, uint32_t tbl, Zmap zmap, uint32_t lane,
+                                                bool mark_slot0 = false) {
+    // mark_slot0 (last-writers passes of the segmented stream decode): a PLAIN zero quad written to slot 0 marks the slot as written
     while (ipos < elen) {
         const uint64_t rem = elen - ipos;
         const uint8_t* rec = src + ipos;
@@ -208,7 +210,7 @@ __device__ __forceinline__ bool decode_in_order(const uint8_t* __restrict__ src,
 
         bool empty = false;                                       // MAP on a never-written slot yields the zero quad
         const bool hsusp = active && hit && !has_pred && old == 0 && h != 0;
-        const bool psusp = active && !hit && e == 0 && h != 0;
+        const bool psusp = active && !hit && e == 0 && (h != 0 || mark_slot0);
         if (ballot64(hsusp || psusp)) {
             if (hsusp) empty = !zmap.test(h);
             if (psusp) zmap.set(h);

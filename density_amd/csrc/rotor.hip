@@ -917,6 +917,54 @@ __global__ __launch_bounds__(256) void compact_bytes_kernel(const uint8_t* __res
 // ---------------------------------------------------------------------------------------------------------------
 // decode (index-fed): Codec::decode (codec/codec.rs:82-126), Chameleon::decode_plain / decode_map (chameleon.rs:56-68)
 // ---------------------------------------------------------------------------------------------------------------
+// The raw-copy bits of a chunk's block index against the blow-up protection (protection_state.rs:19-47, codec.rs:89-91), WITHOUT walking
+// the FSM over the chunk: called for block i only where it is raw or incompressible (a coded record of 256 bytes or more: at most 4 MAP
+// flags), it checks what the FSM implies locally —
+//   * a run of raw blocks starts right behind a TRIGGER: an incompressible coded block whose nearest earlier coded block (looking through
+//     a raw run) was incompressible too (:38-47: `update` is not called for raw blocks, `prev` survives them);
+//   * every trigger is followed by a raw block (unless the chunk ends there);
+//   * the run is `copy_penalty_start` blocks long (or cut by the chunk's end).  That value is 1 at the chunk's start, grows by one at the end of
+//     every run (:30-35) and is halved at every 16th block while above 1 (:19-27) — so it follows from the PREVIOUS run alone (whose
+//     length is its own value when it was triggered, checked by that run's thread), and is back at 1 if no run ended within the last 8
+//     sixteen-block boundaries (a u8 halves to 1 in at most 8 steps).
+// Every thread checks its own blocks against the index copy in LDS; all of them passing is equivalent to the FSM walk
+// (tests/test_index_fsm_model.py holds the same rules, in numpy, against the oracle's FSM).  A chunk starts with a fresh FSM.
+__device__ __forceinline__ bool index_fsm_consistent(const uint8_t* ix, uint32_t i, uint32_t nblk) {
+    auto raw = [&](uint32_t b) -> bool { return (ix[b] & kIdxCopy) != 0; };
+    auto inc = [&](uint32_t b) -> bool { return ix[b] <= 4u; };                   // coded, at most 4 MAP flags (a ragged block says 0x7f)
+    auto mult16 = [](uint32_t lo, uint32_t hi) -> uint32_t { return hi / 16u + 1u - (lo + 15u) / 16u; };   // multiples of 16 in [lo, hi], lo <= hi + 1
+    auto halve = [](uint32_t s, uint32_t k) -> uint32_t { const uint32_t h = k < 32u ? s >> k : 0u; return s > 1u ? (h ? h : 1u) : s; };
+    if (!raw(i)) {
+        // an incompressible coded block: a trigger iff the coded block before it was incompressible as well
+        uint32_t u = i;
+        while (u > 0 && raw(u - 1)) --u;                                          // (u - 1: the nearest earlier coded block, if any)
+        const bool trigger = u > 0 && inc(u - 1);
+        return !trigger || i + 1 >= nblk || raw(i + 1);
+    }
+    if (i > 0 && raw(i - 1)) return true;                                         // inside a run: the run's first block answers for it
+    if (i == 0 || !inc(i - 1)) return false;                                      // a run must start behind an incompressible coded block ...
+    const uint32_t t = i - 1;
+    uint32_t u = t;
+    while (u > 0 && raw(u - 1)) --u;
+    if (u == 0 || !inc(u - 1)) return false;                                      // ... whose coded predecessor was incompressible too
+    uint32_t L = 1;
+    while (i + L < nblk && raw(i + L)) ++L;
+    // copy_penalty_start when t triggered: from the previous run, if one ended within reach
+    uint32_t s = 1;
+    const uint32_t reach = t > 143u ? t - 143u : 0u;
+    uint32_t e = t;                                                               // (search (reach, t) backwards for a raw block: the previous run's last)
+    while (e > reach && !raw(e - 1)) --e;
+    if (e > reach) {
+        const uint32_t last = e - 1;
+        uint32_t a = last;
+        while (a > 0 && raw(a - 1) && last - a < 255u) --a;                       // its first block; its trigger is a - 1
+        const uint32_t Lp = last - a + 1u;
+        const uint32_t s_end = (halve(Lp, a <= last ? mult16(a, last) : 0u) + 1u) & 0xffu;   // halvings at the run's own blocks, then + 1 at its end
+        s = halve(s_end, mult16(last + 1u, t));
+    }
+    return L == s || (L < s && i + L == nblk);
+}
+
 template <int R, int W, bool kProf>
 __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __restrict__ in, const uint64_t* __restrict__ offsets,
                                                               const uint64_t* __restrict__ sizes, uint8_t* __restrict__ out,
@@ -962,6 +1010,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
     }
     __syncthreads();
 
+    uint32_t bad_index = 0;
     // ---- record positions of the whole chunk: one prefix sum over the index (consecutive entries per thread).  A record is
     // pipelined only if it is complete and followed by at least 2 more stream bytes (a MAP item is fetched as a dword); the first
     // one that is not (ragged block, end of the stream, end of the output, an index that disagrees with the stream length) and
@@ -991,6 +1040,8 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
 #pragma unroll
             for (uint32_t k = 0; k < kPerThread; ++k) {
                 const uint32_t i = first + k, ent = smem[kDecIdx + i], l = rec_len(ent);
+                // the raw-copy flags must be what the blow-up protection would have decided (below): looked at only where a block is raw or incompressible
+                if (exact && i < nblk && __builtin_expect((ent & kIdxCopy) != 0 || ent <= 4u, 0) && !index_fsm_consistent(smem + kDecIdx, i, nblk)) bad_index = 1;
                 if (i % R == 0) *reinterpret_cast<uint32_t*>(smem + kDecPos + (i / R) * 4u) = pos;
                 const bool stop = (ent & 0x7fu) == kIdxRagged || i >= nblk || ((uint64_t)i + 1) * kBlock > cap || pos >= elen || elen - pos < l + 2u;
                 if (stop && stop_key == ~0ull) stop_key = ((uint64_t)i << 33) | ((uint64_t)((ent & kIdxCopy) && i < nblk ? 1u : 0u) << 32) | pos;
@@ -1027,7 +1078,6 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
         m.sgv = *reinterpret_cast<const u32x2_u*>(src + ((lane < R && !(e & kIdxCopy)) ? m.posv : base));   // codec.rs:28-31 (idle lanes: any valid address)
         m.cnt = e & 0x7fu;                                                        // the entry's MAP count: checked against the signature in stage B
     };
-    uint32_t bad_index = 0;
     const uint32_t minus_2lane = 0u - 2u * lane;
     auto stage_b = [&](const Meta& m, uint32_t& hits, uint32_t (&item)[R]) {    // signatures -> MAP/PLAIN flags, item loads
         // the index must agree with the stream it describes: a record's MAP count is its signature's popcount (lane j < R: record j)
@@ -1098,7 +1148,10 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
             ra[j] = coded ? ((h >> 1) << 2) : 4u * lane;                          // raw / absent records: a harmless conflict-free read
             mask[j] = writes ? (0xffffu << sh) : 0u;
             val[j] = writes ? (e << sh) : 0u;
-            zacc |= (writes && e == 0 && h != 0) ? (1u << j) : 0u;                  // bit j: record j has a zero-entry quad in this lane
+            // bit j: record j has a zero-entry quad in this lane.  (A last-writers pass also marks slot 0 when the zero quad is WRITTEN there — PLAIN,
+            // so the slot held something else: the mark then says "this segment wrote the slot", which an entry of 0 alone does not say to
+            // merge_images_kernel; chameleon_lastwriters_rot does the same on the encode side.)
+            zacc |= (writes && e == 0 && (h != 0 || seg.lastwriters_only)) ? (1u << j) : 0u;
         }
         const uint32_t tokaddr = lane == 0 ? sy + kSyD : sy + kSySink + 4u * lane;
         pin_operands<R>(ra, mask, val);                                           // complete before the wait for the token
@@ -1155,7 +1208,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
                 const uint32_t qv = pick<R>(itemc, j), cur = pick<R>(ra, j);
                 const uint32_t P = qv * kHashMul;
                 const uint32_t h = hit ? (qv & 0xffffu) : (P >> 16);
-                const bool zset = coded && !hit && stored_entry(qv, P) == 0 && h != 0;
+                const bool zset = coded && !hit && stored_entry(qv, P) == 0 && (h != 0 || seg.lastwriters_only);
                 const bool ztest = coded && hit && h != 0 && cur == entry_to_quad(h, 0) && !seg.lastwriters_only;
                 uint64_t todo = ballot64(zset || ztest);
                 uint32_t out = cur;
@@ -1203,11 +1256,11 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
             const uint32_t ent = smem[kDecIdx + i];
             const uint64_t rec_end = ip + ((ent & kIdxCopy) ? kBlock : kSig + kBlock - 2u * (ent & 0x7fu));
             g.penalty = (ent & kIdxCopy) ? 1u : 0u; g.start = 1; g.prev = 0; g.counter = 1;
-            bad = !decode_in_order(src, rec_end, dst, cap, g, ip, op, 0u, zmap, lane) || ip != rec_end;
+            bad = !decode_in_order(src, rec_end, dst, cap, g, ip, op, 0u, zmap, lane, seg.lastwriters_only != 0) || ip != rec_end;
         }
         g.penalty = (uint32_t)(end_key >> 32) & 1u; g.start = 1; g.prev = 0; g.counter = 1;    // the stopping block's raw-copy flag is all that is left of the FSM
         if (!bad && (ip != (uint32_t)end_key || op != (uint64_t)nvalid * kBlock)) bad = true;
-        if (!bad) bad = !decode_in_order(src, elen64, dst, cap, g, ip, op, 0u, zmap, lane);
+        if (!bad) bad = !decode_in_order(src, elen64, dst, cap, g, ip, op, 0u, zmap, lane, seg.lastwriters_only != 0);
         if (exact && !bad && op != cap) bad = true;
         if (lane == 0) {
             produced[chunk] = op;

@@ -187,8 +187,10 @@ __global__ __launch_bounds__(64) void parse_emit_kernel(const uint8_t* __restric
 }
 
 // two incompressible records in a row (a record of 256 bytes or more: at most 4 MAP flags): the FSM would have answered with raw copies
-__global__ __launch_bounds__(256) void parse_check_kernel(const uint8_t* __restrict__ index, uint32_t* __restrict__ info) {
-    const uint32_t total = info[4], b0 = info[1];
+__global__ __launch_bounds__(256) void parse_check_kernel(const uint8_t* __restrict__ index, uint64_t index_cap, uint32_t* __restrict__ info) {
+    // (info[4] is a count of blocks the STREAM claims: an untrusted stream may claim more than the index holds — the host then sends the call
+    // down the sequential path — so it is clamped here)
+    const uint32_t total = info[4] < index_cap ? info[4] : (uint32_t)index_cap, b0 = info[1];
     if (info[0] == 0) return;
     const uint32_t from = b0 ? b0 - 1 : 0;
     for (uint64_t i = from + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i + 1 < total; i += (uint64_t)gridDim.x * blockDim.x) {
@@ -225,7 +227,7 @@ hipError_t launch_stream_parse(const uint8_t* d_in, uint64_t E, uint64_t from_po
     hipLaunchKernelGGL(parse_top_kernel, dim3(1), dim3(64), 0, stream, GT, GC, ng, d_info, gent, gbase);
     hipLaunchKernelGGL(parse_entries_kernel, dim3(ng), dim3(64), group_lds, stream, T, C, nw, gent, gbase, went, wbase);
     hipLaunchKernelGGL(parse_emit_kernel, dim3((nw + 63) / 64), dim3(64), 0, stream, d_in, E, d_info, went, wbase, nw, d_index, index_cap, d_chunk_offset, chunk_blocks, d_pos32);
-    hipLaunchKernelGGL(parse_check_kernel, dim3(256), dim3(256), 0, stream, d_index, d_info);
+    hipLaunchKernelGGL(parse_check_kernel, dim3(256), dim3(256), 0, stream, d_index, index_cap, d_info);
     return hipGetLastError();
 }
 

@@ -227,6 +227,28 @@ def test_corrupt_block_index_is_a_format_error(kernel_variant):
         bad[base + b] = (int(bad[base + b]) + int(rng.integers(1, 5))) % 65
         with pytest.raises(DecodeError):
             container.decode(bad, out)
+    # the raw-copy bits are checked against the blow-up protection (rotor.hip::index_fsm_consistent): a coded block flagged raw, a raw block
+    # flagged coded, on calm text and on data with raw copies in it — wrong bytes of the right length would otherwise come back as OK
+    for kind, seed in (("prose", 9), ("mixed", 19), ("random", 29)):
+        data = datagen.by_kind(kind, n, seed=seed)
+        cn = container.encode(ALGO, data, cont, chunk)
+        good = cont[:cn].copy()
+        assert container.decode(good, out) == n and np.array_equal(out, data), kind
+        ix = good[base:base + (n + 255) // 256]
+        raws, coded = np.flatnonzero(ix & 0x80), np.flatnonzero((ix & 0x80) == 0)
+        assert (raws.size > 0) == (kind != "prose")
+        picks = [("to-raw", int(b)) for b in rng.choice(coded, size=6)] + [("to-coded", int(b)) for b in (rng.choice(raws, size=6) if raws.size else [])]
+        if raws.size:
+            picks += [("to-raw", int(raws[-1]) + 1), ("to-coded", int(raws[0]))]        # a run one block longer / one block shorter
+        for how, b in picks:
+            if b >= ix.size or (good[base + b] & 0x7F) == 0x7F:
+                continue
+            bad = good.copy()
+            bad[base + b] = 0x80 if how == "to-raw" else 0
+            if bad[base + b] == good[base + b]:
+                continue
+            with pytest.raises(DecodeError):
+                container.decode(bad, out)
 
 
 def test_corrupt_size_table_is_a_format_error():
@@ -296,7 +318,7 @@ def test_full_size_properties_device_resident():
 
 @pytest.mark.parametrize("kind,n", [("rep", 48 * 1024 * 1024 + 12345), ("prose", 20 * 1024 * 1024), ("patchy", 40 * 1024 * 1024 + 7), ("random", 17 * 1024 * 1024),
                                     ("zeros", 16 * 1024 * 1024 + 4), ("saltzero", 24 * 1024 * 1024 + 258), ("samehash", 16 * 1024 * 1024), ("zeropatch", 32 * 1024 * 1024),
-                                    ("prose", 6 * 1024 * 1024 + 300), ("rep", 5 * 1024 * 1024)])
+                                    ("prose", 6 * 1024 * 1024 + 300), ("rep", 5 * 1024 * 1024), ("hash0patch", 24 * 1024 * 1024)])
 def test_long_stream_encode_in_segments_is_the_reference_stream(kind, n, kernel_variant):
     """`chameleon_encode` of ONE long stream runs in parallel segments (api.hip::run_stream_encode_segmented) and must still be the
     reference's single stream, byte for byte: calm text (one pass), text with incompressible patches (raw-copy blocks break the
@@ -319,6 +341,23 @@ def test_long_stream_encode_in_segments_is_the_reference_stream(kind, n, kernel_
                 data[start:start + (64 << 10)] = 0
             else:
                 data[start:start + (256 << 10)] = salted[:256 << 10]
+    elif kind == "hash0patch":
+        # non-zero quads whose hash is 0 (slot 0 then holds them), zero quads written over them (PLAIN: the LAST WRITER of slot 0 in that
+        # segment is the zero quad, whose entry is 0), zero quads read back in later segments (MAP of slot 0 must give 0, not the old quad)
+        data = datagen.by_kind("prose", n, seed=41).copy()
+        half = 0x9D6EF916 >> 1
+        inv = pow(half, -1, 1 << 31)
+        quads = []
+        for P in (2, 6, 1000, 65534):
+            for top in (0, 1):
+                q = (((P >> 1) * inv) % (1 << 31)) | (top << 31)
+                assert q != 0 and ((q * 0x9D6EF916) & 0xFFFFFFFF) >> 16 == 0
+                quads.append(q)
+        for i, start in enumerate(range(1 << 20, n - (4 << 20), 5 << 19)):
+            q = quads[i % len(quads)]
+            data[start:start + 4] = np.frombuffer(int(q).to_bytes(4, "little"), dtype=np.uint8)           # slot 0 := q
+            data[start + (1 << 19):start + (1 << 19) + 64] = 0                                            # zero quad PLAIN over it, then MAPs
+            data[start + (3 << 19):start + (3 << 19) + 32] = 0                                            # MAPs of slot 0, segments later
     else:
         data = datagen.by_kind(kind, n, seed=13)
     import ctypes
@@ -335,7 +374,7 @@ def test_long_stream_encode_in_segments_is_the_reference_stream(kind, n, kernel_
     assert got == want
     assert s1[0] == s0[0] + 1                                     # encoded in segments ...
     calm = st["copy_blocks"] == 0                                 # no raw-copy block anywhere in the reference's stream
-    assert calm == (kind in ("rep", "prose", "zeros", "saltzero", "zeropatch"))
+    assert calm == (kind in ("rep", "prose", "zeros", "saltzero", "zeropatch", "hash0patch"))
     assert (s1[1] - s0[1] == 1) == calm, (kind, s1[1] - s0[1])    # ... in one pass iff nothing breaks the speculation
     assert gpu_decode(want, n) == data.tobytes()
     s2 = stats()
@@ -383,3 +422,88 @@ def test_long_stream_decode_errors_match_the_sequential_path(kernel_variant):
     assert a[0] == b[0], (a[0], b[0])
     if a[0] == "ok":
         assert a[1:] == b[1:]
+
+
+def _stream_stats():
+    import ctypes
+    from density_amd import _lib
+    a = (ctypes.c_uint64 * 4)()
+    _lib.lib().density_hip_stream_stats(a)
+    return list(a)
+
+
+def test_config2_full_size_every_chunk_is_the_oracle_stream(kernel_variant):
+    """BASELINE config 2 at its real size — 1 GiB of rep-text (period 1,000,003), 4 MiB chunks, device-resident like the bench:
+    ALL 256 chunk payloads equal the oracle's stream of that chunk byte for byte (one oracle encode per host thread), the block
+    index describes them, and decode(container) == input."""
+    if kernel_variant != "rotor":
+        pytest.skip("full-size config runs on the default kernels")
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    n, chunk = 1 << 30, 4 << 20
+    host = datagen.rep_text(n)
+    x = torch.from_numpy(host).cuda()
+    cap = container.container_bound(ALGO, n, chunk)
+    cont = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    back = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    hdr = container.encode_device(ALGO, x.data_ptr(), n, cont.data_ptr(), cap, chunk, stream=s)
+    assert (hdr.n_chunks, hdr.total_len, hdr.chunk_size) == (256, n, chunk)
+    assert container.decode_device(cont.data_ptr(), hdr.container_len, back.data_ptr(), n, header=hdr, stream=s) == n
+    assert torch.equal(back, x)
+    raw = cont[:hdr.container_len].cpu().numpy()
+    _, payloads = container.chunk_payloads(raw)
+    idx = container.block_index(raw)
+
+    def check(i):
+        want = pyoracle.encode(ALGO, host[i * chunk:(i + 1) * chunk])
+        if payloads[i] != want:
+            return False
+        # the index bytes of the chunk's first records: MAP count == popcount of the signature found there
+        pos = 0
+        for b in range(64):
+            e = idx[i * (chunk // 256) + b]
+            if e & 0x80:
+                pos += 256
+                continue
+            if bin(int.from_bytes(want[pos:pos + 8], "little")).count("1") != e:
+                return False
+            pos += 8 + 256 - 2 * e
+        return True
+
+    with ThreadPoolExecutor(os.cpu_count() or 4) as ex:
+        ok = list(ex.map(check, range(hdr.n_chunks)))
+    assert all(ok), [i for i, v in enumerate(ok) if not v][:8]
+
+
+def test_config2_full_size_strict_stream_is_the_reference_stream(kernel_variant):
+    """`chameleon_encode` of the whole 1 GiB as ONE reference stream (device-resident entry point of the same code path) equals
+    `oracle_encode(1 GiB)` byte for byte, `chameleon_decode` of it gives the input back, and density_hip_stream_stats says the parallel
+    segment paths served both (one encode pass: every speculation held)."""
+    if kernel_variant != "rotor":
+        pytest.skip("full-size config runs on the default kernels")
+    import torch
+    n = 1 << 30
+    host = datagen.rep_text(n)
+    want = np.frombuffer(pyoracle.encode(ALGO, host), dtype=np.uint8)
+    x = torch.from_numpy(host).cuda()
+    enc = torch.zeros(Chameleon.safe_encode_buffer_size(n), dtype=torch.uint8, device="cuda")
+    back = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    s0 = _stream_stats()
+    m = container.stream_encode_device(ALGO, x.data_ptr(), n, enc.data_ptr(), enc.numel())
+    s1 = _stream_stats()
+    assert m == want.size
+    assert torch.equal(enc[:m].cpu(), torch.from_numpy(want.copy()))
+    assert (s1[0] - s0[0], s1[1] - s0[1]) == (1, 1)
+    k = container.stream_decode_device(ALGO, enc.data_ptr(), m, back.data_ptr(), n)
+    s2 = _stream_stats()
+    assert k == n and torch.equal(back, x)
+    assert (s2[2] - s1[2], s2[3] - s1[3]) == (1, 0)
+    # ... and the reference's own symbols (host pointers: chameleon.rs:70-78) on the same gigabyte
+    out = np.zeros(Chameleon.safe_encode_buffer_size(n), dtype=np.uint8)
+    m2 = Chameleon.encode(host, out)
+    assert m2 == want.size and np.array_equal(out[:m2], want)
+    hback = np.zeros(n, dtype=np.uint8)
+    assert Chameleon.decode(out[:m2], hback) == n and np.array_equal(hback, host)
+    s3 = _stream_stats()
+    assert (s3[0] - s2[0], s3[2] - s2[2]) == (1, 1)

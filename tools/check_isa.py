@@ -3,14 +3,15 @@
 The next round's quads are loaded by hand into the wave's R highest registers (v(256-R)..v255, 8-wave kernels) and read out of
 them, behind a hand-counted wait, by one later statement; the compiler knows the registers only as clobbered by both
 statements.  The scheme is sound as long as the compiler itself never puts a value there, which it has no reason to (it
-allocates upwards from v0 and these kernels need fewer than 240 registers) but is not forced to.  This script compiles
-rotor.hip to assembly and checks, for every 8-wave encoder instance, that
+allocates upwards from v0 and these kernels need fewer than 240 registers) but is not forced to.  This script disassembles
+the code objects inside the BUILT library (density_amd/libdensity_hip.so, or the path given: the shipped ISA, not a second compile)
+and checks, for every 8-wave encoder instance, that
   * the only instructions naming a staging register are those loads (global_load_dword vN, ..) and the moves out of them
     (v_mov_b32 vX, vN), and
   * every run of moves directly follows an s_waitcnt vmcnt(..).
 Also checked: the default decoder's stage B waits with vmcnt(12) and nothing in its round loop drains the memory queue; the
 exchange stage kernels of exchange_stages.hip fit their 256 registers without scratch memory.
-usage: python tools/check_isa.py   (exit code 1 on a violation; run by density_amd.build)"""
+usage: python tools/check_isa.py [lib.so]   (exit code 1 on a violation; run by density_amd.build)"""
 import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -47,64 +48,73 @@ def check_function(name, rounds, body):
         bad += 1
     return loads, bad
 
-def main():
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+def shipped_code(lib):
+    """Disassembly and kernel metadata of the code objects INSIDE the built library (what ships is what is checked: not a second
+    compile with a compiler and flags of its own).  The .hip_fatbin section is a run of clang offload bundles, one per source file."""
+    funcs, notes = {}, ""
     with tempfile.TemporaryDirectory() as tmp:
-        out = os.path.join(tmp, "rotor.s")
-        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", out,
-                        os.path.join(ROOT, "density_amd", "csrc", "rotor.hip")], check=True, stderr=subprocess.DEVNULL)
-        lines = open(out).read().split("\n")
+        fat = os.path.join(tmp, "fat.bin")
+        subprocess.run([os.path.join(LLVM, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, lib], check=True)
+        blob = open(fat, "rb").read()
+        starts = [m.start() for m in re.finditer(b"__CLANG_OFFLOAD_BUNDLE__", blob)]
+        for k, a in enumerate(starts):
+            part, obj = os.path.join(tmp, f"b{k}.bin"), os.path.join(tmp, f"co{k}.o")
+            open(part, "wb").write(blob[a:starts[k + 1] if k + 1 < len(starts) else len(blob)])
+            subprocess.run([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                            "--input=" + part, "--output=" + obj], check=True, stderr=subprocess.DEVNULL)
+            if not os.path.exists(obj) or os.path.getsize(obj) == 0:
+                continue
+            dis = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--mcpu=gfx950", obj], check=True, capture_output=True, text=True).stdout
+            cur = None
+            for line in dis.split("\n"):
+                m = re.match(r"^[0-9a-f]+ <(\S+)>:$", line)
+                if m:
+                    cur = funcs.setdefault(m.group(1), [])
+                    continue
+                t = line.split("//")[0].strip()
+                if cur is not None and t and not t.startswith("."):
+                    cur.append(t)
+            notes += subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", obj], check=True, capture_output=True, text=True).stdout
+    return funcs, notes
+
+def main():
+    lib = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "density_amd", "libdensity_hip.so")
+    if not os.path.exists(lib):
+        print(f"check_isa: {lib} not built")
+        return 1
+    funcs, notes = shipped_code(lib)
     total = bad = 0
-    i = 0
-    while i < len(lines):
-        m = re.match(r"^(_ZN7density20chameleon_encode_rotILi(\d+)ELi8ELb[01]E\w*):", lines[i])
+    for name, body in funcs.items():
+        m = re.match(r"^_ZN7density20chameleon_encode_rotILi(\d+)ELi8ELb[01]E", name)
         if not m:
-            i += 1
             continue
-        j = i
-        while not lines[j].startswith(".Lfunc_end"):
-            j += 1
-        body = [l.split(";")[0].strip() for l in lines[i:j]]
-        body = [t for t in body if t and not t.startswith(".")]
-        g, b = check_function(m.group(1), int(m.group(2)), body)
+        g, b = check_function(name, int(m.group(1)), body)
         total += g; bad += b
-        i = j
     # the decoder's exact waits: stage B must wait for "all but the last 12 (stores)", not for everything (a branch around the record stores,
     # a load left pending across the loop head ... turn it into vmcnt(0) and cost 5-10 % without a test failing)
-    i = 0
     dec = 0
-    while i < len(lines):
-        m = re.match(r"^(_ZN7density20chameleon_decode_rotILi12ELi12ELb0E\w*):", lines[i])
-        if not m:
-            i += 1
+    for name, body in funcs.items():
+        if not re.match(r"^_ZN7density20chameleon_decode_rotILi12ELi12ELb0E", name):
             continue
-        j = i
-        while not lines[j].startswith(".Lfunc_end"):
-            j += 1
-        body = [l.split(";")[0].strip() for l in lines[i:j]]
-        body = [t for t in body if t and not t.startswith(".")]
         first = next(k for k, t in enumerate(body) if t.startswith("ds_mskor_rtn_b32"))
         window = body[max(0, first - 900):first]
         waits = [t for t in window if t.startswith("s_waitcnt vmcnt(") and "lgkmcnt" not in t]
         if "s_waitcnt vmcnt(12)" not in waits:
-            print(f"{m.group(1)}: stage B no longer waits with vmcnt(12): {waits}")
+            print(f"{name}: stage B no longer waits with vmcnt(12): {waits}")
             bad += 1
         elif "s_waitcnt vmcnt(0)" in waits[waits.index("s_waitcnt vmcnt(12)"):]:
-            print(f"{m.group(1)}: a full drain (vmcnt(0)) inside the round loop: {waits}")
+            print(f"{name}: a full drain (vmcnt(0)) inside the round loop: {waits}")
             bad += 1
         dec += 1
-        i = j
     if not dec:
         print("check_isa: decoder instance not found")
         bad += 1
     # exchange_stages.hip: eight waves of a stage work-group share a CU, two per SIMD — 256 registers each.  A stage kernel that needs
     # more spills to scratch memory inside the token's critical path without a test failing.
-    with tempfile.TemporaryDirectory() as tmp:
-        out = os.path.join(tmp, "stages.s")
-        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", out,
-                        os.path.join(ROOT, "density_amd", "csrc", "exchange_stages.hip")], check=True, stderr=subprocess.DEVNULL)
-        text = open(out).read()
     stages = 0
-    for m in re.finditer(r"\.name:\s+(\S*exchange_stage\S*)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)\n(?:.*\n)*?\s+\.vgpr_spill_count:\s+(\d+)", text):
+    for m in re.finditer(r"\.name:\s+(\S*exchange_stage\S*)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)\n(?:.*\n)*?\s+\.vgpr_spill_count:\s+(\d+)", notes):
         stages += 1
         if int(m.group(2)) or int(m.group(4)) or int(m.group(3)) > 256:
             print(f"{m.group(1)}: scratch {m.group(2)} bytes, {m.group(3)} registers, {m.group(4)} spilled")
@@ -112,7 +122,7 @@ def main():
     if not stages:
         print("check_isa: no exchange stage kernels found")
         bad += 1
-    print(f"check_isa: {total} hand-issued loads in the 8-wave encoder instances, decoder waits checked, {stages} exchange stage kernels without scratch, {bad} violation(s)")
+    print(f"check_isa: {os.path.basename(lib)}: {total} hand-issued loads in the 8-wave encoder instances, decoder waits checked, {stages} exchange stage kernels without scratch, {bad} violation(s)")
     return 1 if bad or not total else 0
 
 if __name__ == "__main__":
