@@ -176,6 +176,118 @@ def size_sweep(container, algo, x, sizes, steps=5):
     return out
 
 
+
+def roofline_entry(name, alg_bytes, ms):
+    ach = alg_bytes / (ms * 1e-3) / 1e9 if ms else 0.0
+    return {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
+            "traffic": None, "algorithmic_bytes_per_launch": int(alg_bytes), "kernel_avg_ms": round(ms, 4)}
+
+
+def other_config(container, algo, label, host, steps=3, warmup=1, cpu_sample=32 << 20, chunk=0):
+    """One of BASELINE's other configurations, measured like the headline workload (device-resident container encode + decode, HIP events
+    around every kernel) with a bounded CPU sample beside it.  Returns a dict for the `other_configs` list of the bench line."""
+    import torch
+    from density_amd import _lib
+    from oracle import pyoracle
+    n = host.size
+    chunk = chunk or int(_lib.lib().density_hip_auto_chunk_for(_lib.ALGO_IDS[algo], n))
+    x = torch.from_numpy(host).cuda()
+    cap = container.container_bound(algo, n, chunk)
+    cont = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    back = torch.empty(n, dtype=torch.uint8, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    hdr = container.encode_device(algo, x.data_ptr(), n, cont.data_ptr(), cap, chunk, stream=s)
+    assert container.decode_device(cont.data_ptr(), hdr.container_len, back.data_ptr(), n, header=hdr, stream=s) == n and torch.equal(back, x), f"{algo}: round trip mismatch"
+    E = int(hdr.container_len)
+    _, payloads = container.chunk_payloads(cont[:E].cpu().numpy())
+
+    def step():
+        container.encode_device(algo, x.data_ptr(), n, cont.data_ptr(), cap, chunk, stream=s, want_header=False)
+        container.decode_device(cont.data_ptr(), E, back.data_ptr(), n, header=hdr, stream=s, sync=False)
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    container.set_profiling(True)
+    container.last_timings()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    timings = container.last_timings()
+    container.set_profiling(False)
+    assert torch.equal(back, x), f"{algo}: round trip mismatch after the timed steps"
+    tot = {}
+    for name, ms in timings:
+        tot[name] = tot.get(name, 0.0) + ms / steps
+    dec_names = ("layout_decode", f"{algo}_decode_chunks")
+    t_dec = sum(v for k, v in tot.items() if k in dec_names)
+    t_enc = sum(v for k, v in tot.items() if k not in dec_names)
+    # CPU beside it: the oracle, one thread, on a bounded sample; every chunk of the sample compared with the GPU's payloads
+    m = min(cpu_sample, n) // chunk * chunk or min(cpu_sample, n)
+    src = np.ascontiguousarray(host[:m])
+    ccap = pyoracle.safe_encode_buffer_size(algo, m)
+    enc = np.empty(ccap, dtype=np.uint8)
+    dec = np.empty(m, dtype=np.uint8)
+    c0 = time.perf_counter(); es = pyoracle.encode_into(algo, src.ctypes.data, m, enc.ctypes.data, ccap)
+    c1 = time.perf_counter(); got = pyoracle.decode_into(algo, enc.ctypes.data, es, dec.ctypes.data, m); c2 = time.perf_counter()
+    assert got == m and np.array_equal(dec, src)
+    nchk = max(m // chunk, 1)
+    bad = [i for i in range(min(nchk, len(payloads))) if payloads[i] != pyoracle.encode(algo, host[i * chunk:(i + 1) * chunk])]
+    assert not bad, f"{algo}: GPU chunk streams differ from the oracle: {bad[:8]}"
+    return {"config": label, "algorithm": algo, "bytes": int(n), "chunk_bytes": int(chunk), "n_chunks": int(hdr.n_chunks),
+            "value": round(n * steps / dt / 1e6, 1), "unit": "MB/s", "steps": steps, "ms_per_step": round(dt / steps * 1e3, 4),
+            "compression_ratio": round(n / E, 4), "encoded_bytes": E,
+            "encode_ms": round(t_enc, 4), "decode_ms": round(t_dec, 4), "kernel_ms": {k: round(v, 4) for k, v in tot.items()},
+            "residency": "HBM-bound" if 2 * n > (256 << 20) else "cache-resident (fits the 256 MiB Infinity Cache)",
+            "roofline": {"encode": roofline_entry(f"{algo} encode (all kernels of the direction)", n + E, t_enc),
+                         "decode": roofline_entry(f"{algo} decode (all kernels of the direction)", n + E, t_dec)},
+            "cpu_baseline": {"value": round(m / (c2 - c0) / 1e6, 1), "unit": "MB/s", "cores": 1, "kind": "port",
+                             "encode_MBps": round(m / (c1 - c0) / 1e6, 1), "decode_MBps": round(m / (c2 - c1) / 1e6, 1),
+                             "ratio_whole_stream": round(m / es, 4),
+                             "sample": f"first {m >> 20} MiB, whole-stream {algo} encode+decode, 1 thread, C restatement of density-rs 0.16.6",
+                             "gpu_chunks_compared_bit_exact": int(min(nchk, len(payloads)))}}
+
+
+def strict_stream_leg(host, x, steps=3):
+    """The reference's own call shape on the headline buffer: ONE Chameleon stream over the whole input (chameleon.rs:45-53), encoded and
+    decoded in parallel segments on the device, buffers device-resident.  Byte-identity with the reference's stream is the
+    GPU suite's to show at full size (tests/test_gpu_chameleon.py::test_config2_full_size_strict_stream...); here: decode == input, and the
+    stream of the first 64 MiB — a prefix of the whole stream, blocks being coded in order — equals the oracle's."""
+    import ctypes
+    import torch
+    from density_amd import Chameleon, _lib
+    from oracle import pyoracle
+    lib = _lib.lib()
+    n = host.size
+    d_out = torch.empty(Chameleon.safe_encode_buffer_size(n) + 64, dtype=torch.uint8, device="cuda")
+    d_back = torch.empty(n + 64, dtype=torch.uint8, device="cuda")
+    size, back = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    enc = lambda: lib.density_hip_stream_encode_device(0, ctypes.c_void_p(x.data_ptr()), n, ctypes.c_void_p(d_out.data_ptr()), d_out.numel(), None, ctypes.byref(size))
+    assert enc() == 0
+    dec = lambda: lib.density_hip_stream_decode_device(0, ctypes.c_void_p(d_out.data_ptr()), size.value, ctypes.c_void_p(d_back.data_ptr()), n, None, ctypes.byref(back))
+    assert dec() == 0 and back.value == n and torch.equal(d_back[:n], x), "strict stream: decode != input"
+    m = min(64 << 20, n) // 256 * 256
+    want = pyoracle.encode("chameleon", host[:m])
+    # (the whole stream's records of the first m bytes: the oracle's stream of that prefix, unless the prefix ends inside the stream's last record)
+    k = len(want) if m < n else size.value
+    assert bytes(d_out[:k].cpu().numpy()) == want[:k], "strict stream: prefix differs from the oracle's stream"
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(steps):
+        assert enc() == 0
+    torch.cuda.synchronize(); t1 = time.perf_counter()
+    for _ in range(steps):
+        assert dec() == 0
+    torch.cuda.synchronize(); t2 = time.perf_counter()
+    E = int(size.value)
+    e_ms, d_ms = (t1 - t0) / steps * 1e3, (t2 - t1) / steps * 1e3
+    return {"config": "2 (strict): ONE reference stream over the whole buffer, chameleon_encode / chameleon_decode shape, device-resident",
+            "bytes": int(n), "encoded_bytes": E, "compression_ratio": round(n / E, 4), "encode_ms": round(e_ms, 4), "decode_ms": round(d_ms, 4),
+            "value": round(n / ((e_ms + d_ms) * 1e-3) / 1e6, 1), "unit": "MB/s", "timing": "wall clock around the call (host orchestration of the passes included)",
+            "oracle_prefix_compared_bytes": int(k), "decode_is_the_input": True,
+            "roofline": {"encode": roofline_entry("strict stream encode (all passes)", n + E, e_ms), "decode": roofline_entry("strict stream decode (all passes)", n + E, d_ms)}}
+
 def self_launch(args):
     """--gpus N without a torchrun environment: start the N ranks ourselves (one node, 127.0.0.1 rendezvous)."""
     import socket
@@ -426,6 +538,16 @@ def main():
             nchk = (min(args.cpu_sample, n) + chunk - 1) // chunk
             result["cpu_baseline"] = cpu_baseline(host, chunk, args.cpu_sample, algo, gpu_payloads=payloads[:nchk])
             result["host_api"] = host_api_rates(algo, host, chunk, args.host_sample)
+        if n_gpus == 1 and not args.no_extra and algo == "chameleon" and args.data == "rep-text":
+            # BASELINE's other configurations in the same run (never `value`): configs 3 / 4 on the enwik8 stand-in, and the headline buffer as
+            # ONE reference stream (the reference's own call shape)
+            extra = [strict_stream_leg(host, x)]
+            del cont, back
+            prose = datagen.prose(100_000_000, seed=0xD1B54A32D192ED03)
+            for a, lbl in (("cheetah", "3: Cheetah on synth-prose-100M (enwik8 stand-in: 100,000,000 B of non-periodic synthetic prose)"),
+                           ("lion", "4: Lion on synth-prose-100M (enwik8 stand-in: 100,000,000 B of non-periodic synthetic prose)")):
+                extra.append(other_config(container, a, lbl, prose))
+            result["other_configs"] = extra
         print(json.dumps(result))
     if use_pg:
         dist.barrier()

@@ -42,6 +42,13 @@ def parse_header(raw32):
 
 
 FLAG_BLOCK_INDEX = 1
+FLAG_SLOTTED = 2
+
+
+def slot_stride(algo, chunk_size):
+    """Distance between the payload slots of a slotted container (include/density_hip.h: DENSITY_HIP_FLAG_SLOTTED)."""
+    safe = getattr(_lib.lib(), f"{algo}_safe_encode_buffer_size")(chunk_size)
+    return (safe + 255) // 256 * 256
 
 
 def block_index(container):
@@ -63,9 +70,13 @@ def chunk_payloads(container):
     if h.flags & FLAG_BLOCK_INDEX:
         off = (off + (h.total_len + 255) // 256 + 15) // 16 * 16
     out = []
-    for s in sizes:
-        out.append(b[off:off + s])
-        off = (off + s + 15) // 16 * 16
+    stride = slot_stride(_lib.ALGO_NAMES[h.algo], h.chunk_size) if h.flags & FLAG_SLOTTED else 0
+    for i, s in enumerate(sizes):
+        if stride:
+            out.append(b[off + i * stride:off + i * stride + s])
+        else:
+            out.append(b[off:off + s])
+            off = (off + s + 15) // 16 * 16
     return h, out
 
 
@@ -79,6 +90,28 @@ def encode_device(algo, d_in, n, d_out, cap, chunk_size=0, stream=0, workspace=(
     hdr = _lib.Header() if want_header else None
     rc = _lib.lib().density_hip_encode_device(_lib.ALGO_IDS[algo], d_in, n, d_out, cap, chunk_size, workspace[0], workspace[1], stream,
                                               ctypes.byref(hdr) if want_header else None)
+    _check(rc, EncodeError)
+    return hdr
+
+
+def container_bound_slotted(algo, input_size, chunk_size=0):
+    return _lib.lib().density_hip_container_bound_slotted(_lib.ALGO_IDS[algo], input_size, chunk_size)
+
+
+def encode_device_slotted(algo, d_in, n, d_out, cap, chunk_size=0, stream=0, workspace=(0, 0), want_header=True):
+    """As encode_device, but every chunk stream stays in its slot inside the container (no stitch pass): DENSITY_HIP_FLAG_SLOTTED."""
+    hdr = _lib.Header() if want_header else None
+    rc = _lib.lib().density_hip_encode_device_slotted(_lib.ALGO_IDS[algo], d_in, n, d_out, cap, chunk_size, workspace[0], workspace[1], stream,
+                                                      ctypes.byref(hdr) if want_header else None)
+    _check(rc, EncodeError)
+    return hdr
+
+
+def pack_device(d_container, container_size, d_out, cap, header=None, stream=0, workspace=(0, 0), want_header=True):
+    """Slotted container -> packed container (the wire form).  Returns the packed container's header (synchronises) or None."""
+    hdr = _lib.Header() if want_header else None
+    rc = _lib.lib().density_hip_pack_device(d_container, container_size, ctypes.byref(header) if header is not None else None, d_out, cap,
+                                            workspace[0], workspace[1], stream, ctypes.byref(hdr) if want_header else None)
     _check(rc, EncodeError)
     return hdr
 

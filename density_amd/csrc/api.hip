@@ -225,11 +225,19 @@ size_t container_bound(int algo, size_t n, size_t chunk) {
     return bound;
 }
 
+// a slotted container: every payload in its worst-case slot (the last one as long as its chunk can get)
+size_t container_bound_slotted(int algo, size_t n, size_t chunk) {
+    const size_t nc = chunk_count(n, chunk);
+    size_t bound = payload_base(nc, n, true);
+    if (nc) bound += (nc - 1) * slot_stride(algo, chunk) + safe_size(algo, n - (nc - 1) * chunk);
+    return bound;
+}
+
 int check_header(const density_hip_header_t& h, size_t container_size) {
     if (h.magic != DENSITY_HIP_MAGIC || h.version != 1 || !valid_algo(h.algo)) return DENSITY_HIP_ERR_FORMAT;
     if (!valid_chunk(h.chunk_size)) return DENSITY_HIP_ERR_FORMAT;
     if (h.n_chunks != chunk_count(h.total_len, h.chunk_size)) return DENSITY_HIP_ERR_FORMAT;
-    if (h.flags & ~DENSITY_HIP_FLAG_BLOCK_INDEX) return DENSITY_HIP_ERR_FORMAT;
+    if (h.flags & ~(DENSITY_HIP_FLAG_BLOCK_INDEX | DENSITY_HIP_FLAG_SLOTTED)) return DENSITY_HIP_ERR_FORMAT;
     if (h.container_len > container_size || h.container_len < payload_base(h.n_chunks, h.total_len, h.flags & DENSITY_HIP_FLAG_BLOCK_INDEX)) return DENSITY_HIP_ERR_FORMAT;
     return DENSITY_HIP_OK;
 }
@@ -237,17 +245,18 @@ int check_header(const density_hip_header_t& h, size_t container_size) {
 // ---- device-side drivers (ctx already acquired; `ws` points at a workspace of sufficient size) ----
 
 int run_encode_container(DeviceCtx* c, int algo, const uint8_t* d_in, size_t n, uint8_t* d_out, size_t cap, size_t chunk,
-                         uint8_t* ws, hipStream_t s, density_hip_header_t* header_out) {
+                         uint8_t* ws, hipStream_t s, density_hip_header_t* header_out, bool slotted = false) {
     const EncodePlan p = plan_encode(algo, n, chunk);
     if (p.n_chunks > 0xffffffffull) { set_error("too many chunks"); return DENSITY_HIP_ERR_ARGUMENT; }
-    if (cap < container_bound(algo, n, chunk)) { set_error("output capacity below density_hip_container_bound()"); return DENSITY_HIP_ERR_CAPACITY; }
+    if (p.n_chunks <= 1) slotted = false;                                              // (one chunk encodes straight into place either way)
+    if (cap < (slotted ? container_bound_slotted(algo, n, chunk) : container_bound(algo, n, chunk))) { set_error("output capacity below density_hip_container_bound()"); return DENSITY_HIP_ERR_CAPACITY; }
     uint32_t* d_err = reinterpret_cast<uint32_t*>(ws + p.off_err);
     uint64_t* d_sizes = reinterpret_cast<uint64_t*>(ws + p.off_sizes);
     uint64_t* d_offsets = reinterpret_cast<uint64_t*>(ws + p.off_offsets);
     uint8_t* d_slots = ws + p.off_slots;
     uint32_t* d_zmap = zmap_bytes(algo, p.n_chunks) ? reinterpret_cast<uint32_t*>(ws + p.off_zmap) : nullptr;
     density_hip_header_t hdr{};
-    hdr.magic = DENSITY_HIP_MAGIC; hdr.algo = (uint8_t)algo; hdr.version = 1; hdr.flags = want_index(algo) ? DENSITY_HIP_FLAG_BLOCK_INDEX : 0;
+    hdr.magic = DENSITY_HIP_MAGIC; hdr.algo = (uint8_t)algo; hdr.version = 1; hdr.flags = (want_index(algo) ? DENSITY_HIP_FLAG_BLOCK_INDEX : 0) | (slotted ? DENSITY_HIP_FLAG_SLOTTED : 0);
     hdr.chunk_size = (uint32_t)chunk; hdr.n_chunks = (uint32_t)p.n_chunks; hdr.total_len = n; hdr.container_len = 0;
 
     const bool with_index = hdr.flags & DENSITY_HIP_FLAG_BLOCK_INDEX;
@@ -261,6 +270,15 @@ int run_encode_container(DeviceCtx* c, int algo, const uint8_t* d_in, size_t n, 
         e = codec_encode(algo, d_in, n, chunk, 1, d_out + pbase, 0, d_sizes, d_index, ws + p.off_tables, d_zmap, p.total > p.off_stage ? ws + p.off_stage : nullptr, d_err, s);
         prof.mark(encode_kernel_name(algo));
         if (e == hipSuccess) e = launch_layout_encode(d_sizes, 1, hdr, pbase, d_out, cap, d_offsets, d_err, s);
+        prof.mark("layout_encode");
+    } else if (slotted) {
+        // Slotted container: the chunk streams stay where the encoder put them — worst-case slots INSIDE the container, at payload_base +
+        // i * slot_stride — and the size table says how much of each slot is stream.  No gather: the decoder reads the slots through the
+        // same arithmetic; the packed wire form is made when the container leaves the device (density_hip_pack_device: a copy happens there anyway).
+        e = codec_encode(algo, d_in, n, chunk, (uint32_t)p.n_chunks, d_out + pbase, p.stride, d_sizes, d_index, ws + p.off_tables, d_zmap,
+                         p.total > p.off_stage ? ws + p.off_stage : nullptr, d_err, s);
+        prof.mark(encode_kernel_name(algo));
+        if (e == hipSuccess) e = launch_layout_encode(d_sizes, (uint32_t)p.n_chunks, hdr, pbase, d_out, cap, d_offsets, d_err, s, p.stride);
         prof.mark("layout_encode");
     } else {
         // Chunk streams go to worst-case slots; their sizes are known only afterwards (write_buffer.rs:29-31 keeps a running total: in
@@ -327,7 +345,8 @@ int run_decode_container(DeviceCtx* c, const uint8_t* d_in, size_t container_siz
     hipError_t e = hipMemsetAsync(d_err, 0, sizeof(uint32_t), s);
     const bool with_index = h.flags & DENSITY_HIP_FLAG_BLOCK_INDEX;
     const uint8_t* d_index = with_index ? d_in + index_base(h.n_chunks) : nullptr;
-    if (e == hipSuccess) e = launch_layout_decode(d_in, container_size, h.n_chunks, payload_base(h.n_chunks, h.total_len, with_index), d_sizes, d_offsets, d_err, s);
+    if (e == hipSuccess) e = launch_layout_decode(d_in, container_size, h.n_chunks, payload_base(h.n_chunks, h.total_len, with_index), d_sizes, d_offsets, d_err, s,
+                                                  (h.flags & DENSITY_HIP_FLAG_SLOTTED) ? slot_stride(h.algo, h.chunk_size) : 0);
     prof.mark("layout_decode");
     if (e == hipSuccess) e = codec_decode(h.algo, d_in, d_offsets, d_sizes, h.n_chunks, d_out, h.chunk_size, h.total_len, true, d_index, d_produced, d_err, ws + p.off_tables, zmap_bytes(h.algo, h.n_chunks) ? reinterpret_cast<uint32_t*>(ws + p.off_zmap) : nullptr, s);
     prof.mark(decode_kernel_name(h.algo));
@@ -339,6 +358,45 @@ int run_decode_container(DeviceCtx* c, const uint8_t* d_in, size_t container_siz
         if (e != hipSuccess) { set_error("decode (device)", e); return DENSITY_HIP_ERR_RUNTIME; }
         if (h_err) { set_error("malformed or truncated container payload"); *decoded_out = 0; return DENSITY_HIP_ERR_FORMAT; }
         *decoded_out = h.total_len;
+    }
+    return DENSITY_HIP_OK;
+}
+
+// slotted container -> packed container (the wire form): header, size table and block index are copied, the payloads gathered
+int run_pack_container(DeviceCtx* c, const uint8_t* d_in, size_t container_size, const density_hip_header_t& h, uint8_t* d_out, size_t cap, uint8_t* ws,
+                       hipStream_t s, density_hip_header_t* header_out) {
+    const DecodePlan p = plan_decode(h.algo, h.n_chunks);
+    uint32_t* d_err = reinterpret_cast<uint32_t*>(ws + p.off_err);
+    uint64_t* d_sizes = reinterpret_cast<uint64_t*>(ws + p.off_sizes);
+    uint64_t* d_offsets = reinterpret_cast<uint64_t*>(ws + p.off_offsets);
+    uint64_t* d_sizes64 = reinterpret_cast<uint64_t*>(ws + p.off_produced);           // (the u64 sizes the layout kernel wants)
+    const bool with_index = h.flags & DENSITY_HIP_FLAG_BLOCK_INDEX;
+    const uint64_t pbase = payload_base(h.n_chunks, h.total_len, with_index);
+    if (cap < container_bound(h.algo, h.total_len, h.chunk_size)) { set_error("output capacity below density_hip_container_bound()"); return DENSITY_HIP_ERR_CAPACITY; }
+    Profiler prof(c, s);
+    hipError_t e = hipMemsetAsync(d_err, 0, sizeof(uint32_t), s);
+    const uint64_t stride = (h.flags & DENSITY_HIP_FLAG_SLOTTED) ? slot_stride(h.algo, h.chunk_size) : 0;
+    // sizes (u64) and source offsets from the slotted container's table, then the packed layout into the output
+    if (e == hipSuccess) e = launch_layout_decode(d_in, container_size, h.n_chunks, pbase, d_sizes64, d_offsets, d_err, s, stride);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_out + sizeof(h), d_in + sizeof(h), pbase - sizeof(h), hipMemcpyDeviceToDevice, s);   // size table + block index
+    density_hip_header_t out_h = h;
+    out_h.flags = h.flags & ~DENSITY_HIP_FLAG_SLOTTED;
+    out_h.container_len = 0;
+    if (e == hipSuccess) e = launch_layout_encode(d_sizes64, h.n_chunks, out_h, pbase, d_out, cap, d_sizes /* packed offsets */, d_err, s);
+    prof.mark("layout_encode");
+    if (e == hipSuccess) {
+        if (stride) e = launch_compact(d_in + pbase, stride, d_sizes64, d_sizes, h.n_chunks, d_out, d_err, s);
+        else e = hipMemcpyAsync(d_out + pbase, d_in + pbase, container_size - pbase, hipMemcpyDeviceToDevice, s);
+    }
+    prof.mark("compact");
+    if (e != hipSuccess) { set_error("kernel launch (pack)", e); return DENSITY_HIP_ERR_RUNTIME; }
+    if (header_out) {
+        uint32_t h_err = 0;
+        e = hipMemcpyAsync(header_out, d_out, sizeof(*header_out), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(&h_err, d_err, sizeof(h_err), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) { set_error("pack (device)", e); return DENSITY_HIP_ERR_RUNTIME; }
+        if (h_err) { set_error("malformed slotted container"); return DENSITY_HIP_ERR_FORMAT; }
     }
     return DENSITY_HIP_OK;
 }
@@ -707,6 +765,53 @@ int density_hip_encode_device(int algo, const void* d_input, size_t input_size, 
     else { hipError_t e = c->work.ensure(need); if (e != hipSuccess) { set_error("workspace allocation", e); return DENSITY_HIP_ERR_RUNTIME; } ws = (uint8_t*)c->work.p; }
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     return run_encode_container(c, algo, (const uint8_t*)d_input, input_size, (uint8_t*)d_output, output_capacity, chunk_size, ws, s, header_out);
+}
+
+int density_hip_encode_device_slotted(int algo, const void* d_input, size_t input_size, void* d_output, size_t output_capacity,
+                                      size_t chunk_size, void* d_workspace, size_t workspace_size, void* stream,
+                                      density_hip_header_t* header_out) {
+    g_last_error.clear();
+    chunk_size = normalise_chunk(chunk_size, input_size, algo);
+    if (!valid_algo(algo) || !valid_chunk(chunk_size) || (!d_input && input_size) || !d_output) { set_error("bad argument"); return DENSITY_HIP_ERR_ARGUMENT; }
+    DeviceCtx* c = acquire_ctx();
+    if (!c) return DENSITY_HIP_ERR_RUNTIME;
+    std::lock_guard<std::mutex> lk(c->mu);
+    const size_t need = plan_encode(algo, input_size, chunk_size).total;
+    uint8_t* ws = (uint8_t*)d_workspace;
+    if (ws) { if (workspace_size < need) { set_error("workspace too small"); return DENSITY_HIP_ERR_CAPACITY; } }
+    else { hipError_t e = c->work.ensure(need); if (e != hipSuccess) { set_error("workspace allocation", e); return DENSITY_HIP_ERR_RUNTIME; } ws = (uint8_t*)c->work.p; }
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    return run_encode_container(c, algo, (const uint8_t*)d_input, input_size, (uint8_t*)d_output, output_capacity, chunk_size, ws, s, header_out, true);
+}
+
+size_t density_hip_container_bound_slotted(int algo, size_t input_size, size_t chunk_size) {
+    chunk_size = normalise_chunk(chunk_size, input_size, algo);
+    if (!valid_algo(algo) || !valid_chunk(chunk_size)) return 0;
+    const size_t a = container_bound_slotted(algo, input_size, chunk_size), b = container_bound(algo, input_size, chunk_size);
+    return a > b ? a : b;
+}
+
+int density_hip_pack_device(const void* d_container, size_t container_size, const density_hip_header_t* header, void* d_output,
+                            size_t output_capacity, void* d_workspace, size_t workspace_size, void* stream, density_hip_header_t* header_out) {
+    g_last_error.clear();
+    if (!d_container || container_size < sizeof(density_hip_header_t) || !d_output) { set_error("bad argument"); return DENSITY_HIP_ERR_ARGUMENT; }
+    DeviceCtx* c = acquire_ctx();
+    if (!c) return DENSITY_HIP_ERR_RUNTIME;
+    std::lock_guard<std::mutex> lk(c->mu);
+    density_hip_header_t h;
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    if (header) h = *header;
+    else {
+        hipError_t e = hipMemcpyAsync(&h, d_container, sizeof(h), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) { set_error("header read-back", e); return DENSITY_HIP_ERR_RUNTIME; }
+    }
+    if (check_header(h, container_size) != DENSITY_HIP_OK) { set_error("bad container header"); return DENSITY_HIP_ERR_FORMAT; }
+    const size_t need = plan_decode(h.algo, h.n_chunks).total;
+    uint8_t* ws = (uint8_t*)d_workspace;
+    if (ws) { if (workspace_size < need) { set_error("workspace too small"); return DENSITY_HIP_ERR_CAPACITY; } }
+    else { hipError_t e = c->work.ensure(need); if (e != hipSuccess) { set_error("workspace allocation", e); return DENSITY_HIP_ERR_RUNTIME; } ws = (uint8_t*)c->work.p; }
+    return run_pack_container(c, (const uint8_t*)d_container, container_size, h, (uint8_t*)d_output, output_capacity, ws, s, header_out);
 }
 
 int density_hip_decode_device(const void* d_container, size_t container_size, const density_hip_header_t* header, void* d_output,

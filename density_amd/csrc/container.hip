@@ -38,19 +38,22 @@ __device__ __forceinline__ uint64_t block_inclusive_scan(uint64_t v, uint64_t* w
     return v + prefix;
 }
 
+// slot_stride != 0: a SLOTTED container (DENSITY_HIP_FLAG_SLOTTED) — payload i sits in its worst-case slot at base + i * slot_stride, no scan
 template <typename SizeT>
 __device__ __forceinline__ void layout_common(const SizeT* __restrict__ sizes_in, uint32_t n, uint64_t base,
                                               uint64_t* __restrict__ sizes_out, uint32_t* __restrict__ table_out,
-                                              uint64_t* __restrict__ offsets, uint64_t* end_out, uint64_t limit, uint32_t* __restrict__ err) {
+                                              uint64_t* __restrict__ offsets, uint64_t* end_out, uint64_t limit, uint32_t* __restrict__ err,
+                                              uint64_t slot_stride = 0) {
     __shared__ uint64_t wave_sums[kScanThreads / 64];
     uint64_t carry = base, last_end = base;
     for (uint32_t t0 = 0; t0 < n; t0 += kScanThreads) {
         const uint32_t i = t0 + threadIdx.x;
         const uint64_t sz = i < n ? (uint64_t)sizes_in[i] : 0ull;
-        uint64_t tile_total;
-        const uint64_t incl = block_inclusive_scan(align16(sz), wave_sums, &tile_total);
+        uint64_t tile_total = 0;
+        const uint64_t incl = slot_stride ? 0ull : block_inclusive_scan(align16(sz), wave_sums, &tile_total);
         if (i < n) {
-            uint64_t off = carry + incl - align16(sz);
+            uint64_t off = slot_stride ? base + (uint64_t)i * slot_stride : carry + incl - align16(sz);
+            if (slot_stride && sz > slot_stride) { atomicOr(err, 4u); }   // (a size table entry larger than a slot: never from this library)
             uint64_t keep = sz;
             if (off + sz > limit) {                     // a size table that runs past the container: the codec kernels must not follow it
                 off = base; keep = 0;
@@ -69,10 +72,10 @@ __device__ __forceinline__ void layout_common(const SizeT* __restrict__ sizes_in
 __global__ __launch_bounds__(kScanThreads) void layout_encode_kernel(const uint64_t* __restrict__ sizes, uint32_t n,
                                                                      density_hip_header_t hdr, uint64_t base, uint8_t* __restrict__ container,
                                                                      uint64_t capacity, uint64_t* __restrict__ offsets,
-                                                                     uint64_t* __restrict__ end_scratch, uint32_t* __restrict__ err) {
+                                                                     uint64_t* __restrict__ end_scratch, uint32_t* __restrict__ err, uint64_t slot_stride) {
     if (threadIdx.x == 0) *end_scratch = base;
     __syncthreads();
-    layout_common<uint64_t>(sizes, n, base, nullptr, reinterpret_cast<uint32_t*>(container + kHeaderBytes), offsets, end_scratch, ~0ull, err);
+    layout_common<uint64_t>(sizes, n, base, nullptr, reinterpret_cast<uint32_t*>(container + kHeaderBytes), offsets, end_scratch, ~0ull, err, slot_stride);
     __syncthreads();
     if (threadIdx.x == 0) {
         hdr.container_len = *end_scratch;
@@ -107,10 +110,10 @@ __global__ __launch_bounds__(kScanThreads) void layout_encode_batch_kernel(const
 __global__ __launch_bounds__(kScanThreads) void layout_decode_kernel(const uint8_t* __restrict__ container, uint64_t container_size,
                                                                      uint32_t n, uint64_t base, uint64_t* __restrict__ sizes,
                                                                      uint64_t* __restrict__ offsets, uint64_t* __restrict__ end_scratch,
-                                                                     uint32_t* __restrict__ err) {
+                                                                     uint32_t* __restrict__ err, uint64_t slot_stride) {
     if (threadIdx.x == 0) *end_scratch = base;
     __syncthreads();
-    layout_common<uint32_t>(reinterpret_cast<const uint32_t*>(container + kHeaderBytes), n, base, sizes, nullptr, offsets, end_scratch, container_size, err);
+    layout_common<uint32_t>(reinterpret_cast<const uint32_t*>(container + kHeaderBytes), n, base, sizes, nullptr, offsets, end_scratch, container_size, err, slot_stride);
     __syncthreads();
     if (threadIdx.x == 0 && *end_scratch > container_size) atomicOr(err, 4u);   // truncated container
 }
@@ -180,10 +183,10 @@ __global__ __launch_bounds__(64) void selftest_kernel(uint32_t* __restrict__ fai
 }  // namespace
 
 hipError_t launch_layout_encode(const uint64_t* d_sizes, uint32_t n_chunks, density_hip_header_t hdr, uint64_t payload_base, uint8_t* d_container,
-                                uint64_t capacity, uint64_t* d_offsets, uint32_t* d_err, hipStream_t stream) {
+                                uint64_t capacity, uint64_t* d_offsets, uint32_t* d_err, hipStream_t stream, uint64_t slot_stride) {
     // d_offsets has n_chunks + 1 entries; the extra one is scratch for the end offset
     hipLaunchKernelGGL(layout_encode_kernel, dim3(1), dim3(kScanThreads), 0, stream, d_sizes, n_chunks, hdr, payload_base, d_container, capacity,
-                       d_offsets, d_offsets + n_chunks, d_err);
+                       d_offsets, d_offsets + n_chunks, d_err, slot_stride);
     return hipGetLastError();
 }
 
@@ -196,9 +199,9 @@ hipError_t launch_layout_encode_batch(const uint64_t* d_sizes, uint32_t first, u
 }
 
 hipError_t launch_layout_decode(const uint8_t* d_container, uint64_t container_size, uint32_t n_chunks, uint64_t payload_base, uint64_t* d_sizes,
-                                uint64_t* d_offsets, uint32_t* d_err, hipStream_t stream) {
+                                uint64_t* d_offsets, uint32_t* d_err, hipStream_t stream, uint64_t slot_stride) {
     hipLaunchKernelGGL(layout_decode_kernel, dim3(1), dim3(kScanThreads), 0, stream, d_container, container_size, n_chunks, payload_base, d_sizes,
-                       d_offsets, d_offsets + n_chunks, d_err);
+                       d_offsets, d_offsets + n_chunks, d_err, slot_stride);
     return hipGetLastError();
 }
 

@@ -104,15 +104,16 @@ hipError_t launch_stream_parse(const uint8_t* d_in, uint64_t E, uint64_t from_po
 // ---- container.hip ----
 // Exclusive scan of 16-byte-aligned chunk sizes -> payload offsets; writes the container header and the u32 size
 // table (encode side).
+// slot_stride != 0: a slotted container (DENSITY_HIP_FLAG_SLOTTED): payload i stays in its slot at payload_base + i * slot_stride
 hipError_t launch_layout_encode(const uint64_t* d_sizes, uint32_t n_chunks, density_hip_header_t hdr, uint64_t payload_base, uint8_t* d_container,
-                                uint64_t capacity, uint64_t* d_offsets, uint32_t* d_err, hipStream_t stream);
+                                uint64_t capacity, uint64_t* d_offsets, uint32_t* d_err, hipStream_t stream, uint64_t slot_stride = 0);
 // The same for a slice of the chunks (batched encode): offsets continue from *d_carry, which is left at the slice's end.
 hipError_t launch_layout_encode_batch(const uint64_t* d_sizes, uint32_t first, uint32_t count, bool is_first, bool is_last, density_hip_header_t hdr,
                                       uint64_t payload_base, uint8_t* d_container, uint64_t capacity, uint64_t* d_offsets, uint64_t* d_carry, uint32_t* d_err,
                                       hipStream_t stream);
 // Decode side: reads the u32 size table of a container, produces u64 sizes + offsets, validates against container_size.
 hipError_t launch_layout_decode(const uint8_t* d_container, uint64_t container_size, uint32_t n_chunks, uint64_t payload_base,
-                                uint64_t* d_sizes, uint64_t* d_offsets, uint32_t* d_err, hipStream_t stream);
+                                uint64_t* d_sizes, uint64_t* d_offsets, uint32_t* d_err, hipStream_t stream, uint64_t slot_stride = 0);
 // Gathers chunk streams from their worst-case slots into the packed container.
 hipError_t launch_compact(const uint8_t* d_slots, uint64_t slot_stride, const uint64_t* d_sizes, const uint64_t* d_offsets,
                           uint32_t n_chunks, uint8_t* d_container, const uint32_t* d_err, hipStream_t stream);

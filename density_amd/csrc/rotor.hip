@@ -210,6 +210,76 @@ __device__ __forceinline__ void exchange_round(uint32_t (&ret)[kR], const uint32
 #define DENSITY_ROT_MV16_OUTS "=v"(q[0]), "=v"(q[1]), "=v"(q[2]), "=v"(q[3]), "=v"(q[4]), "=v"(q[5]), "=v"(q[6]), "=v"(q[7]), "=v"(q[8]), "=v"(q[9]), "=v"(q[10]), "=v"(q[11]), "=v"(q[12]), "=v"(q[13]), "=v"(q[14]), "=v"(q[15])
 #define DENSITY_ROT_STAGE16 "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255"
 
+// the same for the 12-wave kernels (168 registers a wave): staging in v(168-R)..v167
+#define DENSITY_ROT_PF12W12 \
+    "global_load_dword v156, %0, off offset:0\n\t" \
+    "global_load_dword v157, %0, off offset:256\n\t" \
+    "global_load_dword v158, %0, off offset:512\n\t" \
+    "global_load_dword v159, %0, off offset:768\n\t" \
+    "global_load_dword v160, %0, off offset:1024\n\t" \
+    "global_load_dword v161, %0, off offset:1280\n\t" \
+    "global_load_dword v162, %0, off offset:1536\n\t" \
+    "global_load_dword v163, %0, off offset:1792\n\t" \
+    "global_load_dword v164, %0, off offset:2048\n\t" \
+    "global_load_dword v165, %0, off offset:2304\n\t" \
+    "global_load_dword v166, %0, off offset:2560\n\t" \
+    "global_load_dword v167, %0, off offset:2816\n\t" \
+    ""
+#define DENSITY_ROT_MV12W12 \
+    "v_mov_b32 %0, v156\n\t" \
+    "v_mov_b32 %1, v157\n\t" \
+    "v_mov_b32 %2, v158\n\t" \
+    "v_mov_b32 %3, v159\n\t" \
+    "v_mov_b32 %4, v160\n\t" \
+    "v_mov_b32 %5, v161\n\t" \
+    "v_mov_b32 %6, v162\n\t" \
+    "v_mov_b32 %7, v163\n\t" \
+    "v_mov_b32 %8, v164\n\t" \
+    "v_mov_b32 %9, v165\n\t" \
+    "v_mov_b32 %10, v166\n\t" \
+    "v_mov_b32 %11, v167\n\t" \
+    ""
+#define DENSITY_ROT_MV12W12_OUTS "=v"(q[0]), "=v"(q[1]), "=v"(q[2]), "=v"(q[3]), "=v"(q[4]), "=v"(q[5]), "=v"(q[6]), "=v"(q[7]), "=v"(q[8]), "=v"(q[9]), "=v"(q[10]), "=v"(q[11])
+#define DENSITY_ROT_STAGE12W12 "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167"
+#define DENSITY_ROT_PF16W12 \
+    "global_load_dword v152, %0, off offset:0\n\t" \
+    "global_load_dword v153, %0, off offset:256\n\t" \
+    "global_load_dword v154, %0, off offset:512\n\t" \
+    "global_load_dword v155, %0, off offset:768\n\t" \
+    "global_load_dword v156, %0, off offset:1024\n\t" \
+    "global_load_dword v157, %0, off offset:1280\n\t" \
+    "global_load_dword v158, %0, off offset:1536\n\t" \
+    "global_load_dword v159, %0, off offset:1792\n\t" \
+    "global_load_dword v160, %0, off offset:2048\n\t" \
+    "global_load_dword v161, %0, off offset:2304\n\t" \
+    "global_load_dword v162, %0, off offset:2560\n\t" \
+    "global_load_dword v163, %0, off offset:2816\n\t" \
+    "global_load_dword v164, %0, off offset:3072\n\t" \
+    "global_load_dword v165, %0, off offset:3328\n\t" \
+    "global_load_dword v166, %0, off offset:3584\n\t" \
+    "global_load_dword v167, %0, off offset:3840\n\t" \
+    ""
+#define DENSITY_ROT_MV16W12 \
+    "v_mov_b32 %0, v152\n\t" \
+    "v_mov_b32 %1, v153\n\t" \
+    "v_mov_b32 %2, v154\n\t" \
+    "v_mov_b32 %3, v155\n\t" \
+    "v_mov_b32 %4, v156\n\t" \
+    "v_mov_b32 %5, v157\n\t" \
+    "v_mov_b32 %6, v158\n\t" \
+    "v_mov_b32 %7, v159\n\t" \
+    "v_mov_b32 %8, v160\n\t" \
+    "v_mov_b32 %9, v161\n\t" \
+    "v_mov_b32 %10, v162\n\t" \
+    "v_mov_b32 %11, v163\n\t" \
+    "v_mov_b32 %12, v164\n\t" \
+    "v_mov_b32 %13, v165\n\t" \
+    "v_mov_b32 %14, v166\n\t" \
+    "v_mov_b32 %15, v167\n\t" \
+    ""
+#define DENSITY_ROT_MV16W12_OUTS "=v"(q[0]), "=v"(q[1]), "=v"(q[2]), "=v"(q[3]), "=v"(q[4]), "=v"(q[5]), "=v"(q[6]), "=v"(q[7]), "=v"(q[8]), "=v"(q[9]), "=v"(q[10]), "=v"(q[11]), "=v"(q[12]), "=v"(q[13]), "=v"(q[14]), "=v"(q[15])
+#define DENSITY_ROT_STAGE16W12 "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167"
+
 // element j (wave-uniform, not a compile-time constant) of a register array, for the rolled loops of the rare paths: a chain of
 // selects, so the array stays in registers (a dynamically indexed copy would live in scratch memory, and the compiler's waits for
 // its loads would also hold the common path at the top of every round)
@@ -231,22 +301,47 @@ __device__ __forceinline__ uint32_t pick(const uint32_t (&a)[R], uint32_t j) {
 // accumulation registers would be the natural staging area, but a kernel that names one has its register file split in halves.)
 // `quads_landed` waits — every load is older than the `kYounger` memory operations the
 // caller guarantees to have issued since (vmcnt counts a wave's loads and stores in order) — and reads them into `q`.
-template <int R>
+template <int R, int W>
 __device__ __forceinline__ void prefetch_quads(const uint8_t* p);
 template <>
-__device__ __forceinline__ void prefetch_quads<8>(const uint8_t* p) { asm volatile(DENSITY_ROT_PF8 : : "v"(p) : "memory", DENSITY_ROT_STAGE8); }
+__device__ __forceinline__ void prefetch_quads<8, 8>(const uint8_t* p) { asm volatile(DENSITY_ROT_PF8 : : "v"(p) : "memory", DENSITY_ROT_STAGE8); }
 template <>
-__device__ __forceinline__ void prefetch_quads<16>(const uint8_t* p) { asm volatile(DENSITY_ROT_PF16 : : "v"(p) : "memory", DENSITY_ROT_STAGE16); }
-template <int R, int kYounger>
+__device__ __forceinline__ void prefetch_quads<16, 8>(const uint8_t* p) { asm volatile(DENSITY_ROT_PF16 : : "v"(p) : "memory", DENSITY_ROT_STAGE16); }
+template <>
+__device__ __forceinline__ void prefetch_quads<12, 12>(const uint8_t* p) { asm volatile(DENSITY_ROT_PF12W12 : : "v"(p) : "memory", DENSITY_ROT_STAGE12W12); }
+template <>
+__device__ __forceinline__ void prefetch_quads<16, 12>(const uint8_t* p) { asm volatile(DENSITY_ROT_PF16W12 : : "v"(p) : "memory", DENSITY_ROT_STAGE16W12); }
+// (never instantiated: geometries without kept quads)
+template <>
+__device__ __forceinline__ void prefetch_quads<8, 16>(const uint8_t*) {}
+template <>
+__device__ __forceinline__ void prefetch_quads<8, 12>(const uint8_t*) {}
+template <>
+__device__ __forceinline__ void prefetch_quads<12, 8>(const uint8_t*) {}
+template <>
+__device__ __forceinline__ void prefetch_quads<12, 16>(const uint8_t*) {}
+template <>
+__device__ __forceinline__ void prefetch_quads<16, 16>(const uint8_t*) {}
+template <int R, int W, bool kDrained>
 __device__ __forceinline__ void quads_landed(uint32_t (&q)[R]);
 template <>
-__device__ __forceinline__ void quads_landed<8, 8>(uint32_t (&q)[8]) { asm volatile("s_waitcnt vmcnt(8)\n\t" DENSITY_ROT_MV8 : DENSITY_ROT_MV8_OUTS : : DENSITY_ROT_STAGE8); }
+__device__ __forceinline__ void quads_landed<8, 8, false>(uint32_t (&q)[8]) { asm volatile("s_waitcnt vmcnt(8)\n\t" DENSITY_ROT_MV8 : DENSITY_ROT_MV8_OUTS : : DENSITY_ROT_STAGE8); }
 template <>
-__device__ __forceinline__ void quads_landed<8, 0>(uint32_t (&q)[8]) { asm volatile("s_waitcnt vmcnt(0)\n\t" DENSITY_ROT_MV8 : DENSITY_ROT_MV8_OUTS : : DENSITY_ROT_STAGE8); }
+__device__ __forceinline__ void quads_landed<8, 8, true>(uint32_t (&q)[8]) { asm volatile("s_waitcnt vmcnt(0)\n\t" DENSITY_ROT_MV8 : DENSITY_ROT_MV8_OUTS : : DENSITY_ROT_STAGE8); }
 template <>
-__device__ __forceinline__ void quads_landed<16, 16>(uint32_t (&q)[16]) { asm volatile("s_waitcnt vmcnt(16)\n\t" DENSITY_ROT_MV16 : DENSITY_ROT_MV16_OUTS : : DENSITY_ROT_STAGE16); }
+__device__ __forceinline__ void quads_landed<16, 8, false>(uint32_t (&q)[16]) { asm volatile("s_waitcnt vmcnt(16)\n\t" DENSITY_ROT_MV16 : DENSITY_ROT_MV16_OUTS : : DENSITY_ROT_STAGE16); }
 template <>
-__device__ __forceinline__ void quads_landed<16, 0>(uint32_t (&q)[16]) { asm volatile("s_waitcnt vmcnt(0)\n\t" DENSITY_ROT_MV16 : DENSITY_ROT_MV16_OUTS : : DENSITY_ROT_STAGE16); }
+__device__ __forceinline__ void quads_landed<16, 8, true>(uint32_t (&q)[16]) { asm volatile("s_waitcnt vmcnt(0)\n\t" DENSITY_ROT_MV16 : DENSITY_ROT_MV16_OUTS : : DENSITY_ROT_STAGE16); }
+template <>
+__device__ __forceinline__ void quads_landed<12, 12, false>(uint32_t (&q)[12]) { asm volatile("s_waitcnt vmcnt(12)\n\t" DENSITY_ROT_MV12W12 : DENSITY_ROT_MV12W12_OUTS : : DENSITY_ROT_STAGE12W12); }
+template <>
+__device__ __forceinline__ void quads_landed<12, 12, true>(uint32_t (&q)[12]) { asm volatile("s_waitcnt vmcnt(0)\n\t" DENSITY_ROT_MV12W12 : DENSITY_ROT_MV12W12_OUTS : : DENSITY_ROT_STAGE12W12); }
+template <>
+__device__ __forceinline__ void quads_landed<16, 12, false>(uint32_t (&q)[16]) { asm volatile("s_waitcnt vmcnt(16)\n\t" DENSITY_ROT_MV16W12 : DENSITY_ROT_MV16W12_OUTS : : DENSITY_ROT_STAGE16W12); }
+template <>
+__device__ __forceinline__ void quads_landed<16, 12, true>(uint32_t (&q)[16]) { asm volatile("s_waitcnt vmcnt(0)\n\t" DENSITY_ROT_MV16W12 : DENSITY_ROT_MV16W12_OUTS : : DENSITY_ROT_STAGE16W12); }
+template <int R, int W, bool kDrained>
+__device__ __forceinline__ void quads_landed(uint32_t (&)[R]) {}                // (geometries without kept quads: never called)
 
 #define DENSITY_ROT_X12 \
     "ds_mskor_rtn_b32 %0, %0, %12, %24\n\t" \
@@ -372,12 +467,13 @@ __device__ __forceinline__ bool poll_word(uint32_t addr, uint32_t want, uint32_t
 // ---------------------------------------------------------------------------------------------------------------
 // encode: Codec::encode / encode_block (codec/codec.rs:34-80), Chameleon::encode_quad (chameleon.rs:88-100)
 // ---------------------------------------------------------------------------------------------------------------
-template <int R, int W, bool kProf>
+template <int R, int W, bool kProf, bool KEEP = (W == 8), bool EARLY = false>
 __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __restrict__ in, uint64_t total, uint64_t chunk_bytes,
                                                                    uint8_t* __restrict__ out, uint64_t out_stride, uint64_t* __restrict__ sizes,
                                                                    uint8_t* __restrict__ index, uint32_t* __restrict__ err, SegArgs seg,
                                                                    uint64_t* __restrict__ prof) {
-    static_assert((R == 8 || R == 16) && (W == 8 || W == 12 || W == 16), "round = 8 or 16 blocks; 8, 12 or 16 waves");
+    static_assert((R == 8 || R == 12 || R == 16) && (W == 8 || W == 12 || W == 16), "round = 8, 12 or 16 blocks; 8, 12 or 16 waves");
+    static_assert(!KEEP || W == 8 || (W == 12 && R >= 12), "kept quads: staging registers exist for the 8-wave kernels and for 12 / 16 blocks on 12 waves");
     // (rounds of 16 on 16 waves fit the 128 registers a wave then has because nothing but the exchange operands is kept across the wait for the
     // dictionary token: the quads themselves are loaded again — from L2 — once the exchanges are out)
     const uint32_t lane = threadIdx.x & 63u;
@@ -412,7 +508,8 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
 
     // 8 waves have 256 registers each: the quads stay in registers across the waits and the next round's are fetched a round ahead;
     // 12 and 16 waves load them again instead
-    constexpr bool kKeepQuads = W == 8;
+    constexpr bool kKeepQuads = KEEP;
+    constexpr bool kKeepHash = KEEP && W == 8;                                    // (12 waves have 168 registers each: the hash product is made again for the emit)
     uint32_t q[R], hp[R];                                                         // hp: the quads' hash products (kept with them)
 #pragma unroll
     for (uint32_t j = 0; j < R; ++j) hp[j] = 0;
@@ -488,7 +585,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
             const uint64_t sg = ((uint64_t)rlane_u(shi, (int)j) << 32) | rlane_u(slo, (int)j);
             const uint64_t plain = ~sg;
             const uint32_t off = pos + c_base + 2u * mbcnt64(plain);              // 8 + 2*lane + 2*(PLAIN lanes below) = 8 + 4*lane - 2*(MAP lanes below)
-            const uint32_t P = kKeepQuads ? hp[j] : q[j] * kHashMul;              // (the hash is the MAP item: chameleon.rs:92)
+            const uint32_t P = kKeepHash ? hp[j] : q[j] * kHashMul;               // (the hash is the MAP item: chameleon.rs:92)
             asm volatile(
                 "s_mov_b64 exec, %4\n\t"
                 "global_store_short_d16_hi %0, %1, %3\n\t"
@@ -538,7 +635,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
     if (kKeepQuads) {
         // (by hand like every later fetch: a load the compiler can see ahead of the loop would make it wait, at the top of every
         // iteration, until all but a few of the previous round's record stores have been acknowledged)
-        if (wave < nrounds) { prefetch_quads<R>(src + (uint64_t)wave * (R * kBlock) + 4u * lane); quads_landed<R, 0>(q); }
+        if (wave < nrounds) { prefetch_quads<R, W>(src + (uint64_t)wave * (R * kBlock) + 4u * lane); quads_landed<R, W, true>(q); }
     } else {
         load_round(q, wave);
     }
@@ -547,12 +644,12 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
         __builtin_amdgcn_s_setprio(1);                                   // (see the priorities note at the exchange)
         uint32_t slo = 0, shi = 0;                                                // lane j: the signature of block j (codec.rs:24-26)
         uint32_t copy_mask = 0, opos = 0;
-        bool fast_commit = false;
+        bool fast_commit = false, prefetched = false;
       for (;;) {   // (re-entered after an abort: the answers have replaced the addresses, so the operands are made again)
         uint32_t zmin = 0xffffffffu;
 #pragma unroll
         for (uint32_t j = 0; j < R; ++j) {
-            operands(q[j], ra[j], mask[j], val[j], kKeepQuads ? &hp[j] : nullptr);
+            operands(q[j], ra[j], mask[j], val[j], kKeepHash ? &hp[j] : nullptr);
             zmin = val[j] < zmin ? val[j] : zmin;
             __builtin_amdgcn_sched_barrier(0);                                    // block by block: short live ranges, not maximal overlap
         }
@@ -601,6 +698,9 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
                 __builtin_amdgcn_s_setprio(2);
                 clk.mark(2);
                 clk.stamp(r, 2, lane);
+                // EARLY: the next round's quads are asked for HERE, a signature pass and a commit wait earlier than behind the commit (their
+                // latency under load is of the order of a whole emit); once per round, whatever becomes of it (an abort re-enters the loop)
+                if (EARLY && kKeepQuads && !prefetched && r + W < nrounds) { prefetch_quads<R, W>(src + (uint64_t)(r + W) * (R * kBlock) + 4u * lane); prefetched = true; }
                 uint32_t hits = 0;
 #pragma unroll
                 for (uint32_t j = 0; j < R; ++j) {
@@ -683,7 +783,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
                 copy_mask = 0;
                 __builtin_amdgcn_s_setprio(0);
                 fast_commit = true;
-                if (kKeepQuads && r + W < nrounds) prefetch_quads<R>(src + (uint64_t)(r + W) * (R * kBlock) + 4u * lane);   // next round's quads: in flight behind the commit, landed by the end of the emit
+                if (kKeepQuads && !prefetched && r + W < nrounds) prefetch_quads<R, W>(src + (uint64_t)(r + W) * (R * kBlock) + 4u * lane);   // next round's quads: in flight behind the commit, landed by the end of the emit
                 clk.mark(4);
                 break;
             }
@@ -728,7 +828,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
                 lds_poke(sy + kSyO, r + 1u);
                 lds_poke(sy + kSyD, ((r + 1u) << 1) | stay_slow);
             }
-            if (kKeepQuads && r + W < nrounds) prefetch_quads<R>(src + (uint64_t)(r + W) * (R * kBlock) + 4u * lane);   // (as behind a fast commit)
+            if (kKeepQuads && !prefetched && r + W < nrounds) prefetch_quads<R, W>(src + (uint64_t)(r + W) * (R * kBlock) + 4u * lane);   // (as behind a fast commit)
             clk.mark(7);
             break;
         }
@@ -756,7 +856,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
             if (r + W < nrounds) {
                 // behind a fast commit at least R stores are younger than the R loads (emit_round_coded: every record stores its MAP items,
                 // its PLAIN items or both — a store none of whose lanes is active is not counted — and the signatures go out in one more)
-                if (fast_commit) quads_landed<R, R>(q); else quads_landed<R, 0>(q);
+                if (fast_commit) quads_landed<R, W, false>(q); else quads_landed<R, W, true>(q);
             }
         } else {
             load_round(q, r + W);                                                 // next round's quads (their latency is this wave's slack, not the chain's)
@@ -1440,10 +1540,14 @@ hipError_t launch_rotor_encode(const uint8_t* d_in, uint64_t total, uint64_t chu
     uint64_t* prof = rot_prof_buffer();
     // geometry (DENSITY_HIP_TUNE bits 2..4): 0 = default = rounds of 16 blocks on 8 waves (the longer round amortises the hand-off, and 8
     // waves have the registers to keep their quads), 1 = 8 blocks on 16 waves, 2 = 16 blocks on 12 waves (as fast as the default, more code)
+    // (12 or 16 blocks on 12 waves with kept quads do not fit: the compiler needs the staging registers / spills 43 registers)
+    // bit 8: the default geometry with the next round's quads asked for right behind the exchanges (EARLY)
     const uint32_t sel = (rot_tune() >> 2) & 7u;
+    const bool early = (rot_tune() >> 8) & 1u;
     const uint32_t waves = sel == 1 ? 16 : sel == 2 ? 12 : 8;
     auto kernel = sel == 1 ? (prof ? chameleon_encode_rot<8, 16, true> : chameleon_encode_rot<8, 16, false>)
                 : sel == 2 ? (prof ? chameleon_encode_rot<16, 12, true> : chameleon_encode_rot<16, 12, false>)
+                : early    ? (prof ? chameleon_encode_rot<16, 8, true, true, true> : chameleon_encode_rot<16, 8, false, true, true>)
                            : (prof ? chameleon_encode_rot<16, 8, true> : chameleon_encode_rot<16, 8, false>);
     hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEncLds);
     if (e != hipSuccess) return e;

@@ -94,6 +94,14 @@ enum {
  * decodes through the record-walking path.
  */
 #define DENSITY_HIP_FLAG_BLOCK_INDEX 1u
+/* Slotted container (device-resident form): payload i is NOT packed behind payload i-1 but stays in the worst-case slot the encoder
+ * wrote it to, at payload_base + i * slot_stride, slot_stride = round_up({algo}_safe_encode_buffer_size(chunk_size), 256); the size
+ * table says how much of each slot is stream; container_len is the end of the last payload.  The chunk streams themselves are the
+ * same bytes.  This is what density_hip_encode_device_slotted() produces and what density_hip_decode_device() also accepts: the
+ * gather into the packed form (one more pass over every encoded byte: write_buffer.rs:29-31's running total has no parallel
+ * equivalent until the sizes exist) is left to the moment the container leaves the device — density_hip_pack_device(), or the
+ * host-pointer density_hip_encode(), which always returns the packed form. */
+#define DENSITY_HIP_FLAG_SLOTTED 2u
 #define DENSITY_HIP_MAGIC 0x31434844u /* "DHC1" */
 #define DENSITY_HIP_DEFAULT_CHUNK (1u << 20)
 
@@ -141,6 +149,16 @@ size_t density_hip_decode_workspace_size(uint32_t n_chunks);
 int density_hip_encode_device(int algo, const void* d_input, size_t input_size, void* d_output, size_t output_capacity,
                               size_t chunk_size, void* d_workspace, size_t workspace_size, void* stream,
                               density_hip_header_t* header_out);
+/* The same, leaving every chunk stream in its slot inside the output (DENSITY_HIP_FLAG_SLOTTED): no stitch pass.  `output_capacity` must be at
+ * least density_hip_container_bound_slotted().  With one chunk the result is the ordinary (packed) container. */
+size_t density_hip_container_bound_slotted(int algo, size_t input_size, size_t chunk_size);
+int density_hip_encode_device_slotted(int algo, const void* d_input, size_t input_size, void* d_output, size_t output_capacity,
+                                      size_t chunk_size, void* d_workspace, size_t workspace_size, void* stream,
+                                      density_hip_header_t* header_out);
+/* Slotted (or packed) container -> packed container: byte for byte what density_hip_encode_device() writes for the same input.  Workspace as for
+ * decode. */
+int density_hip_pack_device(const void* d_container, size_t container_size, const density_hip_header_t* header, void* d_output,
+                            size_t output_capacity, void* d_workspace, size_t workspace_size, void* stream, density_hip_header_t* header_out);
 /* `header` may be NULL: it is then read back from the device (one small synchronous copy). */
 int density_hip_decode_device(const void* d_container, size_t container_size, const density_hip_header_t* header,
                               void* d_output, size_t output_capacity, void* d_workspace, size_t workspace_size,
