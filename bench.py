@@ -192,18 +192,23 @@ def other_config(container, algo, label, host, steps=3, warmup=1, cpu_sample=32 
     n = host.size
     chunk = chunk or int(_lib.lib().density_hip_auto_chunk_for(_lib.ALGO_IDS[algo], n))
     x = torch.from_numpy(host).cuda()
-    cap = container.container_bound(algo, n, chunk)
+    cap = container.container_bound_slotted(algo, n, chunk)
     cont = torch.empty(cap, dtype=torch.uint8, device="cuda")
     back = torch.empty(n, dtype=torch.uint8, device="cuda")
     s = torch.cuda.current_stream().cuda_stream
     hdr = container.encode_device(algo, x.data_ptr(), n, cont.data_ptr(), cap, chunk, stream=s)
     assert container.decode_device(cont.data_ptr(), hdr.container_len, back.data_ptr(), n, header=hdr, stream=s) == n and torch.equal(back, x), f"{algo}: round trip mismatch"
-    E = int(hdr.container_len)
+    E = int(hdr.container_len)                                                         # the packed container: the algorithmic E
     _, payloads = container.chunk_payloads(cont[:E].cpu().numpy())
+    # timed like the headline workload: the slotted container (no stitch pass; same chunk streams)
+    back.zero_()
+    hdr = container.encode_device_slotted(algo, x.data_ptr(), n, cont.data_ptr(), cap, chunk, stream=s)
+    Ec = int(hdr.container_len)
+    assert container.decode_device(cont.data_ptr(), Ec, back.data_ptr(), n, header=hdr, stream=s) == n and torch.equal(back, x), f"{algo}: round trip mismatch (slotted)"
 
     def step():
-        container.encode_device(algo, x.data_ptr(), n, cont.data_ptr(), cap, chunk, stream=s, want_header=False)
-        container.decode_device(cont.data_ptr(), E, back.data_ptr(), n, header=hdr, stream=s, sync=False)
+        container.encode_device_slotted(algo, x.data_ptr(), n, cont.data_ptr(), cap, chunk, stream=s, want_header=False)
+        container.decode_device(cont.data_ptr(), Ec, back.data_ptr(), n, header=hdr, stream=s, sync=False)
 
     for _ in range(warmup):
         step()
@@ -250,7 +255,7 @@ def other_config(container, algo, label, host, steps=3, warmup=1, cpu_sample=32 
                              "gpu_chunks_compared_bit_exact": int(min(nchk, len(payloads)))}}
 
 
-def strict_stream_leg(host, x, steps=3):
+def strict_stream_leg(host, x, steps=5):
     """The reference's own call shape on the headline buffer: ONE Chameleon stream over the whole input (chameleon.rs:45-53), encoded and
     decoded in parallel segments on the device, buffers device-resident.  Byte-identity with the reference's stream is the
     GPU suite's to show at full size (tests/test_gpu_chameleon.py::test_config2_full_size_strict_stream...); here: decode == input, and the
@@ -273,18 +278,23 @@ def strict_stream_leg(host, x, steps=3):
     # (the whole stream's records of the first m bytes: the oracle's stream of that prefix, unless the prefix ends inside the stream's last record)
     k = len(want) if m < n else size.value
     assert bytes(d_out[:k].cpu().numpy()) == want[:k], "strict stream: prefix differs from the oracle's stream"
-    torch.cuda.synchronize(); t0 = time.perf_counter()
+    # (the GPU has idled during the oracle call above: two untimed round trips bring its clocks back before anything is timed; then the
+    # median of `steps` individually timed calls per direction)
+    for _ in range(2):
+        assert enc() == 0 and dec() == 0
+    te, td = [], []
     for _ in range(steps):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
         assert enc() == 0
-    torch.cuda.synchronize(); t1 = time.perf_counter()
-    for _ in range(steps):
+        torch.cuda.synchronize(); t1 = time.perf_counter()
         assert dec() == 0
-    torch.cuda.synchronize(); t2 = time.perf_counter()
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+        te.append(t1 - t0); td.append(t2 - t1)
     E = int(size.value)
-    e_ms, d_ms = (t1 - t0) / steps * 1e3, (t2 - t1) / steps * 1e3
+    e_ms, d_ms = sorted(te)[len(te) // 2] * 1e3, sorted(td)[len(td) // 2] * 1e3
     return {"config": "2 (strict): ONE reference stream over the whole buffer, chameleon_encode / chameleon_decode shape, device-resident",
             "bytes": int(n), "encoded_bytes": E, "compression_ratio": round(n / E, 4), "encode_ms": round(e_ms, 4), "decode_ms": round(d_ms, 4),
-            "value": round(n / ((e_ms + d_ms) * 1e-3) / 1e6, 1), "unit": "MB/s", "timing": "wall clock around the call (host orchestration of the passes included)",
+            "value": round(n / ((e_ms + d_ms) * 1e-3) / 1e6, 1), "unit": "MB/s", "timing": "wall clock around each call (host orchestration of the passes included), median of 5",
             "oracle_prefix_compared_bytes": int(k), "decode_is_the_input": True,
             "roofline": {"encode": roofline_entry("strict stream encode (all passes)", n + E, e_ms), "decode": roofline_entry("strict stream decode (all passes)", n + E, d_ms)}}
 
@@ -346,6 +356,7 @@ def main():
     ap.add_argument("--no-sweep", action="store_true", help="skip the size sweep (profiling runs: only the headline workload's launches)")
     ap.add_argument("--no-extra", action="store_true", help="skip the other_configs legs (configs 3/4, strict stream): only the headline workload")
     ap.add_argument("--no-gpu", action="store_true", help="dry mode: launcher + distributed bookkeeping on CPU/gloo (tests)")
+    ap.add_argument("--packed", action="store_true", help="time the packed container (encode + stitch pass + decode) instead of the slotted one")
     ap.add_argument("--concat", action="store_true", help="also time the optional gather-to-rank-0 stitch (N > 1)")
     ap.add_argument("--variant", type=int, default=0, help="kernel variant bit mask (density_hip_set_kernel_variant): 0 = default")
     ap.add_argument("--algo", default="chameleon", choices=["chameleon", "cheetah", "lion"],
@@ -394,29 +405,48 @@ def main():
         host = datagen.prose(n, seed=0xD1B54A32D192ED03 + rank)
     x = torch.from_numpy(host).cuda()
     algo = args.algo
-    cap = container.container_bound(algo, n, chunk)
+    cap = container.container_bound_slotted(algo, n, chunk)
     cont = torch.empty(cap, dtype=torch.uint8, device="cuda")
     back = torch.empty(n, dtype=torch.uint8, device="cuda")
     ws_size = max(int(density_ws(container, n, chunk, args.algo)), 1)
     ws = torch.empty(ws_size, dtype=torch.uint8, device="cuda")
     stream = torch.cuda.current_stream()
     s = stream.cuda_stream
+    # The timed container is the SLOTTED form (include/density_hip.h: every chunk stream stays in the slot the encoder wrote it to, the
+    # decoder reads it there; same chunk streams, same size table, same block index) unless --packed: the packed wire form costs one more
+    # pass over every encoded byte (the stitch), which the library leaves to the moment a container leaves the device
+    # (density_hip_pack_device).  Both forms are checked here, and the packed form's time is reported beside `value` (`packed_container`).
+    slotted = not args.packed
+    enc_dev = container.encode_device_slotted if slotted else container.encode_device
 
     # correctness before any timing: decode(encode(x)) == x, and chunk streams equal to the oracle's (all of the CPU sample's chunks are
     # compared in cpu_baseline; here a spread of chunks so that --no-cpu runs are checked too)
-    hdr = container.encode_device(algo, x.data_ptr(), n, cont.data_ptr(), cap, chunk, stream=s, workspace=(ws.data_ptr(), ws_size))
-    got = container.decode_device(cont.data_ptr(), hdr.container_len, back.data_ptr(), n, header=hdr, stream=s, workspace=(ws.data_ptr(), ws_size))
+    hdr_p = container.encode_device(algo, x.data_ptr(), n, cont.data_ptr(), cap, chunk, stream=s, workspace=(ws.data_ptr(), ws_size))
+    got = container.decode_device(cont.data_ptr(), hdr_p.container_len, back.data_ptr(), n, header=hdr_p, stream=s, workspace=(ws.data_ptr(), ws_size))
     assert got == n and torch.equal(back, x), "round trip mismatch"
-    raw = cont[:hdr.container_len].cpu().numpy()
+    raw = cont[:hdr_p.container_len].cpu().numpy()
     _, payloads = container.chunk_payloads(raw)
-    for i in sorted(set([0, hdr.n_chunks // 3, hdr.n_chunks - 1])):
+    for i in sorted(set([0, hdr_p.n_chunks // 3, hdr_p.n_chunks - 1])):
         assert payloads[i] == pyoracle.encode(algo, host[i * chunk:(i + 1) * chunk]), f"chunk {i} differs from the oracle"
-    E = int(hdr.container_len)
+    E = int(hdr_p.container_len)                       # encoded bytes = the packed container (what leaves the device): the algorithmic E
+    hdr, Ec = hdr_p, E
+    if slotted:
+        # the slotted form: decodes to the input, and packing it gives the packed container byte for byte
+        packed_ref = cont[:E].clone()
+        back.zero_()
+        hdr = container.encode_device_slotted(algo, x.data_ptr(), n, cont.data_ptr(), cap, chunk, stream=s, workspace=(ws.data_ptr(), ws_size))
+        Ec = int(hdr.container_len)
+        got = container.decode_device(cont.data_ptr(), Ec, back.data_ptr(), n, header=hdr, stream=s, workspace=(ws.data_ptr(), ws_size))
+        assert got == n and torch.equal(back, x), "round trip mismatch (slotted container)"
+        repacked = torch.empty(cap, dtype=torch.uint8, device="cuda")
+        hr = container.pack_device(cont.data_ptr(), Ec, repacked.data_ptr(), cap, header=hdr, stream=s, workspace=(ws.data_ptr(), ws_size))
+        assert hr.container_len == E and torch.equal(repacked[:E], packed_ref), "pack(slotted) differs from the packed container"
+        del repacked, packed_ref
     del raw
 
     def step():
-        container.encode_device(algo, x.data_ptr(), n, cont.data_ptr(), cap, chunk, stream=s, workspace=(ws.data_ptr(), ws_size), want_header=False)
-        container.decode_device(cont.data_ptr(), E, back.data_ptr(), n, header=hdr, stream=s, workspace=(ws.data_ptr(), ws_size), sync=False)
+        enc_dev(algo, x.data_ptr(), n, cont.data_ptr(), cap, chunk, stream=s, workspace=(ws.data_ptr(), ws_size), want_header=False)
+        container.decode_device(cont.data_ptr(), Ec, back.data_ptr(), n, header=hdr, stream=s, workspace=(ws.data_ptr(), ws_size), sync=False)
 
     for _ in range(args.warmup):
         step()
@@ -443,10 +473,41 @@ def main():
         per_rank_ms = [float(v.item()) / args.steps * 1e3 for v in all_t]
         dt = max(float(v.item()) for v in all_t)
     assert torch.equal(back, x), "round trip mismatch after timed steps"
+    packed_cmp = None
+    if slotted and not args.no_extra:
+        # the same round trip through the packed container (stitch pass included), a few steps, for the record
+        def pstep():
+            container.encode_device(algo, x.data_ptr(), n, cont.data_ptr(), cap, chunk, stream=s, workspace=(ws.data_ptr(), ws_size), want_header=False)
+            container.decode_device(cont.data_ptr(), E, back.data_ptr(), n, header=hdr_p, stream=s, workspace=(ws.data_ptr(), ws_size), sync=False)
+        pstep(); torch.cuda.synchronize()
+        container.set_profiling(True); container.last_timings()
+        tp0 = time.perf_counter()
+        for _ in range(5):
+            pstep()
+        torch.cuda.synchronize()
+        dtp = (time.perf_counter() - tp0) / 5
+        pk = {}
+        for name, ms in container.last_timings():
+            pk[name] = pk.get(name, 0.0) + ms / 5
+        container.set_profiling(False)
+        assert torch.equal(back, x)
+        packed_cmp = {"value": round(n / dtp / 1e6, 1), "unit": "MB/s", "ms_per_step": round(dtp * 1e3, 4), "kernel_ms": {k: round(v, 4) for k, v in pk.items()},
+                      "whole_path_hbm_frac": round(2.0 * (n + E) / dtp / 1e9 / HBM_PEAK_GBS, 5),
+                      "note": "encode + stitch (compact: 2E bytes, none of them algorithmic) + decode of the packed container; the bytes are what density_hip_pack_device makes of the slotted one"}
+        # restore the slotted container for the multi-GPU bookkeeping below
+        enc_dev(algo, x.data_ptr(), n, cont.data_ptr(), cap, chunk, stream=s, workspace=(ws.data_ptr(), ws_size), want_header=False)
+        torch.cuda.synchronize()
 
     # the path's only collective: all-gather of per-shard (chunks, payload bytes) -> offsets in the global container
     from density_amd import parallel
-    hdr_l, table_l, index_l, payload_l = parallel.parse_local(cont[:E])
+    if slotted and hdr.flags & container.FLAG_SLOTTED:
+        # export: the packed wire form of this rank's container (what the size all-gather and the optional concat describe / move)
+        packed_local = torch.empty(container.container_bound(algo, n, chunk), dtype=torch.uint8, device="cuda")
+        container.pack_device(cont.data_ptr(), Ec, packed_local.data_ptr(), packed_local.numel(), header=hdr, stream=s, workspace=(ws.data_ptr(), ws_size))
+        local_cont = packed_local[:E]
+    else:
+        local_cont = cont[:E]
+    hdr_l, table_l, index_l, payload_l = parallel.parse_local(local_cont)
     if use_pg:
         torch.cuda.synchronize(); tg0 = time.perf_counter()
         lay = parallel.exchange_layout(hdr_l["n_chunks"], payload_l.numel(), n, x.device)
@@ -457,13 +518,13 @@ def main():
     concat_ms, concat_checked = None, None
     if use_pg and args.concat:
         torch.cuda.synchronize(); dist.barrier(); tc0 = time.perf_counter()
-        merged = parallel.concat_to_rank0(cont[:E], chunk)
+        merged = parallel.concat_to_rank0(local_cont, chunk)
         torch.cuda.synchronize(); dist.barrier(); concat_ms = (time.perf_counter() - tc0) * 1e3
         if rank == 0:
             # the stitched global container decodes on this GPU to the ranks' inputs one after the other; with one rank it IS the local container
             assert merged.numel() == glob["container_len"]
             if n_gpus == 1:
-                assert torch.equal(merged, cont[:E]), "world-size-1 concat differs from the local container"
+                assert torch.equal(merged, local_cont), "world-size-1 concat differs from the local container"
             mh = container.parse_header(bytes(merged[:32].cpu().numpy()))
             gback = torch.empty(int(mh.total_len), dtype=torch.uint8, device="cuda")
             assert container.decode_device(merged.data_ptr(), merged.numel(), gback.data_ptr(), gback.numel(), header=mh, stream=s) == mh.total_len
@@ -519,6 +580,9 @@ def main():
                        "parallelism": f"chunk-sharded x{n_gpus}, no data-path collective"},
             "compression_ratio": round(n / E, 4),
             "encoded_bytes": E,
+            "container_form": ("slotted: chunk streams left in their slots, read there by the decoder; the stitch into the packed wire form is density_hip_pack_device's, "
+                               "at export" if slotted and (hdr.flags & container.FLAG_SLOTTED) else "packed"),
+            "packed_container": packed_cmp,
             "encode_ms": round(t_enc, 4), "decode_ms": round(t_dec, 4),
             "per_rank_ms_per_step": [round(v, 4) for v in per_rank_ms],
             "kernel_ms": {k: round(v, 4) for k, v in tot.items()},
