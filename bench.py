@@ -620,7 +620,7 @@ def main():
 
 def density_ws(container, n, chunk, algo="chameleon"):
     from density_amd import _lib
-    return max(_lib.lib().density_hip_encode_workspace_size(_lib.ALGO_IDS[algo], n, chunk), _lib.lib().density_hip_decode_workspace_size((n + chunk - 1) // chunk))
+    return max(_lib.lib().density_hip_encode_workspace_size(_lib.ALGO_IDS[algo], n, chunk), _lib.lib().density_hip_decode_workspace_size_for(_lib.ALGO_IDS[algo], n, chunk))
 
 
 if __name__ == "__main__":

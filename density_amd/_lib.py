@@ -43,6 +43,8 @@ SYMBOLS.update({
     "density_hip_decoded_size": (_SZ, [_VP, _SZ]),
     "density_hip_encode_workspace_size": (_SZ, [_I, _SZ, _SZ]),
     "density_hip_decode_workspace_size": (_SZ, [ctypes.c_uint32]),
+    "density_hip_decode_workspace_size_for": (_SZ, [_I, _SZ, _SZ]),
+    "density_hip_decode_pass_count": (ctypes.c_uint64, []),
     "density_hip_encode_device": (_I, [_I, _VP, _SZ, _VP, _SZ, _SZ, _VP, _SZ, _VP, ctypes.POINTER(Header)]),
     "density_hip_decode_device": (_I, [_VP, _SZ, ctypes.POINTER(Header), _VP, _SZ, _VP, _SZ, _VP, ctypes.POINTER(_SZ)]),
     "density_hip_container_bound_slotted": (_SZ, [_I, _SZ, _SZ]),

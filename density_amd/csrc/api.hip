@@ -58,6 +58,7 @@ inline size_t index_base(size_t n_chunks) { return align_up(sizeof(density_hip_h
 inline size_t index_bytes(size_t total_len, bool with_index) { return with_index ? (total_len + 255) / 256 : 0; }
 inline size_t payload_base(size_t n_chunks, size_t total_len, bool with_index) { return align_up(index_base(n_chunks) + index_bytes(total_len, with_index), 16); }
 int g_variant = 0;   // density_hip_set_kernel_variant
+uint64_t g_pass_decodes = 0;                 // density_hip_decode_pass_count: Cheetah decodes served by the decode passes
 uint64_t g_stream_stats[4] = {0, 0, 0, 0};   // density_hip_stream_stats: long streams encoded in segments | encode passes | decoded in segments | long streams decoded sequentially
 inline bool want_index(int algo) { return algo == DENSITY_HIP_CHAMELEON && !(g_variant & 2); }
 inline size_t slot_stride(int algo, size_t chunk) { return align_up(safe_size(algo, chunk), kAlign); }
@@ -187,9 +188,11 @@ EncodePlan plan_encode(int algo, size_t n, size_t chunk) {
     return p;
 }
 struct DecodePlan {
-    size_t off_err, off_sizes, off_offsets, off_produced, off_tables, off_zmap, total;
+    size_t off_err, off_sizes, off_offsets, off_produced, off_tables, off_zmap, off_pass, total, total_with_passes;
 };
-DecodePlan plan_decode(int algo, size_t n_chunks) {
+// out_stride != 0 (the container's chunk size / a stream's output capacity): Cheetah's decode passes (decode_passes.hip) want a dword and
+// a half per quad of scratch behind everything else; `total` is what the one-wave decoders need, `total_with_passes` what the passes need
+DecodePlan plan_decode(int algo, size_t n_chunks, size_t out_stride = 0) {
     DecodePlan p{};
     p.off_err = 0;
     p.off_sizes = kAlign;
@@ -198,6 +201,10 @@ DecodePlan plan_decode(int algo, size_t n_chunks) {
     p.off_tables = p.off_produced + align_up(8 * (n_chunks ? n_chunks : 1), kAlign);
     p.off_zmap = p.off_tables + serial_tables(algo, n_chunks ? n_chunks : 1);
     p.total = p.off_zmap + zmap_bytes(algo, n_chunks);
+    p.off_pass = p.total;
+    p.total_with_passes = p.total;
+    if (algo == DENSITY_HIP_CHEETAH && out_stride && n_chunks)
+        p.total_with_passes = p.off_pass + align_up(decode_pass_scratch_bytes(n_chunks == 1 ? align_up(out_stride, 256) : out_stride, (uint32_t)n_chunks), kAlign);
     return p;
 }
 
@@ -211,8 +218,10 @@ hipError_t codec_encode(int algo, const uint8_t* d_in, uint64_t total, uint64_t 
 }
 hipError_t codec_decode(int algo, const uint8_t* d_in, const uint64_t* d_offsets, const uint64_t* d_sizes, uint32_t n_chunks, uint8_t* d_out,
                         uint64_t out_stride, uint64_t out_total, bool exact, const uint8_t* d_index, uint64_t* d_produced, uint32_t* d_err,
-                        uint8_t* d_tables, uint32_t* d_zmap, hipStream_t s) {
+                        uint8_t* d_tables, uint32_t* d_zmap, hipStream_t s, uint8_t* d_pass = nullptr) {
     if (algo == DENSITY_HIP_CHAMELEON) return launch_chameleon_decode(d_in, d_offsets, d_sizes, n_chunks, d_out, out_stride, out_total, exact, d_index, d_zmap, d_produced, d_err, s);
+    if (d_pass && decode_pass_eligible(algo, d_out, n_chunks, out_stride, out_total) && ++g_pass_decodes)   // Cheetah: parallel inside the chunk but for the chain of contexts
+        return launch_decode_passes(algo, d_in, d_offsets, d_sizes, n_chunks, d_out, out_stride, out_total, exact, d_produced, d_err, d_pass, s);
     return launch_serial_decode(algo, d_in, d_offsets, d_sizes, n_chunks, d_out, out_stride, out_total, exact, d_produced, d_err, d_tables, (uint32_t)serial_slots(algo, n_chunks), s);
 }
 const char* encode_kernel_name(int algo) { return algo == DENSITY_HIP_CHAMELEON ? "chameleon_encode_chunks" : algo == DENSITY_HIP_CHEETAH ? "cheetah_encode_chunks" : "lion_encode_chunks"; }
@@ -334,9 +343,10 @@ int run_encode_container(DeviceCtx* c, int algo, const uint8_t* d_in, size_t n, 
 }
 
 int run_decode_container(DeviceCtx* c, const uint8_t* d_in, size_t container_size, const density_hip_header_t& h, uint8_t* d_out,
-                         size_t cap, uint8_t* ws, hipStream_t s, size_t* decoded_out) {
+                         size_t cap, uint8_t* ws, hipStream_t s, size_t* decoded_out, size_t ws_size = 0) {
     if (cap < h.total_len) { set_error("output capacity below the container's total_len"); return DENSITY_HIP_ERR_CAPACITY; }
-    const DecodePlan p = plan_decode(h.algo, h.n_chunks);
+    const DecodePlan p = plan_decode(h.algo, h.n_chunks, h.chunk_size);
+    uint8_t* d_pass = (ws_size >= p.total_with_passes && p.total_with_passes > p.total) ? ws + p.off_pass : nullptr;   // (a caller's smaller workspace: the one-wave decoder)
     uint32_t* d_err = reinterpret_cast<uint32_t*>(ws + p.off_err);
     uint64_t* d_sizes = reinterpret_cast<uint64_t*>(ws + p.off_sizes);
     uint64_t* d_offsets = reinterpret_cast<uint64_t*>(ws + p.off_offsets);
@@ -348,7 +358,7 @@ int run_decode_container(DeviceCtx* c, const uint8_t* d_in, size_t container_siz
     if (e == hipSuccess) e = launch_layout_decode(d_in, container_size, h.n_chunks, payload_base(h.n_chunks, h.total_len, with_index), d_sizes, d_offsets, d_err, s,
                                                   (h.flags & DENSITY_HIP_FLAG_SLOTTED) ? slot_stride(h.algo, h.chunk_size) : 0);
     prof.mark("layout_decode");
-    if (e == hipSuccess) e = codec_decode(h.algo, d_in, d_offsets, d_sizes, h.n_chunks, d_out, h.chunk_size, h.total_len, true, d_index, d_produced, d_err, ws + p.off_tables, zmap_bytes(h.algo, h.n_chunks) ? reinterpret_cast<uint32_t*>(ws + p.off_zmap) : nullptr, s);
+    if (e == hipSuccess) e = codec_decode(h.algo, d_in, d_offsets, d_sizes, h.n_chunks, d_out, h.chunk_size, h.total_len, true, d_index, d_produced, d_err, ws + p.off_tables, zmap_bytes(h.algo, h.n_chunks) ? reinterpret_cast<uint32_t*>(ws + p.off_zmap) : nullptr, s, d_pass);
     prof.mark(decode_kernel_name(h.algo));
     if (e != hipSuccess) { set_error("kernel launch (decode)", e); return DENSITY_HIP_ERR_RUNTIME; }
     if (decoded_out) {
@@ -767,6 +777,12 @@ int density_hip_encode_device(int algo, const void* d_input, size_t input_size, 
     return run_encode_container(c, algo, (const uint8_t*)d_input, input_size, (uint8_t*)d_output, output_capacity, chunk_size, ws, s, header_out);
 }
 
+size_t density_hip_decode_workspace_size_for(int algo, size_t total_len, size_t chunk_size) {
+    chunk_size = normalise_chunk(chunk_size, total_len, algo);
+    if (!valid_algo(algo) || !valid_chunk(chunk_size)) return 0;
+    return plan_decode(algo, chunk_count(total_len, chunk_size), chunk_size).total_with_passes;
+}
+
 int density_hip_encode_device_slotted(int algo, const void* d_input, size_t input_size, void* d_output, size_t output_capacity,
                                       size_t chunk_size, void* d_workspace, size_t workspace_size, void* stream,
                                       density_hip_header_t* header_out) {
@@ -831,12 +847,13 @@ int density_hip_decode_device(const void* d_container, size_t container_size, co
         if (e != hipSuccess) { set_error("header read-back", e); return DENSITY_HIP_ERR_RUNTIME; }
     }
     if (check_header(h, container_size) != DENSITY_HIP_OK) { set_error("bad container header"); return DENSITY_HIP_ERR_FORMAT; }
-    const size_t need = plan_decode(h.algo, h.n_chunks).total;
+    const DecodePlan dp = plan_decode(h.algo, h.n_chunks, h.chunk_size);
+    const size_t need = dp.total;
     uint8_t* ws = (uint8_t*)d_workspace;
     if (ws) { if (workspace_size < need) { set_error("workspace too small"); return DENSITY_HIP_ERR_CAPACITY; } }
-    else { hipError_t e = c->work.ensure(need); if (e != hipSuccess) { set_error("workspace allocation", e); return DENSITY_HIP_ERR_RUNTIME; } ws = (uint8_t*)c->work.p; }
+    else { hipError_t e = c->work.ensure(dp.total_with_passes); if (e != hipSuccess) { set_error("workspace allocation", e); return DENSITY_HIP_ERR_RUNTIME; } ws = (uint8_t*)c->work.p; workspace_size = c->work.cap; }
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
-    return run_decode_container(c, (const uint8_t*)d_container, container_size, h, (uint8_t*)d_output, output_capacity, ws, s, decoded_size_out);
+    return run_decode_container(c, (const uint8_t*)d_container, container_size, h, (uint8_t*)d_output, output_capacity, ws, s, decoded_size_out, workspace_size);
 }
 
 int density_hip_stream_encode_device(int algo, const void* d_input, size_t input_size, void* d_output, size_t output_capacity,
@@ -886,6 +903,7 @@ size_t density_hip_encode(int algo, const uint8_t* input, size_t input_size, uin
     return (size_t)h.container_len;
 }
 
+uint64_t density_hip_decode_pass_count(void) { return g_pass_decodes; }
 void density_hip_stage_stats(uint64_t* out2) { if (out2) { out2[0] = density::g_stage_stats[0]; out2[1] = density::g_stage_stats[1]; } }
 void density_hip_stream_stats(uint64_t* out4) { if (out4) for (int i = 0; i < 4; ++i) out4[i] = g_stream_stats[i]; }
 size_t density_hip_auto_chunk(size_t input_size) { return auto_chunk(input_size); }
@@ -911,18 +929,18 @@ size_t density_hip_decode(const uint8_t* container, size_t container_size, uint8
     std::lock_guard<std::mutex> lk(c->mu);
     hipError_t e = c->stage_in.ensure(h.container_len);
     if (e == hipSuccess) e = c->stage_out.ensure(h.total_len);
-    if (e == hipSuccess) e = c->work.ensure(plan_decode(h.algo, h.n_chunks).total);
+    if (e == hipSuccess) e = c->work.ensure(plan_decode(h.algo, h.n_chunks, h.chunk_size).total_with_passes);
     if (e == hipSuccess) e = hipMemcpyAsync(c->stage_in.p, container, h.container_len, hipMemcpyHostToDevice, c->stream);
     if (e != hipSuccess) { set_error("staging (H2D)", e); return 0; }
     size_t produced = 0;
-    if (run_decode_container(c, (const uint8_t*)c->stage_in.p, h.container_len, h, (uint8_t*)c->stage_out.p, h.total_len, (uint8_t*)c->work.p, c->stream, &produced) != DENSITY_HIP_OK) return 0;
+    if (run_decode_container(c, (const uint8_t*)c->stage_in.p, h.container_len, h, (uint8_t*)c->stage_out.p, h.total_len, (uint8_t*)c->work.p, c->stream, &produced, c->work.cap) != DENSITY_HIP_OK) return 0;
     e = hipMemcpy(output, c->stage_out.p, produced, hipMemcpyDeviceToHost);
     if (e != hipSuccess) { set_error("staging (D2H)", e); return 0; }
     return produced;
 }
 
 void density_hip_set_profiling(int enabled) { g_profiling = enabled; }
-void density_hip_set_kernel_variant(int variant) { g_variant = variant;   /* bit 3 (8): encode in batches with the stitch of one batch beside the encoding of the next */ density::g_force_simple = (variant & 1) != 0; density::g_force_pipeline = (variant & 4) != 0; density::g_force_lane_codec = (variant & 16) != 0; density::g_force_wave_codec = (variant & 32) != 0; density::g_stage_audit = (variant & 64) != 0; }
+void density_hip_set_kernel_variant(int variant) { g_variant = variant;   /* bit 3 (8): encode in batches with the stitch of one batch beside the encoding of the next */ density::g_force_simple = (variant & 1) != 0; density::g_force_pipeline = (variant & 4) != 0; density::g_force_lane_codec = (variant & 16) != 0; density::g_force_wave_codec = (variant & 32) != 0; density::g_stage_audit = (variant & 64) != 0; density::g_force_serial_decode = (variant & 128) != 0; }
 
 int density_hip_last_timings(float* milliseconds, const char** names, int capacity) {
     int dev = -1;

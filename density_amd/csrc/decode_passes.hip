@@ -1,0 +1,483 @@
+// decode_passes.hip — Cheetah container DECODING in passes (gfx950): everything that is parallel inside a chunk runs as ordered LDS
+// exchange passes over the whole chunk, and what is not — one chain of dependent 16-bit look-ups per chunk — runs alone, in LDS.
+//
+// The reference decodes a chunk quad by quad through three tables (cheetah.rs:68-103,154-163).  Taken apart:
+//
+//   records    A stream has no framing: a record's length follows from its signature, raw-copy blocks from the blow-up protection over
+//              the lengths before them (codec.rs:88-123, protection_state.rs).  `parse`: one wave per chunk chases the records through
+//              an LDS window of the stream (one LDS round trip per record) and leaves every record's position and kind.
+//   flags      `prepare`: one lane per quad reads its flag and item (io/read_signature.rs:9-15): PLAIN quads go straight to the output,
+//              every quad gets a descriptor {slot, flag}.
+//   dictionary chunk_map[h] = {a, b} is touched by the non-predicted quads only, at slots the STREAM names (the hash of a PLAIN quad, the
+//              item of a MAP quad): nothing in it depends on a predicted quad.  PLAIN: (a, b) <- (q, a); MAP_A reads a; MAP_B reads b and
+//              swaps (cheetah.rs:76-93).  With two cells X, Y per slot and an order bit o (a = o ? Y : X, b = o ? X : Y) this is:
+//              PLAIN writes the cell b sits in and toggles o; MAP_B toggles o; MAP_A changes nothing.  So `order` — an ordered XOR per
+//              slot over the chunk — gives every quad the o it meets, and then X and Y are plain last-writer cells: `cells`, an ordered
+//              exchange pass per cell (mask 0 = read), exactly what the encoder's stages do (exchange_stages.hip).  Every MAP quad is
+//              then known, without a single dependent look-up.
+//   contexts   prediction_map[last_hash] is read by predicted quads and written by the others (:72,81,90,98).  Its SLOT is the hash of the
+//              quad before — for a quad behind a predicted one the hash of a value that has to be looked up first: a chain of dependent
+//              reads through the data being produced.  This is the only sequential part, and it needs hashes, not quads: H[c] = hash of
+//              what follows context c is a table of 64 Ki x 16 bits = 128 KiB of LDS.  `walk`: one wave per chunk runs c' = H[c] for
+//              predicted quads (an LDS round trip each: the chain) and H[c] = h for runs of the others (one ordered 16-bit store per run),
+//              and leaves every quad's context.
+//   values     With the contexts known the prediction table is one more ordered exchange pass: predicted quads read T[c], the others write
+//              their quad (`values`); the answers are the predicted quads.
+//
+// The output buffer itself holds the quads between the passes (PLAIN from `prepare`, MAP from `cells`, predicted from `values`).
+// Bit-exact for ANY input: tables start as the reference's zeroed tables and hold full 32-bit quads; a stream the reference would panic
+// on (truncated, output too small) raises the error word.  Lion keeps its one-wave decoder: its five-deep prediction rows would need
+// 640 KiB of hashes for the walk (lion.rs:29-48), four CUs' worth of LDS.
+#include "common.hpp"
+#include "kernels.hpp"
+
+#include <cstdlib>
+
+namespace density {
+
+extern __shared__ __attribute__((aligned(16))) uint8_t pass_lds[];
+bool g_force_serial_decode = false;   // density_hip_set_kernel_variant(128): Cheetah containers on the one-wave decoder instead
+
+namespace {
+
+constexpr uint32_t kRecBytes = 128, kRecQuads = 32, kSigBytes = 8;        // cheetah.rs:188-196
+constexpr uint32_t kRaw = 0x80000000u;                                    // rec[]: the block is a raw copy (codec.rs:89-91)
+constexpr uint32_t kFlagPlain = 0, kFlagMapA = 1, kFlagMapB = 2, kFlagPred = 3;   // cheetah.rs:17-23
+// descriptor of a quad: slot [0,16) | flag [16,18) | order bit it meets [18] | takes no part (raw block, beyond the end) [19]
+constexpr uint32_t kDescO = 1u << 18, kDescNone = 1u << 19;
+constexpr uint32_t kErrFormat = 1u, kErrWatchdog = 16u;
+constexpr uint32_t kSpinLimit = 1u << 22, kPoison = 0xfffffffeu;
+
+__device__ __forceinline__ uint32_t hash16(uint32_t q) { return (q * kHashMul) >> 16; }
+
+// per chunk, left by `parse`: blocks, decoded bytes, quads and raw tail bytes of a ragged last record, where those bytes sit in the stream
+struct ChunkInfo { uint32_t blocks, produced, last_quads, tail_bytes, tail_at, bad, ragged, pad1; };   // ragged: the last block is a partial record of last_quads quads + tail_bytes raw bytes
+
+struct PassArgs {
+    const uint8_t* in; const uint64_t* offsets; const uint64_t* sizes; uint32_t n_chunks;
+    uint8_t* out; uint64_t out_stride, out_total;
+    uint32_t* rec; uint32_t* desc; uint16_t* ctx; ChunkInfo* info; uint32_t* err;
+};
+__device__ __forceinline__ uint64_t chunk_cap(const PassArgs& a, uint64_t chunk) {
+    const uint64_t room = a.out_total - chunk * a.out_stride;
+    return room < a.out_stride ? room : a.out_stride;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// parse: Codec::decode's walk over the records (codec/codec.rs:82-126) without decoding them
+// ---------------------------------------------------------------------------------------------------------------
+constexpr uint32_t kWin = 8192;                                           // bytes of stream staged in LDS at a time
+__global__ __launch_bounds__(64) void cheetah_parse(PassArgs a) {
+    __shared__ __attribute__((aligned(16))) uint8_t win[kWin + 16];
+    const uint32_t lane = threadIdx.x;
+    const uint64_t chunk = blockIdx.x;
+    const uint8_t* src = a.in + a.offsets[chunk];
+    const uint64_t elen64 = a.sizes[chunk];
+    const uint64_t cap = chunk_cap(a, chunk);
+    uint32_t* rec = a.rec + chunk * (a.out_stride / kRecBytes);
+    const uint32_t max_blocks = (uint32_t)((cap + kRecBytes - 1) / kRecBytes);
+    ChunkInfo ci{};
+    if (elen64 >= 0x7fffff00ull) { ci.bad = 1; }                           // 31-bit stream positions (a chunk stream: the launcher bounds it)
+    const uint32_t elen = (uint32_t)elen64;
+    Guard g;
+    uint32_t ip = 0, op = 0, b = 0;
+    uint32_t w0 = 0xffffffffu;                                            // stream offset of win[0] (16-byte aligned); nothing loaded yet
+    const uint32_t misalign = (uint32_t)(reinterpret_cast<uintptr_t>(src) & 15u);   // (the window is loaded from 16-byte aligned addresses)
+    while (!ci.bad && ip < elen) {
+        const uint32_t left = elen - ip;
+        const bool fast = left >= kSigBytes + kRecBytes;                  // codec.rs:88: a whole record is certainly there
+        if (g.block_is_copy()) {                                         // codec.rs:89-91,103-110
+            const uint32_t take = left > kRecBytes ? kRecBytes : left;
+            if (b >= max_blocks || (uint64_t)op + take > cap) { ci.bad = 1; break; }
+            if (lane == 0) rec[b] = ip | kRaw;
+            ++b; ip += take; op += take;
+            if (!fast && ip == elen) break;                               // :107-109: no decay behind the last raw block
+            g.decay();
+            continue;
+        }
+        if (left < kSigBytes) { ci.bad = 1; break; }                      // reference: read_u64_le panics
+        // the signature, through the LDS window
+        if (w0 == 0xffffffffu || ip + misalign < w0 || ip + misalign + kSigBytes + 4 > w0 + kWin) {
+            __syncthreads();
+            w0 = (ip + misalign) & ~15u;
+            const uint8_t* base = src - misalign + w0;                    // 16-byte aligned
+            const uint32_t have = elen + misalign - w0;                   // bytes of stream from base on
+            for (uint32_t i = lane * 16u; i < kWin; i += 64u * 16u) {
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (i < have) v = *reinterpret_cast<const uint4*>(base + i);   // (reads at most 15 bytes past the stream's end, inside its 16-byte line)
+                *reinterpret_cast<uint4*>(win + i) = v;
+            }
+            __syncthreads();
+        }
+        const uint32_t at = ip + misalign - w0;
+        const uint32_t* wd = reinterpret_cast<const uint32_t*>(win + (at & ~3u));
+        const uint32_t d0 = wd[0], d1 = wd[1], d2 = wd[2];
+        const uint64_t sig = (at & 2u) ? (((uint64_t)((d1 >> 16) | (d2 << 16)) << 32) | ((d0 >> 16) | (d1 << 16))) : (((uint64_t)d1 << 32) | d0);
+        const uint64_t lo = sig & 0x5555555555555555ull, hi = (sig >> 1) & 0x5555555555555555ull;
+        if (fast) {
+            const uint32_t nplain = kRecQuads - (uint32_t)__builtin_popcountll(lo | hi), npred = (uint32_t)__builtin_popcountll(lo & hi);
+            const uint32_t bytes = 4u * nplain + 2u * (kRecQuads - nplain - npred);
+            if (b >= max_blocks || (uint64_t)op + kRecBytes > cap) { ci.bad = 1; break; }
+            if (lane == 0) rec[b] = ip;
+            ++b; ip += kSigBytes + bytes; op += kRecBytes;
+            g.update(kSigBytes + bytes >= kRecBytes);                     // codec.rs:98
+            continue;
+        }
+        // tail loop (codec.rs:102-123 with cheetah.rs:165-185): lane k looks at quad k of the record
+        const uint32_t k = lane & 31u;
+        const uint32_t f = (uint32_t)(sig >> (2u * k)) & 3u;
+        const uint64_t below = (1ull << (2u * k)) - 1ull;
+        const uint32_t pl_b = k - (uint32_t)__builtin_popcountll((lo | hi) & below), pr_b = (uint32_t)__builtin_popcountll(lo & hi & below);
+        const uint32_t before = 4u * pl_b + 2u * (k - pl_b - pr_b);       // item bytes in front of mine
+        const uint32_t rem = left - kSigBytes;
+        const uint32_t mine = f == kFlagPlain ? 4u : f == kFlagPred ? 0u : 2u;
+        const bool gone = before > rem;                                   // (cannot be reached without an earlier stop or error)
+        const bool stop = !gone && f == kFlagPlain && rem - before < 4u;  // :169-176: implicit PLAIN at the end of the data
+        const bool fail = !gone && !stop && rem - before < mine;          // reference: slice panic
+        const uint64_t stops = ballot64(lane < 32 && (stop || gone)), fails = ballot64(lane < 32 && fail);
+        const uint32_t ks = stops ? (uint32_t)__builtin_ctzll(stops) : 32u;
+        if (fails && (uint32_t)__builtin_ctzll(fails) < ks) { ci.bad = 1; break; }
+        if (ks < 32u) {
+            const uint32_t at_stop = rfl(bperm(ks, before));
+            const uint32_t tail = rem - at_stop;                          // 0..3 raw bytes
+            if (b >= max_blocks || (uint64_t)op + 4u * ks + tail > cap) { ci.bad = 1; break; }
+            if (lane == 0) rec[b] = ip;
+            ++b;
+            ci.ragged = 1; ci.last_quads = ks; ci.tail_bytes = tail; ci.tail_at = ip + kSigBytes + at_stop;
+            op += 4u * ks + tail; ip = elen;
+            break;
+        }
+        // a whole (short) record after all
+        const uint32_t nplain = kRecQuads - (uint32_t)__builtin_popcountll(lo | hi), npred = (uint32_t)__builtin_popcountll(lo & hi);
+        const uint32_t bytes = 4u * nplain + 2u * (kRecQuads - nplain - npred);
+        if (b >= max_blocks || (uint64_t)op + kRecBytes > cap) { ci.bad = 1; break; }
+        if (lane == 0) rec[b] = ip;
+        ++b; ip += kSigBytes + bytes; op += kRecBytes;
+        g.update(kSigBytes + bytes >= kRecBytes);
+    }
+    ci.blocks = b; ci.produced = op;
+    if (lane == 0) {
+        a.info[chunk] = ci;
+        if (ci.bad) atomicOr(a.err, kErrFormat);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// prepare: flags and items of every quad (one lane per quad, two records per wave)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cheetah_prepare(PassArgs a, uint32_t blocks_per_chunk) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t pair = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);   // 64 quads = two records
+    const uint64_t pairs_per_chunk = blocks_per_chunk / 2;
+    const uint64_t chunk = pair / pairs_per_chunk;
+    if (chunk >= a.n_chunks) return;
+    const uint32_t pb = (uint32_t)(pair % pairs_per_chunk) * 2u + (lane >> 5);   // my record's block in the chunk
+    const uint32_t k = lane & 31u;
+    const ChunkInfo ci = a.info[chunk];
+    const uint64_t step = chunk * (a.out_stride / 4) + (uint64_t)pb * kRecQuads + k;
+    uint32_t d = kDescNone;
+    if (!ci.bad && pb < ci.blocks) {
+        const uint8_t* src = a.in + a.offsets[chunk];
+        uint8_t* dst = a.out + chunk * a.out_stride + (uint64_t)pb * kRecBytes;
+        const uint32_t r = a.rec[chunk * (a.out_stride / kRecBytes) + pb];
+        const bool last = pb + 1 == ci.blocks;
+        const uint32_t block_len = last ? ci.produced - pb * kRecBytes : kRecBytes;   // decoded bytes of this block
+        if (r & kRaw) {
+            const uint8_t* p = src + (r & ~kRaw);
+            if (4u * k + 4u <= block_len) st32u(dst + 4u * k, ld32u(p + 4u * k));
+            else for (uint32_t i = 4u * k; i < block_len; ++i) dst[i] = p[i];
+        } else {
+            const uint8_t* p = src + r;
+            const uint64_t sig = (uint64_t)ld32u(p) | ((uint64_t)ld32u(p + 4) << 32);
+            const uint32_t nq = (last && ci.ragged) ? ci.last_quads : kRecQuads;
+            if (k < nq) {
+                const uint32_t f = (uint32_t)(sig >> (2u * k)) & 3u;
+                const uint64_t lo = sig & 0x5555555555555555ull, hi = (sig >> 1) & 0x5555555555555555ull, below = (1ull << (2u * k)) - 1ull;
+                const uint32_t pl_b = k - (uint32_t)__builtin_popcountll((lo | hi) & below), pr_b = (uint32_t)__builtin_popcountll(lo & hi & below);
+                const uint8_t* item = p + kSigBytes + 4u * pl_b + 2u * (k - pl_b - pr_b);
+                uint32_t slot = 0;
+                if (f == kFlagPlain) { const uint32_t q = ld32u(item); slot = hash16(q); *reinterpret_cast<uint32_t*>(dst + 4u * k) = q; }   // cheetah.rs:69-70
+                else if (f != kFlagPred) slot = ld16u(item);                                                                           // :79,86
+                d = slot | (f << 16);
+            }
+            if (last && ci.ragged && k < ci.tail_bytes) dst[4u * nq + k] = src[ci.tail_at + k];   // cheetah.rs:171-174
+        }
+    }
+    a.desc[step] = d;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// ordered passes: one table (a half of its slots) per work-group, the quads of the chunk in stream order behind an LDS token
+// ---------------------------------------------------------------------------------------------------------------
+constexpr uint32_t kHalfSlots = 32768, kTable = kHalfSlots * 4, kAhead = 16, kPassWaves = 8;
+constexpr uint32_t pass_lds_bytes() { return kTable + kPassWaves * 64 * 4 + 16; }
+
+#define DENSITY_PASS_X16(OP, ra, m, v, tokaddr, tokval)                                                                            \
+    asm volatile(                                                                                                                 \
+        OP " %0, %0, %16, %32\n\t" OP " %1, %1, %17, %33\n\t" OP " %2, %2, %18, %34\n\t" OP " %3, %3, %19, %35\n\t"                   \
+        OP " %4, %4, %20, %36\n\t" OP " %5, %5, %21, %37\n\t" OP " %6, %6, %22, %38\n\t" OP " %7, %7, %23, %39\n\t"                   \
+        OP " %8, %8, %24, %40\n\t" OP " %9, %9, %25, %41\n\t" OP " %10, %10, %26, %42\n\t" OP " %11, %11, %27, %43\n\t"               \
+        OP " %12, %12, %28, %44\n\t" OP " %13, %13, %29, %45\n\t" OP " %14, %14, %30, %46\n\t" OP " %15, %15, %31, %47\n\t"           \
+        "ds_write_b32 %48, %49\n\t"                                                                                               \
+        "s_waitcnt lgkmcnt(0)"                                                                                                    \
+        : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(ra[4]), "+v"(ra[5]), "+v"(ra[6]), "+v"(ra[7]),                 \
+          "+v"(ra[8]), "+v"(ra[9]), "+v"(ra[10]), "+v"(ra[11]), "+v"(ra[12]), "+v"(ra[13]), "+v"(ra[14]), "+v"(ra[15])            \
+        : "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]), "v"(m[6]), "v"(m[7]),                                 \
+          "v"(m[8]), "v"(m[9]), "v"(m[10]), "v"(m[11]), "v"(m[12]), "v"(m[13]), "v"(m[14]), "v"(m[15]),                           \
+          "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]),                                 \
+          "v"(v[8]), "v"(v[9]), "v"(v[10]), "v"(v[11]), "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]),                           \
+          "v"(tokaddr), "v"(tokval)                                                                                               \
+        : "memory")
+// (the XOR form takes no mask: ds_xor_rtn_b32 vdst, addr, data)
+#define DENSITY_PASS_XOR16(ra, v, tokaddr, tokval)                                                                                 \
+    asm volatile(                                                                                                                 \
+        "ds_xor_rtn_b32 %0, %0, %16\n\t" "ds_xor_rtn_b32 %1, %1, %17\n\t" "ds_xor_rtn_b32 %2, %2, %18\n\t" "ds_xor_rtn_b32 %3, %3, %19\n\t"         \
+        "ds_xor_rtn_b32 %4, %4, %20\n\t" "ds_xor_rtn_b32 %5, %5, %21\n\t" "ds_xor_rtn_b32 %6, %6, %22\n\t" "ds_xor_rtn_b32 %7, %7, %23\n\t"         \
+        "ds_xor_rtn_b32 %8, %8, %24\n\t" "ds_xor_rtn_b32 %9, %9, %25\n\t" "ds_xor_rtn_b32 %10, %10, %26\n\t" "ds_xor_rtn_b32 %11, %11, %27\n\t"     \
+        "ds_xor_rtn_b32 %12, %12, %28\n\t" "ds_xor_rtn_b32 %13, %13, %29\n\t" "ds_xor_rtn_b32 %14, %14, %30\n\t" "ds_xor_rtn_b32 %15, %15, %31\n\t" \
+        "ds_write_b32 %32, %33\n\t"                                                                                               \
+        "s_waitcnt lgkmcnt(0)"                                                                                                    \
+        : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(ra[4]), "+v"(ra[5]), "+v"(ra[6]), "+v"(ra[7]),                 \
+          "+v"(ra[8]), "+v"(ra[9]), "+v"(ra[10]), "+v"(ra[11]), "+v"(ra[12]), "+v"(ra[13]), "+v"(ra[14]), "+v"(ra[15])            \
+        : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]),                                 \
+          "v"(v[8]), "v"(v[9]), "v"(v[10]), "v"(v[11]), "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]),                           \
+          "v"(tokaddr), "v"(tokval)                                                                                               \
+        : "memory")
+
+// PASS 0 `order`: slot = the quad's dictionary slot; PLAIN and MAP_B toggle the slot's order bit, MAP_A reads it (cheetah.rs:71-72,87-89)
+// PASS 1 `cells`: cell = blockIdx & 1 (X = 0, Y = 1): PLAIN writes its quad to the cell b sits in, MAP_A / MAP_B read the cell a / b sits in
+// PASS 2 `values`: slot = the quad's context; predicted quads read, the others write their quad (cheetah.rs:72,81,90,98)
+// Work-groups: (chunk, [cell,] half of the slots); 8 waves take the trips of 16 blocks of 64 quads in rotation (exchange_stages.hip).
+template <int PASS>
+__global__ __launch_bounds__(kPassWaves * 64) void cheetah_pass(PassArgs a) {
+    constexpr uint32_t W = kPassWaves;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = rfl(threadIdx.x >> 6);
+    const uint32_t parts = PASS == 1 ? 4u : 2u;
+    const uint64_t chunk = blockIdx.x / parts;
+    const uint32_t half = blockIdx.x & 1u, cell = (blockIdx.x >> 1) & 1u;
+    const ChunkInfo ci = a.info[chunk];
+    if (ci.bad) return;
+    const uint32_t nsteps = ci.blocks * kRecQuads;                                 // (quads of a ragged last record beyond its end carry kDescNone)
+    const uint32_t trips = (nsteps + kAhead * 64u - 1u) / (kAhead * 64u);
+    const uint64_t s0 = chunk * (a.out_stride / 4);
+    uint32_t* w = reinterpret_cast<uint32_t*>(pass_lds);
+    for (uint32_t k = threadIdx.x; k < kHalfSlots + W * 64u + 4u; k += W * 64u) w[k] = 0u;   // the reference's zeroed tables; sinks; the token
+    __syncthreads();
+    uint32_t* __restrict__ desc = a.desc + s0;
+    const uint16_t* __restrict__ ctx = a.ctx + s0;
+    uint32_t* __restrict__ val = reinterpret_cast<uint32_t*>(a.out + chunk * a.out_stride);
+    const uint32_t lds0 = lds_addr(pass_lds);
+    const uint32_t sink = lds0 + kTable + threadIdx.x * 4u;
+    const uint32_t token = lds0 + kTable + W * 256u;
+    const uint32_t limit = (uint32_t)((chunk_cap(a, chunk) + 3) / 4);              // dwords of this chunk's output that exist
+    for (uint32_t t = wave; t < trips; t += W) {
+        uint32_t ra[kAhead], m[kAhead], v[kAhead];
+        uint32_t dd[kAhead];
+        bool rd[kAhead];
+#pragma unroll
+        for (uint32_t j = 0; j < kAhead; ++j) {
+            const uint32_t i = (t * kAhead + j) * 64u + lane;
+            const uint32_t d = i < nsteps ? desc[i] : kDescNone;
+            dd[j] = d;
+            const uint32_t f = (d >> 16) & 3u;
+            const bool none = (d & kDescNone) != 0;
+            uint32_t key = d & 0xffffu;
+            bool part, write;
+            uint32_t value = 0;
+            if (PASS == 0) {
+                part = !none && f != kFlagPred;
+                write = f != kFlagMapA;                                            // toggles
+                value = write ? 1u : 0u;
+            } else if (PASS == 1) {
+                const uint32_t o = (d >> 18) & 1u;
+                // a sits in cell o, b in cell 1 - o (X = 0, Y = 1): PLAIN writes b's cell, MAP_A reads a's, MAP_B reads b's
+                const uint32_t mycell = f == kFlagMapA ? o : 1u - o;
+                part = !none && f != kFlagPred && mycell == cell;
+                write = f == kFlagPlain;
+                if (part && write) value = val[i];
+            } else {
+                key = i < nsteps ? ctx[i] : 0u;
+                part = !none;
+                write = f != kFlagPred;
+                if (part && write) value = val[i];
+            }
+            part = part && (key >> 15) == half;
+            ra[j] = part ? lds0 + (key & (kHalfSlots - 1u)) * 4u : sink;
+            m[j] = (part && write) ? 0xffffffffu : 0u;
+            v[j] = (part && write) ? value : 0u;
+            rd[j] = part && !write;
+        }
+        bool poisoned = false;
+        for (uint32_t spins = 0;; ++spins) {                                       // my turn: every earlier trip's exchanges are queued
+            uint32_t seen;
+            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(seen) : "v"(token) : "memory");
+            seen = rfl(seen);
+            if (seen == t) break;
+            if (seen == kPoison || spins > kSpinLimit) {
+                if (seen != kPoison && lane == 0) { atomicOr(a.err, kErrWatchdog); w[kHalfSlots + W * 64u] = kPoison; }
+                poisoned = true;
+                break;
+            }
+        }
+        if (poisoned) break;
+        const uint32_t tokaddr = lane == 0 ? token : sink, tokval = t + 1u;
+        if (PASS == 0) { DENSITY_PASS_XOR16(ra, v, tokaddr, tokval); }
+        else { DENSITY_PASS_X16("ds_mskor_rtn_b32", ra, m, v, tokaddr, tokval); }
+#pragma unroll
+        for (uint32_t j = 0; j < kAhead; ++j) {
+            const uint32_t i = (t * kAhead + j) * 64u + lane;
+            if (PASS == 0) {
+                // every taking-part quad of this half learns the order bit it met
+                const bool mine = i < nsteps && !(dd[j] & kDescNone) && ((dd[j] >> 16) & 3u) != kFlagPred && ((dd[j] & 0xffffu) >> 15) == half;
+                if (mine && (ra[j] & 1u)) desc[i] = dd[j] | kDescO;
+            } else if (rd[j] && i < limit) {
+                val[i] = ra[j];                                                    // cheetah.rs:80,87 / :96: the quad
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// walk: the contexts (cheetah.rs:97-102,161: last_hash) — the one chain of the decoder, on 16-bit hashes in LDS
+// ---------------------------------------------------------------------------------------------------------------
+constexpr uint32_t kWalkLds = 65536u * 2u;
+__global__ __launch_bounds__(64) void cheetah_walk(PassArgs a) {
+    const uint32_t lane = threadIdx.x;
+    const uint64_t chunk = blockIdx.x;
+    const ChunkInfo ci = a.info[chunk];
+    if (ci.bad) return;
+    const uint32_t nsteps = ci.blocks * kRecQuads;
+    const uint32_t nblk = (nsteps + 63u) / 64u;
+    const uint64_t s0 = chunk * (a.out_stride / 4);
+    const uint32_t* __restrict__ desc = a.desc + s0;
+    uint16_t* __restrict__ ctx = a.ctx + s0;
+    const uint32_t* __restrict__ val = reinterpret_cast<const uint32_t*>(a.out + chunk * a.out_stride);
+    {   // H starts as the hash of the reference's zeroed prediction table: hash(0) = 0
+        uint4* p = reinterpret_cast<uint4*>(pass_lds);
+        for (uint32_t i = lane; i < kWalkLds / 16; i += 64) p[i] = make_uint4(0, 0, 0, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    const uint32_t lds0 = lds_addr(pass_lds);
+    uint32_t c = 0;                                                                // cheetah.rs:52: last_hash = 0
+    uint32_t dn = nblk ? (lane < nsteps ? desc[lane] : kDescNone) : kDescNone;
+    // a MAP quad's hash is its item, a PLAIN quad's the hash of its value (in the descriptor either way); a predicted quad's comes out of H
+    for (uint32_t blk = 0; blk < nblk; ++blk) {
+        const uint32_t d = dn;
+        {
+            const uint32_t i = (blk + 1u) * 64u + lane;
+            dn = i < nsteps ? desc[i] : kDescNone;                                  // the next block's descriptors: in flight across this one
+        }
+        const uint32_t h = d & 0xffffu;
+        const bool none = (d & kDescNone) != 0, pred = ((d >> 16) & 3u) == kFlagPred;
+        const uint64_t P = ballot64(!none && pred), N = ballot64(!none && !pred);
+        // what the quad before me hashed to: my context if that quad was not predicted (lane 0: the running context)
+        const uint32_t hprev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h, 0x138, 0xf, 0xf, false);   // wave_shr:1
+        uint32_t cv = 0;                                                           // my context
+        uint32_t pos = 0;
+        const uint64_t active = P | N;
+        while (pos < 64u) {
+            const uint64_t rest = active >> pos;
+            if (!rest) break;
+            pos += (uint32_t)__builtin_ctzll(rest);                                // (raw blocks and the end take no part: the context passes through)
+            if ((N >> pos) & 1ull) {
+                // a run of quads that are not predicted: each writes H[its context] = its hash (cheetah.rs:72,81,90), in stream order;
+                // the first one's context is the running one, the others' the hash of the quad before
+                const uint64_t inv = ~(N >> pos);
+                const uint32_t r = inv ? (uint32_t)__builtin_ctzll(inv) : 64u - pos;
+                const bool in = lane >= pos && lane < pos + r;
+                const uint32_t mine = lane == pos ? c : hprev;
+                if (in) {
+                    cv = mine;
+                    asm volatile("ds_write_b16 %0, %1" ::"v"(lds0 + 2u * mine), "v"(h) : "memory");
+                }
+                c = (uint32_t)__builtin_amdgcn_readlane((int)h, (int)(pos + r - 1u));
+                pos += r;
+            } else {
+                // a run of predicted quads: context -> hash of the predicted quad -> next context (cheetah.rs:97-102), one LDS round trip each
+                const uint64_t inv = ~(P >> pos);
+                const uint32_t r = inv ? (uint32_t)__builtin_ctzll(inv) : 64u - pos;
+                for (uint32_t t = 0; t < r; ++t) {
+                    if (lane == pos + t) cv = c;
+                    uint32_t nx;
+                    asm volatile("ds_read_u16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(nx) : "v"(lds0 + 2u * c) : "memory");
+                    nx = rfl(nx);
+                    if (nx == c) {                                                 // a fixed point: the table does not change inside a run
+                        if (lane > pos + t && lane < pos + r) cv = c;
+                        break;
+                    }
+                    c = nx;
+                }
+                pos += r;
+            }
+        }
+        const uint32_t i = blk * 64u + lane;
+        if (i < nsteps) ctx[i] = (uint16_t)cv;
+    }
+    (void)val;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------
+// scratch: rec (a dword per 128-byte block) | desc (a dword per quad) | ctx (16 bits per quad) | chunk info
+uint64_t decode_pass_scratch_bytes(uint64_t out_stride, uint32_t n_chunks) {
+    const uint64_t span = (uint64_t)n_chunks * out_stride;                         // (arrays are indexed chunk * stride + ...)
+    return ((span / kRecBytes * 4 + 255) & ~255ull) + ((span + 255) & ~255ull) + ((span / 2 + 255) & ~255ull) + (((uint64_t)n_chunks * sizeof(ChunkInfo) + 255) & ~255ull) + 256;
+}
+bool decode_pass_eligible(int algo, const uint8_t* d_out, uint32_t n_chunks, uint64_t out_stride, uint64_t out_total) {
+    if (algo != DENSITY_HIP_CHEETAH || g_force_serial_decode || g_force_lane_codec || g_force_wave_codec || g_rotor_unsafe) return false;
+    if (n_chunks == 0 || (uintptr_t)d_out % 4 != 0) return false;
+    // one chunk (a stream): the output capacity is the stride; chunks: whole pairs of records
+    if (n_chunks > 1 && out_stride % 256 != 0) return false;
+    const uint64_t per_chunk = n_chunks == 1 ? out_total : out_stride;
+    return per_chunk >= 64 * 1024 && per_chunk < (1ull << 31);                      // (short chunks: the one-wave decoder has less to set up)
+}
+hipError_t launch_decode_passes(int algo, const uint8_t* d_in, const uint64_t* d_offsets, const uint64_t* d_sizes, uint32_t n_chunks, uint8_t* d_out,
+                                uint64_t out_stride, uint64_t out_total, bool exact, uint64_t* d_produced, uint32_t* d_err, uint8_t* d_scratch,
+                                hipStream_t stream);
+
+namespace {
+__global__ __launch_bounds__(256) void cheetah_finish(PassArgs a, uint32_t exact, uint64_t* __restrict__ produced) {
+    const uint32_t chunk = blockIdx.x * 256u + threadIdx.x;
+    if (chunk >= a.n_chunks) return;
+    const ChunkInfo ci = a.info[chunk];
+    produced[chunk] = ci.bad ? 0 : ci.produced;
+    if (!ci.bad && exact && ci.produced != chunk_cap(a, chunk)) atomicOr(a.err, kErrFormat);
+}
+}  // namespace
+
+hipError_t launch_decode_passes(int algo, const uint8_t* d_in, const uint64_t* d_offsets, const uint64_t* d_sizes, uint32_t n_chunks, uint8_t* d_out,
+                                uint64_t out_stride, uint64_t out_total, bool exact, uint64_t* d_produced, uint32_t* d_err, uint8_t* d_scratch,
+                                hipStream_t stream) {
+    (void)algo;
+    if (n_chunks == 1) out_stride = (out_total + 255) & ~255ull;                    // a single stream: its chunk is the whole output
+    PassArgs a{};
+    a.in = d_in; a.offsets = d_offsets; a.sizes = d_sizes; a.n_chunks = n_chunks; a.out = d_out; a.out_stride = out_stride; a.out_total = out_total;
+    const uint64_t span = (uint64_t)n_chunks * out_stride;
+    uint8_t* p = d_scratch;
+    a.rec = reinterpret_cast<uint32_t*>(p); p += (span / kRecBytes * 4 + 255) & ~255ull;
+    a.desc = reinterpret_cast<uint32_t*>(p); p += (span + 255) & ~255ull;
+    a.ctx = reinterpret_cast<uint16_t*>(p); p += (span / 2 + 255) & ~255ull;
+    a.info = reinterpret_cast<ChunkInfo*>(p);
+    a.err = d_err;
+    const uint32_t blocks_per_chunk = (uint32_t)(out_stride / kRecBytes);
+    hipError_t e = hipFuncSetAttribute((const void*)cheetah_pass<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pass_lds_bytes());
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)cheetah_pass<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pass_lds_bytes());
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)cheetah_pass<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pass_lds_bytes());
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)cheetah_walk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWalkLds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(cheetah_parse, dim3(n_chunks), dim3(64), 0, stream, a);
+    const uint64_t pairs = (uint64_t)n_chunks * (blocks_per_chunk / 2);
+    hipLaunchKernelGGL(cheetah_prepare, dim3((uint32_t)((pairs + 3) / 4)), dim3(256), 0, stream, a, blocks_per_chunk);
+    hipLaunchKernelGGL(cheetah_pass<0>, dim3(2 * n_chunks), dim3(kPassWaves * 64), pass_lds_bytes(), stream, a);
+    hipLaunchKernelGGL(cheetah_pass<1>, dim3(4 * n_chunks), dim3(kPassWaves * 64), pass_lds_bytes(), stream, a);
+    hipLaunchKernelGGL(cheetah_walk, dim3(n_chunks), dim3(64), kWalkLds, stream, a);
+    hipLaunchKernelGGL(cheetah_pass<2>, dim3(2 * n_chunks), dim3(kPassWaves * 64), pass_lds_bytes(), stream, a);
+    hipLaunchKernelGGL(cheetah_finish, dim3((n_chunks + 255) / 256), dim3(256), 0, stream, a, exact ? 1u : 0u, d_produced);
+    return hipGetLastError();
+}
+
+}  // namespace density

@@ -91,6 +91,15 @@ uint64_t stage_scratch_bytes(int algo, uint64_t total, uint32_t n_chunks);
 hipError_t launch_stage_encode(int algo, const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_out, uint64_t out_stride,
                                uint64_t* d_sizes, uint8_t* d_tables, uint32_t n_slots, uint8_t* d_scratch, uint32_t* d_err, hipStream_t stream);
 
+// ---- decode_passes.hip (Cheetah container decode, the default: records parsed per chunk, dictionary and prediction tables as ordered LDS
+// exchange passes over the whole chunk, the chain of contexts alone on one wave per chunk) ----
+extern bool g_force_serial_decode;   // density_hip_set_kernel_variant(128): the one-wave-per-stream decoder instead
+bool decode_pass_eligible(int algo, const uint8_t* d_out, uint32_t n_chunks, uint64_t out_stride, uint64_t out_total);
+uint64_t decode_pass_scratch_bytes(uint64_t out_stride, uint32_t n_chunks);
+hipError_t launch_decode_passes(int algo, const uint8_t* d_in, const uint64_t* d_offsets, const uint64_t* d_sizes, uint32_t n_chunks, uint8_t* d_out,
+                                uint64_t out_stride, uint64_t out_total, bool exact, uint64_t* d_produced, uint32_t* d_err, uint8_t* d_scratch,
+                                hipStream_t stream);
+
 // ---- stream_parse.hip: record boundaries of one calm Chameleon stream, in parallel ----
 // d_info (16 words): 0 status (1 = a calm head was found), 1 first block behind the sequentially walked head, 2-3 its stream offset, 4 whole
 // blocks of the stream, 5-6 stream offset where they end (the ragged end, if any, starts there), 7 first block of a pair of incompressible

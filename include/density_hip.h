@@ -146,6 +146,10 @@ size_t density_hip_decoded_size(const uint8_t* container, size_t container_size)
  * Returns DENSITY_HIP_OK or an error code. */
 size_t density_hip_encode_workspace_size(int algo, size_t input_size, size_t chunk_size);
 size_t density_hip_decode_workspace_size(uint32_t n_chunks);
+/* The same for a container of known shape: includes the scratch of Cheetah's decode passes (a dword and a half per quad: 1.5 x total_len
+ * + 1/32; decode_passes.hip).  A workspace of only density_hip_decode_workspace_size() bytes still decodes — Cheetah then on one wave per
+ * chunk stream. */
+size_t density_hip_decode_workspace_size_for(int algo, size_t total_len, size_t chunk_size);
 int density_hip_encode_device(int algo, const void* d_input, size_t input_size, void* d_output, size_t output_capacity,
                               size_t chunk_size, void* d_workspace, size_t workspace_size, void* stream,
                               density_hip_header_t* header_out);
@@ -182,6 +186,8 @@ int density_hip_last_timings(float* milliseconds, const char** names, int capaci
  * out4[0] streams encoded in parallel segments, [1] passes those encodes took (1 per stream if every speculation held),
  * [2] streams decoded in parallel segments, [3] long streams decoded sequentially (mostly raw copies, or buffers the parallel path does not take). */
 void density_hip_stream_stats(uint64_t* out4);
+/* ... how many Cheetah decodes the decode passes (decode_passes.hip) have served so far (process-wide) ... */
+uint64_t density_hip_decode_pass_count(void);
 /* ... and of Cheetah container encodes under kernel variant bit 64: out2[0] chunks that went through the exchange passes, [1] how many
  * of them were handed back to the in-order kernel (raw-copy blocks, a ragged end). */
 void density_hip_stage_stats(uint64_t* out2);
@@ -191,7 +197,8 @@ void density_hip_stage_stats(uint64_t* out2);
  * 8 = encode in batches with the stitch of one batch beside the encoding of the next, 16 = Cheetah / Lion on the
  * one-lane-per-stream kernels instead of the one-wave-per-stream kernels (serial_codec.hip), 32 = Cheetah containers on the
  * one-wave-per-stream encoder instead of the exchange passes (exchange_stages.hip), 64 = count the chunks the exchange passes
- * keep / hand back (density_hip_stage_stats; reads the verdicts back, so the encode call synchronises).
+ * keep / hand back (density_hip_stage_stats; reads the verdicts back, so the encode call synchronises), 128 = Cheetah containers on the
+ * one-wave-per-stream decoder instead of the decode passes (decode_passes.hip).
  * Payload bytes are identical in every variant. */
 void density_hip_set_kernel_variant(int variant);
 
