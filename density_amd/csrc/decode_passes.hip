@@ -49,6 +49,12 @@ constexpr uint32_t kErrFormat = 1u, kErrWatchdog = 16u;
 constexpr uint32_t kSpinLimit = 1u << 22, kPoison = 0xfffffffeu;
 
 __device__ __forceinline__ uint32_t hash16(uint32_t q) { return (q * kHashMul) >> 16; }
+// vec[lane] = val (both wave-uniform scalars; the lane select goes through M0: an SGPR value and an SGPR lane select together would
+// break gfx9's one-scalar-operand rule)
+__device__ __forceinline__ uint32_t writelane(uint32_t vec, uint32_t val, uint32_t lane) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(vec) : "s"(val), "s"(lane) : "m0");
+    return vec;
+}
 
 // per chunk, left by `parse`: blocks, decoded bytes, quads and raw tail bytes of a ragged last record, where those bytes sit in the stream
 struct ChunkInfo { uint32_t blocks, produced, last_quads, tail_bytes, tail_at, bad, ragged, pad1; };   // ragged: the last block is a partial record of last_quads quads + tail_bytes raw bytes
@@ -111,7 +117,8 @@ __global__ __launch_bounds__(64) void cheetah_parse(PassArgs a) {
         }
         const uint32_t at = ip + misalign - w0;
         const uint32_t* wd = reinterpret_cast<const uint32_t*>(win + (at & ~3u));
-        const uint32_t d0 = wd[0], d1 = wd[1], d2 = wd[2];
+        // (every lane reads the same three dwords; taken as scalars so that the record arithmetic below runs on the scalar unit)
+        const uint32_t d0 = rfl(wd[0]), d1 = rfl(wd[1]), d2 = rfl(wd[2]);
         const uint64_t sig = (at & 2u) ? (((uint64_t)((d1 >> 16) | (d2 << 16)) << 32) | ((d0 >> 16) | (d1 << 16))) : (((uint64_t)d1 << 32) | d0);
         const uint64_t lo = sig & 0x5555555555555555ull, hi = (sig >> 1) & 0x5555555555555555ull;
         if (fast) {
@@ -373,42 +380,78 @@ __global__ __launch_bounds__(64) void cheetah_walk(PassArgs a) {
         const uint64_t P = ballot64(!none && pred), N = ballot64(!none && !pred);
         // what the quad before me hashed to: my context if that quad was not predicted (lane 0: the running context)
         const uint32_t hprev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h, 0x138, 0xf, 0xf, false);   // wave_shr:1
-        uint32_t cv = 0;                                                           // my context
-        uint32_t pos = 0;
+        uint32_t cv = hprev;                                                       // my context: the hash of the quad before me, unless patched below
         const uint64_t active = P | N;
-        while (pos < 64u) {
-            const uint64_t rest = active >> pos;
-            if (!rest) break;
-            pos += (uint32_t)__builtin_ctzll(rest);                                // (raw blocks and the end take no part: the context passes through)
-            if ((N >> pos) & 1ull) {
-                // a run of quads that are not predicted: each writes H[its context] = its hash (cheetah.rs:72,81,90), in stream order;
-                // the first one's context is the running one, the others' the hash of the quad before
-                const uint64_t inv = ~(N >> pos);
-                const uint32_t r = inv ? (uint32_t)__builtin_ctzll(inv) : 64u - pos;
-                const bool in = lane >= pos && lane < pos + r;
-                const uint32_t mine = lane == pos ? c : hprev;
-                if (in) {
-                    cv = mine;
-                    asm volatile("ds_write_b16 %0, %1" ::"v"(lds0 + 2u * mine), "v"(h) : "memory");
+        if (__builtin_expect(active == ~0ull, 1)) {
+            // Every quad of the block takes part (no raw-copy block, not the chunk's end): the chain in as few instructions as it takes —
+            // per run of quads that are not predicted ONE ordered 16-bit store (each writes H[its context] = its hash, cheetah.rs:72,81,90;
+            // the first one's context is the running one, patched into its lane), per predicted quad one LDS round trip (:97-102).
+            uint32_t addrv = lds0 + 2u * hprev;
+            uint64_t prem = P;                                                     // predicted lanes not yet passed
+            uint32_t pos = 0;
+            for (;;) {
+                const uint32_t p = prem ? (uint32_t)__builtin_ctzll(prem) : 64u;
+                if (p > pos) {
+                    const uint32_t r = p - pos;
+                    const uint64_t m = (r == 64u ? ~0ull : ((1ull << r) - 1ull)) << pos;
+                    const uint32_t a1 = writelane(addrv, lds0 + 2u * c, pos);
+                    cv = writelane(cv, c, pos);
+                    asm volatile("s_mov_b64 exec, %2\n\tds_write_b16 %0, %1\n\ts_mov_b64 exec, -1" ::"v"(a1), "v"(h), "s"(m) : "memory");
+                    c = (uint32_t)__builtin_amdgcn_readlane((int)h, (int)(p - 1u));
                 }
-                c = (uint32_t)__builtin_amdgcn_readlane((int)h, (int)(pos + r - 1u));
-                pos += r;
-            } else {
-                // a run of predicted quads: context -> hash of the predicted quad -> next context (cheetah.rs:97-102), one LDS round trip each
-                const uint64_t inv = ~(P >> pos);
-                const uint32_t r = inv ? (uint32_t)__builtin_ctzll(inv) : 64u - pos;
-                for (uint32_t t = 0; t < r; ++t) {
-                    if (lane == pos + t) cv = c;
+                if (p == 64u) break;
+                const uint64_t np = ~(P >> p);                                      // (bits above the block read as "not predicted")
+                const uint32_t e = np ? p + (uint32_t)__builtin_ctzll(np) : 64u;              // (np == 0: the whole block is predicted)
+                uint32_t t = p;
+                for (; t < e; ++t) {
+                    cv = writelane(cv, c, t);
                     uint32_t nx;
                     asm volatile("ds_read_u16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(nx) : "v"(lds0 + 2u * c) : "memory");
                     nx = rfl(nx);
-                    if (nx == c) {                                                 // a fixed point: the table does not change inside a run
-                        if (lane > pos + t && lane < pos + r) cv = c;
-                        break;
-                    }
+                    if (nx == c) break;                                            // a fixed point: the table does not change inside a run
                     c = nx;
                 }
-                pos += r;
+                if (t < e && lane > t && lane < e) cv = c;                         // (the rest of a run that sits on a fixed point)
+                pos = e;
+                if (e >= 64u) break;
+                prem = P & (~0ull << e);
+            }
+        } else {
+            // a block with quads that take no part (a raw-copy block's, the chunk's end): the same, run by run, stepping over them — the
+            // context passes through (codec.rs:89-91: a raw block touches no state)
+            cv = 0;
+            uint32_t pos = 0;
+            while (pos < 64u) {
+                const uint64_t rest = active >> pos;
+                if (!rest) break;
+                pos += (uint32_t)__builtin_ctzll(rest);
+                if ((N >> pos) & 1ull) {
+                    const uint64_t inv = ~(N >> pos);
+                    const uint32_t r = inv ? (uint32_t)__builtin_ctzll(inv) : 64u - pos;
+                    const bool in = lane >= pos && lane < pos + r;
+                    const uint32_t mine = lane == pos ? c : hprev;
+                    if (in) {
+                        cv = mine;
+                        asm volatile("ds_write_b16 %0, %1" ::"v"(lds0 + 2u * mine), "v"(h) : "memory");
+                    }
+                    c = (uint32_t)__builtin_amdgcn_readlane((int)h, (int)(pos + r - 1u));
+                    pos += r;
+                } else {
+                    const uint64_t inv = ~(P >> pos);
+                    const uint32_t r = inv ? (uint32_t)__builtin_ctzll(inv) : 64u - pos;
+                    for (uint32_t t = 0; t < r; ++t) {
+                        if (lane == pos + t) cv = c;
+                        uint32_t nx;
+                        asm volatile("ds_read_u16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(nx) : "v"(lds0 + 2u * c) : "memory");
+                        nx = rfl(nx);
+                        if (nx == c) {                                             // a fixed point: the table does not change inside a run
+                            if (lane > pos + t && lane < pos + r) cv = c;
+                            break;
+                        }
+                        c = nx;
+                    }
+                    pos += r;
+                }
             }
         }
         const uint32_t i = blk * 64u + lane;
