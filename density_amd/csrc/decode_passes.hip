@@ -72,9 +72,9 @@ __device__ __forceinline__ uint64_t chunk_cap(const PassArgs& a, uint64_t chunk)
 // ---------------------------------------------------------------------------------------------------------------
 // parse: Codec::decode's walk over the records (codec/codec.rs:82-126) without decoding them
 // ---------------------------------------------------------------------------------------------------------------
-constexpr uint32_t kWin = 8192;                                           // bytes of stream staged in LDS at a time
+constexpr uint32_t kWin = 8192, kWinStride = kWin - 64;                   // bytes of stream per LDS window; windows overlap by 64 bytes (a signature + slack)
 __global__ __launch_bounds__(64) void cheetah_parse(PassArgs a) {
-    __shared__ __attribute__((aligned(16))) uint8_t win[kWin + 16];
+    __shared__ __attribute__((aligned(16))) uint8_t win[2][kWin];
     const uint32_t lane = threadIdx.x;
     const uint64_t chunk = blockIdx.x;
     const uint8_t* src = a.in + a.offsets[chunk];
@@ -87,8 +87,25 @@ __global__ __launch_bounds__(64) void cheetah_parse(PassArgs a) {
     const uint32_t elen = (uint32_t)elen64;
     Guard g;
     uint32_t ip = 0, op = 0, b = 0;
-    uint32_t w0 = 0xffffffffu;                                            // stream offset of win[0] (16-byte aligned); nothing loaded yet
-    const uint32_t misalign = (uint32_t)(reinterpret_cast<uintptr_t>(src) & 15u);   // (the window is loaded from 16-byte aligned addresses)
+    const uint32_t misalign = (uint32_t)(reinterpret_cast<uintptr_t>(src) & 15u);   // (windows are loaded from 16-byte aligned addresses)
+    const uint8_t* base0 = src - misalign;
+    const uint32_t have = elen + misalign;                                // bytes from base0 to the stream's end
+    // window k = bytes [k * kWinStride, k * kWinStride + kWin) from base0, in win[k & 1]; window k + 1 is in flight (registers) while k is walked
+    uint4 pf[kWin / 1024];
+    auto fetch = [&](uint32_t k) {
+#pragma unroll
+        for (uint32_t j = 0; j < kWin / 1024; ++j) {
+            const uint32_t i = k * kWinStride + (j * 64u + lane) * 16u;
+            pf[j] = i < have ? *reinterpret_cast<const uint4*>(base0 + i) : make_uint4(0, 0, 0, 0);   // (at most 15 bytes past the end, inside its 16-byte line)
+        }
+    };
+    auto land = [&](uint32_t k) {
+#pragma unroll
+        for (uint32_t j = 0; j < kWin / 1024; ++j) *reinterpret_cast<uint4*>(&win[k & 1u][(j * 64u + lane) * 16u]) = pf[j];
+        __syncthreads();
+    };
+    uint32_t wk = 0;                                                      // the window being walked
+    fetch(0); land(0); fetch(1);
     while (!ci.bad && ip < elen) {
         const uint32_t left = elen - ip;
         const bool fast = left >= kSigBytes + kRecBytes;                  // codec.rs:88: a whole record is certainly there
@@ -103,20 +120,15 @@ __global__ __launch_bounds__(64) void cheetah_parse(PassArgs a) {
         }
         if (left < kSigBytes) { ci.bad = 1; break; }                      // reference: read_u64_le panics
         // the signature, through the LDS window
-        if (w0 == 0xffffffffu || ip + misalign < w0 || ip + misalign + kSigBytes + 4 > w0 + kWin) {
-            __syncthreads();
-            w0 = (ip + misalign) & ~15u;
-            const uint8_t* base = src - misalign + w0;                    // 16-byte aligned
-            const uint32_t have = elen + misalign - w0;                   // bytes of stream from base on
-            for (uint32_t i = lane * 16u; i < kWin; i += 64u * 16u) {
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (i < have) v = *reinterpret_cast<const uint4*>(base + i);   // (reads at most 15 bytes past the stream's end, inside its 16-byte line)
-                *reinterpret_cast<uint4*>(win + i) = v;
-            }
-            __syncthreads();
+        const uint32_t want = (ip + misalign) / kWinStride;
+        if (want != wk) {
+            if (want != wk + 1u) fetch(want);                             // (never: a record is far shorter than a window)
+            land(want);
+            wk = want;
+            fetch(want + 1u);
         }
-        const uint32_t at = ip + misalign - w0;
-        const uint32_t* wd = reinterpret_cast<const uint32_t*>(win + (at & ~3u));
+        const uint32_t at = ip + misalign - wk * kWinStride;
+        const uint32_t* wd = reinterpret_cast<const uint32_t*>(&win[wk & 1u][at & ~3u]);
         // (every lane reads the same three dwords; taken as scalars so that the record arithmetic below runs on the scalar unit)
         const uint32_t d0 = rfl(wd[0]), d1 = rfl(wd[1]), d2 = rfl(wd[2]);
         const uint64_t sig = (at & 2u) ? (((uint64_t)((d1 >> 16) | (d2 << 16)) << 32) | ((d0 >> 16) | (d1 << 16))) : (((uint64_t)d1 << 32) | d0);
@@ -348,7 +360,7 @@ __global__ __launch_bounds__(kPassWaves * 64) void cheetah_pass(PassArgs a) {
 // ---------------------------------------------------------------------------------------------------------------
 // walk: the contexts (cheetah.rs:97-102,161: last_hash) — the one chain of the decoder, on 16-bit hashes in LDS
 // ---------------------------------------------------------------------------------------------------------------
-constexpr uint32_t kWalkLds = 65536u * 2u;
+constexpr uint32_t kWalkTable = 65536u * 2u, kTileBlocks = 16, kTileBytes = kTileBlocks * 256u, kWalkLds = kWalkTable + 2u * kTileBytes;
 __global__ __launch_bounds__(64) void cheetah_walk(PassArgs a) {
     const uint32_t lane = threadIdx.x;
     const uint64_t chunk = blockIdx.x;
@@ -362,19 +374,33 @@ __global__ __launch_bounds__(64) void cheetah_walk(PassArgs a) {
     const uint32_t* __restrict__ val = reinterpret_cast<const uint32_t*>(a.out + chunk * a.out_stride);
     {   // H starts as the hash of the reference's zeroed prediction table: hash(0) = 0
         uint4* p = reinterpret_cast<uint4*>(pass_lds);
-        for (uint32_t i = lane; i < kWalkLds / 16; i += 64) p[i] = make_uint4(0, 0, 0, 0);
+        for (uint32_t i = lane; i < kWalkTable / 16; i += 64) p[i] = make_uint4(0, 0, 0, 0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     const uint32_t lds0 = lds_addr(pass_lds);
+    uint32_t* stage = reinterpret_cast<uint32_t*>(pass_lds + kWalkTable);           // two tiles of 16 blocks of descriptors
     uint32_t c = 0;                                                                // cheetah.rs:52: last_hash = 0
-    uint32_t dn = nblk ? (lane < nsteps ? desc[lane] : kDescNone) : kDescNone;
+    // The chain below never waits for memory: the descriptors of tile t + 1 are in flight (registers) while tile t is walked out of LDS
+    // (one wave has one load's latency — microseconds — per request: with a block per request the walk ran at the speed of its loads).
+    uint32_t tile[kTileBlocks];
+    auto fetch = [&](uint32_t t) {
+#pragma unroll
+        for (uint32_t j = 0; j < kTileBlocks; ++j) {
+            const uint32_t i = (t * kTileBlocks + j) * 64u + lane;
+            tile[j] = i < nsteps ? desc[i] : kDescNone;
+        }
+    };
+    auto land = [&](uint32_t t) {
+#pragma unroll
+        for (uint32_t j = 0; j < kTileBlocks; ++j) stage[(t & 1u) * (kTileBytes / 4) + j * 64u + lane] = tile[j];
+    };
+    fetch(0); land(0);
     // a MAP quad's hash is its item, a PLAIN quad's the hash of its value (in the descriptor either way); a predicted quad's comes out of H
     for (uint32_t blk = 0; blk < nblk; ++blk) {
-        const uint32_t d = dn;
-        {
-            const uint32_t i = (blk + 1u) * 64u + lane;
-            dn = i < nsteps ? desc[i] : kDescNone;                                  // the next block's descriptors: in flight across this one
-        }
+        const uint32_t t = blk / kTileBlocks, j = blk % kTileBlocks;
+        if (j == 0) fetch(t + 1u);
+        const uint32_t d = stage[(t & 1u) * (kTileBytes / 4) + j * 64u + lane];
+        if (j == kTileBlocks - 1u || blk + 1u == nblk) land(t + 1u);                 // (behind the read of the tile's last block: the other buffer)
         const uint32_t h = d & 0xffffu;
         const bool none = (d & kDescNone) != 0, pred = ((d >> 16) & 3u) == kFlagPred;
         const uint64_t P = ballot64(!none && pred), N = ballot64(!none && !pred);
