@@ -106,38 +106,70 @@ __global__ __launch_bounds__(64) void cheetah_parse(PassArgs a) {
     };
     uint32_t wk = 0;                                                      // the window being walked
     fetch(0); land(0); fetch(1);
-    while (!ci.bad && ip < elen) {
-        const uint32_t left = elen - ip;
-        const bool fast = left >= kSigBytes + kRecBytes;                  // codec.rs:88: a whole record is certainly there
-        if (g.block_is_copy()) {                                         // codec.rs:89-91,103-110
-            const uint32_t take = left > kRecBytes ? kRecBytes : left;
-            if (b >= max_blocks || (uint64_t)op + take > cap) { ci.bad = 1; break; }
-            if (lane == 0) rec[b] = ip | kRaw;
-            ++b; ip += take; op += take;
-            if (!fast && ip == elen) break;                               // :107-109: no decay behind the last raw block
-            g.decay();
-            continue;
-        }
-        if (left < kSigBytes) { ci.bad = 1; break; }                      // reference: read_u64_le panics
-        // the signature, through the LDS window
-        const uint32_t want = (ip + misalign) / kWinStride;
+    // record positions are collected 64 at a time in a register (lane b % 64) and stored together
+    uint32_t recv = 0;
+    auto put = [&](uint32_t blk, uint32_t value) {
+        recv = writelane(recv, value, blk & 63u);
+        if ((blk & 63u) == 63u && (blk & ~63u) + lane < max_blocks) rec[(blk & ~63u) + lane] = recv;   // (never into the next chunk's positions)
+    };
+    auto window_for = [&](uint32_t pos) {                                  // the window that holds the 12 bytes at stream offset pos
+        const uint32_t want = (pos + misalign) / kWinStride;
         if (want != wk) {
             if (want != wk + 1u) fetch(want);                             // (never: a record is far shorter than a window)
             land(want);
             wk = want;
             fetch(want + 1u);
         }
-        const uint32_t at = ip + misalign - wk * kWinStride;
+    };
+    auto signature_at = [&](uint32_t pos) -> uint64_t {                   // 8 bytes at a 2-byte aligned stream offset, as a scalar
+        const uint32_t at = pos + misalign - wk * kWinStride;
         const uint32_t* wd = reinterpret_cast<const uint32_t*>(&win[wk & 1u][at & ~3u]);
-        // (every lane reads the same three dwords; taken as scalars so that the record arithmetic below runs on the scalar unit)
         const uint32_t d0 = rfl(wd[0]), d1 = rfl(wd[1]), d2 = rfl(wd[2]);
-        const uint64_t sig = (at & 2u) ? (((uint64_t)((d1 >> 16) | (d2 << 16)) << 32) | ((d0 >> 16) | (d1 << 16))) : (((uint64_t)d1 << 32) | d0);
+        return (at & 2u) ? (((uint64_t)((d1 >> 16) | (d2 << 16)) << 32) | ((d0 >> 16) | (d1 << 16))) : (((uint64_t)d1 << 32) | d0);
+    };
+    const uint32_t full_blocks = (uint32_t)(cap / kRecBytes);             // blocks of 128 decoded bytes the output has room for
+    while (!ci.bad && ip < elen) {
+        window_for(ip);
+        {   // The common case in as few (scalar) instructions as it takes — a lone wave issues one instruction every 4-5 cycles: records that
+            // are whole (codec.rs:88: 136 bytes are left), whose signature lies in this window, with the blow-up protection at rest (no
+            // penalty, penalty start 1: protection_state.rs:19-27 then only counts) and room in the output.
+            const uint32_t wend = (wk + 1u) * kWinStride - misalign;       // stream offsets below this have their 12 bytes in the window
+            const uint32_t whole_end = elen >= kSigBytes + kRecBytes ? elen - (kSigBytes + kRecBytes) + 1u : 0u;
+            const uint32_t hot_end = wend < whole_end ? wend : whole_end;
+            while (ip < hot_end && g.penalty == 0 && g.start == 1 && b < full_blocks) {
+                const uint64_t sig = signature_at(ip);
+                const uint64_t lo = sig & 0x5555555555555555ull, hi = (sig >> 1) & 0x5555555555555555ull;
+                // 4 bytes per PLAIN quad, 2 per MAP quad, none per predicted one (cheetah.rs:17-23): 128 - 2 * (flags with a bit set) - 2 * (flags with both)
+                const uint32_t bytes = 4u * kRecQuads - 2u * (uint32_t)__builtin_popcountll(lo | hi) - 2u * (uint32_t)__builtin_popcountll(lo & hi);
+                put(b, ip);
+                ++b; ip += kSigBytes + bytes; op += kRecBytes;
+                ++g.counter;
+                const uint32_t inc = kSigBytes + bytes >= kRecBytes ? 1u : 0u;   // codec.rs:98
+                if (inc & g.prev) g.penalty = g.start;                    // protection_state.rs:38-47
+                g.prev = inc;
+            }
+            if (ip >= elen) break;
+            window_for(ip);
+        }
+        const uint32_t left = elen - ip;
+        const bool fast = left >= kSigBytes + kRecBytes;                  // codec.rs:88: a whole record is certainly there
+        if (g.block_is_copy()) {                                         // codec.rs:89-91,103-110
+            const uint32_t take = left > kRecBytes ? kRecBytes : left;
+            if (b >= max_blocks || (uint64_t)op + take > cap) { ci.bad = 1; break; }
+            put(b, ip | kRaw);
+            ++b; ip += take; op += take;
+            if (!fast && ip == elen) break;                               // :107-109: no decay behind the last raw block
+            g.decay();
+            continue;
+        }
+        if (left < kSigBytes) { ci.bad = 1; break; }                      // reference: read_u64_le panics
+        const uint64_t sig = signature_at(ip);
         const uint64_t lo = sig & 0x5555555555555555ull, hi = (sig >> 1) & 0x5555555555555555ull;
         if (fast) {
             const uint32_t nplain = kRecQuads - (uint32_t)__builtin_popcountll(lo | hi), npred = (uint32_t)__builtin_popcountll(lo & hi);
             const uint32_t bytes = 4u * nplain + 2u * (kRecQuads - nplain - npred);
             if (b >= max_blocks || (uint64_t)op + kRecBytes > cap) { ci.bad = 1; break; }
-            if (lane == 0) rec[b] = ip;
+            put(b, ip);
             ++b; ip += kSigBytes + bytes; op += kRecBytes;
             g.update(kSigBytes + bytes >= kRecBytes);                     // codec.rs:98
             continue;
@@ -160,7 +192,7 @@ __global__ __launch_bounds__(64) void cheetah_parse(PassArgs a) {
             const uint32_t at_stop = rfl(bperm(ks, before));
             const uint32_t tail = rem - at_stop;                          // 0..3 raw bytes
             if (b >= max_blocks || (uint64_t)op + 4u * ks + tail > cap) { ci.bad = 1; break; }
-            if (lane == 0) rec[b] = ip;
+            put(b, ip);
             ++b;
             ci.ragged = 1; ci.last_quads = ks; ci.tail_bytes = tail; ci.tail_at = ip + kSigBytes + at_stop;
             op += 4u * ks + tail; ip = elen;
@@ -170,10 +202,11 @@ __global__ __launch_bounds__(64) void cheetah_parse(PassArgs a) {
         const uint32_t nplain = kRecQuads - (uint32_t)__builtin_popcountll(lo | hi), npred = (uint32_t)__builtin_popcountll(lo & hi);
         const uint32_t bytes = 4u * nplain + 2u * (kRecQuads - nplain - npred);
         if (b >= max_blocks || (uint64_t)op + kRecBytes > cap) { ci.bad = 1; break; }
-        if (lane == 0) rec[b] = ip;
+        put(b, ip);
         ++b; ip += kSigBytes + bytes; op += kRecBytes;
         g.update(kSigBytes + bytes >= kRecBytes);
     }
+    if ((b & 63u) != 0 && lane < (b & 63u)) rec[(b & ~63u) + lane] = recv;   // the positions not yet stored
     ci.blocks = b; ci.produced = op;
     if (lane == 0) {
         a.info[chunk] = ci;
@@ -408,40 +441,64 @@ __global__ __launch_bounds__(64) void cheetah_walk(PassArgs a) {
         const uint32_t hprev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h, 0x138, 0xf, 0xf, false);   // wave_shr:1
         uint32_t cv = hprev;                                                       // my context: the hash of the quad before me, unless patched below
         const uint64_t active = P | N;
-        if (__builtin_expect(active == ~0ull, 1)) {
-            // Every quad of the block takes part (no raw-copy block, not the chunk's end): the chain in as few instructions as it takes —
-            // per run of quads that are not predicted ONE ordered 16-bit store (each writes H[its context] = its hash, cheetah.rs:72,81,90;
-            // the first one's context is the running one, patched into its lane), per predicted quad one LDS round trip (:97-102).
+        if (__builtin_expect(active == ~0ull && P != 0 && P != ~0ull, 1)) {
+            // Every quad of the block takes part (no raw-copy block, not the chunk's end) and some, not all, are predicted: the chain in as
+            // few instructions as it takes — a lone wave issues one instruction every 4-5 cycles, so the instruction count IS the walk's
+            // time (the compiled form of the loop below spent ~110 instructions per run, this one ~29).  Per run of quads that are not
+            // predicted ONE ordered 16-bit store under an exec mask (each writes H[its context] = its hash, cheetah.rs:72,81,90; the first
+            // one's context is the running one, patched into its lane), per predicted quad one LDS round trip (:97-102).
+            // (v_writelane takes its lane from M0: an SGPR value and an SGPR lane select in one instruction break gfx9's one-scalar rule)
             uint32_t addrv = lds0 + 2u * hprev;
-            uint64_t prem = P;                                                     // predicted lanes not yet passed
-            uint32_t pos = 0;
-            for (;;) {
-                const uint32_t p = prem ? (uint32_t)__builtin_ctzll(prem) : 64u;
-                if (p > pos) {
-                    const uint32_t r = p - pos;
-                    const uint64_t m = (r == 64u ? ~0ull : ((1ull << r) - 1ull)) << pos;
-                    const uint32_t a1 = writelane(addrv, lds0 + 2u * c, pos);
-                    cv = writelane(cv, c, pos);
-                    asm volatile("s_mov_b64 exec, %2\n\tds_write_b16 %0, %1\n\ts_mov_b64 exec, -1" ::"v"(a1), "v"(h), "s"(m) : "memory");
-                    c = (uint32_t)__builtin_amdgcn_readlane((int)h, (int)(p - 1u));
-                }
-                if (p == 64u) break;
-                const uint64_t np = ~(P >> p);                                      // (bits above the block read as "not predicted")
-                const uint32_t e = np ? p + (uint32_t)__builtin_ctzll(np) : 64u;              // (np == 0: the whole block is predicted)
-                uint32_t t = p;
-                for (; t < e; ++t) {
-                    cv = writelane(cv, c, t);
-                    uint32_t nx;
-                    asm volatile("ds_read_u16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(nx) : "v"(lds0 + 2u * c) : "memory");
-                    nx = rfl(nx);
-                    if (nx == c) break;                                            // a fixed point: the table does not change inside a run
-                    c = nx;
-                }
-                if (t < e && lane > t && lane < e) cv = c;                         // (the rest of a run that sits on a fixed point)
-                pos = e;
-                if (e >= 64u) break;
-                prem = P & (~0ull << e);
-            }
+            uint64_t prem = P;
+            uint32_t s_pos, s_p, s_r, s_a, v_t;
+            uint64_t s_m;
+            asm volatile(
+                "s_mov_b32 %[pos], 0\n"
+                "1:\n\t"                                                             // ---- next run of quads that are not predicted: [pos, p)
+                "s_ff1_i32_b64 %[p], %[prem]\n\t"
+                "s_cmp_lt_i32 %[p], 0\n\t"
+                "s_cselect_b32 %[p], 64, %[p]\n\t"
+                "s_sub_u32 %[r], %[p], %[pos]\n\t"
+                "s_cmp_eq_u32 %[r], 0\n\t"
+                "s_cbranch_scc1 2f\n\t"
+                "s_bfm_b64 %[m], %[r], %[pos]\n\t"                                   // r bits from pos on (r < 64: some quad is predicted)
+                "s_lshl_b32 %[a], %[c], 1\n\t"
+                "s_add_u32 %[a], %[a], %[lds0]\n\t"
+                "s_mov_b32 m0, %[pos]\n\t"
+                "s_nop 0\n\t"
+                "v_writelane_b32 %[addr], %[a], m0\n\t"
+                "v_writelane_b32 %[cv], %[c], m0\n\t"
+                "s_mov_b64 exec, %[m]\n\t"
+                "ds_write_b16 %[addr], %[h]\n\t"
+                "s_mov_b64 exec, -1\n\t"
+                "s_add_u32 %[r], %[p], -1\n\t"
+                "s_nop 0\n\t"
+                "v_readlane_b32 %[c], %[h], %[r]\n"
+                "2:\n\t"
+                "s_cmp_ge_u32 %[p], 64\n\t"
+                "s_cbranch_scc1 4f\n"
+                "3:\n\t"                                                             // ---- a predicted quad at lane p: c <- H[c]
+                "s_lshl_b32 %[a], %[c], 1\n\t"
+                "s_add_u32 %[a], %[a], %[lds0]\n\t"
+                "s_mov_b32 m0, %[p]\n\t"
+                "v_mov_b32 %[t], %[a]\n\t"
+                "v_writelane_b32 %[cv], %[c], m0\n\t"
+                "ds_read_u16 %[t], %[t]\n\t"
+                "s_bitset0_b64 %[prem], %[p]\n\t"
+                "s_add_u32 %[p], %[p], 1\n\t"
+                "s_waitcnt lgkmcnt(0)\n\t"
+                "v_readfirstlane_b32 %[c], %[t]\n\t"
+                "s_cmp_ge_u32 %[p], 64\n\t"
+                "s_cbranch_scc1 4f\n\t"
+                "s_bitcmp1_b64 %[prem], %[p]\n\t"
+                "s_cbranch_scc1 3b\n\t"
+                "s_mov_b32 %[pos], %[p]\n\t"
+                "s_branch 1b\n"
+                "4:\n\t"
+                : [addr] "+v"(addrv), [cv] "+v"(cv), [c] "+s"(c), [prem] "+s"(prem), [pos] "=&s"(s_pos), [p] "=&s"(s_p), [r] "=&s"(s_r), [a] "=&s"(s_a),
+                  [m] "=&s"(s_m), [t] "=&v"(v_t)
+                : [h] "v"(h), [lds0] "s"(lds0)
+                : "memory", "m0", "scc", "vcc");
         } else {
             // a block with quads that take no part (a raw-copy block's, the chunk's end): the same, run by run, stepping over them — the
             // context passes through (codec.rs:89-91: a raw block touches no state)
