@@ -42,12 +42,13 @@ inline bool valid_algo(int algo) { return algo >= DENSITY_HIP_CHAMELEON && algo 
 // CUs (256) where that is possible without dropping below 64 KiB (small chunks restart the dictionary and cost ratio), and no finer than that
 // (every chunk start costs a table clear and a few in-order rounds): never above 4 MiB, the largest chunk the index-fed decoder takes.
 // Power of two: 10 MB -> 64 KiB (153 chunks), 100 MB -> 256 KiB (382), 256 MiB -> 1 MiB, >= 1 GiB -> 4 MiB.
-// Cheetah and Lion run one WAVE per chunk stream and are bound by memory latency per stream, not by a CU's LDS: they want eight
-// streams per CU (2048) and start from 1 MiB.
+// Lion runs one WAVE per chunk stream and is bound by memory latency per stream, not by a CU's LDS: it wants eight streams per CU (2048)
+// and starts from 1 MiB.  Cheetah's decode passes (decode_passes.hip) walk one chunk per CU: the largest power of two up to 1 MiB that
+// still gives most CUs a chunk (160 chunks: 100 MB -> 512 KiB, ratio 1.73 where 64 KiB chunks gave 1.34, at the same round-trip time).
 inline size_t auto_chunk(size_t n, int algo = DENSITY_HIP_CHAMELEON) {
     const bool lds = algo == DENSITY_HIP_CHAMELEON;
     size_t c = lds ? (4u << 20) : (1u << 20);
-    const size_t streams = lds ? 256 : 2048;
+    const size_t streams = lds ? 256 : algo == DENSITY_HIP_CHEETAH ? 160 : 2048;
     while (c > (64u << 10) && n / c < streams) c >>= 1;
     return c;
 }

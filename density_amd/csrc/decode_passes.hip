@@ -558,10 +558,10 @@ bool decode_pass_eligible(int algo, const uint8_t* d_out, uint32_t n_chunks, uin
     if (n_chunks == 0 || (uintptr_t)d_out % 4 != 0) return false;
     // one chunk (a stream): the output capacity is the stride; chunks: whole pairs of records
     if (n_chunks > 1 && out_stride % 256 != 0) return false;
-    // Where the passes win (measured, 100 MB of prose: decode at 512 KiB chunks 8.4 ms against 10.5 on one wave per stream, at 1 MiB 16.6 against
-    // 20.3; at 256 KiB and below the one-wave decoder has more streams in flight than the walk has CUs, and less to set up: 6.2 against 7.0).
-    // DENSITY_HIP_PASS_MIN (bytes, tuning and tests) moves the threshold.
-    static const uint64_t min_chunk = getenv("DENSITY_HIP_PASS_MIN") ? (uint64_t)atoll(getenv("DENSITY_HIP_PASS_MIN")) : 512ull * 1024;
+    // Where the passes win: from 64 KiB chunks on (measured, 100 MB of prose, decode ms passes / one wave per stream: 64 KiB 3.2 / 3.6,
+    // 128 KiB 3.3 / 4.2, 256 KiB 4.4 / 6.2, 512 KiB 5.2 / 10.5, 1 MiB 9.8 / 20.2); shorter chunks have less to parse than the passes have to
+    // set up.  DENSITY_HIP_PASS_MIN (bytes; tuning runs) moves the threshold.
+    static const uint64_t min_chunk = getenv("DENSITY_HIP_PASS_MIN") ? (uint64_t)atoll(getenv("DENSITY_HIP_PASS_MIN")) : 64ull * 1024;
     const uint64_t per_chunk = n_chunks == 1 ? out_total : out_stride;
     return per_chunk >= min_chunk && per_chunk >= 65536 && per_chunk < (1ull << 31);
 }

@@ -3,9 +3,6 @@ import sys
 
 import pytest
 
-# Cheetah's decode passes (decode_passes.hip) serve chunks of 512 KiB and more by default — where they beat the one-wave decoder; the tests
-# lower the threshold (read once by the library) so that their small containers reach the passes too; kernel variant 128 is the cross-check.
-os.environ.setdefault("DENSITY_HIP_PASS_MIN", "65536")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
