@@ -688,7 +688,14 @@ int run_stream_decode(DeviceCtx* c, int algo, const uint8_t* d_in, size_t n, uin
     if (e == hipSuccess) e = hipMemcpyAsync(d_sizes, &h_size, 8, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemcpyAsync(d_offsets, &h_off, 8, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);   // h_size/h_off live on this stack frame
-    if (e == hipSuccess) e = codec_decode(algo, d_in, d_offsets, d_sizes, 1, d_out, cap, cap, false, nullptr, d_produced, d_err, ws + p.off_tables, zmap_bytes(algo, 1) ? reinterpret_cast<uint32_t*>(ws + p.off_zmap) : nullptr, s);
+    // a Cheetah stream is ONE chunk for the decode passes (decode_passes.hip): everything but its chain of contexts in parallel; their scratch
+    // comes from the context
+    uint8_t* d_pass = nullptr;
+    if (e == hipSuccess && decode_pass_eligible(algo, d_out, 1, cap, cap)) {
+        e = c->seg.ensure(decode_pass_scratch_bytes(align_up(cap, 256), 1) + kAlign);
+        d_pass = (uint8_t*)c->seg.p;
+    }
+    if (e == hipSuccess) e = codec_decode(algo, d_in, d_offsets, d_sizes, 1, d_out, cap, cap, false, nullptr, d_produced, d_err, ws + p.off_tables, zmap_bytes(algo, 1) ? reinterpret_cast<uint32_t*>(ws + p.off_zmap) : nullptr, s, d_pass);
     prof.mark(decode_kernel_name(algo));
     uint64_t h_prod = 0;
     uint32_t h_err = 0;

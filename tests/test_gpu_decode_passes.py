@@ -156,3 +156,32 @@ def test_truncated_and_corrupt_payloads_end_like_the_one_wave_decoder():
         assert a[0] == b[0], (trial, at, a[0], b[0])
         if a[0] == "ok":
             assert a[1] == b[1], (trial, at)
+
+
+@pytest.mark.parametrize("kind", ["prose", "mixed", "pairs", "random", "zeros"])
+def test_reference_shaped_streams_decode_in_passes(kind):
+    """`cheetah_decode` (the reference's symbol: ONE stream, host pointers) of 64 KiB and more goes through the same passes as one chunk;
+    oracle streams in, the input out; truncated streams end like the one-wave decoder."""
+    from density_amd import Cheetah, _lib
+    lib = _lib.lib()
+    n = 1_500_003
+    data = make(kind, n, seed=17)
+    enc = np.frombuffer(pyoracle.encode(ALGO, data), dtype=np.uint8)
+    out = np.zeros(n, dtype=np.uint8)
+    c0 = lib.density_hip_decode_pass_count()
+    assert Cheetah.decode(enc, out) == n and np.array_equal(out, data)
+    assert lib.density_hip_decode_pass_count() == c0 + 1
+    big = np.zeros(n + 100_000, dtype=np.uint8)                                           # an output buffer larger than the data
+    assert Cheetah.decode(enc, big) == n and np.array_equal(big[:n], data)
+    for cut in (1, 2, 7, 1000):
+        res = []
+        for variant in (0, 128):
+            container.set_kernel_variant(variant)
+            buf = np.zeros(n, dtype=np.uint8)
+            try:
+                m = Cheetah.decode(enc[:-cut].copy(), buf)
+                res.append(("ok", m, buf[:m].tobytes()))
+            except DecodeError:
+                res.append(("error",))
+        container.set_kernel_variant(0)
+        assert res[0] == res[1], (kind, cut, res[0][0], res[1][0])
