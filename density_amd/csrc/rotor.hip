@@ -575,15 +575,16 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
         incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xf, 0xf, true);   // row_shr:2
         incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xf, 0xf, true);   // row_shr:4
         if (R > 8) incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xf, 0xf, true);   // row_shr:8
+        const uint32_t posv = pos0 + incl - lenv;                                                 // lane j: where record j starts
         if (lane < R) {
-            *reinterpret_cast<u32x2_u*>(dst + (pos0 + incl - lenv)) = u32x2{slo, shi};         // codec.rs:24-26
+            *reinterpret_cast<u32x2_u*>(dst + posv) = u32x2{slo, shi};                             // codec.rs:24-26
             if (idxp) idxp[lane] = (uint8_t)nhv;
         }
-        uint32_t pos = pos0;
 #pragma unroll
         for (uint32_t j = 0; j < R; ++j) {
             const uint64_t sg = ((uint64_t)rlane_u(shi, (int)j) << 32) | rlane_u(slo, (int)j);
             const uint64_t plain = ~sg;
+            const uint32_t pos = rlane_u(posv, (int)j);                           // (one read instead of a scalar running sum: popcount, shift, subtract, add)
             const uint32_t off = pos + c_base + 2u * mbcnt64(plain);              // 8 + 2*lane + 2*(PLAIN lanes below) = 8 + 4*lane - 2*(MAP lanes below)
             const uint32_t P = kKeepHash ? hp[j] : q[j] * kHashMul;               // (the hash is the MAP item: chameleon.rs:92)
             asm volatile(
@@ -593,7 +594,6 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
                 "global_store_dword %0, %2, %3\n\t"
                 "s_mov_b64 exec, -1"
                 ::"v"(off), "v"(P), "v"(q[j]), "s"(dst), "s"(sg), "s"(plain) : "memory");
-            pos += kSig + kBlock - 2u * (uint32_t)__builtin_popcountll(sg);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -1541,9 +1541,9 @@ hipError_t launch_rotor_encode(const uint8_t* d_in, uint64_t total, uint64_t chu
     // geometry (DENSITY_HIP_TUNE bits 2..4): 0 = default = rounds of 16 blocks on 8 waves (the longer round amortises the hand-off, and 8
     // waves have the registers to keep their quads), 1 = 8 blocks on 16 waves, 2 = 16 blocks on 12 waves (as fast as the default, more code)
     // (12 or 16 blocks on 12 waves with kept quads do not fit: the compiler needs the staging registers / spills 43 registers)
-    // bit 8: the default geometry with the next round's quads asked for right behind the exchanges (EARLY)
+    // The default asks for the next round's quads right behind its exchanges (EARLY: 2 % faster than behind the commit); bit 8: behind the commit
     const uint32_t sel = (rot_tune() >> 2) & 7u;
-    const bool early = (rot_tune() >> 8) & 1u;
+    const bool early = !((rot_tune() >> 8) & 1u);
     const uint32_t waves = sel == 1 ? 16 : sel == 2 ? 12 : 8;
     auto kernel = sel == 1 ? (prof ? chameleon_encode_rot<8, 16, true> : chameleon_encode_rot<8, 16, false>)
                 : sel == 2 ? (prof ? chameleon_encode_rot<16, 12, true> : chameleon_encode_rot<16, 12, false>)
@@ -1587,7 +1587,7 @@ hipError_t launch_rotor_selftest(uint32_t* d_fail, hipStream_t stream) {
 
 hipError_t launch_rotor_encode_seg(const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_out, uint64_t out_stride,
                                    uint64_t* d_sizes, uint32_t* d_err, SegArgs seg, hipStream_t stream) {
-    auto kernel = chameleon_encode_rot<16, 8, false>;
+    auto kernel = chameleon_encode_rot<16, 8, false, true, true>;
     hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEncLds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3(n_chunks), dim3(512), kEncLds, stream, d_in, total, chunk_bytes, d_out, out_stride, d_sizes, (uint8_t*)nullptr, d_err, seg, (uint64_t*)nullptr);
