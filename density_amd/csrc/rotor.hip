@@ -45,18 +45,25 @@ constexpr uint32_t kRotWaves = 16, kRotThreads = kRotWaves * 64;
 constexpr uint32_t kR = 8;                                   // blocks per round
 constexpr uint32_t kNone = 0xffffffffu;
 // sync block (bytes from its base): D line {D, A}; O line {O, A', P0, P1}; a 256-byte sink for the idle lanes of a token write;
-// 16 words "rounds whose zero-entry-map phase this wave has finished" (decoder)
-constexpr uint32_t kSyD = 0, kSyO = 16, kSyZ = 32, kSyEnd = 48, kSySink = 64, kSyZdone = 64 + 256, kSyWsum = 64 + 256 + 64, kSyBytes = 64 + 256 + 64 + 64;
+// 16 words "rounds whose zero-entry-map phase this wave has finished" (decoder); 16 words "the round of this wave that is about to mark the map" (decoder)
+constexpr uint32_t kSyD = 0, kSyO = 16, kSyZ = 32, kSyEnd = 48, kSySink = 64, kSyZdone = 64 + 256, kSyWsum = 64 + 256 + 64, kSyZset = 64 + 256 + 64 + 64, kSyBytes = 64 + 256 + 64 + 64 + 64;
 // encoder LDS: table | zero-entry map | sync
 constexpr uint32_t kEncZmap = kTableBytes, kEncSync = kTableBytes + kZmapBytes, kEncStage = kEncSync + kSyBytes;
 // (encoder staging: two arrays of up to 16 blocks x 64 lanes for the rolled loops of the rare paths — rollback, in-order rounds, zero-entry
 // quads at commit — which exclude one another in time, so the whole work-group shares one copy)
 constexpr uint32_t kEncStageBytes = 2u * 16u * 256u, kEncLds = kEncStage + kEncStageBytes;
-// decoder LDS: table | block-index copy | round positions | sync   (zero-entry map in global memory: ZmapGlobal)
+// decoder LDS: table | block-index copy | round positions | zero-entry map (rounds of 12 and more; else in global memory: ZmapGlobal) | sync
 constexpr uint32_t kRotMaxBlocks = 16384;                    // blocks per chunk the decoder keeps an index copy for (4 MiB chunks)
-constexpr uint32_t kDecIdx = kTableBytes, kDecPos = kDecIdx + kRotMaxBlocks, kDecSync = kDecPos + (kRotMaxBlocks / kR) * 4u,
-                   kDecLds = kDecSync + kSyBytes;
-static_assert(kEncLds <= 160u * 1024u && kDecLds <= 160u * 1024u, "LDS budget");
+// (per round length R: rounds of 12 and more leave room for the zero-entry map in LDS — a look-up in global memory is a memory round trip
+// of microseconds, and one round in 25 has one on repetitive text; rounds of 8 keep it in global memory)
+constexpr uint32_t kDecIdx = kTableBytes, kDecPos = kDecIdx + kRotMaxBlocks;
+constexpr uint32_t dec_pos_bytes(uint32_t R) { return ((kRotMaxBlocks / R + 1u) * 4u + 15u) & ~15u; }
+constexpr bool dec_zmap_in_lds(uint32_t R) { return kDecPos + dec_pos_bytes(R) + kZmapBytes + kSyBytes <= 160u * 1024u; }
+constexpr uint32_t dec_zmap_at(uint32_t R) { return kDecPos + dec_pos_bytes(R); }
+constexpr uint32_t dec_sync_at(uint32_t R) { return dec_zmap_at(R) + (dec_zmap_in_lds(R) ? kZmapBytes : 0u); }
+constexpr uint32_t dec_lds_bytes(uint32_t R) { return dec_sync_at(R) + kSyBytes; }
+static_assert(kEncLds <= 160u * 1024u && dec_lds_bytes(8) <= 160u * 1024u && dec_lds_bytes(12) <= 160u * 1024u && dec_lds_bytes(16) <= 160u * 1024u, "LDS budget");
+static_assert(dec_zmap_in_lds(12) && !dec_zmap_in_lds(8), "where the decoder's zero-entry map lives");
 
 
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -1086,9 +1093,13 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
     const uint64_t cap = room_all < out_stride ? room_all : out_stride;
     const uint32_t elen = elen64 > 0xfff00000ull ? 0xfff00000u : (uint32_t)elen64;   // 32-bit stream offsets in the pipeline; the in-order loop finishes longer streams
     const uint32_t nblk = (uint32_t)((cap + kBlock - 1) / kBlock);               // <= kRotMaxBlocks (launcher)
-    const ZmapGlobal zmap{zmap_words + chunk * (kZmapBytes / 4)};
+    constexpr uint32_t dSync = dec_sync_at(R);
+    constexpr bool kZmapLds = dec_zmap_in_lds(R);
+    typedef typename std::conditional<kZmapLds, ZmapLds, ZmapGlobal>::type Zmap;
+    Zmap zmap;
+    if constexpr (kZmapLds) zmap = Zmap{dec_zmap_at(R)}; else zmap = Zmap{zmap_words + chunk * (kZmapBytes / 4)};
     // the table sits at LDS address 0 (this kernel has no static LDS): slot addresses need no base
-    const uint32_t sy = kDecSync;
+    const uint32_t sy = dSync;
 
     {   // fresh dictionary, this chunk's zero-entry map, the block index into LDS (a segment of a longer stream — SegArgs — starts from
         // the dictionary image it is given instead)
@@ -1096,16 +1107,17 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
         const uint4 z = make_uint4(0, 0, 0, 0);
         const uint4* image = seg.init_images ? reinterpret_cast<const uint4*>(seg.init_images + chunk * kSegImageBytes) : nullptr;
         for (uint32_t i = threadIdx.x; i < kTableBytes / 16; i += kThreads) p[i] = image ? image[i] : z;
-        for (uint32_t i = threadIdx.x; i < kZmapBytes / 16; i += kThreads) reinterpret_cast<uint4*>(zmap.words)[i] = image ? image[kTableBytes / 16 + i] : z;
+        if constexpr (kZmapLds) { for (uint32_t i = threadIdx.x; i < kZmapBytes / 16; i += kThreads) reinterpret_cast<uint4*>(smem + dec_zmap_at(R))[i] = image ? image[kTableBytes / 16 + i] : z; }
+        else { for (uint32_t i = threadIdx.x; i < kZmapBytes / 16; i += kThreads) reinterpret_cast<uint4*>(zmap_words + chunk * (kZmapBytes / 4))[i] = image ? image[kTableBytes / 16 + i] : z; }
         const uint32_t* iw = reinterpret_cast<const uint32_t*>(idx);
         uint32_t* lw = reinterpret_cast<uint32_t*>(smem + kDecIdx);
         for (uint32_t i = threadIdx.x; i < kRotMaxBlocks / 4; i += kThreads) lw[i] = i < (nblk + 3u) / 4u ? iw[i] : 0x7f7f7f7fu;   // beyond the chunk: "ragged" = stop
         if (threadIdx.x == 0) {
-            *reinterpret_cast<uint4*>(smem + kDecSync + kSyD) = make_uint4(0u, kNone, 0u, 0u);
-            *reinterpret_cast<uint64_t*>(smem + kDecSync + kSyEnd) = ~0ull;
+            *reinterpret_cast<uint4*>(smem + dSync + kSyD) = make_uint4(0u, kNone, 0u, 0u);
+            *reinterpret_cast<uint64_t*>(smem + dSync + kSyEnd) = ~0ull;
             if (lds_addr(smem) != 0) atomicOr(err, kErrWatchdog);                 // (cannot happen: see above)
         }
-        if (threadIdx.x < W) *reinterpret_cast<uint32_t*>(smem + kDecSync + kSyZdone + 4u * threadIdx.x) = 0u;
+        if (threadIdx.x < W) { *reinterpret_cast<uint32_t*>(smem + dSync + kSyZdone + 4u * threadIdx.x) = 0u; *reinterpret_cast<uint32_t*>(smem + dSync + kSyZset + 4u * threadIdx.x) = 0u; }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         // the map is used through L2 atomics by this work-group only (chameleon.hip)
     }
     __syncthreads();
@@ -1116,7 +1128,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
     // one that is not (ragged block, end of the stream, end of the output, an index that disagrees with the stream length) and
     // everything behind it is finished by the in-order loop (codec.rs:102-123).
     {
-        uint32_t* wave_sums = reinterpret_cast<uint32_t*>(smem + kDecSync + kSyWsum);
+        uint32_t* wave_sums = reinterpret_cast<uint32_t*>(smem + dSync + kSyWsum);
         const bool scans = threadIdx.x < kScanThreads;                            // (with 12 waves the first 8 do the scan)
         const uint32_t first = threadIdx.x * kPerThread;
         auto rec_len = [&](uint32_t ent) -> uint32_t { return (ent & kIdxCopy) ? kBlock : kSig + kBlock - 2u * (ent & 0x7fu); };
@@ -1148,11 +1160,11 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
                 pos += l;
             }
             if (threadIdx.x == kScanThreads - 1 && stop_key == ~0ull) stop_key = ((uint64_t)kRotMaxBlocks << 33) | pos;
-            if (stop_key != ~0ull) atomicMin(reinterpret_cast<unsigned long long*>(smem + kDecSync + kSyEnd), (unsigned long long)stop_key);
+            if (stop_key != ~0ull) atomicMin(reinterpret_cast<unsigned long long*>(smem + dSync + kSyEnd), (unsigned long long)stop_key);
         }
     }
     __syncthreads();
-    const uint64_t end_key = *reinterpret_cast<const uint64_t*>(smem + kDecSync + kSyEnd);
+    const uint64_t end_key = *reinterpret_cast<const uint64_t*>(smem + dSync + kSyEnd);
     const uint32_t nvalid = rfl((uint32_t)(end_key >> 33));                      // records [0, nvalid) are complete and followed by more data
     const uint32_t npr = nvalid / R;                                              // whole rounds: these rotate; the rest (< R records + the ragged end) is the epilogue
 
@@ -1232,26 +1244,43 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
         clk.mark(0);
 
         // ---- C: operands of the dictionary step ----
+        // (Instruction count is this kernel's time: a wave whose iteration is longer than W hand-offs arrives late for its turn, and every
+        // late arrival stalls the chain — six instructions per record less made the kernel 17 % faster.  Hence: the loop below treats every
+        // record as coded and a rare branch behind it takes the raw-copy records' operands back (a chunk's cold start; incompressible
+        // data), and the rare zero-entry candidates are found by ONE running minimum instead of a bit per record.)
         const uint32_t coded_mask = ((1u << R) - 1u) & ~mc.copy_mask;             // records that go through the dictionary
-        const uint32_t map_mask = seg.lastwriters_only ? 0u : coded_mask;         // ... and whose MAP quads are looked up
-        uint32_t zacc = 0;
+        const uint32_t hit_mask = seg.lastwriters_only ? 0u : hitsc;              // MAP quads that are looked up (raw records have no hit bits: stage B)
+        // zmin == 0 afterwards: some lane of some record has a zero-entry CANDIDATE — a PLAIN quad whose stored entry is 0, or a MAP quad that
+        // read 0 — sorted out record by record in the rare path below
+        uint32_t zmin = 1;
 #pragma unroll
         for (uint32_t j = 0; j < R; ++j) {
-            const bool coded = (coded_mask >> j) & 1u;
             const bool hit = (hitsc >> j) & 1u;
             const uint32_t qv = itemc[j];
             const uint32_t P = qv * kHashMul;
             const uint32_t h = hit ? (qv & 0xffffu) : (P >> 16);                  // MAP: the item is the slot (chameleon.rs:64-68)
             const uint32_t sh = (h & 1u) << 4;
             const uint32_t e = stored_entry(qv, P);
-            const bool writes = coded && !hit;                                    // PLAIN writes its entry (chameleon.rs:56-61), MAP only reads
-            ra[j] = coded ? ((h >> 1) << 2) : 4u * lane;                          // raw / absent records: a harmless conflict-free read
-            mask[j] = writes ? (0xffffu << sh) : 0u;
-            val[j] = writes ? (e << sh) : 0u;
-            // bit j: record j has a zero-entry quad in this lane.  (A last-writers pass also marks slot 0 when the zero quad is WRITTEN there — PLAIN,
-            // so the slot held something else: the mark then says "this segment wrote the slot", which an entry of 0 alone does not say to
-            // merge_images_kernel; chameleon_lastwriters_rot does the same on the encode side.)
-            zacc |= (writes && e == 0 && (h != 0 || seg.lastwriters_only)) ? (1u << j) : 0u;
+            ra[j] = (h >> 1) << 2;
+            mask[j] = hit ? 0u : (0xffffu << sh);                                 // PLAIN writes its entry (chameleon.rs:56-61), MAP only reads
+            val[j] = hit ? 0u : (e << sh);
+            const uint32_t ez = hit ? 1u : e;
+            zmin = ez < zmin ? ez : zmin;
+        }
+        // A round that will MARK the zero-entry map (a PLAIN quad whose entry is 0: about four per 4 MiB of text) says so before its exchanges:
+        // rounds behind it that only LOOK a slot up in the map (every recurrence of such a quad: one round in 25) then wait for nothing but
+        // earlier rounds that have said so — almost never — instead of for every earlier round to finish.
+        const bool marks = ballot64(zmin == 0) != 0;
+        if (__builtin_expect(marks, 0)) { if (lane == 0) lds_poke(sy + kSyZset + 4u * wave, x + 1u); }
+        if (__builtin_expect(mc.copy_mask != 0, 0)) {
+            // raw-copy records (codec.rs:89-91) touch no state: their lanes read a harmless conflict-free word instead
+#pragma unroll
+            for (uint32_t j = 0; j < R; ++j) {
+                const bool raw = (mc.copy_mask >> j) & 1u;
+                ra[j] = raw ? 4u * lane : ra[j];
+                mask[j] = raw ? 0u : mask[j];
+                val[j] = raw ? 0u : val[j];
+            }
         }
         const uint32_t tokaddr = lane == 0 ? sy + kSyD : sy + kSySink + 4u * lane;
         pin_operands<R>(ra, mask, val);                                           // complete before the wait for the token
@@ -1278,29 +1307,44 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
         // ---- what each slot holds at this lane's turn -> quads (in place of the answers) ----
 #pragma unroll
         for (uint32_t j = 0; j < R; ++j) {
-            const bool maps = ((map_mask & hitsc) >> j) & 1u;
+            const bool maps = (hit_mask >> j) & 1u;
             const uint32_t h = itemc[j] & 0xffffu;
             const uint32_t cur = (ra[j] >> ((h & 1u) << 4)) & 0xffffu;
-            zacc |= (maps && cur == 0 && h != 0) ? (1u << j) : 0u;                // MAP of a slot holding 0: never written, or a genuine zero entry?
+            const uint32_t cz = maps ? cur : 1u;                                  // MAP of a slot holding 0: never written, or a genuine zero entry?
+            zmin = cz < zmin ? cz : zmin;
             ra[j] = maps ? entry_to_quad(h, cur) : itemc[j];
         }
         clk.mark(5);
         // ---- zero-entry map, in stream order (rare: stored entries are salted).  A round with no such quad only reports "done"; one that
         // has any first waits until every earlier round has reported (wave w' owns the rounds = w' mod W). ----
-        if (__builtin_expect(ballot64(zacc != 0) != 0, 0)) {
+        if (__builtin_expect(ballot64(zmin == 0) != 0, 0)) {
             clk.note(x, 1, lane);
             for (uint32_t spins = 0;;) {
                 const uint32_t wv = lane % W;
-                const uint32_t d = (wave + W - wv) % W;                           // wave wv's last round before x is x - d
-                const uint32_t done = lds_peek1(sy + kSyZdone + 4u * wv);        // (rounds finished: last round + 1)
-                if (ballot64(d != 0 && x >= d && done < x - d + 1u) == 0) break;
+                if (marks) {
+                    // marks must not be seen by look-ups of earlier rounds: every earlier round has finished its zero-entry phase
+                    const uint32_t d = (wave + W - wv) % W;                       // wave wv's last round before x is x - d
+                    const uint32_t done = lds_peek1(sy + kSyZdone + 4u * wv);    // (rounds finished: last round + 1)
+                    if (ballot64(d != 0 && x >= d && done < x - d + 1u) == 0) break;
+                } else {
+                    // look-ups only: the marks of earlier rounds must be in — those rounds said so before their exchanges, i.e. before ours
+                    const uint32_t pending = lds_peek1(sy + kSyZset + 4u * wv);  // (round + 1, 0: none)
+                    if (ballot64(pending != 0 && pending - 1u < x) == 0) break;
+                }
                 if (rfl(lds_peek1(sy + kSyD)) == kPoison) wave_exit();
                 watchdog(spins, sy, err, lane);
             }
-            // which records have such a quad, then those records one by one — usually one
+            // which records have such a quad — from what is still in registers, a few instructions per record (about one round in 25 comes
+            // here on repetitive text: every recurrence of a quad whose entry is 0 does) — then those records one by one, usually one
             uint32_t zblocks = 0;
 #pragma unroll
-            for (uint32_t j = 0; j < R; ++j) zblocks |= (ballot64((zacc >> j) & 1u) != 0 ? 1u : 0u) << j;
+            for (uint32_t j = 0; j < R; ++j) {
+                // a PLAIN quad with stored entry 0 (its exchange operands: a write of 0), or a MAP quad whose slot gave the quad that an entry of 0 stands for
+                const bool wrote0 = mask[j] != 0 && val[j] == 0;
+                const bool read0 = ((hit_mask >> j) & 1u) && ra[j] == entry_to_quad(itemc[j] & 0xffffu, 0);
+                zblocks |= (ballot64(wrote0 || read0) != 0 ? 1u : 0u) << j;
+            }
+            zblocks &= coded_mask;
             for (uint32_t zb = zblocks; zb; zb &= zb - 1u) {
                 const uint32_t j = (uint32_t)__builtin_ctz(zb);
                 const bool coded = (coded_mask >> j) & 1u;
@@ -1328,7 +1372,10 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
                 }
             }
         }
-        if (lane == 0) lds_poke(sy + kSyZdone + 4u * wave, x + 1u);
+        if (lane == 0) {
+            if (marks) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); lds_poke(sy + kSyZset + 4u * wave, 0u); }   // (behind the marks: LDS operations of a wave execute in order; in L2: ZmapGlobal::set consumed the atomics' answers)
+            lds_poke(sy + kSyZdone + 4u * wave, x + 1u);
+        }
         clk.mark(6);
 
         // ---- stores: 256 coalesced bytes per record ----
@@ -1373,9 +1420,14 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
         uint4* image = reinterpret_cast<uint4*>(seg.final_images + chunk * kSegImageBytes);
         const uint4* p = reinterpret_cast<const uint4*>(smem);
         for (uint32_t i = threadIdx.x; i < kTableBytes / 16; i += kThreads) image[i] = p[i];
-        for (uint32_t i = threadIdx.x; i < kZmapBytes / 16; i += kThreads)
-            image[kTableBytes / 16 + i] = make_uint4(__hip_atomic_load(zmap.words + 4 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(zmap.words + 4 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                                                      __hip_atomic_load(zmap.words + 4 * i + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(zmap.words + 4 * i + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if constexpr (kZmapLds) {
+            for (uint32_t i = threadIdx.x; i < kZmapBytes / 16; i += kThreads) image[kTableBytes / 16 + i] = reinterpret_cast<const uint4*>(smem + dec_zmap_at(R))[i];
+        } else {
+            const uint32_t* zw = zmap_words + chunk * (kZmapBytes / 4);
+            for (uint32_t i = threadIdx.x; i < kZmapBytes / 16; i += kThreads)
+                image[kTableBytes / 16 + i] = make_uint4(__hip_atomic_load(zw + 4 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(zw + 4 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                                                          __hip_atomic_load(zw + 4 * i + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(zw + 4 * i + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        }
     }
 }
 
@@ -1572,9 +1624,10 @@ hipError_t launch_rotor_decode(const uint8_t* d_in, const uint64_t* d_offsets, c
     const uint32_t waves = sel == 1 ? 16 : 12;
     auto kernel = sel == 1 ? (prof ? chameleon_decode_rot<8, 16, true> : chameleon_decode_rot<8, 16, false>)
                            : (prof ? chameleon_decode_rot<12, 12, true> : chameleon_decode_rot<12, 12, false>);
-    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDecLds);
+    const uint32_t lds = sel == 1 ? dec_lds_bytes(8) : dec_lds_bytes(12);
+    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kernel, dim3(n_chunks), dim3(waves * 64), kDecLds, stream, d_in, d_offsets, d_sizes, d_out, out_stride, out_total,
+    hipLaunchKernelGGL(kernel, dim3(n_chunks), dim3(waves * 64), lds, stream, d_in, d_offsets, d_sizes, d_out, out_stride, out_total,
                        exact ? 1u : 0u, d_index, d_zmap, d_produced, d_err, SegArgs{}, prof);
     rot_prof_report("decode", "stage A | stage B | operands | D wait | exchange | quads | Z chain | stores", prof, stream, waves);
     return hipGetLastError();
@@ -1620,9 +1673,9 @@ hipError_t launch_rotor_decode_seg(const uint8_t* d_in, const uint64_t* d_offset
                                    uint64_t out_stride, uint64_t out_total, const uint8_t* d_index, uint32_t* d_zmap, uint64_t* d_produced, uint32_t* d_err,
                                    SegArgs seg, hipStream_t stream) {
     auto kernel = chameleon_decode_rot<12, 12, false>;
-    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDecLds);
+    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dec_lds_bytes(12));
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kernel, dim3(n_chunks), dim3(768), kDecLds, stream, d_in, d_offsets, d_sizes, d_out, out_stride, out_total, 0u, d_index, d_zmap, d_produced, d_err,
+    hipLaunchKernelGGL(kernel, dim3(n_chunks), dim3(768), dec_lds_bytes(12), stream, d_in, d_offsets, d_sizes, d_out, out_stride, out_total, 0u, d_index, d_zmap, d_produced, d_err,
                        seg, (uint64_t*)nullptr);
     return hipGetLastError();
 }
