@@ -35,7 +35,9 @@ __device__ __forceinline__ uint32_t stored_entry(uint32_t q, uint32_t P) { retur
 __device__ __forceinline__ uint32_t entry_to_quad(uint32_t h, uint32_t stored) {
     const uint32_t e = stored ^ slot_salt(h);
     const uint32_t Pfull = (h << 16) | (e & 0xfffeu);
-    return (((Pfull >> 1) * kHalfMulInv) & 0x7fffffffu) | ((e & 1u) << 31);
+    // ((Pfull >> 1) * inv) mod 2^31 == ((Pfull * inv) mod 2^32) >> 1 (Pfull is even), and bit 31 of the quad is bit 0 of the entry: one funnel
+    // shift of {e, Pfull * inv} by one position does both
+    return __builtin_amdgcn_alignbit(e, Pfull * kHalfMulInv, 1);
 }
 
 // the four-instruction dictionary step described in the file header; the caller masks inactive lanes with exec

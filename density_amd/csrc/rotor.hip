@@ -1195,19 +1195,21 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
         // the index must agree with the stream it describes: a record's MAP count is its signature's popcount (lane j < R: record j)
         bad_index |= (lane < R && !((m.copy_mask >> lane) & 1u) && (uint32_t)(__builtin_popcount(m.sgv.x) + __builtin_popcount(m.sgv.y)) != m.cnt) ? 1u : 0u;
         hits = 0;
+        // (lane j < R prepares record j for all lanes at once — a raw record has no signature: no MAP flags, its 256 bytes are its "items" —
+        // so that the loop below is three lane reads per record and no scalar arithmetic)
+        const uint32_t codedv = ((m.copy_mask >> lane) & 1u) ? 0u : ~0u;             // all ones, or 0 for 256 raw bytes without a signature (codec.rs:89-91)
+        const uint32_t sxv = m.sgv.x & codedv, syv = m.sgv.y & codedv, pbv = m.posv + (codedv & kSig);
 #pragma unroll
         for (uint32_t j = 0; j < R; ++j) {                                        // (straight-line: selects, no branches)
-            const uint32_t pos = rlane_u(m.posv, (int)j);
-            const uint32_t coded = 0u - ((~m.copy_mask >> j) & 1u);               // all ones, or 0 for 256 raw bytes without a signature (codec.rs:89-91)
-            const uint32_t slo = rlane_u(m.sgv.x, (int)j) & coded, shi = rlane_u(m.sgv.y, (int)j) & coded;
+            const uint32_t slo = rlane_u(sxv, (int)j), shi = rlane_u(syv, (int)j), pos = rlane_u(pbv, (int)j);
             uint32_t bit;                                                         // this lane's flag: one select on the signature as a lane mask
             asm("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(bit) : "s"(((uint64_t)shi << 32) | slo));
             hits |= bit << j;
-            // this lane's item sits 4 bytes further per PLAIN lane below it and 2 per MAP lane: 4*lane - 2*(MAP lanes below)
+            // this lane's item sits 4 bytes further per PLAIN lane below it and 2 per MAP lane: 4*lane - 2*(MAP lanes below), from the record's items on
             const uint32_t t = __builtin_amdgcn_mbcnt_hi(shi, __builtin_amdgcn_mbcnt_lo(slo, minus_2lane));   // MAP lanes below - 2*lane
-            const uint32_t voff = (uint32_t)__mul24((int)t, -2);
-            const uint8_t* base = src + (pos + (coded & kSig));                   // (wave-uniform: the load takes it as a scalar base)
-            item[j] = ld32u(base + voff);
+            uint32_t off;                                                         // (one multiply-add — left to the compiler: a shift pair and a subtract; the stream's base is the load's scalar operand)
+            asm("v_mad_i32_i24 %0, %1, -2, %2" : "=v"(off) : "v"(t), "s"(pos));
+            item[j] = ld32u(src + off);
         }
     };
 
@@ -1312,7 +1314,9 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
             const uint32_t cur = (ra[j] >> ((h & 1u) << 4)) & 0xffffu;
             const uint32_t cz = maps ? cur : 1u;                                  // MAP of a slot holding 0: never written, or a genuine zero entry?
             zmin = cz < zmin ? cz : zmin;
-            ra[j] = maps ? entry_to_quad(h, cur) : itemc[j];
+            uint32_t mq = entry_to_quad(h, cur);                                  // (for every lane, then one select: cheaper than an exec mask around it)
+            asm volatile("" : "+v"(mq));
+            ra[j] = maps ? mq : itemc[j];
         }
         clk.mark(5);
         // ---- zero-entry map, in stream order (rare: stored entries are salted).  A round with no such quad only reports "done"; one that
@@ -1620,11 +1624,12 @@ hipError_t launch_rotor_decode(const uint8_t* d_in, const uint64_t* d_offsets, c
     uint64_t* prof = rot_prof_buffer();
     // geometry (DENSITY_HIP_TUNE bits 5..7): 0 = default = rounds of 12 records on 12 waves (168 registers each: the longest round that does
     // not spill, i.e. the shortest chain per record), 1 = 8 records on 16 waves
-    const uint32_t sel = (rot_tune() >> 5) & 7u;
+    const uint32_t sel = (rot_tune() >> 5) & 7u;                                 // 2: rounds of 16 records on 12 waves
     const uint32_t waves = sel == 1 ? 16 : 12;
     auto kernel = sel == 1 ? (prof ? chameleon_decode_rot<8, 16, true> : chameleon_decode_rot<8, 16, false>)
+                : sel == 2 ? (prof ? chameleon_decode_rot<16, 12, true> : chameleon_decode_rot<16, 12, false>)
                            : (prof ? chameleon_decode_rot<12, 12, true> : chameleon_decode_rot<12, 12, false>);
-    const uint32_t lds = sel == 1 ? dec_lds_bytes(8) : dec_lds_bytes(12);
+    const uint32_t lds = sel == 1 ? dec_lds_bytes(8) : sel == 2 ? dec_lds_bytes(16) : dec_lds_bytes(12);
     hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3(n_chunks), dim3(waves * 64), lds, stream, d_in, d_offsets, d_sizes, d_out, out_stride, out_total,
