@@ -1257,16 +1257,22 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
         uint32_t zmin = 1;
 #pragma unroll
         for (uint32_t j = 0; j < R; ++j) {
-            const bool hit = (hitsc >> j) & 1u;
             const uint32_t qv = itemc[j];
             const uint32_t P = qv * kHashMul;
-            const uint32_t h = hit ? (qv & 0xffffu) : (P >> 16);                  // MAP: the item is the slot (chameleon.rs:64-68)
+            // MAP: the item is the slot (chameleon.rs:64-68); PLAIN: the upper half of the hash product — one select with a half-word pick per
+            // side; `em`: 0xffff for the lanes that write (PLAIN: chameleon.rs:56-61), 0 for those that only read (MAP)
+            uint32_t h, em;
+            asm("v_and_b32 %0, %4, %2\n\t"
+                "v_cmp_ne_u32 vcc, 0, %0\n\t"
+                "v_cndmask_b32_sdwa %0, %3, %5, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_0\n\t"
+                "v_cndmask_b32 %1, %6, 0, vcc"
+                : "=&v"(h), "=&v"(em) : "v"(hitsc), "v"(P), "n"(1u << j), "v"(qv), "v"(0xffffu) : "vcc");
             const uint32_t sh = (h & 1u) << 4;
-            const uint32_t e = stored_entry(qv, P);
+            const uint32_t e = stored_entry(qv, P) & em;                          // (0 for a MAP lane)
             ra[j] = (h >> 1) << 2;
-            mask[j] = hit ? 0u : (0xffffu << sh);                                 // PLAIN writes its entry (chameleon.rs:56-61), MAP only reads
-            val[j] = hit ? 0u : (e << sh);
-            const uint32_t ez = hit ? 1u : e;
+            mask[j] = em << sh;
+            val[j] = e << sh;
+            const uint32_t ez = e | (em ^ 0xffffu);                               // a PLAIN lane's entry; 0xffff for a MAP lane
             zmin = ez < zmin ? ez : zmin;
         }
         // A round that will MARK the zero-entry map (a PLAIN quad whose entry is 0: about four per 4 MiB of text) says so before its exchanges:
