@@ -524,7 +524,7 @@ int run_stream_encode_segmented(DeviceCtx* c, const uint8_t* d_in, size_t n, uin
 int run_stream_encode(DeviceCtx* c, int algo, const uint8_t* d_in, size_t n, uint8_t* d_out, size_t cap, uint8_t* ws, hipStream_t s,
                       size_t* size_out) {
     if (cap < safe_size(algo, n)) { set_error("output capacity below safe_encode_buffer_size()"); return DENSITY_HIP_ERR_CAPACITY; }
-    if (algo == DENSITY_HIP_CHAMELEON && n >= kSegMinStream && n < (1ull << 31) && (reinterpret_cast<uintptr_t>(d_in) & 3) == 0 && !(g_variant & 5) && !g_rotor_unsafe) {
+    if (algo == DENSITY_HIP_CHAMELEON && n >= kSegMinStream && n < (64ull << 30) && (reinterpret_cast<uintptr_t>(d_in) & 3) == 0 && !(g_variant & 5) && !g_rotor_unsafe) {   // (segments are at most 4 MiB: 32-bit positions inside them; 64 GiB = 16384 segments)
         *size_out = 0;
         return run_stream_encode_segmented(c, d_in, n, d_out, s, size_out);
     }
@@ -670,7 +670,7 @@ int run_stream_decode(DeviceCtx* c, int algo, const uint8_t* d_in, size_t n, uin
                       size_t* size_out) {
     *size_out = 0;
     if (n == 0) return DENSITY_HIP_OK;
-    if (algo == DENSITY_HIP_CHAMELEON && n >= kSegDecodeMin && n < (1ull << 31) && !(g_variant & 5) && !g_rotor_unsafe) {
+    if (algo == DENSITY_HIP_CHAMELEON && n >= kSegDecodeMin && n < (1ull << 32) && !(g_variant & 5) && !g_rotor_unsafe) {   // (the parse keeps 32-bit stream positions)
         bool handled = false;
         const int rc = run_stream_decode_segmented(c, d_in, n, d_out, cap, s, size_out, &handled);
         if (rc != DENSITY_HIP_OK || handled) return rc;

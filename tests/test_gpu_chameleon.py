@@ -507,3 +507,31 @@ def test_config2_full_size_strict_stream_is_the_reference_stream(kernel_variant)
     assert Chameleon.decode(out[:m2], hback) == n and np.array_equal(hback, host)
     s3 = _stream_stats()
     assert (s3[0] - s2[0], s3[2] - s2[2]) == (1, 1)
+
+
+def test_strict_stream_beyond_2_gib(kernel_variant):
+    """The reference takes any usize (codec/codec.rs:72-80): ONE stream of 3.5 GiB — the input above 2^31 bytes, and its stream too — is
+    still encoded and decoded in parallel segments, byte for byte the oracle's stream."""
+    if kernel_variant != "rotor":
+        pytest.skip("long streams belong to the default kernels")
+    import torch
+    n = (7 << 29) + 777
+    host = datagen.rep_text(n, period=1_000_003, seed=5)
+    cap = pyoracle.safe_encode_buffer_size(ALGO, n)
+    want = np.empty(cap, dtype=np.uint8)
+    m_want = pyoracle.encode_into(ALGO, host.ctypes.data, n, want.ctypes.data, cap)
+    assert m_want > (1 << 31)
+    x = torch.from_numpy(host).cuda()
+    enc = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+    s0 = _stream_stats()
+    m = container.stream_encode_device(ALGO, x.data_ptr(), n, enc.data_ptr(), cap)
+    s1 = _stream_stats()
+    assert m == m_want and s1[0] == s0[0] + 1
+    w = torch.from_numpy(want[:m_want]).cuda()
+    assert torch.equal(enc[:m], w)
+    del w
+    back = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    k = container.stream_decode_device(ALGO, enc.data_ptr(), m, back.data_ptr(), n)
+    s2 = _stream_stats()
+    assert k == n and torch.equal(back, x)
+    assert (s2[2] - s1[2], s2[3] - s1[3]) == (1, 0)
