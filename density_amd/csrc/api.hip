@@ -43,12 +43,19 @@ inline bool valid_algo(int algo) { return algo >= DENSITY_HIP_CHAMELEON && algo 
 // (every chunk start costs a table clear and a few in-order rounds): never above 4 MiB, the largest chunk the index-fed decoder takes.
 // Power of two: 10 MB -> 64 KiB (153 chunks), 100 MB -> 256 KiB (382), 256 MiB -> 1 MiB, >= 1 GiB -> 4 MiB.
 // Lion runs one WAVE per chunk stream and is bound by memory latency per stream, not by a CU's LDS: it wants eight streams per CU (2048)
-// and starts from 1 MiB.  Cheetah's decode passes (decode_passes.hip) walk one chunk per CU: the largest power of two up to 1 MiB that
-// still gives most CUs a chunk (160 chunks: 100 MB -> 512 KiB, ratio 1.73 where 64 KiB chunks gave 1.34, at the same round-trip time).
+// and starts from 1 MiB.  Cheetah's decode passes (decode_passes.hip) walk one chunk per CU, in time proportional to the chunk: one
+// chunk per CU exactly — the input over 256, up to whole 4 KiB trips of the encoder's passes — between 64 KiB and 1 MiB (100 MB -> 384 KiB:
+// ratio 1.67 where 64 KiB chunks gave 1.34, and a faster round trip).
 inline size_t auto_chunk(size_t n, int algo = DENSITY_HIP_CHAMELEON) {
+    if (algo == DENSITY_HIP_CHEETAH) {
+        size_t c = align_up((n + 255) / 256, 4096);
+        if (c < (64u << 10)) c = 64u << 10;
+        if (c > (1u << 20)) c = 1u << 20;
+        return c;
+    }
     const bool lds = algo == DENSITY_HIP_CHAMELEON;
     size_t c = lds ? (4u << 20) : (1u << 20);
-    const size_t streams = lds ? 256 : algo == DENSITY_HIP_CHEETAH ? 160 : 2048;
+    const size_t streams = lds ? 256 : 2048;
     while (c > (64u << 10) && n / c < streams) c >>= 1;
     return c;
 }

@@ -448,57 +448,55 @@ __global__ __launch_bounds__(64) void cheetah_walk(PassArgs a) {
             // predicted ONE ordered 16-bit store under an exec mask (each writes H[its context] = its hash, cheetah.rs:72,81,90; the first
             // one's context is the running one, patched into its lane), per predicted quad one LDS round trip (:97-102).
             // (v_writelane takes its lane from M0: an SGPR value and an SGPR lane select in one instruction break gfx9's one-scalar rule)
-            uint32_t addrv = lds0 + 2u * hprev;
+            // State in the loop: `c2` = LDS address of H[running context]; `av` = per lane the LDS address of H[its context] (2 * hash of the quad
+            // before it, patched where the context is the running one) — the store's address operand and, shifted back, the context to report.
+            uint32_t av = lds0 + 2u * hprev;
+            const uint32_t h2 = lds0 + 2u * h;                                      // what the running context becomes behind a quad that is not predicted
             uint64_t prem = P;
-            uint32_t s_pos, s_p, s_r, s_a, v_t;
+            uint32_t c2 = lds0 + 2u * c;
+            uint32_t s_pos, s_p, s_r, v_t;
             uint64_t s_m;
             asm volatile(
                 "s_mov_b32 %[pos], 0\n"
                 "1:\n\t"                                                             // ---- next run of quads that are not predicted: [pos, p)
                 "s_ff1_i32_b64 %[p], %[prem]\n\t"
-                "s_cmp_lt_i32 %[p], 0\n\t"
-                "s_cselect_b32 %[p], 64, %[p]\n\t"
+                "s_min_u32 %[p], %[p], 64\n\t"                                       // (no predicted quad left: -1 -> 64)
                 "s_sub_u32 %[r], %[p], %[pos]\n\t"
                 "s_cmp_eq_u32 %[r], 0\n\t"
                 "s_cbranch_scc1 2f\n\t"
                 "s_bfm_b64 %[m], %[r], %[pos]\n\t"                                   // r bits from pos on (r < 64: some quad is predicted)
-                "s_lshl_b32 %[a], %[c], 1\n\t"
-                "s_add_u32 %[a], %[a], %[lds0]\n\t"
                 "s_mov_b32 m0, %[pos]\n\t"
-                "s_nop 0\n\t"
-                "v_writelane_b32 %[addr], %[a], m0\n\t"
-                "v_writelane_b32 %[cv], %[c], m0\n\t"
-                "s_mov_b64 exec, %[m]\n\t"
-                "ds_write_b16 %[addr], %[h]\n\t"
-                "s_mov_b64 exec, -1\n\t"
                 "s_add_u32 %[r], %[p], -1\n\t"
-                "s_nop 0\n\t"
-                "v_readlane_b32 %[c], %[h], %[r]\n"
+                "v_writelane_b32 %[av], %[c2], m0\n\t"
+                "s_mov_b64 exec, %[m]\n\t"
+                "ds_write_b16 %[av], %[h]\n\t"
+                "s_mov_b64 exec, -1\n\t"
+                "v_readlane_b32 %[c2], %[h2], %[r]\n"
                 "2:\n\t"
                 "s_cmp_ge_u32 %[p], 64\n\t"
-                "s_cbranch_scc1 4f\n"
+                "s_cbranch_scc1 4f\n\t"
+                "v_mov_b32 %[t], %[c2]\n"
                 "3:\n\t"                                                             // ---- a predicted quad at lane p: c <- H[c]
-                "s_lshl_b32 %[a], %[c], 1\n\t"
-                "s_add_u32 %[a], %[a], %[lds0]\n\t"
                 "s_mov_b32 m0, %[p]\n\t"
-                "v_mov_b32 %[t], %[a]\n\t"
-                "v_writelane_b32 %[cv], %[c], m0\n\t"
                 "ds_read_u16 %[t], %[t]\n\t"
+                "v_writelane_b32 %[av], %[c2], m0\n\t"
                 "s_bitset0_b64 %[prem], %[p]\n\t"
                 "s_add_u32 %[p], %[p], 1\n\t"
                 "s_waitcnt lgkmcnt(0)\n\t"
-                "v_readfirstlane_b32 %[c], %[t]\n\t"
+                "v_lshl_add_u32 %[t], %[t], 1, %[lds0]\n\t"
                 "s_cmp_ge_u32 %[p], 64\n\t"
+                "v_readfirstlane_b32 %[c2], %[t]\n\t"
                 "s_cbranch_scc1 4f\n\t"
                 "s_bitcmp1_b64 %[prem], %[p]\n\t"
                 "s_cbranch_scc1 3b\n\t"
                 "s_mov_b32 %[pos], %[p]\n\t"
                 "s_branch 1b\n"
                 "4:\n\t"
-                : [addr] "+v"(addrv), [cv] "+v"(cv), [c] "+s"(c), [prem] "+s"(prem), [pos] "=&s"(s_pos), [p] "=&s"(s_p), [r] "=&s"(s_r), [a] "=&s"(s_a),
-                  [m] "=&s"(s_m), [t] "=&v"(v_t)
-                : [h] "v"(h), [lds0] "s"(lds0)
-                : "memory", "m0", "scc", "vcc");
+                : [av] "+v"(av), [c2] "+s"(c2), [prem] "+s"(prem), [pos] "=&s"(s_pos), [p] "=&s"(s_p), [r] "=&s"(s_r), [m] "=&s"(s_m), [t] "=&v"(v_t)
+                : [h] "v"(h), [h2] "v"(h2), [lds0] "s"(lds0)
+                : "memory", "m0", "scc");
+            c = (c2 - lds0) >> 1;
+            cv = (av - lds0) >> 1;
         } else {
             // a block with quads that take no part (a raw-copy block's, the chunk's end): the same, run by run, stepping over them — the
             // context passes through (codec.rs:89-91: a raw block touches no state)

@@ -120,9 +120,9 @@ typedef struct density_hip_header {
  * still gives every CU of the device a chunk (a chunk is one work-group; small chunks restart the dictionary and cost ratio, every
  * chunk start costs a table clear: 10 MB -> 64 KiB, 100 MB -> 256 KiB, 256 MiB -> 1 MiB, >= 1 GiB -> 4 MiB). */
 size_t density_hip_auto_chunk(size_t input_size);
-/* The same per algorithm, 64 KiB .. 1 MiB: Lion (one wave per chunk stream, memory-latency bound) takes the largest chunk that still gives
- * the device 2048 streams; Cheetah (decode passes: one chunk's chain of contexts per CU) the largest that gives it 160 chunks
- * (100 MB -> 512 KiB). */
+/* The same per algorithm, 64 KiB .. 1 MiB: Lion (one wave per chunk stream, memory-latency bound) takes the largest power of two that
+ * still gives the device 2048 streams; Cheetah (decode passes: one chunk's chain of contexts per CU, in time proportional to the chunk)
+ * one chunk per CU: the input over 256, rounded up to 4 KiB (100 MB -> 384 KiB). */
 size_t density_hip_auto_chunk_for(int algo, size_t input_size);
 
 /* Upper bound of the container size for `input_size` bytes (0 if the arguments are invalid). */
