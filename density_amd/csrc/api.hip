@@ -437,6 +437,7 @@ inline size_t seg_bytes_for(size_t n) {
 }
 int run_stream_encode_segmented(DeviceCtx* c, const uint8_t* d_in, size_t n, uint8_t* d_out, hipStream_t s, size_t* size_out) {
     // the first segment runs alone, ahead of everything else: a quarter of the others' length (whole rounds)
+    const bool trace = getenv("DENSITY_HIP_PROF") != nullptr;
     const size_t C = seg_bytes_for(n), C0 = ((C / 4) + 4095) & ~(size_t)4095, S = 1 + (n - C0 + C - 1) / C, stride = slot_stride(DENSITY_HIP_CHAMELEON, C), img = kSegImageBytes;
     auto seg_at = [&](size_t k) -> size_t { return k == 0 ? 0 : C0 + (k - 1) * C; };   // where segment k starts
     const size_t off_lw = align_up(S * stride, kAlign), off_start = off_lw + S * img, off_final = off_start + S * img, off_small = off_final + S * img;
@@ -499,7 +500,7 @@ int run_stream_encode_segmented(DeviceCtx* c, const uint8_t* d_in, size_t n, uin
         // segment first+1 started from the truth; k >= first+2 is final iff every segment first+1 .. k-1 coded all its blocks and k-1 ended calm
         size_t k = first + 2;
         while (k < S && h_raw[k - 1] == 0 && (h_gfinal[k - 1] & 0x7fffffffu) == 0) ++k;
-        if (getenv("DENSITY_HIP_PROF")) fprintf(stderr, "[density_hip prof] segmented stream encode: pass %d, %zu segments of %zu bytes, final up to segment %zu\n", pass, S, C, k);
+        if (trace) fprintf(stderr, "[density_hip prof] segmented stream encode: pass %d, %zu segments of %zu bytes, final up to segment %zu\n", pass, S, C, k);
         advanced = k - first;
         first = k;                                                                // (== S: done)
         ++g_stream_stats[1];

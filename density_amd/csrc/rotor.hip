@@ -1,8 +1,11 @@
 // rotor.hip — Chameleon wave-rotation kernels for gfx950 (MI355X): the default encode / index-fed decode path.
 //
-// One work-group of 16 wavefronts owns one chunk (= one independent reference stream, chameleon.rs:45-53) and its dictionary
-// (64 Ki exact 16-bit entries = 128 KiB of LDS, chameleon_dev.hpp).  The chunk is cut into ROUNDS of 8 blocks (2 KiB); wave w
-// takes the rounds r = w, w + 16, w + 32, ... and does EVERYTHING for its round itself, in registers: global loads, hashing,
+// One work-group of W wavefronts owns one chunk (= one independent reference stream, chameleon.rs:45-53) and its dictionary
+// (64 Ki exact 16-bit entries = 128 KiB of LDS, chameleon_dev.hpp).  The chunk is cut into ROUNDS of R blocks; the kernels are
+// templates <R, W> and what ships is R = 16 on W = 8 waves for the encoder (4 KiB rounds, 256 registers per wave: the quads of a
+// round stay in registers from the hash to the emit) and R = 12 on W = 12 for the decoder (the numbers 8 and 16 in the text
+// below are the original geometry, rounds of 8 on 16 waves, still selectable: DENSITY_HIP_TUNE).  Wave w
+// takes the rounds r = w, w + W, w + 2W, ... and does EVERYTHING for its round itself, in registers: global loads, hashing,
 // the dictionary step, signatures, the copy-mode FSM, record offsets, stores.  There are no staging rings and no per-round
 // work-group barrier.  What IS sequential in the reference — the dictionary (every quad sees the table its predecessors left,
 // chameleon.rs:88-100) and the running output position / ProtectionState (codec.rs:34-70) — is passed from round to round by

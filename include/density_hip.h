@@ -34,8 +34,11 @@ extern "C" {
  *    for decode (the stream does not carry its decoded length; codec/codec.rs:72-80).
  *
  *    These calls stage through device memory (H2D, kernels, D2H) on a per-device internal stream and are
- *    thread-safe.  One reference stream is one sequential dependency chain, so this entry point runs a single
- *    work-group; the data-parallel path is the container API of section 2.
+ *    thread-safe.  How one stream is spread over the device: chameleon_encode / _decode of a few MiB
+ *    and more in ~256 parallel segments; cheetah_encode / lion_encode of 64 / 192 KiB and more in passes of ordered LDS
+ *    exchanges, cheetah_decode of 64 KiB and more in decode passes (everything but its chain of contexts in parallel);
+ *    lion_decode and short streams on one wave or one work-group.  The data-parallel path proper is the container API
+ *    of section 2.
  * ---------------------------------------------------------------------------------------------------------- */
 
 /* algorithms/chameleon/chameleon.rs:70-73 */

@@ -66,6 +66,10 @@ with open(f"profiles/{tag}_lds_counters.txt", "w") as fh:
             fh.write(f"  -> per CU: LDS array busy {vals['SQ_LDS_IDX_ACTIVE'] / 256 / cyc:.1%} of the kernel's {cyc:.4g} cycles")
         fh.write("\n")
 shutil.copy(f"{src}/phase_profile.txt", f"profiles/{tag}_phase_profile.txt")
+for extra in ("packed", "cheetah"):
+    m = glob.glob(f"{src}/stats_{extra}/**/*_kernel_stats.csv", recursive=True)
+    if m:
+        shutil.copy(m[0], f"profiles/{tag}_{extra}_kernel_stats.csv")
 shutil.copy(f"{src}/bench.json", f"profiles/{tag}_bench.json")
 for row in csv.DictReader(open(stats)):
     if "density::" in row["Name"]:
