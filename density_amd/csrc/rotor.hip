@@ -1252,36 +1252,37 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
         // (Instruction count is this kernel's time: a wave whose iteration is longer than W hand-offs arrives late for its turn, and every
         // late arrival stalls the chain — six instructions per record less made the kernel 17 % faster.  Hence: the loop below treats every
         // record as coded and a rare branch behind it takes the raw-copy records' operands back (a chunk's cold start; incompressible
-        // data), and the rare zero-entry candidates are found by ONE running minimum instead of a bit per record.)
+        // data), and the rare zero-entry candidates cost one compare per record each way, their lanes collected in scalar registers.)
         const uint32_t coded_mask = ((1u << R) - 1u) & ~mc.copy_mask;             // records that go through the dictionary
         const uint32_t hit_mask = seg.lastwriters_only ? 0u : hitsc;              // MAP quads that are looked up (raw records have no hit bits: stage B)
-        // zmin == 0 afterwards: some lane of some record has a zero-entry CANDIDATE — a PLAIN quad whose stored entry is 0, or a MAP quad that
-        // read 0 — sorted out record by record in the rare path below
-        uint32_t zmin = 1;
+        // zplain: lanes with a zero-entry CANDIDATE that writes — a PLAIN quad whose stored entry is 0 (those that read 0: zm[] below)
+        uint64_t zplain = 0;
 #pragma unroll
         for (uint32_t j = 0; j < R; ++j) {
             const uint32_t qv = itemc[j];
             const uint32_t P = qv * kHashMul;
             // MAP: the item is the slot (chameleon.rs:64-68); PLAIN: the upper half of the hash product — one select with a half-word pick per
-            // side; `em`: 0xffff for the lanes that write (PLAIN: chameleon.rs:56-61), 0 for those that only read (MAP)
+            // side; `em`: 0xffff for the lanes that write (PLAIN: chameleon.rs:56-61), 0 for those that only read (MAP); `mm`: the MAP lanes
             uint32_t h, em;
-            asm("v_and_b32 %0, %4, %2\n\t"
+            uint64_t mm;
+            asm("v_and_b32 %0, %5, %3\n\t"
                 "v_cmp_ne_u32 vcc, 0, %0\n\t"
-                "v_cndmask_b32_sdwa %0, %3, %5, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_0\n\t"
-                "v_cndmask_b32 %1, %6, 0, vcc"
-                : "=&v"(h), "=&v"(em) : "v"(hitsc), "v"(P), "n"(1u << j), "v"(qv), "v"(0xffffu) : "vcc");
-            const uint32_t sh = (h & 1u) << 4;
-            const uint32_t e = stored_entry(qv, P) & em;                          // (0 for a MAP lane)
+                "v_cndmask_b32_sdwa %0, %4, %6, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_0\n\t"
+                "v_cndmask_b32 %1, %7, 0, vcc\n\t"
+                "s_mov_b64 %2, vcc"
+                : "=&v"(h), "=&v"(em), "=s"(mm) : "v"(hitsc), "v"(P), "n"(1u << j), "v"(qv), "v"(0xffffu) : "vcc");
+            const uint32_t sh = h << 4;                                           // (a shift takes the low five bits of its count: (h & 1) << 4)
+            // stored_entry(qv, P) for the lanes that write, 0 for a MAP lane (`em` is 0xffff or 0: the salt needs no mask of its own)
+            const uint32_t e = (((P & 0xfffeu) | (qv >> 31)) ^ __umul24(P >> 16, 0x9e5bu)) & em;
             ra[j] = (h >> 1) << 2;
             mask[j] = em << sh;
             val[j] = e << sh;
-            const uint32_t ez = e | (em ^ 0xffffu);                               // a PLAIN lane's entry; 0xffff for a MAP lane
-            zmin = ez < zmin ? ez : zmin;
+            zplain |= ballot64(e == 0) & ~mm;                                     // a PLAIN quad whose stored entry is 0 (one compare; the rest is scalar)
         }
         // A round that will MARK the zero-entry map (a PLAIN quad whose entry is 0: about four per 4 MiB of text) says so before its exchanges:
         // rounds behind it that only LOOK a slot up in the map (every recurrence of such a quad: one round in 25) then wait for nothing but
         // earlier rounds that have said so — almost never — instead of for every earlier round to finish.
-        const bool marks = ballot64(zmin == 0) != 0;
+        const bool marks = zplain != 0;
         if (__builtin_expect(marks, 0)) { if (lane == 0) lds_poke(sy + kSyZset + 4u * wave, x + 1u); }
         if (__builtin_expect(mc.copy_mask != 0, 0)) {
             // raw-copy records (codec.rs:89-91) touch no state: their lanes read a harmless conflict-free word instead
@@ -1316,21 +1317,24 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
         clk.stamp(x, 2, lane);
 
         // ---- what each slot holds at this lane's turn -> quads (in place of the answers) ----
+        // (a MAP quad that read 0 — never written, or a genuine zero entry? — is a lane of zm[j]: the compare costs what the running minimum
+        // it replaces cost, its answer lands in scalar registers, and the rare path below knows record and lanes without working them out again)
+        uint64_t zm[R], zany = 0;
 #pragma unroll
         for (uint32_t j = 0; j < R; ++j) {
             const bool maps = (hit_mask >> j) & 1u;
             const uint32_t h = itemc[j] & 0xffffu;
-            const uint32_t cur = (ra[j] >> ((h & 1u) << 4)) & 0xffffu;
-            const uint32_t cz = maps ? cur : 1u;                                  // MAP of a slot holding 0: never written, or a genuine zero entry?
-            zmin = cz < zmin ? cz : zmin;
-            uint32_t mq = entry_to_quad(h, cur);                                  // (for every lane, then one select: cheaper than an exec mask around it)
-            asm volatile("" : "+v"(mq));
-            ra[j] = maps ? mq : itemc[j];
+            const uint32_t cur = __builtin_amdgcn_ubfe(ra[j], itemc[j] << 4, 16);  // the slot's half of the word ((h & 1) << 4: a bit-field offset is five bits)
+            const uint64_t mm = ballot64(maps);                                   // the MAP lanes as a lane mask: for the select below and, in scalar registers, for
+            zm[j] = ballot64(cur == 0) & mm;                                      // "MAP of a slot holding 0": never written, or a genuine zero entry?
+            zany |= zm[j];
+            const uint32_t mq = entry_to_quad(h, cur);                            // (for every lane, then one select: cheaper than an exec mask around it)
+            asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(ra[j]) : "v"(itemc[j]), "v"(mq), "s"(mm));
         }
         clk.mark(5);
         // ---- zero-entry map, in stream order (rare: stored entries are salted).  A round with no such quad only reports "done"; one that
         // has any first waits until every earlier round has reported (wave w' owns the rounds = w' mod W). ----
-        if (__builtin_expect(ballot64(zmin == 0) != 0, 0)) {
+        if (__builtin_expect(marks || zany != 0, 0)) {
             clk.note(x, 1, lane);
             for (uint32_t spins = 0;;) {
                 const uint32_t wv = lane % W;
@@ -1347,8 +1351,21 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
                 if (rfl(lds_peek1(sy + kSyD)) == kPoison) wave_exit();
                 watchdog(spins, sy, err, lane);
             }
-            // which records have such a quad — from what is still in registers, a few instructions per record (about one round in 25 comes
-            // here on repetitive text: every recurrence of a quad whose entry is 0 does) — then those records one by one, usually one
+            if (kZmapLds && !marks) {
+                // Look-ups only (about one round in 25 on repetitive text: every recurrence of a quad whose entry is 0): nothing in this round
+                // changes the map, so its look-ups need no order among themselves — all lanes of a record at once, usually one lane of one record
+#pragma unroll
+                for (uint32_t j = 0; j < R; ++j) {
+                    if (zm[j] != 0) {
+                        const uint32_t h = itemc[j] & 0xffffu;
+                        const bool t = ((zm[j] >> lane) & 1u) && h != 0;          // (slot 0: "never written" and its zero entry both stand for the zero quad)
+                        uint32_t bit = 1;
+                        if (t) bit = zmap.test(h);
+                        ra[j] = (t && !bit) ? 0u : ra[j];                         // chameleon.rs:64-68 on a never-written (zero) word
+                    }
+                }
+            } else {
+            // which records have such a quad — from what is still in registers, a few instructions per record — then those records one by one, usually one
             uint32_t zblocks = 0;
 #pragma unroll
             for (uint32_t j = 0; j < R; ++j) {
@@ -1383,6 +1400,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
                     asm volatile("" : "+s"(jj));                                  // (opaque, as in pick)
                     ra[k] = jj == k ? out : ra[k];
                 }
+            }
             }
         }
         if (lane == 0) {
@@ -1634,9 +1652,10 @@ hipError_t launch_rotor_decode(const uint8_t* d_in, const uint64_t* d_offsets, c
     // geometry (DENSITY_HIP_TUNE bits 5..7): 0 = default = rounds of 12 records on 12 waves (168 registers each: the longest round that does
     // not spill, i.e. the shortest chain per record), 1 = 8 records on 16 waves
     const uint32_t sel = (rot_tune() >> 5) & 7u;                                 // 2: rounds of 16 records on 12 waves
-    const uint32_t waves = sel == 1 ? 16 : 12;
+    const uint32_t waves = sel == 1 || sel == 3 ? 16 : 12;                       // 3: rounds of 12 records on 16 waves
     auto kernel = sel == 1 ? (prof ? chameleon_decode_rot<8, 16, true> : chameleon_decode_rot<8, 16, false>)
                 : sel == 2 ? (prof ? chameleon_decode_rot<16, 12, true> : chameleon_decode_rot<16, 12, false>)
+                : sel == 3 ? (prof ? chameleon_decode_rot<12, 16, true> : chameleon_decode_rot<12, 16, false>)
                            : (prof ? chameleon_decode_rot<12, 12, true> : chameleon_decode_rot<12, 12, false>);
     const uint32_t lds = sel == 1 ? dec_lds_bytes(8) : sel == 2 ? dec_lds_bytes(16) : dec_lds_bytes(12);
     hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

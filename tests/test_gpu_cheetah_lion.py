@@ -118,13 +118,39 @@ def test_errors_are_reported(algo):
         C.decode(enc, np.zeros(100, dtype=np.uint8))
     with pytest.raises(EncodeError):
         C.encode(datagen.random_bytes(3000, 1), np.zeros(100, dtype=np.uint8))
-    out = np.zeros(3000, dtype=np.uint8)
-    for cut in (1, 2, 5, 9, 100):
-        try:
-            m = C.decode(enc[:-cut], out)
-            assert out[:m].tobytes() != data.tobytes()
-        except DecodeError:
-            pass
+    # a truncated stream ends exactly like the oracle's decode of it: the same bytes, or an error where the oracle returns 0
+    # (the reference panics there: io/read_buffer.rs:22)
+    wrong = []
+    for kind, n in (("prose", 3000), ("mixed", 70_000), ("random", 5000)):
+        data = datagen.by_kind(kind, n, seed=41)
+        enc = pyoracle.encode(algo, data)
+        out = np.zeros(n, dtype=np.uint8)
+        for cut in (1, 2, 3, 5, 9, 100, 257, 1000):
+            want = pyoracle.decode(algo, enc[:-cut], n)
+            try:
+                m = C.decode(enc[:-cut], out)
+                got = out[:m].tobytes()
+            except DecodeError:
+                got = b""
+            if got != want:
+                wrong.append((kind, cut, len(got), len(want)))
+    assert not wrong, wrong
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("kind", ["prose", "rep", "random", "zeros", "samehash", "binaryish"])
+def test_container_chunks_match_oracle_by_kind(algo, kind):
+    chunk = 65536
+    n = 5 * chunk + 4321
+    data = datagen.by_kind(kind, n, seed=7)
+    cont = np.zeros(container.container_bound(algo, n, chunk), dtype=np.uint8)
+    cn = container.encode(algo, data, cont, chunk)
+    hdr, payloads = container.chunk_payloads(cont[:cn])
+    for i, p in enumerate(payloads):
+        assert p == pyoracle.encode(algo, data[i * chunk:(i + 1) * chunk]), (kind, i)
+    back = np.zeros(n, dtype=np.uint8)
+    assert container.decode(cont[:cn], back) == n
+    assert np.array_equal(back, data)
 
 
 _PROSE_100M = {}
