@@ -576,7 +576,6 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
     // The records of a round without raw blocks, straight-line: the signatures and the index bytes leave from lanes 0..R-1 in one
     // store each (lane j: record j, offsets by a DPP prefix over the record lengths); per block the MAP lanes store the 2-byte slot
     // index (the upper half of the hash product), the PLAIN lanes the quad, through an SGPR base (io/write_buffer.rs:13-27).
-    const uint32_t c_base = kSig + 2u * lane;
     auto emit_round_coded = [&](uint32_t pos0, uint8_t* idxp, uint32_t slo, uint32_t shi) {
         const uint32_t nhv = (uint32_t)(__builtin_popcount(slo) + __builtin_popcount(shi));
         const uint32_t lenv = kSig + kBlock - 2u * nhv;
@@ -590,20 +589,21 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
             *reinterpret_cast<u32x2_u*>(dst + posv) = u32x2{slo, shi};                             // codec.rs:24-26
             if (idxp) idxp[lane] = (uint8_t)nhv;
         }
+        const uint32_t itemsv = posv + kSig;                                                      // lane j: where record j's items start
 #pragma unroll
         for (uint32_t j = 0; j < R; ++j) {
-            const uint64_t sg = ((uint64_t)rlane_u(shi, (int)j) << 32) | rlane_u(slo, (int)j);
-            const uint64_t plain = ~sg;
-            const uint32_t pos = rlane_u(posv, (int)j);                           // (one read instead of a scalar running sum: popcount, shift, subtract, add)
-            const uint32_t off = pos + c_base + 2u * mbcnt64(plain);              // 8 + 2*lane + 2*(PLAIN lanes below) = 8 + 4*lane - 2*(MAP lanes below)
+            const uint64_t plain = ~(((uint64_t)rlane_u(shi, (int)j) << 32) | rlane_u(slo, (int)j));
+            const uint32_t pos = rlane_u(itemsv, (int)j);                         // (one read instead of a scalar running sum: popcount, shift, subtract, add)
+            // 2 * (lane + PLAIN lanes below) = 4*lane - 2*(MAP lanes below): the count seeded with the lane, doubled and added in one instruction
+            const uint32_t off = pos + 2u * __builtin_amdgcn_mbcnt_hi((uint32_t)(plain >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)plain, lane));
             const uint32_t P = kKeepHash ? hp[j] : q[j] * kHashMul;               // (the hash is the MAP item: chameleon.rs:92)
             asm volatile(
                 "s_mov_b64 exec, %4\n\t"
-                "global_store_short_d16_hi %0, %1, %3\n\t"
-                "s_mov_b64 exec, %5\n\t"
                 "global_store_dword %0, %2, %3\n\t"
+                "s_not_b64 exec, exec\n\t"
+                "global_store_short_d16_hi %0, %1, %3\n\t"
                 "s_mov_b64 exec, -1"
-                ::"v"(off), "v"(P), "v"(q[j]), "s"(dst), "s"(sg), "s"(plain) : "memory");
+                ::"v"(off), "v"(P), "v"(q[j]), "s"(dst), "s"(plain) : "memory", "scc");
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -711,18 +711,43 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
                 // EARLY: the next round's quads are asked for HERE, a signature pass and a commit wait earlier than behind the commit (their
                 // latency under load is of the order of a whole emit); once per round, whatever becomes of it (an abort re-enters the loop)
                 if (EARLY && kKeepQuads && !prefetched && r + W < nrounds) { prefetch_quads<R, W>(src + (uint64_t)(r + W) * (R * kBlock) + 4u * lane); prefetched = true; }
-                uint32_t hits = 0;
-#pragma unroll
-                for (uint32_t j = 0; j < R; ++j) {
-                    const uint64_t sg = ballot64(((ra[j] ^ val[j]) & mask[j]) == 0);   // chameleon.rs:90-99: MAP flag = 1 iff the slot held this quad
-                    // (gfx950: an SGPR written by a VALU instruction — the compare — needs 2 wait states before a VALU instruction reads it;
-                    // the compiler inserts them for its own code, not inside an asm statement)
-                    asm("s_nop 1\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4" : "+v"(slo), "+v"(shi) : "s"((uint32_t)sg), "s"((uint32_t)(sg >> 32)), "n"(j));
-                    hits += (uint32_t)__builtin_popcountll(sg);
+                // The signatures (chameleon.rs:90-99: MAP flag = 1 iff the slot held this quad), block j's into lane j of slo / shi.  gfx950: an SGPR
+                // written by a VALU instruction — the compare — needs 2 wait states before a VALU instruction — the lane write — reads it, which the
+                // compiler sees to in its own code but not inside an asm statement: so block j's two lane writes go out behind block j + 1's compare
+                // (and block j's own: three instructions in between), four instructions per block with no idle one.
+                uint64_t sgp;
+                {
+                    const uint32_t x0 = (ra[0] ^ val[0]) & mask[0];
+                    asm volatile("v_cmp_eq_u32_e64 %0, 0, %1" : "=s"(sgp) : "v"(x0));
                 }
-                // everything the commit needs that does not depend on the token: incompressible records (codec.rs:68: 8 + 256 - 2*hits >= 256)
-                uint32_t inc = (uint32_t)ballot64(lane < R && (uint32_t)(__builtin_popcount(slo) + __builtin_popcount(shi)) <= 4u);
-                uint32_t sum = R * (kSig + kBlock) - 2u * hits;
+#pragma unroll
+                for (uint32_t j = 1; j < R; ++j) {
+                    const uint32_t xj = (ra[j] ^ val[j]) & mask[j];
+                    uint64_t sgn;
+                    if (j == 1) {                                                 // (block 0's compare has no lane writes behind it: one idle state)
+                        asm volatile("v_cmp_eq_u32_e64 %2, 0, %3\n\ts_nop 0\n\tv_writelane_b32 %0, %4, %6\n\tv_writelane_b32 %1, %5, %6"
+                                     : "+v"(slo), "+v"(shi), "=&s"(sgn) : "v"(xj), "s"((uint32_t)sgp), "s"((uint32_t)(sgp >> 32)), "n"(0));
+                    } else {
+                        asm volatile("v_cmp_eq_u32_e64 %2, 0, %3\n\tv_writelane_b32 %0, %4, %6\n\tv_writelane_b32 %1, %5, %6"
+                                     : "+v"(slo), "+v"(shi), "=&s"(sgn) : "v"(xj), "s"((uint32_t)sgp), "s"((uint32_t)(sgp >> 32)), "n"(j - 1));
+                    }
+                    sgp = sgn;
+                }
+                asm volatile("s_nop 1\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4" : "+v"(slo), "+v"(shi) : "s"((uint32_t)sgp), "s"((uint32_t)(sgp >> 32)), "n"(R - 1));
+                // everything the commit needs that does not depend on the token: incompressible records (codec.rs:68: 8 + 256 - 2*hits >= 256) and the
+                // bytes of the round — a sum over the lanes' record lengths instead of a scalar count and add per block
+                const uint32_t nhv = (uint32_t)(__builtin_popcount(slo) + __builtin_popcount(shi));
+                uint32_t inc = (uint32_t)ballot64(lane < R && nhv <= 4u);
+                uint32_t sum;
+                {
+                    uint32_t acc = kSig + kBlock - 2u * nhv;                                              // (lanes >= R hold no signature: their slo / shi are 0, and they are not summed)
+                    acc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc, 0x111, 0xf, 0xf, true);     // row_shr:1
+                    acc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc, 0x112, 0xf, 0xf, true);     // row_shr:2
+                    acc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc, 0x114, 0xf, 0xf, true);     // row_shr:4
+                    if (R > 8) acc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc, 0x118, 0xf, 0xf, true);   // row_shr:8
+                    sum = rlane_u(acc, (int)R - 1);
+                }
+                uint32_t hits = 0;                                                                        // (only the rare zero-entry path below wants the count itself)
                 asm volatile("" : "+s"(inc), "+s"(sum));                        // computed HERE: left to itself the compiler sinks both — and the 16 signatures they need — below the token wait, into the commit
                 if (!kKeepQuads) load_round(q, r);                        // the quads again (from L2): not kept across the wait for the token
                 clk.mark(3);
@@ -745,6 +770,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
                 uint32_t flipped = 0;
                 if (__builtin_expect(zero_round, 0)) {
                     clk.note(r, 1, lane);
+                    hits = (R * (kSig + kBlock) - sum) >> 1;
                     bool first = true;
                     for (uint32_t zb = zblocks; zb; zb &= zb - 1u, first = false) {
                         const uint32_t j = (uint32_t)__builtin_ctz(zb);
@@ -1300,12 +1326,20 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
         clk.stamp(x, 0, lane);
         __builtin_amdgcn_s_setprio(2);
         // ---- D chain ----
-        for (uint32_t spins = 0;;) {
-            if (poll_word(sy + kSyD, x, 16)) break;
+        // (Every poll is an LDS instruction in the queue the token holder's exchanges go through.  A wave two or more turns away sleeps for most
+        // of the hand-offs still to come — one takes 600 cycles and more —, the next in line polls; when it has SEEN the token reach its
+        // predecessor it sleeps through the first part of that critical section too.)
+        for (uint32_t spins = 0, seen = ~0u;;) {
             const uint32_t D = rfl(lds_peek1(sy + kSyD));
             if (D == x) break;
             if (D == kPoison) wave_exit();
-            backoff(x - D);
+            const uint32_t dist = x - D;
+            if (dist >= 2) { for (uint32_t k = 1; k < dist && k < 6; ++k) __builtin_amdgcn_s_sleep(5); }   // 320 cycles per hand-off to come
+            else {
+                if (seen != ~0u && seen != D) __builtin_amdgcn_s_sleep(3);        // 192 cycles of a critical section of 450 and more
+                if (poll_word(sy + kSyD, x, 8)) break;
+            }
+            seen = D;
             watchdog(spins, sy, err, lane);
         }
         clk.mark(3);
