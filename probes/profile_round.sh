@@ -9,12 +9,12 @@ mkdir -p $R/$OUT
 cd $R
 B="python bench.py --no-cpu --no-sweep --no-extra"
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/stats -- $B --steps 5 --warmup 1 > $R/$OUT/bench_stats.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/$OUT/fetch -- $B --steps 2 --warmup 1 > $R/$OUT/bench_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/$OUT/write -- $B --steps 2 --warmup 1 > $R/$OUT/bench_write.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/$OUT/fetch -- $B --settle-ms 0 --steps 2 --warmup 1 > $R/$OUT/bench_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/$OUT/write -- $B --settle-ms 0 --steps 2 --warmup 1 > $R/$OUT/bench_write.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/$OUT/calib_fetch -- ./probes/fetch_calib > $R/$OUT/calib_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/$OUT/calib_write -- ./probes/fetch_calib > $R/$OUT/calib_write.log 2>&1
-rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_ATOMIC_RETURN SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $R/$OUT/lds -- $B --steps 2 --warmup 1 > $R/$OUT/bench_lds.log 2>&1
-DENSITY_HIP_PROF=1 $B --steps 1 --warmup 1 > $R/$OUT/phase_profile.json 2> $R/$OUT/phase_profile.txt
+rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_ATOMIC_RETURN SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $R/$OUT/lds -- $B --settle-ms 0 --steps 2 --warmup 1 > $R/$OUT/bench_lds.log 2>&1
+DENSITY_HIP_PROF=1 $B --settle-ms 0 --steps 1 --warmup 1 > $R/$OUT/phase_profile.json 2> $R/$OUT/phase_profile.txt
 python bench.py --steps 10 --warmup 3 --no-extra > $R/$OUT/bench.json 2>/dev/null
 # the packed container (with the stitch pass) and Cheetah at its automatic chunk, kernel by kernel
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/stats_packed -- $B --packed --steps 5 --warmup 1 > $R/$OUT/bench_stats_packed.log 2>&1
