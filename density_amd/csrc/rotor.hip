@@ -590,20 +590,47 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
             if (idxp) idxp[lane] = (uint8_t)nhv;
         }
         const uint32_t itemsv = posv + kSig;                                                      // lane j: where record j's items start
+        // ONE store per record: every lane writes four bytes at its item's place — a PLAIN lane its quad, a MAP lane its 16-bit hash and, behind
+        // it, the two bytes that FOLLOW its item in the stream: the first two of the next lane's item, or (lane 63) of the next record's
+        // signature.  Neighbours then write the same bytes twice, with the same values.  (A second, 2-byte store for the MAP lanes cost the
+        // texture path as much as the first: the encoder was 13 % faster without it.)  Only the round's last record, whose successor is
+        // another wave's, keeps two masked stores.
 #pragma unroll
         for (uint32_t j = 0; j < R; ++j) {
-            const uint64_t plain = ~(((uint64_t)rlane_u(shi, (int)j) << 32) | rlane_u(slo, (int)j));
+            const uint64_t sg = ((uint64_t)rlane_u(shi, (int)j) << 32) | rlane_u(slo, (int)j);
+            const uint64_t plain = ~sg;
             const uint32_t pos = rlane_u(itemsv, (int)j);                         // (one read instead of a scalar running sum: popcount, shift, subtract, add)
-            // 2 * (lane + PLAIN lanes below) = 4*lane - 2*(MAP lanes below): the count seeded with the lane, doubled and added in one instruction
-            const uint32_t off = pos + 2u * __builtin_amdgcn_mbcnt_hi((uint32_t)(plain >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)plain, lane));
+            // the item's place: 2 * (lane + PLAIN lanes below) = 4*lane - 2*(MAP lanes below) from the record's items on — the count seeded with
+            // the lane, doubled and added in one instruction
             const uint32_t P = kKeepHash ? hp[j] : q[j] * kHashMul;               // (the hash is the MAP item: chameleon.rs:92)
-            asm volatile(
-                "s_mov_b64 exec, %4\n\t"
-                "global_store_dword %0, %2, %3\n\t"
-                "s_not_b64 exec, exec\n\t"
-                "global_store_short_d16_hi %0, %1, %3\n\t"
-                "s_mov_b64 exec, -1"
-                ::"v"(off), "v"(P), "v"(q[j]), "s"(dst), "s"(plain) : "memory", "scc");
+            if (j + 1 < R) {
+                const uint32_t nsig = rlane_u(slo, (int)j + 1);                    // the next record's first bytes: its signature's low word
+                uint32_t val, off;
+                asm volatile(
+                    "s_mov_b64 vcc, %[sg]\n\t"
+                    "v_cndmask_b32_sdwa %[v], %[q], %[P], vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1\n\t"   // an item's first two bytes: MAP the hash, PLAIN the quad's low half
+                    "v_mbcnt_lo_u32_b32 %[o], %[pl], %[ln]\n\t"
+                    "v_mbcnt_hi_u32_b32 %[o], %[ph], %[o]\n\t"                        // (two instructions between the select and the lane shift that reads it: the wait states a DPP source needs)
+                    "v_mov_b32_dpp %[v], %[v] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"   // ... of the NEXT lane's item (lane 63: replaced below)
+                    "v_lshl_add_u32 %[o], %[o], 1, %[pos]\n\t"
+                    "v_writelane_b32 %[v], %[ns], 63\n\t"
+                    "v_perm_b32 %[v], %[v], %[P], %[sel]\n\t"                         // hash | following bytes << 16
+                    "v_cndmask_b32 %[v], %[q], %[v], vcc\n\t"                         // PLAIN lanes: the quad
+                    "global_store_dword %[o], %[v], %[dst]"
+                    : [v] "=&v"(val), [o] "=&v"(off)
+                    : [P] "v"(P), [q] "v"(q[j]), [sg] "s"(sg), [pl] "s"((uint32_t)plain), [ph] "s"((uint32_t)(plain >> 32)), [ln] "v"(lane), [pos] "s"(pos),
+                      [ns] "s"(nsig), [sel] "s"(0x05040302u), [dst] "s"(dst)
+                    : "memory", "vcc");
+            } else {
+                const uint32_t off = pos + 2u * __builtin_amdgcn_mbcnt_hi((uint32_t)(plain >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)plain, lane));
+                asm volatile(
+                    "s_mov_b64 exec, %4\n\t"
+                    "global_store_dword %0, %2, %3\n\t"
+                    "s_not_b64 exec, exec\n\t"
+                    "global_store_short_d16_hi %0, %1, %3\n\t"
+                    "s_mov_b64 exec, -1"
+                    ::"v"(off), "v"(P), "v"(q[j]), "s"(dst), "s"(plain) : "memory", "scc");
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
