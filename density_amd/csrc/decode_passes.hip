@@ -42,7 +42,7 @@ namespace {
 
 constexpr uint32_t kRecBytes = 128, kRecQuads = 32, kSigBytes = 8;        // cheetah.rs:188-196
 constexpr uint32_t kRaw = 0x80000000u;                                    // rec[]: the block is a raw copy (codec.rs:89-91)
-constexpr uint32_t kFlagPlain = 0, kFlagMapA = 1, kFlagMapB = 2, kFlagPred = 3;   // cheetah.rs:17-23
+constexpr uint32_t kFlagPlain = 0, kFlagMapA = 1, kFlagPred = 3;                      // (2: MAP_B)   // cheetah.rs:17-23
 // descriptor of a quad: slot [0,16) | flag [16,18) | order bit it meets [18] | takes no part (raw block, beyond the end) [19]
 constexpr uint32_t kDescO = 1u << 18, kDescNone = 1u << 19;
 constexpr uint32_t kErrFormat = 1u, kErrWatchdog = 16u;

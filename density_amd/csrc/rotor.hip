@@ -159,28 +159,6 @@ __device__ __forceinline__ void exchange_round(uint32_t (&ret)[kR], const uint32
     ""
 #define DENSITY_ROT_X16_OPS : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(ra[4]), "+v"(ra[5]), "+v"(ra[6]), "+v"(ra[7]), "+v"(ra[8]), "+v"(ra[9]), "+v"(ra[10]), "+v"(ra[11]), "+v"(ra[12]), "+v"(ra[13]), "+v"(ra[14]), "+v"(ra[15]) \
     : "v"(mask[0]), "v"(mask[1]), "v"(mask[2]), "v"(mask[3]), "v"(mask[4]), "v"(mask[5]), "v"(mask[6]), "v"(mask[7]), "v"(mask[8]), "v"(mask[9]), "v"(mask[10]), "v"(mask[11]), "v"(mask[12]), "v"(mask[13]), "v"(mask[14]), "v"(mask[15]), "v"(val[0]), "v"(val[1]), "v"(val[2]), "v"(val[3]), "v"(val[4]), "v"(val[5]), "v"(val[6]), "v"(val[7]), "v"(val[8]), "v"(val[9]), "v"(val[10]), "v"(val[11]), "v"(val[12]), "v"(val[13]), "v"(val[14]), "v"(val[15]), "v"(tokaddr), "v"(tokval) : "memory"
-#define DENSITY_ROT_PF8 \
-    "global_load_dword v248, %0, off offset:0\n\t" \
-    "global_load_dword v249, %0, off offset:256\n\t" \
-    "global_load_dword v250, %0, off offset:512\n\t" \
-    "global_load_dword v251, %0, off offset:768\n\t" \
-    "global_load_dword v252, %0, off offset:1024\n\t" \
-    "global_load_dword v253, %0, off offset:1280\n\t" \
-    "global_load_dword v254, %0, off offset:1536\n\t" \
-    "global_load_dword v255, %0, off offset:1792\n\t" \
-    ""
-#define DENSITY_ROT_MV8 \
-    "v_mov_b32 %0, v248\n\t" \
-    "v_mov_b32 %1, v249\n\t" \
-    "v_mov_b32 %2, v250\n\t" \
-    "v_mov_b32 %3, v251\n\t" \
-    "v_mov_b32 %4, v252\n\t" \
-    "v_mov_b32 %5, v253\n\t" \
-    "v_mov_b32 %6, v254\n\t" \
-    "v_mov_b32 %7, v255\n\t" \
-    ""
-#define DENSITY_ROT_MV8_OUTS "=v"(q[0]), "=v"(q[1]), "=v"(q[2]), "=v"(q[3]), "=v"(q[4]), "=v"(q[5]), "=v"(q[6]), "=v"(q[7])
-#define DENSITY_ROT_STAGE8 "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255"
 #define DENSITY_ROT_PF16 \
     "global_load_dword v240, %0, off offset:0\n\t" \
     "global_load_dword v241, %0, off offset:256\n\t" \
@@ -221,74 +199,6 @@ __device__ __forceinline__ void exchange_round(uint32_t (&ret)[kR], const uint32
 #define DENSITY_ROT_STAGE16 "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255"
 
 // the same for the 12-wave kernels (168 registers a wave): staging in v(168-R)..v167
-#define DENSITY_ROT_PF12W12 \
-    "global_load_dword v156, %0, off offset:0\n\t" \
-    "global_load_dword v157, %0, off offset:256\n\t" \
-    "global_load_dword v158, %0, off offset:512\n\t" \
-    "global_load_dword v159, %0, off offset:768\n\t" \
-    "global_load_dword v160, %0, off offset:1024\n\t" \
-    "global_load_dword v161, %0, off offset:1280\n\t" \
-    "global_load_dword v162, %0, off offset:1536\n\t" \
-    "global_load_dword v163, %0, off offset:1792\n\t" \
-    "global_load_dword v164, %0, off offset:2048\n\t" \
-    "global_load_dword v165, %0, off offset:2304\n\t" \
-    "global_load_dword v166, %0, off offset:2560\n\t" \
-    "global_load_dword v167, %0, off offset:2816\n\t" \
-    ""
-#define DENSITY_ROT_MV12W12 \
-    "v_mov_b32 %0, v156\n\t" \
-    "v_mov_b32 %1, v157\n\t" \
-    "v_mov_b32 %2, v158\n\t" \
-    "v_mov_b32 %3, v159\n\t" \
-    "v_mov_b32 %4, v160\n\t" \
-    "v_mov_b32 %5, v161\n\t" \
-    "v_mov_b32 %6, v162\n\t" \
-    "v_mov_b32 %7, v163\n\t" \
-    "v_mov_b32 %8, v164\n\t" \
-    "v_mov_b32 %9, v165\n\t" \
-    "v_mov_b32 %10, v166\n\t" \
-    "v_mov_b32 %11, v167\n\t" \
-    ""
-#define DENSITY_ROT_MV12W12_OUTS "=v"(q[0]), "=v"(q[1]), "=v"(q[2]), "=v"(q[3]), "=v"(q[4]), "=v"(q[5]), "=v"(q[6]), "=v"(q[7]), "=v"(q[8]), "=v"(q[9]), "=v"(q[10]), "=v"(q[11])
-#define DENSITY_ROT_STAGE12W12 "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167"
-#define DENSITY_ROT_PF16W12 \
-    "global_load_dword v152, %0, off offset:0\n\t" \
-    "global_load_dword v153, %0, off offset:256\n\t" \
-    "global_load_dword v154, %0, off offset:512\n\t" \
-    "global_load_dword v155, %0, off offset:768\n\t" \
-    "global_load_dword v156, %0, off offset:1024\n\t" \
-    "global_load_dword v157, %0, off offset:1280\n\t" \
-    "global_load_dword v158, %0, off offset:1536\n\t" \
-    "global_load_dword v159, %0, off offset:1792\n\t" \
-    "global_load_dword v160, %0, off offset:2048\n\t" \
-    "global_load_dword v161, %0, off offset:2304\n\t" \
-    "global_load_dword v162, %0, off offset:2560\n\t" \
-    "global_load_dword v163, %0, off offset:2816\n\t" \
-    "global_load_dword v164, %0, off offset:3072\n\t" \
-    "global_load_dword v165, %0, off offset:3328\n\t" \
-    "global_load_dword v166, %0, off offset:3584\n\t" \
-    "global_load_dword v167, %0, off offset:3840\n\t" \
-    ""
-#define DENSITY_ROT_MV16W12 \
-    "v_mov_b32 %0, v152\n\t" \
-    "v_mov_b32 %1, v153\n\t" \
-    "v_mov_b32 %2, v154\n\t" \
-    "v_mov_b32 %3, v155\n\t" \
-    "v_mov_b32 %4, v156\n\t" \
-    "v_mov_b32 %5, v157\n\t" \
-    "v_mov_b32 %6, v158\n\t" \
-    "v_mov_b32 %7, v159\n\t" \
-    "v_mov_b32 %8, v160\n\t" \
-    "v_mov_b32 %9, v161\n\t" \
-    "v_mov_b32 %10, v162\n\t" \
-    "v_mov_b32 %11, v163\n\t" \
-    "v_mov_b32 %12, v164\n\t" \
-    "v_mov_b32 %13, v165\n\t" \
-    "v_mov_b32 %14, v166\n\t" \
-    "v_mov_b32 %15, v167\n\t" \
-    ""
-#define DENSITY_ROT_MV16W12_OUTS "=v"(q[0]), "=v"(q[1]), "=v"(q[2]), "=v"(q[3]), "=v"(q[4]), "=v"(q[5]), "=v"(q[6]), "=v"(q[7]), "=v"(q[8]), "=v"(q[9]), "=v"(q[10]), "=v"(q[11]), "=v"(q[12]), "=v"(q[13]), "=v"(q[14]), "=v"(q[15])
-#define DENSITY_ROT_STAGE16W12 "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167"
 
 // element j (wave-uniform, not a compile-time constant) of a register array, for the rolled loops of the rare paths: a chain of
 // selects, so the array stays in registers (a dynamically indexed copy would live in scratch memory, and the compiler's waits for
@@ -312,46 +222,15 @@ __device__ __forceinline__ uint32_t pick(const uint32_t (&a)[R], uint32_t j) {
 // `quads_landed` waits — every load is older than the `kYounger` memory operations the
 // caller guarantees to have issued since (vmcnt counts a wave's loads and stores in order) — and reads them into `q`.
 template <int R, int W>
-__device__ __forceinline__ void prefetch_quads(const uint8_t* p);
-template <>
-__device__ __forceinline__ void prefetch_quads<8, 8>(const uint8_t* p) { asm volatile(DENSITY_ROT_PF8 : : "v"(p) : "memory", DENSITY_ROT_STAGE8); }
+__device__ __forceinline__ void prefetch_quads(const uint8_t*) {}                // (geometries without kept quads: never called)
 template <>
 __device__ __forceinline__ void prefetch_quads<16, 8>(const uint8_t* p) { asm volatile(DENSITY_ROT_PF16 : : "v"(p) : "memory", DENSITY_ROT_STAGE16); }
-template <>
-__device__ __forceinline__ void prefetch_quads<12, 12>(const uint8_t* p) { asm volatile(DENSITY_ROT_PF12W12 : : "v"(p) : "memory", DENSITY_ROT_STAGE12W12); }
-template <>
-__device__ __forceinline__ void prefetch_quads<16, 12>(const uint8_t* p) { asm volatile(DENSITY_ROT_PF16W12 : : "v"(p) : "memory", DENSITY_ROT_STAGE16W12); }
-// (never instantiated: geometries without kept quads)
-template <>
-__device__ __forceinline__ void prefetch_quads<8, 16>(const uint8_t*) {}
-template <>
-__device__ __forceinline__ void prefetch_quads<8, 12>(const uint8_t*) {}
-template <>
-__device__ __forceinline__ void prefetch_quads<12, 8>(const uint8_t*) {}
-template <>
-__device__ __forceinline__ void prefetch_quads<12, 16>(const uint8_t*) {}
-template <>
-__device__ __forceinline__ void prefetch_quads<16, 16>(const uint8_t*) {}
 template <int R, int W, bool kDrained>
-__device__ __forceinline__ void quads_landed(uint32_t (&q)[R]);
-template <>
-__device__ __forceinline__ void quads_landed<8, 8, false>(uint32_t (&q)[8]) { asm volatile("s_waitcnt vmcnt(8)\n\t" DENSITY_ROT_MV8 : DENSITY_ROT_MV8_OUTS : : DENSITY_ROT_STAGE8); }
-template <>
-__device__ __forceinline__ void quads_landed<8, 8, true>(uint32_t (&q)[8]) { asm volatile("s_waitcnt vmcnt(0)\n\t" DENSITY_ROT_MV8 : DENSITY_ROT_MV8_OUTS : : DENSITY_ROT_STAGE8); }
+__device__ __forceinline__ void quads_landed(uint32_t (&)[R]) {}                // (likewise)
 template <>
 __device__ __forceinline__ void quads_landed<16, 8, false>(uint32_t (&q)[16]) { asm volatile("s_waitcnt vmcnt(16)\n\t" DENSITY_ROT_MV16 : DENSITY_ROT_MV16_OUTS : : DENSITY_ROT_STAGE16); }
 template <>
 __device__ __forceinline__ void quads_landed<16, 8, true>(uint32_t (&q)[16]) { asm volatile("s_waitcnt vmcnt(0)\n\t" DENSITY_ROT_MV16 : DENSITY_ROT_MV16_OUTS : : DENSITY_ROT_STAGE16); }
-template <>
-__device__ __forceinline__ void quads_landed<12, 12, false>(uint32_t (&q)[12]) { asm volatile("s_waitcnt vmcnt(12)\n\t" DENSITY_ROT_MV12W12 : DENSITY_ROT_MV12W12_OUTS : : DENSITY_ROT_STAGE12W12); }
-template <>
-__device__ __forceinline__ void quads_landed<12, 12, true>(uint32_t (&q)[12]) { asm volatile("s_waitcnt vmcnt(0)\n\t" DENSITY_ROT_MV12W12 : DENSITY_ROT_MV12W12_OUTS : : DENSITY_ROT_STAGE12W12); }
-template <>
-__device__ __forceinline__ void quads_landed<16, 12, false>(uint32_t (&q)[16]) { asm volatile("s_waitcnt vmcnt(16)\n\t" DENSITY_ROT_MV16W12 : DENSITY_ROT_MV16W12_OUTS : : DENSITY_ROT_STAGE16W12); }
-template <>
-__device__ __forceinline__ void quads_landed<16, 12, true>(uint32_t (&q)[16]) { asm volatile("s_waitcnt vmcnt(0)\n\t" DENSITY_ROT_MV16W12 : DENSITY_ROT_MV16W12_OUTS : : DENSITY_ROT_STAGE16W12); }
-template <int R, int W, bool kDrained>
-__device__ __forceinline__ void quads_landed(uint32_t (&)[R]) {}                // (geometries without kept quads: never called)
 
 #define DENSITY_ROT_X12 \
     "ds_mskor_rtn_b32 %0, %0, %12, %24\n\t" \
@@ -483,7 +362,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
                                                                    uint8_t* __restrict__ index, uint32_t* __restrict__ err, SegArgs seg,
                                                                    uint64_t* __restrict__ prof) {
     static_assert((R == 8 || R == 12 || R == 16) && (W == 8 || W == 12 || W == 16), "round = 8, 12 or 16 blocks; 8, 12 or 16 waves");
-    static_assert(!KEEP || W == 8 || (W == 12 && R >= 12), "kept quads: staging registers exist for the 8-wave kernels and for 12 / 16 blocks on 12 waves");
+    static_assert(!KEEP || (R == 16 && W == 8), "kept quads: staging registers exist for rounds of 16 on 8 waves (12 waves: the compiler needs them itself, DESIGN.md 4.3)");
     // (rounds of 16 on 16 waves fit the 128 registers a wave then has because nothing but the exchange operands is kept across the wait for the
     // dictionary token: the quads themselves are loaded again — from L2 — once the exchanges are out)
     const uint32_t lane = threadIdx.x & 63u;
@@ -1711,14 +1590,13 @@ hipError_t launch_rotor_decode(const uint8_t* d_in, const uint64_t* d_offsets, c
                                uint64_t* d_produced, uint32_t* d_err, hipStream_t stream) {
     uint64_t* prof = rot_prof_buffer();
     // geometry (DENSITY_HIP_TUNE bits 5..7): 0 = default = rounds of 12 records on 12 waves (168 registers each: the longest round that does
-    // not spill, i.e. the shortest chain per record), 1 = 8 records on 16 waves
-    const uint32_t sel = (rot_tune() >> 5) & 7u;                                 // 2: rounds of 16 records on 12 waves
-    const uint32_t waves = sel == 1 || sel == 3 ? 16 : 12;                       // 3: rounds of 12 records on 16 waves
+    // not spill, i.e. the shortest chain per record), 1 = 8 records on 16 waves.  (Rounds of 16 on 12 waves and of 12 on 16 were built and
+    // measured in round 3: both spill — 310 / 200 register slots — and are gone.)
+    const uint32_t sel = (rot_tune() >> 5) & 7u;
+    const uint32_t waves = sel == 1 ? 16 : 12;
     auto kernel = sel == 1 ? (prof ? chameleon_decode_rot<8, 16, true> : chameleon_decode_rot<8, 16, false>)
-                : sel == 2 ? (prof ? chameleon_decode_rot<16, 12, true> : chameleon_decode_rot<16, 12, false>)
-                : sel == 3 ? (prof ? chameleon_decode_rot<12, 16, true> : chameleon_decode_rot<12, 16, false>)
                            : (prof ? chameleon_decode_rot<12, 12, true> : chameleon_decode_rot<12, 12, false>);
-    const uint32_t lds = sel == 1 ? dec_lds_bytes(8) : sel == 2 ? dec_lds_bytes(16) : dec_lds_bytes(12);
+    const uint32_t lds = sel == 1 ? dec_lds_bytes(8) : dec_lds_bytes(12);
     hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3(n_chunks), dim3(waves * 64), lds, stream, d_in, d_offsets, d_sizes, d_out, out_stride, out_total,
