@@ -796,8 +796,8 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
         if (kKeepQuads) {
             // (both ways out of the round have asked for the next one's quads)
             if (r + W < nrounds) {
-                // behind a fast commit at least R stores are younger than the R loads (emit_round_coded: every record stores its MAP items,
-                // its PLAIN items or both — a store none of whose lanes is active is not counted — and the signatures go out in one more)
+                // behind a fast commit at least R stores are younger than the R loads (emit_round_coded: one store per record, one or two for the
+                // last — a store none of whose lanes is active is not counted — and the signatures go out in one more)
                 if (fast_commit) quads_landed<R, W, false>(q); else quads_landed<R, W, true>(q);
             }
         } else {
