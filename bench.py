@@ -285,7 +285,7 @@ def other_config(container, algo, label, host, steps=3, warmup=1, cpu_sample=32 
                              "gpu_chunks_compared_bit_exact": int(min(nchk, len(payloads)))}}
 
 
-def strict_stream_leg(host, x, steps=5):
+def strict_stream_leg(host, x, steps=5, label=None):
     """The reference's own call shape on the headline buffer: ONE Chameleon stream over the whole input (chameleon.rs:45-53), encoded and
     decoded in parallel segments on the device, buffers device-resident.  Byte-identity with the reference's stream is the
     GPU suite's to show at full size (tests/test_gpu_chameleon.py::test_config2_full_size_strict_stream...); here: decode == input, and the
@@ -322,7 +322,7 @@ def strict_stream_leg(host, x, steps=5):
         te.append(t1 - t0); td.append(t2 - t1)
     E = int(size.value)
     e_ms, d_ms = sorted(te)[len(te) // 2] * 1e3, sorted(td)[len(td) // 2] * 1e3
-    return {"config": "2 (strict): ONE reference stream over the whole buffer, chameleon_encode / chameleon_decode shape, device-resident",
+    return {"config": label or "2 (strict): ONE reference stream over the whole buffer, chameleon_encode / chameleon_decode shape, device-resident",
             "bytes": int(n), "encoded_bytes": E, "compression_ratio": round(n / E, 4), "encode_ms": round(e_ms, 4), "decode_ms": round(d_ms, 4),
             "value": round(n / ((e_ms + d_ms) * 1e-3) / 1e6, 1), "unit": "MB/s", "timing": "wall clock around each call (host orchestration of the passes included), median of 5",
             "oracle_prefix_compared_bytes": int(k), "decode_is_the_input": True,
@@ -642,6 +642,14 @@ def main():
             # ONE reference stream (the reference's own call shape)
             extra = [strict_stream_leg(host, x)]
             del cont, back
+            # config 1's size (dickens: 10,192,446 B; absent, like every corpus: the stand-in benches/density.py uses): as a container at the
+            # automatic chunk, and as ONE reference stream — the shape the reference's own bench has, with its whole-stream ratio
+            small = datagen.prose(10_192_446, seed=0x9E3779B97F4A7C15)
+            extra.append(other_config(container, "chameleon", "1: Chameleon on synth-prose-10M (dickens stand-in: 10,192,446 B of non-periodic synthetic prose), container at the automatic chunk",
+                                      small, steps=10, warmup=2, cpu_sample=small.size, settle_ms=args.settle_ms / 2))
+            xs = torch.from_numpy(small).cuda()
+            extra.append(strict_stream_leg(small, xs, label="1 (strict): the same 10,192,446 B as ONE reference stream (chameleon_encode / chameleon_decode shape), device-resident"))
+            del xs
             prose = datagen.prose(100_000_000, seed=0xD1B54A32D192ED03)
             for a, lbl in (("cheetah", "3: Cheetah on synth-prose-100M (enwik8 stand-in: 100,000,000 B of non-periodic synthetic prose)"),
                            ("lion", "4: Lion on synth-prose-100M (enwik8 stand-in: 100,000,000 B of non-periodic synthetic prose)")):
