@@ -786,7 +786,7 @@ namespace {
 constexpr uint32_t kDecWaves = 16;
 constexpr uint32_t kRingBytes = 8192;                        // compressed-byte ring (power of two)
 constexpr uint32_t kRingTiles = kRingBytes / 1024;
-constexpr uint32_t kDescBytes = 128, kDescRing = 8;          // dwords 16..23 record positions, 24 copy mask, 25 count, 26 flags, 27 first ordinal
+constexpr uint32_t kDescBytes = 128, kDescRing = 8;          // dwords 16..23 record positions, 24 copy mask, 25 count, 26 flags, 27 first ordinal, 28..29 the records' index entries (indexed feeder)
 constexpr uint32_t kStageRec = 512, kStageRing = 4;          // per record: 64 x {d0, d1}; the dictionary wave turns d1 into the slot's entry
 constexpr uint32_t kDRingBase = kTableBytes;                 // no zero-entry map in LDS here (ZmapGlobal)
 constexpr uint32_t kDDescBase = kDRingBase + kRingBytes;
@@ -952,7 +952,7 @@ __global__ __launch_bounds__(kDecWaves * 64) void chameleon_decode_chunks_pipe(c
     // prefix sum of the record lengths); a round then only publishes its eight.  Kept to a minimum of instructions: a lone
     // wavefront retires roughly one instruction per 8 cycles.
     const uint32_t nblocks_out = (uint32_t)((cap + kBlock - 1) / kBlock);
-    uint32_t win_pos = 0, win_end = 0;                        // per lane: position / end of record idx_base + lane
+    uint32_t win_pos = 0, win_end = 0, win_ent = 0;           // per lane: position / end / index entry of record idx_base + lane
     uint32_t win_base = 0, win_used = 64, win_stop = 0;       // first record of the window, records consumed, first lane that stops the pipeline
     uint64_t win_copy = 0;
     uint32_t idx_staged = 0;                                  // index entries [0, idx_staged) have been requested
@@ -985,6 +985,7 @@ __global__ __launch_bounds__(kDecWaves * 64) void chameleon_decode_chunks_pipe(c
                 incl += (lane >= 16 ? t0 : 0u) + (lane >= 32 ? t1 : 0u) + (lane >= 48 ? t2 : 0u);
                 win_end = ipos + incl;
                 win_pos = win_end - mylen;
+                win_ent = ent;
                 // ragged last block, last block of the chunk, or an index that disagrees with the stream length: the in-order loop
                 // finishes from there, told whether its (single) block is a raw copy
                 const bool stop = (ent & 0x7fu) == kIdxRagged || win_pos >= elen || elen - win_pos <= mylen || ((uint64_t)rec_no + 1) * kBlock > cap;   // (a partial last output block is the in-order loop's)
@@ -996,7 +997,10 @@ __global__ __launch_bounds__(kDecWaves * 64) void chameleon_decode_chunks_pipe(c
             const uint32_t left = win_stop - win_used;           // win_stop >= win_used while !parse_done
             n = left < kRound ? left : kRound;
             copy_mask = (uint32_t)(win_copy >> win_used) & ((1u << n) - 1u);
-            if (lane >= win_used && lane < win_used + n) *reinterpret_cast<uint32_t*>(smem + dbase + 64 + 4u * (lane - win_used)) = win_pos;
+            if (lane >= win_used && lane < win_used + n) {
+                *reinterpret_cast<uint32_t*>(smem + dbase + 64 + 4u * (lane - win_used)) = win_pos;
+                smem[dbase + 112 + (lane - win_used)] = (uint8_t)win_ent;                        // what the index says of the record: held against its signature by the wave that reads it
+            }
             if (n) ipos = rlane(win_end, win_used + n - 1);
             recs += n;
             if (n < kRound) {
@@ -1032,6 +1036,8 @@ __global__ __launch_bounds__(kDecWaves * 64) void chameleon_decode_chunks_pipe(c
             const uint32_t part = lane < 4 ? ring16(pos + 2u * lane) : 0u;       // the record's signature (codec.rs:28-31)
             const uint64_t sig = (uint64_t)(rlane(part, 0) | (rlane(part, 1) << 16)) | ((uint64_t)(rlane(part, 2) | (rlane(part, 3) << 16)) << 32);
             const bool hit = (sig >> lane) & 1ull;
+            // the index must agree with the stream it describes (include/density_hip.h): a coded record's entry is its signature's MAP count
+            if (idx && (uint32_t)__builtin_popcountll(sig) != (uint32_t)(smem[dbase + 112 + w] & 0x7fu)) { if (lane == 0) atomicOr(err, 8u); }
             const uint32_t a = pos + kSig + 4u * lane - 2u * mbcnt64(sig);
             // both halves of a possible quad are read whether or not the lane holds a MAP item (2 bytes): no divergence, one wait
             const uint32_t lo = ring16(a), hi = ring16(a + 2);

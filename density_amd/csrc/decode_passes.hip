@@ -44,7 +44,7 @@ constexpr uint32_t kRecBytes = 128, kRecQuads = 32, kSigBytes = 8;        // che
 constexpr uint32_t kRaw = 0x80000000u;                                    // rec[]: the block is a raw copy (codec.rs:89-91)
 constexpr uint32_t kFlagPlain = 0, kFlagMapA = 1, kFlagPred = 3;                      // (2: MAP_B)   // cheetah.rs:17-23
 // descriptor of a quad: slot [0,16) | flag [16,18) | order bit it meets [18] | takes no part (raw block, beyond the end) [19]
-constexpr uint32_t kDescO = 1u << 18, kDescNone = 1u << 19;
+constexpr uint32_t kDescO = 1u << 18, kDescNone = 1u << 19, kDescZero = 1u << 20;   // kDescZero: a MAP quad that read 0 (see the walk)
 constexpr uint32_t kErrFormat = 1u, kErrWatchdog = 16u;
 constexpr uint32_t kSpinLimit = 1u << 22, kPoison = 0xfffffffeu;
 
@@ -385,6 +385,11 @@ __global__ __launch_bounds__(kPassWaves * 64) void cheetah_pass(PassArgs a) {
                 if (mine && (ra[j] & 1u)) desc[i] = dd[j] | kDescO;
             } else if (rd[j] && i < limit) {
                 val[i] = ra[j];                                                    // cheetah.rs:80,87 / :96: the quad
+                // A MAP quad's NEXT context is its item (cheetah.rs:78-83,85-92: the hash returned is the one read from the stream), but what a
+                // later predicted quad in ITS context hashes to is the hash of the VALUE (:97-102).  The two agree whenever the cell holds a quad
+                // some PLAIN quad put there — its slot is its hash — and differ only for a cell nothing has written yet: 0, whose hash is 0.  No
+                // encoder produces that (a MAP of a never-written slot), a corrupt stream can: the walk needs to know (never taken otherwise).
+                if (PASS == 1 && ra[j] == 0u) desc[i] = dd[j] | kDescZero;
             }
         }
     }
@@ -428,13 +433,15 @@ __global__ __launch_bounds__(64) void cheetah_walk(PassArgs a) {
         for (uint32_t j = 0; j < kTileBlocks; ++j) stage[(t & 1u) * (kTileBytes / 4) + j * 64u + lane] = tile[j];
     };
     fetch(0); land(0);
-    // a MAP quad's hash is its item, a PLAIN quad's the hash of its value (in the descriptor either way); a predicted quad's comes out of H
+    // a MAP quad's hash — the next quad's context — is its item, a PLAIN quad's the hash of its value (in the descriptor either way); a predicted
+    // quad's comes out of H, which holds per context the hash of the VALUE last left there (`hw`)
     for (uint32_t blk = 0; blk < nblk; ++blk) {
         const uint32_t t = blk / kTileBlocks, j = blk % kTileBlocks;
         if (j == 0) fetch(t + 1u);
         const uint32_t d = stage[(t & 1u) * (kTileBytes / 4) + j * 64u + lane];
         if (j == kTileBlocks - 1u || blk + 1u == nblk) land(t + 1u);                 // (behind the read of the tile's last block: the other buffer)
         const uint32_t h = d & 0xffffu;
+        const uint32_t hw = (d & kDescZero) ? 0u : h;                              // what H takes for this quad: the hash of its VALUE (kDescZero: a MAP quad that read a never-written 0)
         const bool none = (d & kDescNone) != 0, pred = ((d >> 16) & 3u) == kFlagPred;
         const uint64_t P = ballot64(!none && pred), N = ballot64(!none && !pred);
         // what the quad before me hashed to: my context if that quad was not predicted (lane 0: the running context)
@@ -493,7 +500,7 @@ __global__ __launch_bounds__(64) void cheetah_walk(PassArgs a) {
                 "s_branch 1b\n"
                 "4:\n\t"
                 : [av] "+v"(av), [c2] "+s"(c2), [prem] "+s"(prem), [pos] "=&s"(s_pos), [p] "=&s"(s_p), [r] "=&s"(s_r), [m] "=&s"(s_m), [t] "=&v"(v_t)
-                : [h] "v"(h), [h2] "v"(h2), [lds0] "s"(lds0)
+                : [h] "v"(hw), [h2] "v"(h2), [lds0] "s"(lds0)
                 : "memory", "m0", "scc");
             c = (c2 - lds0) >> 1;
             cv = (av - lds0) >> 1;
@@ -513,7 +520,7 @@ __global__ __launch_bounds__(64) void cheetah_walk(PassArgs a) {
                     const uint32_t mine = lane == pos ? c : hprev;
                     if (in) {
                         cv = mine;
-                        asm volatile("ds_write_b16 %0, %1" ::"v"(lds0 + 2u * mine), "v"(h) : "memory");
+                        asm volatile("ds_write_b16 %0, %1" ::"v"(lds0 + 2u * mine), "v"(hw) : "memory");
                     }
                     c = (uint32_t)__builtin_amdgcn_readlane((int)h, (int)(pos + r - 1u));
                     pos += r;

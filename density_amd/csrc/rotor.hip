@@ -1362,7 +1362,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
     }
     clk.flush(wave, lane);
 
-    if (bad_index && lane == 0) atomicOr(err, 8u);
+    if (ballot64(bad_index != 0) != 0 && lane == 0) atomicOr(err, 8u);             // (lane j < R holds record j's verdict: any lane's counts)
     wg_barrier();
     // ---- epilogue on one wave, in order: the records of the last, partial round — one call per record, the block's raw-copy flag
     // from the index standing in for the FSM — then the ragged end of the stream (codec.rs:102-123) ----

@@ -265,6 +265,60 @@ def test_corrupt_size_table_is_a_format_error():
             container.decode(bad, out)
 
 
+def test_corrupt_streams_under_a_true_index(kernel_variant):
+    """The payload is corrupted, the block index is not.  A signature whose MAP count no longer is what the index says must be a format error
+    whichever record of a round it belongs to (the index-fed decoders take record lengths from the index: without the check a zeroed
+    signature decodes to wrong bytes of the right length); every corruption the decoder accepts must decode like the oracle decodes the
+    corrupted chunk streams — items changed, MAP flags moved: quads that were never written, zero entries, garbage slots."""
+    if kernel_variant not in ("rotor", "pipelined"):
+        pytest.skip("the index-fed decoders")
+    n, chunk = 3 * 262144 + 999, 262144
+    for kind in ("lowzero", "prose", "zeros"):
+        data = datagen.by_kind(kind, n, seed=21)
+        cont = np.zeros(container.container_bound(ALGO, n, chunk), dtype=np.uint8)
+        cn = container.encode(ALGO, data, cont, chunk)
+        good = cont[:cn].copy()
+        hdr, payloads = container.chunk_payloads(good)
+        assert hdr.flags & 1
+        off = (32 + 4 * hdr.n_chunks + 15) // 16 * 16
+        ix = good[off:off + (n + 255) // 256].copy()
+        off = (off + (hdr.total_len + 255) // 256 + 15) // 16 * 16
+        offs = []
+        for p in payloads:
+            offs.append(off)
+            off = (off + len(p) + 15) // 16 * 16
+        out = np.zeros(n, dtype=np.uint8)
+        # record starts of chunk 0 from its index (coded: 8 + 256 - 2 * MAP count, raw: 256)
+        starts, pos = [], 0
+        for e in ix[:chunk // 256]:
+            starts.append(pos)
+            pos += 256 if e & 0x80 else 8 + 256 - 2 * int(e & 0x7F)
+        coded = [k for k in range(len(starts)) if not ix[k] & 0x80 and (ix[k] & 0x7F) not in (0, 0x7F)]
+        for k in [c for c in coded if c % 24 in (1, 4, 7, 10, 11, 12, 13, 23)][:16] + coded[-3:]:      # every place in a round of 8 or 12, the last rounds
+            bad = good.copy()
+            bad[offs[0] + starts[k]:offs[0] + starts[k] + 8] = 0                                          # MAP count 0 != the index's
+            with pytest.raises(DecodeError):
+                container.decode(bad, out)
+        rng = np.random.default_rng(77)
+        accepted = 0
+        for trial in range(40):
+            bad = good.copy()
+            k = int(rng.integers(0, len(payloads)))
+            at = offs[k] + int(rng.integers(0, len(payloads[k])))
+            if trial % 2:
+                bad[at] ^= int(rng.integers(1, 256))
+            else:
+                bad[at:at + 4] = rng.integers(0, 256, size=min(4, len(bad) - at), dtype=np.uint8)
+            try:
+                m = container.decode(bad, out)
+            except DecodeError:
+                continue
+            accepted += 1
+            want = b"".join(pyoracle.decode(ALGO, bytes(bad[offs[i]:offs[i] + len(payloads[i])]), min(chunk, n - i * chunk)) for i in range(len(payloads)))
+            assert out[:m].tobytes() == want, (kind, trial, k, at - offs[k])
+        assert accepted >= 20, (kind, accepted)
+
+
 def test_abort_and_recovery_paths(kernel_variant):
     """Inputs that flip between compressible and incompressible regions every few KiB: the rotation encoder's speculation
     ("no raw-copy block in this round") fails again and again, so roll-back, slow mode and the way back to fast mode all run."""

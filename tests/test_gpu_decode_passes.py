@@ -158,6 +158,41 @@ def test_truncated_and_corrupt_payloads_end_like_the_one_wave_decoder():
             assert a[1] == b[1], (trial, at)
 
 
+@pytest.mark.parametrize("kind", ["pairs", "patchy", "mixed"])
+def test_corrupt_streams_decode_like_the_oracle(kind):
+    """What no encoder writes a corrupt stream can hold — a MAP flag on a slot nothing has written yet (its value, 0, does not hash to the slot:
+    cheetah.rs:78-92 return the ITEM as the next context, :97-102 the hash of the VALUE), predictions of never-written contexts, garbage items:
+    the passes must decode every such stream exactly like the oracle, and like the one-wave decoder (a seeded fuzz that found the first case)."""
+    n, chunk = 4 * 131072 + 555, 131072
+    data = make(kind, n, seed=11)
+    raw, streams = cpu_container(data, chunk)
+    base = (32 + 4 * len(streams) + 15) // 16 * 16
+    offs, o = [], base
+    for s in streams:
+        offs.append(o)
+        o = (o + len(s) + 15) // 16 * 16
+    rng = np.random.default_rng(4242)
+    compared = 0
+    for t in range(48):
+        bad = raw.copy()
+        mode = t % 3
+        if mode == 0:
+            at = base + int(rng.integers(0, len(raw) - base)); bad[at] ^= int(rng.integers(1, 256))
+        elif mode == 1:
+            at = base + int(rng.integers(0, len(raw) - base - 8)); bad[at:at + 8] = rng.integers(0, 256, size=8, dtype=np.uint8)
+        else:
+            at = (base + int(rng.integers(0, (len(raw) - base) // 2))) & ~1; bad[at] ^= 1 << int(rng.integers(0, 8))
+        a, b = decode_both(bad, n)
+        assert a[0] == b[0], (t, a[0], b[0])
+        if a[0] == "ok":
+            assert a[1] == b[1], t
+            want = b"".join(pyoracle.decode(ALGO, bytes(bad[offs[k]:offs[k] + len(s)]), min(chunk, n - k * chunk)) for k, s in enumerate(streams))
+            if len(want) == n:                                                    # (where the oracle itself stops short the container decode is an error or differs by design)
+                assert a[1] == want, t
+                compared += 1
+    assert compared >= 16, compared
+
+
 @pytest.mark.parametrize("kind", ["prose", "mixed", "pairs", "random", "zeros"])
 def test_reference_shaped_streams_decode_in_passes(kind):
     """`cheetah_decode` (the reference's symbol: ONE stream, host pointers) of 64 KiB and more goes through the same passes as one chunk;
