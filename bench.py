@@ -633,7 +633,7 @@ def main():
         }
         if n_gpus == 1 and not args.no_sweep:
             result["size_sweep"] = size_sweep(container, algo, x, [10_000_000, 100_000_000, n])
-        if not args.no_cpu:
+        if not args.no_cpu and n_gpus == 1:                                              # (rank 0 at N = 1 only: at N > 1 the other ranks would sit in the final barrier meanwhile)
             nchk = (min(args.cpu_sample, n) + chunk - 1) // chunk
             result["cpu_baseline"] = cpu_baseline(host, chunk, args.cpu_sample, algo, gpu_payloads=payloads[:nchk])
             result["host_api"] = host_api_rates(algo, host, chunk, args.host_sample)
