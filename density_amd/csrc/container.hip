@@ -82,6 +82,11 @@ __global__ __launch_bounds__(kScanThreads) void layout_encode_kernel(const uint6
         *reinterpret_cast<density_hip_header_t*>(container) = hdr;
         if (hdr.container_len > capacity) atomicOr(err, 2u);
     }
+    // the gaps in front of the payloads — size table to block index, block index to the first stream — are part of the container: zeros
+    const uint64_t table_end = kHeaderBytes + 4ull * n, ibase = (table_end + 15) / 16 * 16;
+    const uint64_t iend = ibase + ((hdr.flags & DENSITY_HIP_FLAG_BLOCK_INDEX) ? (hdr.total_len + 255) / 256 : 0);
+    if (threadIdx.x < ibase - table_end) container[table_end + threadIdx.x] = 0;
+    if (threadIdx.x >= 32 && threadIdx.x - 32 < base - iend && base <= capacity) container[iend + threadIdx.x - 32] = 0;
 }
 
 // A slice [first, first + count) of the chunks (encode in batches: api.hip): offsets continue from *carry (the end of the previous
@@ -104,6 +109,12 @@ __global__ __launch_bounds__(kScanThreads) void layout_encode_batch_kernel(const
             *reinterpret_cast<density_hip_header_t*>(container) = hdr;
         }
         if (end_scratch > capacity) atomicOr(err, 2u);
+    }
+    if (is_first) {                                              // (as in layout_encode_kernel: the gaps in front of the payloads are zeros)
+        const uint64_t table_end = kHeaderBytes + 4ull * hdr.n_chunks, ibase = (table_end + 15) / 16 * 16;
+        const uint64_t iend = ibase + ((hdr.flags & DENSITY_HIP_FLAG_BLOCK_INDEX) ? (hdr.total_len + 255) / 256 : 0);
+        if (threadIdx.x < ibase - table_end) container[table_end + threadIdx.x] = 0;
+        if (threadIdx.x >= 32 && threadIdx.x - 32 < base - iend && base <= capacity) container[iend + threadIdx.x - 32] = 0;
     }
 }
 
@@ -143,7 +154,12 @@ __global__ __launch_bounds__(kCopyThreads) void compact_kernel(const uint8_t* __
     for (int j = 0; j < 4; ++j) { const uint64_t i = i0 + (uint64_t)j * kCopyThreads; if (i < full) d4[i] = v[j]; }
     // ragged tail (< 16 bytes) handled by the tile that contains it
     const uint64_t tail_at = full * 16;
-    if (tail_at >= begin && tail_at < begin + kCopyTile && threadIdx.x < (uint32_t)(size - tail_at)) d[tail_at + threadIdx.x] = s[tail_at + threadIdx.x];
+    if (tail_at >= begin && tail_at < begin + kCopyTile) {
+        const uint32_t r = (uint32_t)(size - tail_at);
+        if (threadIdx.x < r) d[tail_at + threadIdx.x] = s[tail_at + threadIdx.x];
+        // the gap up to the next stream's 16-byte boundary is part of the container: zeros, not whatever the buffer held
+        else if (threadIdx.x < 16 && r != 0 && chunk + 1 < gridDim.x / tiles_per_chunk) d[tail_at + threadIdx.x] = 0;
+    }
 }
 
 // LDS ordering assumptions of chameleon.hip, checked on the device the library is running on.

@@ -131,7 +131,11 @@ size_t density_hip_auto_chunk_for(int algo, size_t input_size);
 /* Upper bound of the container size for `input_size` bytes (0 if the arguments are invalid). */
 size_t density_hip_container_bound(int algo, size_t input_size, size_t chunk_size);
 
-/* Host-pointer container codec (H2D, kernels, D2H). Return bytes written, 0 on failure. */
+/* Host-pointer container codec (H2D, kernels, D2H). Return bytes written, 0 on failure.
+ * Chameleon inputs worth three slices or more (32 MiB at least; a slice is a twelfth of the input, ten chunks at least) are pipelined: the
+ * caller's buffers are pinned in place for the duration of the call (hipHostRegister), slices of chunks go up on one stream, through the
+ * kernels on others, and down on a third: 46-52 GB/s at 256 MiB .. 1 GiB where the whole buffer staged in sequence gives 33-35.  The
+ * container is byte for byte the same either way.  Where pinning fails the staged path is taken. */
 size_t density_hip_encode(int algo, const uint8_t* input, size_t input_size, uint8_t* output, size_t output_size,
                           size_t chunk_size);
 size_t density_hip_decode(const uint8_t* container, size_t container_size, uint8_t* output, size_t output_size);
@@ -202,7 +206,8 @@ void density_hip_stage_stats(uint64_t* out2);
  * one-lane-per-stream kernels instead of the one-wave-per-stream kernels (serial_codec.hip), 32 = Cheetah containers on the
  * one-wave-per-stream encoder instead of the exchange passes (exchange_stages.hip), 64 = count the chunks the exchange passes
  * keep / hand back (density_hip_stage_stats; reads the verdicts back, so the encode call synchronises), 128 = Cheetah containers on the
- * one-wave-per-stream decoder instead of the decode passes (decode_passes.hip).
+ * one-wave-per-stream decoder instead of the decode passes (decode_passes.hip), 256 = the host-pointer container calls pipelined
+ * whatever the size, a slice per chunk, 512 = never pipelined (below).
  * Payload bytes are identical in every variant. */
 void density_hip_set_kernel_variant(int variant);
 

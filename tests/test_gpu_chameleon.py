@@ -17,7 +17,7 @@ KAT = json.load(open(os.path.join(HERE, "golden", "kat.json")))
 ALGO = "chameleon"
 
 
-VARIANTS = {"rotor": 0, "rotor-noindex": 2, "pipelined": 4, "pipelined-noindex": 6, "simple": 1}
+VARIANTS = {"rotor": 0, "rotor-noindex": 2, "pipelined": 4, "pipelined-noindex": 6, "simple": 1, "rotor-hostpipe": 256}   # 256: the host-pointer container calls pipelined whatever the size, a slice per chunk
 
 
 @pytest.fixture(autouse=True, params=list(VARIANTS))
@@ -317,6 +317,36 @@ def test_corrupt_streams_under_a_true_index(kernel_variant):
             want = b"".join(pyoracle.decode(ALGO, bytes(bad[offs[i]:offs[i] + len(payloads[i])]), min(chunk, n - i * chunk)) for i in range(len(payloads)))
             assert out[:m].tobytes() == want, (kind, trial, k, at - offs[k])
         assert accepted >= 20, (kind, accepted)
+
+
+def test_pipelined_host_calls_make_the_same_container(kernel_variant):
+    """density_hip_encode / _decode through host pointers: inputs of 8 MiB and more go up, through the kernels and down in slices on separate
+    streams (api.hip: *_container_pipelined).  The container must be byte for byte what the staged path (kernel variant 512) writes — header,
+    size table, block index, payloads, zeroed gaps — and both decoders must return the input from either."""
+    if kernel_variant != "rotor":
+        pytest.skip("one configuration is enough: the paths differ on the host side only")
+    for n, chunk in ((40 * (1 << 20) + 12345, 1 << 20), (9 * (1 << 20), 262144), (33 * (1 << 20) + 1, 4 << 20)):
+        data = datagen.by_kind("mixed" if chunk < (4 << 20) else "rep", n, seed=31)
+        made = {}
+        for variant in (0, 512):
+            container.set_kernel_variant(variant)
+            cont = np.full(container.container_bound(ALGO, n, chunk), 0xA5, dtype=np.uint8)
+            cn = container.encode(ALGO, data, cont, chunk)
+            made[variant] = cont[:cn].copy()
+        assert made[0].tobytes() == made[512].tobytes(), (n, chunk)
+        for variant in (0, 512):
+            container.set_kernel_variant(variant)
+            back = np.zeros(n, dtype=np.uint8)
+            assert container.decode(made[0], back) == n and np.array_equal(back, data), (n, chunk, variant)
+        # errors come back as errors from the pipelined path too: a corrupt size table, an output buffer too small
+        container.set_kernel_variant(0)
+        bad = made[0].copy()
+        bad[32:36] = np.frombuffer((0x7FFFFFF0).to_bytes(4, "little"), dtype=np.uint8)
+        with pytest.raises(DecodeError):
+            container.decode(bad, np.zeros(n, dtype=np.uint8))
+        with pytest.raises(EncodeError):
+            container.encode(ALGO, datagen.random_bytes(n, 5), np.zeros(n // 2, dtype=np.uint8), chunk)
+    container.set_kernel_variant(0)
 
 
 def test_abort_and_recovery_paths(kernel_variant):
