@@ -191,6 +191,7 @@ __global__ __launch_bounds__(64) void cheetah_parse(PassArgs a) {
         if (ks < 32u) {
             const uint32_t at_stop = rfl(bperm(ks, before));
             const uint32_t tail = rem - at_stop;                          // 0..3 raw bytes
+            if (ks == 0 && tail == 0) { ip = elen; break; }               // a signature with nothing behind it that yields a byte: the reference stops here, having written nothing (:169-170)
             if (b >= max_blocks || (uint64_t)op + 4u * ks + tail > cap) { ci.bad = 1; break; }
             put(b, ip);
             ++b;

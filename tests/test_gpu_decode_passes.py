@@ -147,6 +147,17 @@ def test_truncated_and_corrupt_payloads_end_like_the_one_wave_decoder():
         assert a[0] == b[0], (cut, a[0], b[0])
         if a[0] == "ok":
             assert a[1] == b[1], cut
+    # ... or made longer: what follows a stream in the container (padding, the next stream's first bytes) is then read as its last record — eight
+    # more bytes are a signature with nothing behind it, which the reference accepts without writing anything when its first flag is PLAIN
+    for grow in (1, 2, 7, 8, 9, 16, 24, 136):
+        for k in (0, 1, 2):
+            bad = raw.copy()
+            sz = len(streams[k])
+            bad[32 + 4 * k:36 + 4 * k] = np.frombuffer(int(sz + grow).to_bytes(4, "little"), dtype=np.uint8)
+            a, b = decode_both(bad, n)
+            assert a[0] == b[0], (grow, k, a[0], b[0])
+            if a[0] == "ok":
+                assert a[1] == b[1], (grow, k)
     # flipped bytes inside payloads: signatures and items go wrong; both decoders must end the same way
     for trial in range(12):
         bad = raw.copy()
