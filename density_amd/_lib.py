@@ -23,6 +23,17 @@ class Header(ctypes.Structure):
                 ("container_len", ctypes.c_uint64)]
 
 
+class Shard(ctypes.Structure):
+    """density_hip_shard_t"""
+    _fields_ = [(k, ctypes.c_uint64) for k in ("chunk_first", "chunk_end", "byte_first", "byte_end")]
+
+
+class GlobalLayout(ctypes.Structure):
+    """density_hip_global_layout_t"""
+    _fields_ = [(k, ctypes.c_uint64) for k in ("n_chunks", "total_len", "index_at", "index_bytes", "payload_at", "container_len",
+                                                "chunk_offset", "payload_offset", "input_offset", "payload_bytes_padded")]
+
+
 _lib = None
 
 # every symbol include/density_hip.h declares: name -> (restype, argtypes)
@@ -59,6 +70,10 @@ SYMBOLS.update({
     "density_hip_selftest_bits": (_I, []),
     "density_hip_last_error": (ctypes.c_char_p, []),
     "density_hip_version": (ctypes.c_char_p, []),
+    "density_hip_shard_range": (_I, [_SZ, _SZ, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(Shard)]),
+    "density_hip_global_layout": (_I, [ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64),
+                                       ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(GlobalLayout)]),
+    "density_hip_shutdown": (None, []),
 })
 
 

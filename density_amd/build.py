@@ -7,12 +7,22 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdensity_hip.so")
-SOURCES = ["api.hip", "chameleon.hip", "rotor.hip", "container.hip", "serial_codec.hip", "stream_parse.hip", "exchange_stages.hip", "decode_passes.hip"]
+SOURCES = ["api.hip", "chameleon.hip", "rotor.hip", "container.hip", "serial_codec.hip", "stream_parse.hip", "exchange_stages.hip", "decode_passes.hip", "placement.hip"]
 HEADERS = ["common.hpp", "chameleon_dev.hpp", "kernels.hpp", os.path.join("..", "..", "include", "density_hip.h")]
 
 
 def _hipcc():
     return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def kernels_id():
+    """A short hash of the kernel sources: density_hip_version() carries it, and measurements that belong to one kernel generation (the PMC
+    traffic in profiles/r*_pmc_summary.json) are quoted by bench.py only for the library they were taken on."""
+    import hashlib
+    h = hashlib.sha1()
+    for f in sorted(SOURCES + HEADERS):
+        h.update(open(os.path.join(CSRC, f), "rb").read())
+    return h.hexdigest()[:12]
 
 
 def needs_build():
@@ -26,7 +36,7 @@ def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-value",
-           "-o", LIB] + [os.path.join(CSRC, f) for f in SOURCES]
+           f'-DDENSITY_HIP_KERNELS_ID="{kernels_id()}"', "-o", LIB] + [os.path.join(CSRC, f) for f in SOURCES]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)

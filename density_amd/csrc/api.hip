@@ -3,6 +3,7 @@
 // and every entry point fails (returns 0 / an error code) when no usable HIP device is present.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -333,7 +334,7 @@ int run_encode_container(DeviceCtx* c, int algo, const uint8_t* d_in, size_t n, 
             } else {
                 e = hipEventRecord(c->batch_done[k], s);
                 if (e == hipSuccess) e = hipStreamWaitEvent(c->stitch_stream, c->batch_done[k], 0);
-                if (e == hipSuccess) e = launch_compact(d_slots + (uint64_t)first * p.stride, p.stride, d_sizes + first, d_offsets + first, count, d_out, d_err, c->stitch_stream);
+                if (e == hipSuccess) e = launch_compact(d_slots + (uint64_t)first * p.stride, p.stride, d_sizes + first, d_offsets + first, count, d_out, d_err, c->stitch_stream, k + 1 < batches);
             }
         }
         if (e == hipSuccess && batches > 1) {                               // the caller's stream continues when the last gather is done
@@ -703,12 +704,18 @@ int run_stream_decode(DeviceCtx* c, int algo, const uint8_t* d_in, size_t n, uin
     if (e == hipSuccess) e = hipStreamSynchronize(s);   // h_size/h_off live on this stack frame
     // a Cheetah stream is ONE chunk for the decode passes (decode_passes.hip): everything but its chain of contexts in parallel; their scratch
     // comes from the context
+    // Their geometry and scratch follow the STREAM, not the caller's capacity (a small stream with a generous output buffer must not plan
+    // passes over gigabytes): n stream bytes decode to at most 128 bytes per 8-byte signature (cheetah.rs:14-23: 32 quads per record, a
+    // record of PREDICTED quads is its signature alone), plus a ragged end.  Short streams stay on one wave; so does any stream whose
+    // scratch cannot be had (the passes are an optimisation, not a requirement).
     uint8_t* d_pass = nullptr;
-    if (e == hipSuccess && decode_pass_eligible(algo, d_out, 1, cap, cap)) {
-        e = c->seg.ensure(decode_pass_scratch_bytes(align_up(cap, 256), 1) + kAlign);
-        d_pass = (uint8_t*)c->seg.p;
+    const size_t pass_cap = algo == DENSITY_HIP_CHEETAH ? std::min<size_t>(cap, (n / 8 + 2) * 128) : cap;
+    if (e == hipSuccess && n >= 16384 && decode_pass_eligible(algo, d_out, 1, pass_cap, pass_cap)) {
+        if (c->seg.ensure(decode_pass_scratch_bytes(align_up(pass_cap, 256), 1) + kAlign) == hipSuccess) d_pass = (uint8_t*)c->seg.p;
+        else (void)hipGetLastError();                                                // (out of memory for the scratch: the one-wave decoder needs none)
     }
-    if (e == hipSuccess) e = codec_decode(algo, d_in, d_offsets, d_sizes, 1, d_out, cap, cap, false, nullptr, d_produced, d_err, ws + p.off_tables, zmap_bytes(algo, 1) ? reinterpret_cast<uint32_t*>(ws + p.off_zmap) : nullptr, s, d_pass);
+    const size_t dec_cap = d_pass ? pass_cap : cap;
+    if (e == hipSuccess) e = codec_decode(algo, d_in, d_offsets, d_sizes, 1, d_out, dec_cap, dec_cap, false, nullptr, d_produced, d_err, ws + p.off_tables, zmap_bytes(algo, 1) ? reinterpret_cast<uint32_t*>(ws + p.off_zmap) : nullptr, s, d_pass);
     prof.mark(decode_kernel_name(algo));
     uint64_t h_prod = 0;
     uint32_t h_err = 0;
@@ -1047,7 +1054,7 @@ size_t encode_container_pipelined(DeviceCtx* c, int algo, const uint8_t* input, 
     const bool with_index = want_index(algo);
     const size_t pbase = payload_base(nc, n, with_index), bound = container_bound(algo, n, chunk);
     if (cap < pbase) return 0;                                                        // (the staged path reports it)
-    PinnedInPlace pin_in(input, n), pin_out(output, cap);
+    PinnedInPlace pin_in(input, n), pin_out(output, std::min(cap, bound));            // (what the container can reach, not the caller's whole capacity)
     if (!pin_in || !pin_out) return 0;
     const uint32_t per = pipe_slice_chunks(n, chunk, nc), slices = (uint32_t)((nc + per - 1) / per);
     if (!pipe_streams(c, 3 * slices)) return 0;
@@ -1095,7 +1102,7 @@ size_t encode_container_pipelined(DeviceCtx* c, int algo, const uint8_t* input, 
         if (e == hipSuccess) e = launch_layout_encode_batch(d_sizes, first, count, k == 0, k + 1 == slices, hdr, pbase, d_out, bound, d_offsets, d_carry, d_err, ks);
         if (e == hipSuccess) e = hipMemcpyAsync(c->pin_sizes + k, d_carry, 8, hipMemcpyDeviceToHost, ks);
         if (e == hipSuccess) e = hipEventRecord(ev_lay, ks);
-        if (e == hipSuccess) e = launch_compact(d_slots + (uint64_t)first * p.stride, p.stride, d_sizes + first, d_offsets + first, count, d_out, d_err, ks);
+        if (e == hipSuccess) e = launch_compact(d_slots + (uint64_t)first * p.stride, p.stride, d_sizes + first, d_offsets + first, count, d_out, d_err, ks, k + 1 < slices);
         if (e == hipSuccess) e = hipEventRecord(ev_enc, ks);
     }
     uint64_t begin = pbase, end = pbase;
@@ -1229,7 +1236,33 @@ int density_hip_selftest_bits(void) {
     return (int)g_ctx[dev].selftest_bits;
 }
 
+void density_hip_shutdown(void) {
+    for (int d = 0; d < kMaxDevices; ++d) {
+        DeviceCtx* c = &g_ctx[d];
+        std::lock_guard<std::mutex> lk(c->mu);
+        if (!c->ready) continue;
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess || hipSetDevice(d) != hipSuccess) { (void)hipGetLastError(); continue; }
+        (void)hipDeviceSynchronize();
+        for (Buffer* b : {&c->work, &c->stage_in, &c->stage_out, &c->seg}) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
+        if (c->pin_sizes) (void)hipHostFree(c->pin_sizes);
+        c->pin_sizes = nullptr; c->pin_sizes_cap = 0;
+        for (hipEvent_t ev : c->pipe_events) (void)hipEventDestroy(ev);
+        c->pipe_events.clear();
+        for (hipEvent_t ev : c->events) (void)hipEventDestroy(ev);
+        c->events.clear(); c->names.clear(); c->n_marks = 0;
+        for (hipStream_t* sp : {&c->up, &c->down, &c->kern[0], &c->kern[1], &c->kern[2], &c->kern[3], &c->stream, &c->stitch_stream}) { if (*sp) (void)hipStreamDestroy(*sp); *sp = nullptr; }
+        for (auto& ev : c->batch_done) { if (ev) (void)hipEventDestroy(ev); ev = nullptr; }
+        if (c->stitch_done) (void)hipEventDestroy(c->stitch_done);
+        c->stitch_done = nullptr;
+        c->ready = false;                                                           // the next call sets the context up again (self-test included)
+        (void)hipSetDevice(cur);
+    }
+}
 const char* density_hip_last_error(void) { return g_last_error.c_str(); }
-const char* density_hip_version(void) { return "density_hip 0.1 (gfx950; reference: density-rs 0.16.6)"; }
+#ifndef DENSITY_HIP_KERNELS_ID
+#define DENSITY_HIP_KERNELS_ID "unversioned"
+#endif
+const char* density_hip_version(void) { return "density_hip 0.2 (gfx950; reference: density-rs 0.16.6; kernels " DENSITY_HIP_KERNELS_ID ")"; }
 
 }  // extern "C"

@@ -53,8 +53,8 @@ __device__ __forceinline__ void layout_common(const SizeT* __restrict__ sizes_in
         const uint64_t incl = slot_stride ? 0ull : block_inclusive_scan(align16(sz), wave_sums, &tile_total);
         if (i < n) {
             uint64_t off = slot_stride ? base + (uint64_t)i * slot_stride : carry + incl - align16(sz);
-            if (slot_stride && sz > slot_stride) { atomicOr(err, 4u); }   // (a size table entry larger than a slot: never from this library)
             uint64_t keep = sz;
+            if (slot_stride && sz > slot_stride) { off = base; keep = 0; atomicOr(err, 4u); }   // a size table entry larger than its slot (never from this library): not followed
             if (off + sz > limit) {                     // a size table that runs past the container: the codec kernels must not follow it
                 off = base; keep = 0;
                 atomicOr(err, 4u);
@@ -135,7 +135,7 @@ constexpr uint32_t kCopyTile = kCopyThreads * 16u * 4u;   // 16 KiB per work-gro
 __global__ __launch_bounds__(kCopyThreads) void compact_kernel(const uint8_t* __restrict__ slots, uint64_t slot_stride,
                                                                const uint64_t* __restrict__ sizes, const uint64_t* __restrict__ offsets,
                                                                uint32_t tiles_per_chunk, uint8_t* __restrict__ container,
-                                                               const uint32_t* __restrict__ err) {
+                                                               const uint32_t* __restrict__ err, uint32_t more_follow) {
     if (*err) return;                                          // layout overflowed the capacity: do not write
     const uint32_t chunk = blockIdx.x / tiles_per_chunk, tile = blockIdx.x % tiles_per_chunk;
     const uint64_t size = sizes[chunk];
@@ -158,7 +158,8 @@ __global__ __launch_bounds__(kCopyThreads) void compact_kernel(const uint8_t* __
         const uint32_t r = (uint32_t)(size - tail_at);
         if (threadIdx.x < r) d[tail_at + threadIdx.x] = s[tail_at + threadIdx.x];
         // the gap up to the next stream's 16-byte boundary is part of the container: zeros, not whatever the buffer held
-        else if (threadIdx.x < 16 && r != 0 && chunk + 1 < gridDim.x / tiles_per_chunk) d[tail_at + threadIdx.x] = 0;
+        // (`more_follow`: this launch gathers a batch and another batch's streams come behind its last one)
+        else if (threadIdx.x < 16 && r != 0 && (chunk + 1 < gridDim.x / tiles_per_chunk || more_follow)) d[tail_at + threadIdx.x] = 0;
     }
 }
 
@@ -222,13 +223,13 @@ hipError_t launch_layout_decode(const uint8_t* d_container, uint64_t container_s
 }
 
 hipError_t launch_compact(const uint8_t* d_slots, uint64_t slot_stride, const uint64_t* d_sizes, const uint64_t* d_offsets,
-                          uint32_t n_chunks, uint8_t* d_container, const uint32_t* d_err, hipStream_t stream) {
+                          uint32_t n_chunks, uint8_t* d_container, const uint32_t* d_err, hipStream_t stream, bool more_follow) {
     if (n_chunks == 0) return hipSuccess;
     const uint32_t tiles = (uint32_t)((slot_stride + kCopyTile - 1) / kCopyTile);
     const uint64_t blocks = (uint64_t)tiles * n_chunks;
     if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
     hipLaunchKernelGGL(compact_kernel, dim3((uint32_t)blocks), dim3(kCopyThreads), 0, stream, d_slots, slot_stride, d_sizes, d_offsets, tiles,
-                       d_container, d_err);
+                       d_container, d_err, more_follow ? 1u : 0u);
     return hipGetLastError();
 }
 

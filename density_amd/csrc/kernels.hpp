@@ -125,7 +125,9 @@ hipError_t launch_layout_decode(const uint8_t* d_container, uint64_t container_s
                                 uint64_t* d_sizes, uint64_t* d_offsets, uint32_t* d_err, hipStream_t stream, uint64_t slot_stride = 0);
 // Gathers chunk streams from their worst-case slots into the packed container.
 hipError_t launch_compact(const uint8_t* d_slots, uint64_t slot_stride, const uint64_t* d_sizes, const uint64_t* d_offsets,
-                          uint32_t n_chunks, uint8_t* d_container, const uint32_t* d_err, hipStream_t stream);
+                          uint32_t n_chunks, uint8_t* d_container, const uint32_t* d_err, hipStream_t stream, bool more_follow = false);
+// (`more_follow`: the launch gathers one batch of a container and further streams follow its last one — the alignment gap behind that stream
+// is then zero-filled like the gaps between the launch's own streams, so that a batched gather writes the same bytes as a single one)
 // LDS same-address ordering self-test (ascending lane order within one ds instruction). *d_fail != 0 on violation.
 hipError_t launch_selftest(uint32_t* d_fail, hipStream_t stream);
 

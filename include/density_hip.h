@@ -168,7 +168,8 @@ int density_hip_encode_device_slotted(int algo, const void* d_input, size_t inpu
                                       size_t chunk_size, void* d_workspace, size_t workspace_size, void* stream,
                                       density_hip_header_t* header_out);
 /* Slotted (or packed) container -> packed container: byte for byte what density_hip_encode_device() writes for the same input.  Workspace as for
- * decode. */
+ * decode.  With header_out == NULL the call is asynchronous and reports nothing about the container it was given (a size table that does not
+ * fit its slots or the container leaves the output unwritten): pass header_out to have it validated. */
 int density_hip_pack_device(const void* d_container, size_t container_size, const density_hip_header_t* header, void* d_output,
                             size_t output_capacity, void* d_workspace, size_t workspace_size, void* stream, density_hip_header_t* header_out);
 /* `header` may be NULL: it is then read back from the device (one small synchronous copy). */
@@ -186,7 +187,8 @@ int density_hip_stream_decode_device(int algo, const void* d_input, size_t input
 /* Profiling: when enabled, the device entry points bracket each kernel with HIP events on the launch stream.
  * density_hip_last_timings() synchronises the last event and returns the duration of every kernel launched on the
  * current device since the previous density_hip_last_timings() call (at most 8192 marks are kept), in launch order;
- * names[i] points to a static string.  Returns the number of entries written (<= capacity). */
+ * names[i] points to a static string.  Returns the number of entries written (<= capacity).  (The pipelined host-pointer container calls
+ * run their slices on streams of their own and record no marks.) */
 void density_hip_set_profiling(int enabled);
 int density_hip_last_timings(float* milliseconds, const char** names, int capacity);
 
@@ -218,8 +220,36 @@ void density_hip_set_kernel_variant(int variant);
  * wave-rotation kernels). */
 int density_hip_selftest(void);
 int density_hip_selftest_bits(void);
+/*
+ * Multi-GPU placement (the arithmetic of density_amd/parallel.py for callers below Python).  The path shards by chunks with no
+ * data-path collective: rank g of G encodes the chunk range density_hip_shard_range() gives it into a container of its own; ONE all-gather of
+ * three u64 per rank — {chunks, payload bytes, input bytes} of the local container, the caller's collective (RCCL ncclAllGather over xGMI) —
+ * then tells every rank, through density_hip_global_layout(), where its size-table entries, its block-index slice and its payload region sit in the
+ * global container (every shard but the last covers whole chunks, so index slices concatenate; every payload region but the last non-empty one
+ * is padded to 16 bytes).  Pure host arithmetic: no device, no HIP call.  Both return DENSITY_HIP_OK or DENSITY_HIP_ERR_ARGUMENT.
+ */
+typedef struct density_hip_shard {
+    uint64_t chunk_first, chunk_end;   /* chunks [first, end) of the global input: contiguous, balanced to within one chunk */
+    uint64_t byte_first, byte_end;     /* the same range in input bytes (chunk-aligned; the last shard ends at total_len) */
+} density_hip_shard_t;
+int density_hip_shard_range(size_t total_len, size_t chunk_size, uint32_t rank, uint32_t world, density_hip_shard_t* out);
+typedef struct density_hip_global_layout {
+    uint64_t n_chunks, total_len;                       /* of the global container */
+    uint64_t index_at, index_bytes, payload_at;         /* its block index (index_bytes == 0 without DENSITY_HIP_FLAG_BLOCK_INDEX) and payload area */
+    uint64_t container_len;
+    uint64_t chunk_offset, payload_offset, input_offset; /* of `rank`: first size-table entry; bytes from payload_at; input bytes before it */
+    uint64_t payload_bytes_padded;                      /* this rank's payload region as it sits in the global container */
+} density_hip_global_layout_t;
+int density_hip_global_layout(const uint64_t* chunks, const uint64_t* payload_bytes, const uint64_t* input_bytes, uint32_t world, uint32_t rank,
+                              uint32_t flags, density_hip_global_layout_t* out);
+
+/* Releases what the library holds on every device it has used (staging buffers, workspaces, streams, events); the next call sets them up
+ * again.  Not needed for correctness — a process may simply exit — and must not run beside other calls into the library. */
+void density_hip_shutdown(void);
+
 /* Thread-local description of the last failure in this thread ("" if none). */
 const char* density_hip_last_error(void);
+/* "density_hip <version> (gfx950; reference: density-rs 0.16.6; kernels <id>)": <id> is a hash of the kernel sources the library was built from. */
 const char* density_hip_version(void);
 
 #ifdef __cplusplus

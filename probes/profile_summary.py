@@ -31,6 +31,11 @@ out = {"unit": "bytes per launch",
        "calibration": {"raw_KB_for_1GiB": calib, "factor_read4": round(k_r4, 4), "factor_read16": round(k_r16, 4), "factor_write4": round(k_w4, 4), "factor_write2": round(k_w2, 4),
                        "note": "probes/fetch_calib.hip streams exactly 1 GiB per kernel at each access width; factor = true bytes / counter bytes"},
        "workload": "bench.py default: chameleon rep-text 1 GiB, automatic chunk (4 MiB), container with block index", "kernels": {}}
+# the kernel generation these counters belong to: bench.py quotes them as `roofline.traffic` only for a library of the same kernels id
+try:
+    out["kernels_id"] = json.load(open(f"{src}/bench.json")).get("kernels_id")
+except Exception:
+    out["kernels_id"] = None
 for k in sorted(set(f) | set(w)):
     fk, wk = f.get(k, 0.0), w.get(k, 0.0)
     rot = k.startswith("chameleon_") and k.endswith("_rot")
