@@ -65,7 +65,7 @@ constexpr bool dec_zmap_in_lds(uint32_t R) { return kDecPos + dec_pos_bytes(R) +
 constexpr uint32_t dec_zmap_at(uint32_t R) { return kDecPos + dec_pos_bytes(R); }
 constexpr uint32_t dec_sync_at(uint32_t R) { return dec_zmap_at(R) + (dec_zmap_in_lds(R) ? kZmapBytes : 0u); }
 constexpr uint32_t dec_lds_bytes(uint32_t R) { return dec_sync_at(R) + kSyBytes; }
-static_assert(kEncLds <= 160u * 1024u && dec_lds_bytes(8) <= 160u * 1024u && dec_lds_bytes(12) <= 160u * 1024u && dec_lds_bytes(16) <= 160u * 1024u, "LDS budget");
+static_assert(kEncLds <= 160u * 1024u && dec_lds_bytes(8) <= 160u * 1024u && dec_lds_bytes(12) <= 160u * 1024u && dec_lds_bytes(16) <= 160u * 1024u && dec_lds_bytes(20) <= 160u * 1024u, "LDS budget");
 static_assert(dec_zmap_in_lds(12) && !dec_zmap_in_lds(8), "where the decoder's zero-entry map lives");
 
 
@@ -265,6 +265,36 @@ template <>
 __device__ __forceinline__ void exchange_tied<16>(uint32_t (&ra)[16], const uint32_t (&mask)[16], const uint32_t (&val)[16], uint32_t tokaddr, uint32_t tokval, bool token_after_answers) {
     if (!token_after_answers) asm volatile(DENSITY_ROT_X16 "ds_write_b32 %48, %49\n\ts_waitcnt lgkmcnt(0)" DENSITY_ROT_X16_OPS);
     else asm volatile(DENSITY_ROT_X16 "s_waitcnt lgkmcnt(0)\n\tds_write_b32 %48, %49" DENSITY_ROT_X16_OPS);
+}
+// (rounds of 20: the decoder's longest — tools/gen: one ordered exchange per record, operands %0..%19 tied answers, %20.. masks, %40.. entries)
+#define DENSITY_ROT_X20 \
+    "ds_mskor_rtn_b32 %0, %0, %20, %40\n\t" \
+    "ds_mskor_rtn_b32 %1, %1, %21, %41\n\t" \
+    "ds_mskor_rtn_b32 %2, %2, %22, %42\n\t" \
+    "ds_mskor_rtn_b32 %3, %3, %23, %43\n\t" \
+    "ds_mskor_rtn_b32 %4, %4, %24, %44\n\t" \
+    "ds_mskor_rtn_b32 %5, %5, %25, %45\n\t" \
+    "ds_mskor_rtn_b32 %6, %6, %26, %46\n\t" \
+    "ds_mskor_rtn_b32 %7, %7, %27, %47\n\t" \
+    "ds_mskor_rtn_b32 %8, %8, %28, %48\n\t" \
+    "ds_mskor_rtn_b32 %9, %9, %29, %49\n\t" \
+    "ds_mskor_rtn_b32 %10, %10, %30, %50\n\t" \
+    "ds_mskor_rtn_b32 %11, %11, %31, %51\n\t" \
+    "ds_mskor_rtn_b32 %12, %12, %32, %52\n\t" \
+    "ds_mskor_rtn_b32 %13, %13, %33, %53\n\t" \
+    "ds_mskor_rtn_b32 %14, %14, %34, %54\n\t" \
+    "ds_mskor_rtn_b32 %15, %15, %35, %55\n\t" \
+    "ds_mskor_rtn_b32 %16, %16, %36, %56\n\t" \
+    "ds_mskor_rtn_b32 %17, %17, %37, %57\n\t" \
+    "ds_mskor_rtn_b32 %18, %18, %38, %58\n\t" \
+    "ds_mskor_rtn_b32 %19, %19, %39, %59\n\t" \
+    ""
+#define DENSITY_ROT_X20_OPS : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(ra[4]), "+v"(ra[5]), "+v"(ra[6]), "+v"(ra[7]), "+v"(ra[8]), "+v"(ra[9]), "+v"(ra[10]), "+v"(ra[11]), "+v"(ra[12]), "+v"(ra[13]), "+v"(ra[14]), "+v"(ra[15]), "+v"(ra[16]), "+v"(ra[17]), "+v"(ra[18]), "+v"(ra[19]) \
+    : "v"(mask[0]), "v"(mask[1]), "v"(mask[2]), "v"(mask[3]), "v"(mask[4]), "v"(mask[5]), "v"(mask[6]), "v"(mask[7]), "v"(mask[8]), "v"(mask[9]), "v"(mask[10]), "v"(mask[11]), "v"(mask[12]), "v"(mask[13]), "v"(mask[14]), "v"(mask[15]), "v"(mask[16]), "v"(mask[17]), "v"(mask[18]), "v"(mask[19]), "v"(val[0]), "v"(val[1]), "v"(val[2]), "v"(val[3]), "v"(val[4]), "v"(val[5]), "v"(val[6]), "v"(val[7]), "v"(val[8]), "v"(val[9]), "v"(val[10]), "v"(val[11]), "v"(val[12]), "v"(val[13]), "v"(val[14]), "v"(val[15]), "v"(val[16]), "v"(val[17]), "v"(val[18]), "v"(val[19]), "v"(tokaddr), "v"(tokval) : "memory"
+template <>
+__device__ __forceinline__ void exchange_tied<20>(uint32_t (&ra)[20], const uint32_t (&mask)[20], const uint32_t (&val)[20], uint32_t tokaddr, uint32_t tokval, bool token_after_answers) {
+    if (!token_after_answers) asm volatile(DENSITY_ROT_X20 "ds_write_b32 %60, %61\n\ts_waitcnt lgkmcnt(0)" DENSITY_ROT_X20_OPS);
+    else asm volatile(DENSITY_ROT_X20 "s_waitcnt lgkmcnt(0)\n\tds_write_b32 %60, %61" DENSITY_ROT_X20_OPS);
 }
 // (keeps a set of operands from being scheduled past this point, i.e. into the critical section behind the token wait)
 template <int R>
@@ -1014,7 +1044,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
                                                               const uint8_t* __restrict__ index, uint32_t* __restrict__ zmap_words,
                                                               uint64_t* __restrict__ produced, uint32_t* __restrict__ err, SegArgs seg,
                                                               uint64_t* __restrict__ prof) {
-    static_assert((R == 8 || R == 12 || R == 16) && (W == 8 || W == 12 || W == 16), "round = 8, 12 or 16 records; 8, 12 or 16 waves");
+    static_assert((R == 8 || R == 12 || R == 16 || R == 20) && (W == 8 || W == 12 || W == 16), "round = 8, 12, 16 or 20 records; 8, 12 or 16 waves");
     constexpr uint32_t kThreads = W * 64, kScanThreads = W == 16 ? 1024 : 512, kPerThread = kRotMaxBlocks / kScanThreads;   // position scan: 16 or 32 index entries per thread
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = rfl(threadIdx.x >> 6);
@@ -1120,6 +1150,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
         incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xf, 0xf, true);   // row_shr:2
         incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xf, 0xf, true);   // row_shr:4
         if (R > 8) incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xf, 0xf, true);   // row_shr:8
+        if (R > 16) incl += lane >= 16 ? rlane_u(incl, 15) : 0u;                  // (records 16.. sit in the second row of lanes: plus the first row's total)
         m.posv = base + incl - mylen;
         m.copy_mask = (uint32_t)ballot64((e & kIdxCopy) != 0 && lane < R);
         m.sgv = *reinterpret_cast<const u32x2_u*>(src + ((lane < R && !(e & kIdxCopy)) ? m.posv : base));   // codec.rs:28-31 (idle lanes: any valid address)
@@ -1240,9 +1271,10 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
             if (D == x) break;
             if (D == kPoison) wave_exit();
             const uint32_t dist = x - D;
-            if (dist >= 2) { for (uint32_t k = 1; k < dist && k < 6; ++k) __builtin_amdgcn_s_sleep(5); }   // 320 cycles per hand-off to come
+            // (a hand-off is ~300 cycles + ~30 per record: 670 for rounds of 12, 790 / 910 for 16 / 20; the sleeps cover about half of one)
+            if (dist >= 2) { for (uint32_t k = 1; k < dist && k < 6; ++k) __builtin_amdgcn_s_sleep(R >= 20 ? 7 : R >= 16 ? 6 : 5); }   // 320 cycles (rounds of 12) per hand-off to come
             else {
-                if (seen != ~0u && seen != D) __builtin_amdgcn_s_sleep(3);        // 192 cycles of a critical section of 450 and more
+                if (seen != ~0u && seen != D) __builtin_amdgcn_s_sleep(R >= 20 ? 5 : R >= 16 ? 4 : 3);        // 192 cycles of a critical section of 450 and more (12 records)
                 if (poll_word(sy + kSyD, x, 8)) break;
             }
             seen = D;
@@ -1259,15 +1291,17 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
         // ---- what each slot holds at this lane's turn -> quads (in place of the answers) ----
         // (a MAP quad that read 0 — never written, or a genuine zero entry? — is a lane of zm[j]: the compare costs what the running minimum
         // it replaces cost, its answer lands in scalar registers, and the rare path below knows record and lanes without working them out again)
-        uint64_t zm[R], zany = 0;
+        uint64_t zany = 0;
+        uint32_t zrec = 0;                                                        // the records that have such a lane: one scalar bit per record (a lane mask per record was 2 R scalar registers)
 #pragma unroll
         for (uint32_t j = 0; j < R; ++j) {
             const bool maps = (hit_mask >> j) & 1u;
             const uint32_t h = itemc[j] & 0xffffu;
             const uint32_t cur = __builtin_amdgcn_ubfe(ra[j], itemc[j] << 4, 16);  // the slot's half of the word ((h & 1) << 4: a bit-field offset is five bits)
             const uint64_t mm = ballot64(maps);                                   // the MAP lanes as a lane mask: for the select below and, in scalar registers, for
-            zm[j] = ballot64(cur == 0) & mm;                                      // "MAP of a slot holding 0": never written, or a genuine zero entry?
-            zany |= zm[j];
+            const uint64_t zj = ballot64(cur == 0) & mm;                          // "MAP of a slot holding 0": never written, or a genuine zero entry?
+            zany |= zj;
+            zrec |= (zj != 0 ? 1u : 0u) << j;
             const uint32_t mq = entry_to_quad(h, cur);                            // (for every lane, then one select: cheaper than an exec mask around it)
             asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(ra[j]) : "v"(itemc[j]), "v"(mq), "s"(mm));
         }
@@ -1294,24 +1328,36 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
             if (kZmapLds && !marks) {
                 // Look-ups only (about one round in 25 on repetitive text: every recurrence of a quad whose entry is 0): nothing in this round
                 // changes the map, so its look-ups need no order among themselves — all lanes of a record at once, usually one lane of one record
+                // The records concerned — usually one — one by one, in a ROLLED loop over select chains.  (Round 4: every rare path of this kernel
+                // is rolled now.  Unrolled, their per-record temporaries were all live at once and set the kernel's register need — 160 for rounds
+                // of 12, spills for anything longer — although the common path needs ~120; rolled, rounds of 16 and 20 fit 12 waves' 168.)  Which of
+                // the record's lanes read 0 is worked out again: the quad such a lane holds is the one an entry of 0 stands for in its slot, and
+                // entry -> quad is one-to-one per slot.
+                for (uint32_t zb = zrec; zb; zb &= zb - 1u) {
+                    const uint32_t j = (uint32_t)__builtin_ctz(zb);
+                    const uint32_t it = pick<R>(itemc, j), an = pick<R>(ra, j);
+                    const uint32_t h = it & 0xffffu;
+                    const bool t = ((hit_mask >> j) & 1u) && an == entry_to_quad(h, 0) && h != 0;   // (slot 0: "never written" and its zero entry both stand for the zero quad)
+                    uint32_t bit = 1;
+                    if (t) bit = zmap.test(h);
+                    const uint32_t outv = (t && !bit) ? 0u : an;                  // chameleon.rs:64-68 on a never-written (zero) word
 #pragma unroll
-                for (uint32_t j = 0; j < R; ++j) {
-                    if (zm[j] != 0) {
-                        const uint32_t h = itemc[j] & 0xffffu;
-                        const bool t = ((zm[j] >> lane) & 1u) && h != 0;          // (slot 0: "never written" and its zero entry both stand for the zero quad)
-                        uint32_t bit = 1;
-                        if (t) bit = zmap.test(h);
-                        ra[j] = (t && !bit) ? 0u : ra[j];                         // chameleon.rs:64-68 on a never-written (zero) word
+                    for (uint32_t k = 0; k < R; ++k) {
+                        uint32_t jj = j;
+                        asm volatile("" : "+s"(jj));                              // (opaque, as in pick)
+                        ra[k] = jj == k ? outv : ra[k];
                     }
                 }
             } else {
             // which records have such a quad — from what is still in registers, a few instructions per record — then those records one by one, usually one
             uint32_t zblocks = 0;
-#pragma unroll
-            for (uint32_t j = 0; j < R; ++j) {
-                // a PLAIN quad with stored entry 0 (its exchange operands: a write of 0), or a MAP quad whose slot gave the quad that an entry of 0 stands for
-                const bool wrote0 = mask[j] != 0 && val[j] == 0;
-                const bool read0 = ((hit_mask >> j) & 1u) && ra[j] == entry_to_quad(itemc[j] & 0xffffu, 0);
+#pragma nounroll
+            for (uint32_t j = 0; j < R; ++j) {                                    // (rolled, over select chains: see above)
+                // a PLAIN quad with stored entry 0 (from the item again: the exchange operands are dead by now, and keeping them alive for this path
+                // cost the common one registers), or a MAP quad whose slot gave the quad that an entry of 0 stands for
+                const uint32_t it = pick<R>(itemc, j), an = pick<R>(ra, j);
+                const bool wrote0 = !((hitsc >> j) & 1u) && ((coded_mask >> j) & 1u) && stored_entry(it, it * kHashMul) == 0;
+                const bool read0 = ((hit_mask >> j) & 1u) && an == entry_to_quad(it & 0xffffu, 0);
                 zblocks |= (ballot64(wrote0 || read0) != 0 ? 1u : 0u) << j;
             }
             zblocks &= coded_mask;
@@ -1592,11 +1638,15 @@ hipError_t launch_rotor_decode(const uint8_t* d_in, const uint64_t* d_offsets, c
     // geometry (DENSITY_HIP_TUNE bits 5..7): 0 = default = rounds of 12 records on 12 waves (168 registers each: the longest round that does
     // not spill, i.e. the shortest chain per record), 1 = 8 records on 16 waves.  (Rounds of 16 on 12 waves and of 12 on 16 were built and
     // measured in round 3: both spill — 310 / 200 register slots — and are gone.)
+    // (Round 4, with the rare paths rolled: 2 = 16 records on 12 waves, 3 = 20 on 12, 4 = 12 on 16.)
     const uint32_t sel = (rot_tune() >> 5) & 7u;
-    const uint32_t waves = sel == 1 ? 16 : 12;
+    const uint32_t waves = (sel == 1 || sel == 4) ? 16 : 12;
     auto kernel = sel == 1 ? (prof ? chameleon_decode_rot<8, 16, true> : chameleon_decode_rot<8, 16, false>)
+                : sel == 2 ? (prof ? chameleon_decode_rot<16, 12, true> : chameleon_decode_rot<16, 12, false>)
+                : sel == 3 ? (prof ? chameleon_decode_rot<20, 12, true> : chameleon_decode_rot<20, 12, false>)
+                : sel == 4 ? (prof ? chameleon_decode_rot<12, 16, true> : chameleon_decode_rot<12, 16, false>)
                            : (prof ? chameleon_decode_rot<12, 12, true> : chameleon_decode_rot<12, 12, false>);
-    const uint32_t lds = sel == 1 ? dec_lds_bytes(8) : dec_lds_bytes(12);
+    const uint32_t lds = sel == 1 ? dec_lds_bytes(8) : sel == 2 ? dec_lds_bytes(16) : sel == 3 ? dec_lds_bytes(20) : dec_lds_bytes(12);
     hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3(n_chunks), dim3(waves * 64), lds, stream, d_in, d_offsets, d_sizes, d_out, out_stride, out_total,

@@ -97,16 +97,24 @@ def main():
     # a load left pending across the loop head ... turn it into vmcnt(0) and cost 5-10 % without a test failing)
     dec = 0
     for name, body in funcs.items():
-        if not re.match(r"^_ZN7density20chameleon_decode_rotILi12ELi12ELb0E", name):
+        m = re.match(r"^_ZN7density20chameleon_decode_rotILi(\d+)ELi(\d+)ELb0E", name)       # every shipped geometry (rounds of R records: R stores per round)
+        if not m or int(m.group(1)) < 12:
             continue
+        want = f"s_waitcnt vmcnt({m.group(1)})"
         first = next(k for k, t in enumerate(body) if t.startswith("ds_mskor_rtn_b32"))
-        window = body[max(0, first - 900):first]
+        window = body[max(0, first - 75 * int(m.group(1))):first]
         waits = [t for t in window if t.startswith("s_waitcnt vmcnt(") and "lgkmcnt" not in t]
-        if "s_waitcnt vmcnt(12)" not in waits:
-            print(f"{name}: stage B no longer waits with vmcnt(12): {waits}")
+        if want not in waits:
+            print(f"{name}: stage B no longer waits with {want}: {waits}")
             bad += 1
-        elif "s_waitcnt vmcnt(0)" in waits[waits.index("s_waitcnt vmcnt(12)"):]:
+        elif "s_waitcnt vmcnt(0)" in waits[waits.index(want):]:
             print(f"{name}: a full drain (vmcnt(0)) inside the round loop: {waits}")
+            bad += 1
+        # ... and no scratch memory anywhere in it (a spilled loop invariant is reloaded — and waited for with vmcnt(0) — inside the critical section)
+        # (one store at the kernel's start — the epilogue's in-order state — is not a spill; any reload is)
+        n_ld, n_st = sum(t.startswith("scratch_load") for t in body), sum(t.startswith("scratch_store") for t in body)
+        if n_ld > 1 or n_st > 1:
+            print(f"{name}: spills to scratch memory ({n_st} stores, {n_ld} loads)")
             bad += 1
         dec += 1
     if not dec:
