@@ -30,7 +30,15 @@ __device__ __forceinline__ void lds_clear(uint32_t lane) {
 // bit clear: round floats, small little-endian integers), so the zero-entry map is touched about once per 64 Ki quads on
 // any data.  slot_salt(0) == 0 keeps slot 0 / quad 0 (the reference's zero-initialised table, chameleon.rs:41) valid from
 // the start.
-__device__ __forceinline__ uint32_t slot_salt(uint32_t h) { return __umul24(h, 0x9e5bu) & 0xffffu; }   // 24-bit multiply: full rate (tests/datagen.py::salted_zero_quads mirrors it)
+// The multiplier only decides WHICH quads pay the zero-entry path (one stored value per slot: about one in 64 Ki distinct quads on any data).
+// Round 3's 0x9e5b happened to hit one word of the 4096-word benchmark text — 54 look-ups per 4 MiB chunk, each a late arrival for the chain;
+// 0xb5ad is the first of sixteen candidates that hits none on four text samples (tools/salt_candidates.py).  Internal to the LDS table: the
+// streams do not depend on it.
+#ifndef DENSITY_HIP_SALT_MUL
+#define DENSITY_HIP_SALT_MUL 0xb5adu
+#endif
+constexpr uint32_t kSaltMul = DENSITY_HIP_SALT_MUL;
+__device__ __forceinline__ uint32_t slot_salt(uint32_t h) { return __umul24(h, kSaltMul) & 0xffffu; }   // 24-bit multiply: full rate (tests/datagen.py::salted_zero_quads mirrors it)
 __device__ __forceinline__ uint32_t stored_entry(uint32_t q, uint32_t P) { return ((P & 0xfffeu) | (q >> 31)) ^ slot_salt(P >> 16); }
 __device__ __forceinline__ uint32_t entry_to_quad(uint32_t h, uint32_t stored) {
     const uint32_t e = stored ^ slot_salt(h);

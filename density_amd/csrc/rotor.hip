@@ -1040,12 +1040,22 @@ __device__ __forceinline__ bool index_fsm_consistent(const uint8_t* ix, uint32_t
 template <int R, int W, bool kProf>
 __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __restrict__ in, const uint64_t* __restrict__ offsets,
                                                               const uint64_t* __restrict__ sizes, uint8_t* __restrict__ out,
-                                                              uint64_t out_stride, uint64_t out_total, uint32_t exact,
+                                                              uint64_t out_stride, uint64_t out_total, uint32_t flags,
                                                               const uint8_t* __restrict__ index, uint32_t* __restrict__ zmap_words,
                                                               uint64_t* __restrict__ produced, uint32_t* __restrict__ err, SegArgs seg,
                                                               uint64_t* __restrict__ prof) {
     static_assert((R == 8 || R == 12 || R == 16 || R == 20) && (W == 8 || W == 12 || W == 16), "round = 8, 12, 16 or 20 records; 8, 12 or 16 waves");
     constexpr uint32_t kThreads = W * 64, kScanThreads = W == 16 ? 1024 : 512, kPerThread = kRotMaxBlocks / kScanThreads;   // position scan: 16 or 32 index entries per thread
+    // flags: bit 0 = the output length is known exactly (container decode); bits 8..11 / 16..19 = how long a wave sleeps per hand-off still to
+    // come / once it has seen the token reach its predecessor, in units of 64 cycles (the launcher's choice per round length)
+    const uint32_t exact = flags & 1u, nap_far = (flags >> 8) & 15u, nap_near = (flags >> 16) & 15u;
+    auto nap = [](uint32_t n) {                                                   // s_sleep takes an immediate: 64 cycles per unit, in binary
+        if (n & 8u) __builtin_amdgcn_s_sleep(8);
+        if (n & 4u) __builtin_amdgcn_s_sleep(4);
+        if (n & 2u) __builtin_amdgcn_s_sleep(2);
+        if (n & 1u) __builtin_amdgcn_s_sleep(1);
+    };
+
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = rfl(threadIdx.x >> 6);
     const uint64_t chunk = blockIdx.x;
@@ -1236,7 +1246,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
                 : "=&v"(h), "=&v"(em), "=s"(mm) : "v"(hitsc), "v"(P), "n"(1u << j), "v"(qv), "v"(0xffffu) : "vcc");
             const uint32_t sh = h << 4;                                           // (a shift takes the low five bits of its count: (h & 1) << 4)
             // stored_entry(qv, P) for the lanes that write, 0 for a MAP lane (`em` is 0xffff or 0: the salt needs no mask of its own)
-            const uint32_t e = (((P & 0xfffeu) | (qv >> 31)) ^ __umul24(P >> 16, 0x9e5bu)) & em;
+            const uint32_t e = (((P & 0xfffeu) | (qv >> 31)) ^ __umul24(P >> 16, kSaltMul)) & em;
             ra[j] = (h >> 1) << 2;
             mask[j] = em << sh;
             val[j] = e << sh;
@@ -1271,10 +1281,10 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
             if (D == x) break;
             if (D == kPoison) wave_exit();
             const uint32_t dist = x - D;
-            // (a hand-off is ~300 cycles + ~30 per record: 670 for rounds of 12, 790 / 910 for 16 / 20; the sleeps cover about half of one)
-            if (dist >= 2) { for (uint32_t k = 1; k < dist && k < 6; ++k) __builtin_amdgcn_s_sleep(R >= 20 ? 7 : R >= 16 ? 6 : 5); }   // 320 cycles (rounds of 12) per hand-off to come
+            // (a hand-off is ~480 cycles + ~19 per record — profiles/r04_*: 690 for rounds of 12, 780 for 16; the sleeps cover about half of one)
+            if (dist >= 2) { for (uint32_t k = 1; k < dist && k < 6; ++k) nap(nap_far); }   // 320 cycles (rounds of 12) per hand-off to come
             else {
-                if (seen != ~0u && seen != D) __builtin_amdgcn_s_sleep(R >= 20 ? 5 : R >= 16 ? 4 : 3);        // 192 cycles of a critical section of 450 and more (12 records)
+                if (seen != ~0u && seen != D) nap(nap_near);                      // 192 cycles of a critical section of 450 and more (12 records)
                 if (poll_word(sy + kSyD, x, 8)) break;
             }
             seen = D;
@@ -1594,6 +1604,14 @@ void rot_prof_report(const char* what, const char* phases, uint64_t* buf, hipStr
                 late_after_zero, late_total, zero_rounds);
     }
 }
+// how long the decoder's waiting waves sleep (units of 64 cycles): per hand-off still to come (bits 8..11 of the kernel's flags) and once the token has
+// reached the predecessor (bits 16..19); DENSITY_HIP_NAP="far,near" overrides (tuning runs)
+uint32_t decode_naps(uint32_t round_len) {
+    static const char* env = getenv("DENSITY_HIP_NAP");
+    uint32_t far_ = round_len >= 16 ? 5u : 5u, near_ = round_len >= 16 ? 3u : 3u;
+    if (env) { unsigned a = 0, b = 0; if (sscanf(env, "%u,%u", &a, &b) == 2) { far_ = a & 15u; near_ = b & 15u; } }
+    return (far_ << 8) | (near_ << 16);
+}
 uint32_t rot_tune() {
     static const uint32_t t = getenv("DENSITY_HIP_TUNE") ? (uint32_t)atoi(getenv("DENSITY_HIP_TUNE")) : 0u;   // read once: bit 0 = token after answers
     return t;
@@ -1638,7 +1656,8 @@ hipError_t launch_rotor_decode(const uint8_t* d_in, const uint64_t* d_offsets, c
     // geometry (DENSITY_HIP_TUNE bits 5..7): 0 = default = rounds of 12 records on 12 waves (168 registers each: the longest round that does
     // not spill, i.e. the shortest chain per record), 1 = 8 records on 16 waves.  (Rounds of 16 on 12 waves and of 12 on 16 were built and
     // measured in round 3: both spill — 310 / 200 register slots — and are gone.)
-    // (Round 4, with the rare paths rolled: 2 = 16 records on 12 waves, 3 = 20 on 12, 4 = 12 on 16.)
+    // (Round 4, with the rare paths rolled: 2 = 16 records on 12 waves, 3 = 20 on 12, 4 = 12 on 16.  Rounds of 16 on 16 waves need the next round's item loads behind the
+    // exchanges to fit 128 registers, and the copy that rotates the pipeline then waits for them at the end of every iteration: built, not kept.)
     const uint32_t sel = (rot_tune() >> 5) & 7u;
     const uint32_t waves = (sel == 1 || sel == 4) ? 16 : 12;
     auto kernel = sel == 1 ? (prof ? chameleon_decode_rot<8, 16, true> : chameleon_decode_rot<8, 16, false>)
@@ -1646,11 +1665,13 @@ hipError_t launch_rotor_decode(const uint8_t* d_in, const uint64_t* d_offsets, c
                 : sel == 3 ? (prof ? chameleon_decode_rot<20, 12, true> : chameleon_decode_rot<20, 12, false>)
                 : sel == 4 ? (prof ? chameleon_decode_rot<12, 16, true> : chameleon_decode_rot<12, 16, false>)
                            : (prof ? chameleon_decode_rot<12, 12, true> : chameleon_decode_rot<12, 12, false>);
-    const uint32_t lds = sel == 1 ? dec_lds_bytes(8) : sel == 2 ? dec_lds_bytes(16) : sel == 3 ? dec_lds_bytes(20) : dec_lds_bytes(12);
+    const uint32_t rlen = sel == 1 ? 8 : sel == 2 ? 16 : sel == 3 ? 20 : 12;
+    const uint32_t lds = dec_lds_bytes(rlen);
+    const uint32_t naps = decode_naps(rlen);
     hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3(n_chunks), dim3(waves * 64), lds, stream, d_in, d_offsets, d_sizes, d_out, out_stride, out_total,
-                       exact ? 1u : 0u, d_index, d_zmap, d_produced, d_err, SegArgs{}, prof);
+                       (exact ? 1u : 0u) | naps, d_index, d_zmap, d_produced, d_err, SegArgs{}, prof);
     rot_prof_report("decode", "stage A | stage B | operands | D wait | exchange | quads | Z chain | stores", prof, stream, waves);
     return hipGetLastError();
 }
@@ -1697,7 +1718,7 @@ hipError_t launch_rotor_decode_seg(const uint8_t* d_in, const uint64_t* d_offset
     auto kernel = chameleon_decode_rot<12, 12, false>;
     hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dec_lds_bytes(12));
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kernel, dim3(n_chunks), dim3(768), dec_lds_bytes(12), stream, d_in, d_offsets, d_sizes, d_out, out_stride, out_total, 0u, d_index, d_zmap, d_produced, d_err,
+    hipLaunchKernelGGL(kernel, dim3(n_chunks), dim3(768), dec_lds_bytes(12), stream, d_in, d_offsets, d_sizes, d_out, out_stride, out_total, decode_naps(12), d_index, d_zmap, d_produced, d_err,
                        seg, (uint64_t*)nullptr);
     return hipGetLastError();
 }

@@ -2,6 +2,7 @@
 import numpy as np
 
 _M64 = (1 << 64) - 1
+SALT_MUL = 0xB5AD   # density_amd/csrc/chameleon_dev.hpp::kSaltMul (the GPU table's per-slot salt: internal, but the adversarial inputs below aim at it)
 
 
 def xs_bytes(seed, n):
@@ -104,7 +105,7 @@ def salted_zero_quads(n_quads, seed=7):
     inv = pow(0x9D6EF916 >> 1, -1, 1 << 31)
     rng = np.random.default_rng(seed)
     hs = rng.integers(1, 1 << 16, size=40, dtype=np.uint64)
-    salt = (hs * np.uint64(0x9E5B)) & np.uint64(0xFFFF)           # chameleon_dev.hpp::slot_salt
+    salt = (hs * np.uint64(SALT_MUL)) & np.uint64(0xFFFF)         # chameleon_dev.hpp::slot_salt
     pfull = (hs << np.uint64(16)) | (salt & np.uint64(0xFFFE))
     special = (((pfull >> np.uint64(1)) * np.uint64(inv)) & np.uint64(0x7FFFFFFF)) | ((salt & np.uint64(1)) << np.uint64(31))
     # sanity: they hash to their slot
