@@ -65,7 +65,7 @@ constexpr bool dec_zmap_in_lds(uint32_t R) { return kDecPos + dec_pos_bytes(R) +
 constexpr uint32_t dec_zmap_at(uint32_t R) { return kDecPos + dec_pos_bytes(R); }
 constexpr uint32_t dec_sync_at(uint32_t R) { return dec_zmap_at(R) + (dec_zmap_in_lds(R) ? kZmapBytes : 0u); }
 constexpr uint32_t dec_lds_bytes(uint32_t R) { return dec_sync_at(R) + kSyBytes; }
-static_assert(kEncLds <= 160u * 1024u && dec_lds_bytes(8) <= 160u * 1024u && dec_lds_bytes(12) <= 160u * 1024u && dec_lds_bytes(16) <= 160u * 1024u && dec_lds_bytes(20) <= 160u * 1024u, "LDS budget");
+static_assert(kEncLds <= 160u * 1024u && dec_lds_bytes(8) <= 160u * 1024u && dec_lds_bytes(12) <= 160u * 1024u && dec_lds_bytes(16) <= 160u * 1024u, "LDS budget");
 static_assert(dec_zmap_in_lds(12) && !dec_zmap_in_lds(8), "where the decoder's zero-entry map lives");
 
 
@@ -266,36 +266,6 @@ __device__ __forceinline__ void exchange_tied<16>(uint32_t (&ra)[16], const uint
     if (!token_after_answers) asm volatile(DENSITY_ROT_X16 "ds_write_b32 %48, %49\n\ts_waitcnt lgkmcnt(0)" DENSITY_ROT_X16_OPS);
     else asm volatile(DENSITY_ROT_X16 "s_waitcnt lgkmcnt(0)\n\tds_write_b32 %48, %49" DENSITY_ROT_X16_OPS);
 }
-// (rounds of 20: the decoder's longest — tools/gen: one ordered exchange per record, operands %0..%19 tied answers, %20.. masks, %40.. entries)
-#define DENSITY_ROT_X20 \
-    "ds_mskor_rtn_b32 %0, %0, %20, %40\n\t" \
-    "ds_mskor_rtn_b32 %1, %1, %21, %41\n\t" \
-    "ds_mskor_rtn_b32 %2, %2, %22, %42\n\t" \
-    "ds_mskor_rtn_b32 %3, %3, %23, %43\n\t" \
-    "ds_mskor_rtn_b32 %4, %4, %24, %44\n\t" \
-    "ds_mskor_rtn_b32 %5, %5, %25, %45\n\t" \
-    "ds_mskor_rtn_b32 %6, %6, %26, %46\n\t" \
-    "ds_mskor_rtn_b32 %7, %7, %27, %47\n\t" \
-    "ds_mskor_rtn_b32 %8, %8, %28, %48\n\t" \
-    "ds_mskor_rtn_b32 %9, %9, %29, %49\n\t" \
-    "ds_mskor_rtn_b32 %10, %10, %30, %50\n\t" \
-    "ds_mskor_rtn_b32 %11, %11, %31, %51\n\t" \
-    "ds_mskor_rtn_b32 %12, %12, %32, %52\n\t" \
-    "ds_mskor_rtn_b32 %13, %13, %33, %53\n\t" \
-    "ds_mskor_rtn_b32 %14, %14, %34, %54\n\t" \
-    "ds_mskor_rtn_b32 %15, %15, %35, %55\n\t" \
-    "ds_mskor_rtn_b32 %16, %16, %36, %56\n\t" \
-    "ds_mskor_rtn_b32 %17, %17, %37, %57\n\t" \
-    "ds_mskor_rtn_b32 %18, %18, %38, %58\n\t" \
-    "ds_mskor_rtn_b32 %19, %19, %39, %59\n\t" \
-    ""
-#define DENSITY_ROT_X20_OPS : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(ra[4]), "+v"(ra[5]), "+v"(ra[6]), "+v"(ra[7]), "+v"(ra[8]), "+v"(ra[9]), "+v"(ra[10]), "+v"(ra[11]), "+v"(ra[12]), "+v"(ra[13]), "+v"(ra[14]), "+v"(ra[15]), "+v"(ra[16]), "+v"(ra[17]), "+v"(ra[18]), "+v"(ra[19]) \
-    : "v"(mask[0]), "v"(mask[1]), "v"(mask[2]), "v"(mask[3]), "v"(mask[4]), "v"(mask[5]), "v"(mask[6]), "v"(mask[7]), "v"(mask[8]), "v"(mask[9]), "v"(mask[10]), "v"(mask[11]), "v"(mask[12]), "v"(mask[13]), "v"(mask[14]), "v"(mask[15]), "v"(mask[16]), "v"(mask[17]), "v"(mask[18]), "v"(mask[19]), "v"(val[0]), "v"(val[1]), "v"(val[2]), "v"(val[3]), "v"(val[4]), "v"(val[5]), "v"(val[6]), "v"(val[7]), "v"(val[8]), "v"(val[9]), "v"(val[10]), "v"(val[11]), "v"(val[12]), "v"(val[13]), "v"(val[14]), "v"(val[15]), "v"(val[16]), "v"(val[17]), "v"(val[18]), "v"(val[19]), "v"(tokaddr), "v"(tokval) : "memory"
-template <>
-__device__ __forceinline__ void exchange_tied<20>(uint32_t (&ra)[20], const uint32_t (&mask)[20], const uint32_t (&val)[20], uint32_t tokaddr, uint32_t tokval, bool token_after_answers) {
-    if (!token_after_answers) asm volatile(DENSITY_ROT_X20 "ds_write_b32 %60, %61\n\ts_waitcnt lgkmcnt(0)" DENSITY_ROT_X20_OPS);
-    else asm volatile(DENSITY_ROT_X20 "s_waitcnt lgkmcnt(0)\n\tds_write_b32 %60, %61" DENSITY_ROT_X20_OPS);
-}
 // (keeps a set of operands from being scheduled past this point, i.e. into the critical section behind the token wait)
 template <int R>
 __device__ __forceinline__ void pin_operands(uint32_t (&ra)[R], uint32_t (&mask)[R], uint32_t (&val)[R]) {
@@ -374,11 +344,26 @@ __device__ __forceinline__ void backoff(uint32_t dist) {
     else __builtin_amdgcn_s_sleep(3);
 }
 // up to `tries` back-to-back polls of one token word for one value
+// (Written out: the compiled loop kept its counter in a vector register and took ten instructions per poll — every one of them between
+// "the token is there" and the first exchange of the new holder.  Five here: read, wait, lane 0's copy, compare, branch; the count-down is
+// issued while the read is in flight.)
 __device__ __forceinline__ bool poll_word(uint32_t addr, uint32_t want, uint32_t tries) {
-    for (uint32_t i = 0; i < tries; ++i) {
-        if (rfl(lds_peek1(addr)) == want) return true;
-    }
-    return false;
+    uint32_t v, seen;
+    asm volatile(
+        "1:\n\t"
+        "ds_read_b32 %[v], %[a]\n\t"
+        "s_sub_u32 %[n], %[n], 1\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_readfirstlane_b32 %[s], %[v]\n\t"
+        "s_cmp_eq_u32 %[s], %[w]\n\t"
+        "s_cbranch_scc1 2f\n\t"
+        "s_cmp_lg_u32 %[n], 0\n\t"
+        "s_cbranch_scc1 1b\n"
+        "2:"
+        : [v] "=&v"(v), [s] "=&s"(seen), [n] "+s"(tries)
+        : [a] "v"(addr), [w] "s"(want)
+        : "scc", "memory");
+    return seen == want;
 }
 
 }  // namespace
@@ -533,6 +518,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
             } else {
                 const uint32_t off = pos + 2u * __builtin_amdgcn_mbcnt_hi((uint32_t)(plain >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)plain, lane));
                 asm volatile(
+                    "s_nop 4\n\t"                                                   // (an SGPR a VALU instruction has just written — the compiler reloading a spilled base — needs 5 wait states before a memory instruction reads it: its own code sees to that, an asm statement must)
                     "s_mov_b64 exec, %4\n\t"
                     "global_store_dword %0, %2, %3\n\t"
                     "s_not_b64 exec, exec\n\t"
@@ -614,6 +600,8 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
         }
         const bool zero_round = zblocks != 0;
         const uint32_t tokaddr = lane == 0 ? sy + kSyD : sy + kSySink + 4u * lane;
+        uint32_t tokval = (r + 1u) << 1;                                          // (in its register before the wait, like the operands)
+        asm volatile("" : "+v"(tokval));
         pin_operands<R>(ra, mask, val);                                           // complete before the wait for the token
 
         clk.mark(0);
@@ -640,7 +628,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
                 // inside the exchanges, 2 on the way to the commit and while it waits for a token, 1 while it prepares its next round, 0
                 // while it writes records out (nobody waits for those).
                 __builtin_amdgcn_s_setprio(3);
-                exchange_tied<R>(ra, mask, val, tokaddr, (r + 1u) << 1, false);
+                exchange_tied<R>(ra, mask, val, tokaddr, tokval, false);
                 __builtin_amdgcn_s_setprio(2);
                 clk.mark(2);
                 clk.stamp(r, 2, lane);
@@ -1044,7 +1032,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
                                                               const uint8_t* __restrict__ index, uint32_t* __restrict__ zmap_words,
                                                               uint64_t* __restrict__ produced, uint32_t* __restrict__ err, SegArgs seg,
                                                               uint64_t* __restrict__ prof) {
-    static_assert((R == 8 || R == 12 || R == 16 || R == 20) && (W == 8 || W == 12 || W == 16), "round = 8, 12, 16 or 20 records; 8, 12 or 16 waves");
+    static_assert((R == 8 || R == 12 || R == 16) && (W == 8 || W == 12 || W == 16), "round = 8, 12 or 16 records; 8, 12 or 16 waves");
     constexpr uint32_t kThreads = W * 64, kScanThreads = W == 16 ? 1024 : 512, kPerThread = kRotMaxBlocks / kScanThreads;   // position scan: 16 or 32 index entries per thread
     // flags: bit 0 = the output length is known exactly (container decode); bits 8..11 / 16..19 = how long a wave sleeps per hand-off still to
     // come / once it has seen the token reach its predecessor, in units of 64 cycles (the launcher's choice per round length)
@@ -1160,7 +1148,6 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
         incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xf, 0xf, true);   // row_shr:2
         incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xf, 0xf, true);   // row_shr:4
         if (R > 8) incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xf, 0xf, true);   // row_shr:8
-        if (R > 16) incl += lane >= 16 ? rlane_u(incl, 15) : 0u;                  // (records 16.. sit in the second row of lanes: plus the first row's total)
         m.posv = base + incl - mylen;
         m.copy_mask = (uint32_t)ballot64((e & kIdxCopy) != 0 && lane < R);
         m.sgv = *reinterpret_cast<const u32x2_u*>(src + ((lane < R && !(e & kIdxCopy)) ? m.posv : base));   // codec.rs:28-31 (idle lanes: any valid address)
@@ -1268,6 +1255,8 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
             }
         }
         const uint32_t tokaddr = lane == 0 ? sy + kSyD : sy + kSySink + 4u * lane;
+        uint32_t tokval = x + 1u;                                                 // (in its register before the wait: nothing but the priority change between the token and the exchanges)
+        asm volatile("" : "+v"(tokval));
         pin_operands<R>(ra, mask, val);                                           // complete before the wait for the token
         clk.mark(2);
         clk.stamp(x, 0, lane);
@@ -1293,7 +1282,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
         clk.mark(3);
         clk.stamp(x, 1, lane);
         __builtin_amdgcn_s_setprio(3);
-        exchange_tied<R>(ra, mask, val, tokaddr, x + 1u, false);
+        exchange_tied<R>(ra, mask, val, tokaddr, tokval, false);
         __builtin_amdgcn_s_setprio(0);
         clk.mark(4);
         clk.stamp(x, 2, lane);
@@ -1656,16 +1645,19 @@ hipError_t launch_rotor_decode(const uint8_t* d_in, const uint64_t* d_offsets, c
     // geometry (DENSITY_HIP_TUNE bits 5..7): 0 = default = rounds of 12 records on 12 waves (168 registers each: the longest round that does
     // not spill, i.e. the shortest chain per record), 1 = 8 records on 16 waves.  (Rounds of 16 on 12 waves and of 12 on 16 were built and
     // measured in round 3: both spill — 310 / 200 register slots — and are gone.)
-    // (Round 4, with the rare paths rolled: 2 = 16 records on 12 waves, 3 = 20 on 12, 4 = 12 on 16.  Rounds of 16 on 16 waves need the next round's item loads behind the
-    // exchanges to fit 128 registers, and the copy that rotates the pipeline then waits for them at the end of every iteration: built, not kept.)
+    // Round 4, with the rare paths rolled (120 registers instead of 160), longer rounds and more waves build without spills: 2 = 16 records on
+    // 12 waves, 4 = 12 on 16.  Measured on one box against the default's 0.381 / 0.421 ms (fast / slow box): 16 on 12 0.437 (a round's critical
+    // section grows with its length — 38 cycles per record either way — so only the hand-off's ~210 cycles are spread thinner, 4 cycles per
+    // record, and a wave whose 16 records take longer than 12 hand-offs is late more often than that pays); 12 on 16 0.420 (no gain: the
+    // decoder waits for its chain, not for issue slots).  Also built and measured: 20 on 12 (0.426), one set of item registers with the next
+    // round's loads behind the quads — 16 on 16 0.422, 12 on 12 0.398, 16 on 12 0.426 (the loads' run-up is too short: stalls of 2-8 k cycles).
     const uint32_t sel = (rot_tune() >> 5) & 7u;
     const uint32_t waves = (sel == 1 || sel == 4) ? 16 : 12;
     auto kernel = sel == 1 ? (prof ? chameleon_decode_rot<8, 16, true> : chameleon_decode_rot<8, 16, false>)
                 : sel == 2 ? (prof ? chameleon_decode_rot<16, 12, true> : chameleon_decode_rot<16, 12, false>)
-                : sel == 3 ? (prof ? chameleon_decode_rot<20, 12, true> : chameleon_decode_rot<20, 12, false>)
                 : sel == 4 ? (prof ? chameleon_decode_rot<12, 16, true> : chameleon_decode_rot<12, 16, false>)
                            : (prof ? chameleon_decode_rot<12, 12, true> : chameleon_decode_rot<12, 12, false>);
-    const uint32_t rlen = sel == 1 ? 8 : sel == 2 ? 16 : sel == 3 ? 20 : 12;
+    const uint32_t rlen = sel == 1 ? 8 : sel == 2 ? 16 : 12;
     const uint32_t lds = dec_lds_bytes(rlen);
     const uint32_t naps = decode_naps(rlen);
     hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -18,7 +18,12 @@ s = torch.cuda.current_stream().cuda_stream
 handles = {}
 def use(name, path):
     if name not in handles:
-        _lib._lib = None; _lib.LIB_PATH = path; handles[name] = _lib.lib()
+        import ctypes
+        L = ctypes.CDLL(path)                                    # (older builds lack newer symbols: bind what is there)
+        for sym, (res, args) in _lib.SYMBOLS.items():
+            if hasattr(L, sym):
+                fn = getattr(L, sym); fn.restype, fn.argtypes = res, args
+        handles[name] = L
     _lib._lib = handles[name]
 use("tree", tree_path)
 hdr = container.encode_device_slotted("chameleon", x.data_ptr(), n, cont.data_ptr(), cap, chunk, stream=s)
