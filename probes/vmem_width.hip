@@ -11,31 +11,40 @@ __global__ __launch_bounds__(512) void k(uint8_t* buf, uint64_t* out) {
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint8_t* base = buf + ((uint64_t)blockIdx.x * 8 + wave) * (256u << 10) + lane * BYTES;     // 256 KiB per wave
     uint32_t off = 0;
-    uint4 v = make_uint4(lane, lane + 1, lane + 2, lane + 3), acc = make_uint4(0, 0, 0, 0);
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 v4 = {lane, lane + 1, lane + 2, lane + 3};
+    const u32x2 v2 = {lane, lane + 1};
+    uint32_t acc = 0;
     const uint64_t t0 = __builtin_readcyclecounter();
     for (int it = 0; it < ITERS; ++it) {
+        // 16 instructions per batch, all of them in flight together, landed before anything else touches their registers (one asm statement per
+        // batch: a load left in flight across statements lands in whatever the compiler has put there since)
+        uint8_t* a = base + off;
+        if (STORE) {
 #pragma unroll
-        for (int rep = 0; rep < 16; ++rep) {
-            uint8_t* a = base + off;
-            if (STORE) {
-                if (BYTES == 4) asm volatile("global_store_dword %0, %1, off" ::"v"(a), "v"(v.x) : "memory");
-                else if (BYTES == 8) asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(a), "v"(*reinterpret_cast<uint2*>(&v)) : "memory");
-                else asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(a), "v"(v) : "memory");
-            } else {
-                uint4 r = make_uint4(0, 0, 0, 0);
-                if (BYTES == 4) asm volatile("global_load_dword %0, %1, off" : "=v"(r.x) : "v"(a) : "memory");
-                else if (BYTES == 8) asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(*reinterpret_cast<uint2*>(&r)) : "v"(a) : "memory");
-                else asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(a) : "memory");
-                asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-                acc.x ^= r.x;
+            for (int rep = 0; rep < 16; ++rep) {
+                uint8_t* p = a + rep * 64 * BYTES;
+                if (BYTES == 4) asm volatile("global_store_dword %0, %1, off" ::"v"(p), "v"(v2.x) : "memory");
+                else if (BYTES == 8) asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(v2) : "memory");
+                else asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v4) : "memory");
             }
-            off = (off + 64u * BYTES) & ((256u << 10) - 1u);
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        } else {
+#define L16(OP, T, STEP) { T r0, r1, r2, r3, r4, r5, r6, r7; \
+            asm volatile(OP " %0, %8, off\n\t" OP " %1, %8, off offset:" #STEP "\n\t" OP " %2, %8, off offset:2*" #STEP "\n\t" OP " %3, %8, off offset:3*" #STEP "\n\t" \
+                         OP " %4, %9, off\n\t" OP " %5, %9, off offset:" #STEP "\n\t" OP " %6, %9, off offset:2*" #STEP "\n\t" OP " %7, %9, off offset:3*" #STEP "\n\t" \
+                         "s_waitcnt vmcnt(0)" : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7) : "v"(a), "v"(a + 4 * STEP) : "memory"); \
+            acc ^= *reinterpret_cast<uint32_t*>(&r0) ^ *reinterpret_cast<uint32_t*>(&r7); }
+            if (BYTES == 4) { L16("global_load_dword", uint32_t, 256) L16("global_load_dword", uint32_t, 256) }
+            else if (BYTES == 8) { L16("global_load_dwordx2", u32x2, 512) L16("global_load_dwordx2", u32x2, 512) }
+            else { L16("global_load_dwordx4", u32x4, 1024) L16("global_load_dwordx4", u32x4, 1024) }
         }
-        if (STORE) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+        off = (off + 16u * 64u * BYTES) & ((256u << 10) - 1u);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const uint64_t t1 = __builtin_readcyclecounter();
-    if (lane == 0) out[blockIdx.x * 8 + wave] = (t1 - t0) + (acc.x == 0x12345u);
+    if (lane == 0) out[blockIdx.x * 8 + wave] = (t1 - t0) + (acc == 0x12345u);
 }
 template <int BYTES, bool STORE>
 void run(uint8_t* buf, uint64_t* d, const char* what) {
