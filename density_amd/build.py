@@ -7,8 +7,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdensity_hip.so")
-SOURCES = ["api.hip", "chameleon.hip", "rotor.hip", "container.hip", "serial_codec.hip", "stream_parse.hip", "exchange_stages.hip", "decode_passes.hip", "placement.hip"]
-HEADERS = ["common.hpp", "chameleon_dev.hpp", "kernels.hpp", os.path.join("..", "..", "include", "density_hip.h")]
+SOURCES = ["api.hip", "api_stream.hip", "api_host.hip", "chameleon.hip", "rotor.hip", "container.hip", "serial_codec.hip", "stream_parse.hip", "exchange_stages.hip", "decode_passes.hip", "placement.hip"]
+HEADERS = ["api_internal.hpp", "common.hpp", "chameleon_dev.hpp", "kernels.hpp", os.path.join("..", "..", "include", "density_hip.h")]
 
 
 def _hipcc():

@@ -1,0 +1,170 @@
+// api_internal.hpp — what the three units of the C ABI share (api.hip: per-device context, plans, the container's device-side drivers and
+// entry points; api_stream.hip: ONE reference stream — the reference's nine symbols, the parallel segments of long Chameleon streams;
+// api_host.hip: the host-pointer container calls, staged or pipelined in slices).  Internal to libdensity_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/density_hip.h"
+#include "kernels.hpp"
+
+namespace density {
+namespace api {
+
+constexpr int kMaxDevices = 16;
+constexpr size_t kAlign = 256;
+constexpr size_t kMaxChunk = 1u << 30;   // u32 size table: a chunk stream must stay below 4 GiB
+
+extern thread_local std::string g_last_error;
+extern int g_profiling;
+extern int g_variant;                 // density_hip_set_kernel_variant
+extern uint64_t g_pass_decodes;       // density_hip_decode_pass_count: Cheetah decodes served by the decode passes
+extern uint64_t g_stream_stats[4];    // density_hip_stream_stats: long streams encoded in segments | encode passes | decoded in segments | long streams decoded sequentially
+void set_error(const char* what, hipError_t e = hipSuccess);
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// codec/codec.rs:18-21 with the geometry of chameleon.rs:138-146, cheetah.rs:188-196, lion.rs:317-325
+inline size_t block_bytes(int algo) { return algo == DENSITY_HIP_CHAMELEON ? 256 : algo == DENSITY_HIP_CHEETAH ? 128 : 64; }
+inline size_t sig_bytes(int algo) { return algo == DENSITY_HIP_LION ? 6 : 8; }
+inline size_t safe_size(int algo, size_t n) {
+    const size_t b = block_bytes(algo), s = sig_bytes(algo);
+    return n + (n / b) * s + ((n % b) ? s : 0);
+}
+inline bool valid_algo(int algo) { return algo >= DENSITY_HIP_CHAMELEON && algo <= DENSITY_HIP_LION; }
+// chunk_size 0 = automatic: one chunk is one work-group on one CU, so an input should be cut into at least as many chunks as the device has
+// CUs (256) where that is possible without dropping below 64 KiB (small chunks restart the dictionary and cost ratio), and no finer than that
+// (every chunk start costs a table clear and a few in-order rounds): never above 4 MiB, the largest chunk the index-fed decoder takes.
+// Power of two: 10 MB -> 64 KiB (153 chunks), 100 MB -> 256 KiB (382), 256 MiB -> 1 MiB, >= 1 GiB -> 4 MiB.
+// Lion runs one WAVE per chunk stream and is bound by memory latency per stream, not by a CU's LDS: it wants eight streams per CU (2048)
+// and starts from 1 MiB.  Cheetah's decode passes (decode_passes.hip) walk one chunk per CU, in time proportional to the chunk: one
+// chunk per CU exactly — the input over 256, up to whole 4 KiB trips of the encoder's passes — between 64 KiB and 1 MiB (100 MB -> 384 KiB:
+// ratio 1.67 where 64 KiB chunks gave 1.34, and a faster round trip).
+inline size_t auto_chunk(size_t n, int algo = DENSITY_HIP_CHAMELEON) {
+    if (algo == DENSITY_HIP_CHEETAH) {
+        size_t c = align_up((n + 255) / 256, 4096);
+        if (c < (64u << 10)) c = 64u << 10;
+        if (c > (1u << 20)) c = 1u << 20;
+        return c;
+    }
+    const bool lds = algo == DENSITY_HIP_CHAMELEON;
+    size_t c = lds ? (4u << 20) : (1u << 20);
+    const size_t streams = lds ? 256 : 2048;
+    while (c > (64u << 10) && n / c < streams) c >>= 1;
+    return c;
+}
+inline size_t normalise_chunk(size_t chunk, size_t n, int algo = DENSITY_HIP_CHAMELEON) { return chunk == 0 ? auto_chunk(n, algo) : chunk; }
+inline bool valid_chunk(size_t chunk) { return chunk >= 256 && chunk % 256 == 0 && chunk <= kMaxChunk; }
+inline size_t chunk_count(size_t n, size_t chunk) { return (n + chunk - 1) / chunk; }
+inline size_t index_base(size_t n_chunks) { return align_up(sizeof(density_hip_header_t) + 4 * n_chunks, 16); }
+inline size_t index_bytes(size_t total_len, bool with_index) { return with_index ? (total_len + 255) / 256 : 0; }
+inline size_t payload_base(size_t n_chunks, size_t total_len, bool with_index) { return align_up(index_base(n_chunks) + index_bytes(total_len, with_index), 16); }
+inline bool want_index(int algo) { return algo == DENSITY_HIP_CHAMELEON && !(g_variant & 2); }
+inline size_t slot_stride(int algo, size_t chunk) { return align_up(safe_size(algo, chunk), kAlign); }
+
+struct Buffer {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+        const size_t want = align_up(n + n / 8, 1 << 20);
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { p = nullptr; return e; }
+        cap = want;
+        return hipSuccess;
+    }
+};
+
+struct DeviceCtx {
+    std::mutex mu;
+    bool ready = false, selftest_ok = false;
+    uint32_t selftest_bits = 0;
+    hipStream_t stream = nullptr, stitch_stream = nullptr;   // stitch_stream: the compaction of one batch of chunks beside the encoding of the next
+    hipEvent_t batch_done[8] = {}, stitch_done = nullptr;
+    Buffer work, stage_in, stage_out, seg;   // seg: scratch of the segmented stream encode
+    // the pipelined host-pointer container calls: an upload, a download and four kernel streams, events per slice, the slice sizes in pinned memory
+    hipStream_t up = nullptr, down = nullptr, kern[4] = {};
+    std::vector<hipEvent_t> pipe_events;
+    uint64_t* pin_sizes = nullptr;
+    size_t pin_sizes_cap = 0;
+    // profiling: event marks accumulated since the last density_hip_last_timings() (name == nullptr opens a call)
+    std::vector<hipEvent_t> events;
+    std::vector<const char*> names;
+    size_t n_marks = 0;
+};
+constexpr size_t kMaxMarks = 8192;
+
+extern DeviceCtx g_ctx[kMaxDevices];
+// Returns the context of the current device with its internal stream created and the LDS self-test passed.
+DeviceCtx* acquire_ctx();
+
+struct Profiler {
+    DeviceCtx* c;
+    hipStream_t s;
+    bool on;
+    Profiler(DeviceCtx* ctx, hipStream_t stream) : c(ctx), s(stream), on(g_profiling != 0) { mark(nullptr); }
+    void mark(const char* name) {
+        if (!on) return;
+        if (c->n_marks >= kMaxMarks) { on = false; return; }
+        if (c->n_marks >= c->events.size()) {
+            hipEvent_t ev;
+            if (hipEventCreate(&ev) != hipSuccess) { on = false; return; }
+            c->events.push_back(ev);
+            c->names.push_back(nullptr);
+        }
+        c->names[c->n_marks] = name;
+        (void)hipEventRecord(c->events[c->n_marks++], s);
+    }
+};
+
+constexpr size_t kSerialSlots = 16384;   // concurrent chunk streams of the functional Cheetah/Lion kernels (one lane each; 12 / 28 GiB of tables when all are in use)
+constexpr size_t kSerialTableBudget = 8ull << 30;   // ... but never more than 8 GiB of tables (the count comes from an untrusted header on decode): Cheetah 10922 streams, Lion 4681
+inline size_t serial_slots(int algo, size_t n_chunks) {
+    if (algo == DENSITY_HIP_CHAMELEON) return 0;
+    const size_t by_memory = kSerialTableBudget / serial_table_bytes(algo);
+    const size_t cap = kSerialSlots < by_memory ? kSerialSlots : by_memory;
+    return n_chunks < cap ? n_chunks : cap;
+}
+inline size_t serial_tables(int algo, size_t n_chunks) { return algo == DENSITY_HIP_CHAMELEON ? 0 : align_up(serial_slots(algo, n_chunks) * serial_table_bytes(algo), kAlign); }
+
+inline size_t zmap_bytes(int algo, size_t n_chunks) { return (algo == DENSITY_HIP_CHAMELEON && n_chunks <= kMaxPipelinedChunks) ? align_up((n_chunks ? n_chunks : 1) * kZmapWordsPerChunk * 4, kAlign) : 0; }
+
+struct EncodePlan {
+    size_t chunk, n_chunks, stride, off_err, off_sizes, off_offsets, off_slots, off_tables, off_zmap, off_stage, total;
+};EncodePlan plan_encode(int algo, size_t n, size_t chunk);
+struct DecodePlan {
+    size_t off_err, off_sizes, off_offsets, off_produced, off_tables, off_zmap, off_pass, total, total_with_passes;
+};// out_stride != 0 (the container's chunk size / a stream's output capacity): Cheetah's decode passes (decode_passes.hip) want a dword and
+// a half per quad of scratch behind everything else; `total` is what the one-wave decoders need, `total_with_passes` what the passes need
+DecodePlan plan_decode(int algo, size_t n_chunks, size_t out_stride = 0);
+
+// algorithm dispatch
+hipError_t codec_encode(int algo, const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_out,
+                        uint64_t out_stride, uint64_t* d_sizes, uint8_t* d_index, uint8_t* d_tables, uint32_t* d_zmap, uint8_t* d_stage, uint32_t* d_err, hipStream_t s);
+hipError_t codec_decode(int algo, const uint8_t* d_in, const uint64_t* d_offsets, const uint64_t* d_sizes, uint32_t n_chunks, uint8_t* d_out,
+                        uint64_t out_stride, uint64_t out_total, bool exact, const uint8_t* d_index, uint64_t* d_produced, uint32_t* d_err,
+                        uint8_t* d_tables, uint32_t* d_zmap, hipStream_t s, uint8_t* d_pass = nullptr);
+const char* encode_kernel_name(int algo);
+const char* decode_kernel_name(int algo);
+size_t container_bound(int algo, size_t n, size_t chunk);
+size_t container_bound_slotted(int algo, size_t n, size_t chunk);
+int check_header(const density_hip_header_t& h, size_t container_size);
+
+// device-side drivers of the container (api.hip; ctx already acquired; `ws` points at a workspace of sufficient size)
+int run_encode_container(DeviceCtx* c, int algo, const uint8_t* d_in, size_t n, uint8_t* d_out, size_t cap, size_t chunk,
+                         uint8_t* ws, hipStream_t s, density_hip_header_t* header_out, bool slotted = false);
+int run_decode_container(DeviceCtx* c, const uint8_t* d_in, size_t container_size, const density_hip_header_t& h, uint8_t* d_out,
+                         size_t cap, uint8_t* ws, hipStream_t s, size_t* decoded_out, size_t ws_size = 0);
+// ... of one reference stream (api_stream.hip)
+int run_stream_encode(DeviceCtx* c, int algo, const uint8_t* d_in, size_t n, uint8_t* d_out, size_t cap, uint8_t* ws, hipStream_t s, size_t* size_out);
+int run_stream_decode(DeviceCtx* c, int algo, const uint8_t* d_in, size_t n, uint8_t* d_out, size_t cap, uint8_t* ws, hipStream_t s, size_t* size_out);
+
+}  // namespace api
+}  // namespace density
