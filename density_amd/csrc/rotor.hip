@@ -470,6 +470,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
     // The records of a round without raw blocks, straight-line: the signatures and the index bytes leave from lanes 0..R-1 in one
     // store each (lane j: record j, offsets by a DPP prefix over the record lengths); per block the MAP lanes store the 2-byte slot
     // index (the upper half of the hash product), the PLAIN lanes the quad, through an SGPR base (io/write_buffer.rs:13-27).
+    const uint32_t minus_2lane = 0u - 2u * lane;
     auto emit_round_coded = [&](uint32_t pos0, uint8_t* idxp, uint32_t slo, uint32_t shi) {
         const uint32_t nhv = (uint32_t)(__builtin_popcount(slo) + __builtin_popcount(shi));
         const uint32_t lenv = kSig + kBlock - 2u * nhv;
@@ -494,8 +495,8 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
             const uint64_t sg = ((uint64_t)rlane_u(shi, (int)j) << 32) | rlane_u(slo, (int)j);
             const uint64_t plain = ~sg;
             const uint32_t pos = rlane_u(itemsv, (int)j);                         // (one read instead of a scalar running sum: popcount, shift, subtract, add)
-            // the item's place: 2 * (lane + PLAIN lanes below) = 4*lane - 2*(MAP lanes below) from the record's items on — the count seeded with
-            // the lane, doubled and added in one instruction
+            // the item's place: 4*lane - 2*(MAP lanes below) from the record's items on — the signature itself is the mask that is counted (no
+            // complement to make), the count seeded with -2*lane, times -2 and added in one instruction
             const uint32_t P = kKeepHash ? hp[j] : q[j] * kHashMul;               // (the hash is the MAP item: chameleon.rs:92)
             if (j + 1 < R) {
                 const uint32_t nsig = rlane_u(slo, (int)j + 1);                    // the next record's first bytes: its signature's low word
@@ -503,16 +504,16 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
                 asm volatile(
                     "s_mov_b64 vcc, %[sg]\n\t"
                     "v_cndmask_b32_sdwa %[v], %[q], %[P], vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1\n\t"   // an item's first two bytes: MAP the hash, PLAIN the quad's low half
-                    "v_mbcnt_lo_u32_b32 %[o], %[pl], %[ln]\n\t"
-                    "v_mbcnt_hi_u32_b32 %[o], %[ph], %[o]\n\t"                        // (two instructions between the select and the lane shift that reads it: the wait states a DPP source needs)
+                    "v_mbcnt_lo_u32_b32 %[o], %[sl], %[ln]\n\t"                        // MAP lanes below - 2 * lane (the count seeded with -2 * lane) ...
+                    "v_mbcnt_hi_u32_b32 %[o], %[sh], %[o]\n\t"                        // (two instructions between the select and the lane shift that reads it: the wait states a DPP source needs)
                     "v_mov_b32_dpp %[v], %[v] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"   // ... of the NEXT lane's item (lane 63: replaced below)
-                    "v_lshl_add_u32 %[o], %[o], 1, %[pos]\n\t"
+                    "v_mad_i32_i24 %[o], %[o], -2, %[pos]\n\t"                        // ... times -2, from the record's items on: 4 * lane - 2 * (MAP lanes below)
                     "v_writelane_b32 %[v], %[ns], 63\n\t"
                     "v_perm_b32 %[v], %[v], %[P], %[sel]\n\t"                         // hash | following bytes << 16
                     "v_cndmask_b32 %[v], %[q], %[v], vcc\n\t"                         // PLAIN lanes: the quad
                     "global_store_dword %[o], %[v], %[dst]"
                     : [v] "=&v"(val), [o] "=&v"(off)
-                    : [P] "v"(P), [q] "v"(q[j]), [sg] "s"(sg), [pl] "s"((uint32_t)plain), [ph] "s"((uint32_t)(plain >> 32)), [ln] "v"(lane), [pos] "s"(pos),
+                    : [P] "v"(P), [q] "v"(q[j]), [sg] "s"(sg), [sl] "s"((uint32_t)sg), [sh] "s"((uint32_t)(sg >> 32)), [ln] "v"(minus_2lane), [pos] "s"(pos),
                       [ns] "s"(nsig), [sel] "s"(0x05040302u), [dst] "s"(dst)
                     : "memory", "vcc");
             } else {

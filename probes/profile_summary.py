@@ -71,6 +71,11 @@ with open(f"profiles/{tag}_lds_counters.txt", "w") as fh:
             fh.write(f"  -> per CU: LDS array busy {vals['SQ_LDS_IDX_ACTIVE'] / 256 / cyc:.1%} of the kernel's {cyc:.4g} cycles")
         fh.write("\n")
 shutil.copy(f"{src}/phase_profile.txt", f"profiles/{tag}_phase_profile.txt")
+import os
+if os.path.exists(f"{src}/ta_sq.txt"):
+    shutil.copy(f"{src}/ta_sq.txt", f"profiles/{tag}_ta_sq_counters.txt")
+if os.path.exists(f"{src}/vmem_width.txt"):
+    shutil.copy(f"{src}/vmem_width.txt", f"profiles/{tag}_probe_vmem_width.log")
 for extra in ("packed", "cheetah"):
     m = glob.glob(f"{src}/stats_{extra}/**/*_kernel_stats.csv", recursive=True)
     if m:
