@@ -41,7 +41,7 @@ inline bool valid_algo(int algo) { return algo >= DENSITY_HIP_CHAMELEON && algo 
 // chunk_size 0 = automatic: one chunk is one work-group on one CU, so an input should be cut into at least as many chunks as the device has
 // CUs (256) where that is possible without dropping below 64 KiB (small chunks restart the dictionary and cost ratio), and no finer than that
 // (every chunk start costs a table clear and a few in-order rounds): never above 4 MiB, the largest chunk the index-fed decoder takes.
-// Power of two: 10 MB -> 64 KiB (153 chunks), 100 MB -> 256 KiB (382), 256 MiB -> 1 MiB, >= 1 GiB -> 4 MiB.
+// 10 MB -> 64 KiB (156 chunks), 100 MB -> 384 KiB (255), 256 MiB -> 1 MiB, 1 GiB -> 4 MiB, 1.5 GiB -> 3 MiB (512).
 // Lion runs one WAVE per chunk stream and is bound by memory latency per stream, not by a CU's LDS: it wants eight streams per CU (2048)
 // and starts from 1 MiB.  Cheetah's decode passes (decode_passes.hip) walk one chunk per CU, in time proportional to the chunk: one
 // chunk per CU exactly — the input over 256, up to whole 4 KiB trips of the encoder's passes — between 64 KiB and 1 MiB (100 MB -> 384 KiB:
@@ -53,10 +53,19 @@ inline size_t auto_chunk(size_t n, int algo = DENSITY_HIP_CHAMELEON) {
         if (c > (1u << 20)) c = 1u << 20;
         return c;
     }
-    const bool lds = algo == DENSITY_HIP_CHAMELEON;
-    size_t c = lds ? (4u << 20) : (1u << 20);
-    const size_t streams = lds ? 256 : 2048;
-    while (c > (64u << 10) && n / c < streams) c >>= 1;
+    if (algo == DENSITY_HIP_CHAMELEON) {
+        // (round 4: not a power of two any more.  A chunk is a work-group is a CU, so what counts is WHOLE WAVES of 256 chunks: 100 MB in 382 chunks
+        // of 256 KiB is two rounds of work-groups, the second half empty; in 255 chunks of 384 KiB it is one — a quarter less time, and a better
+        // ratio.  The fewest whole waves of chunks of at most 4 MiB, the input spread evenly over them in whole rounds of 16 blocks.)
+        if (n <= 256u * (size_t)(64u << 10)) return 64u << 10;
+        const size_t waves = (n + 256u * (size_t)(4u << 20) - 1) / (256u * (size_t)(4u << 20));
+        size_t c = align_up((n + 256 * waves - 1) / (256 * waves), 4096);
+        if (c < (64u << 10)) c = 64u << 10;
+        if (c > (4u << 20)) c = 4u << 20;
+        return c;
+    }
+    size_t c = 1u << 20;                                                              // Lion: the largest power of two that still gives the device 2048 streams
+    while (c > (64u << 10) && n / c < 2048) c >>= 1;
     return c;
 }
 inline size_t normalise_chunk(size_t chunk, size_t n, int algo = DENSITY_HIP_CHAMELEON) { return chunk == 0 ? auto_chunk(n, algo) : chunk; }

@@ -119,9 +119,10 @@ typedef struct density_hip_header {
     uint64_t container_len;  /* total container length in bytes (header + table + padded payloads) */
 } density_hip_header_t;
 
-/* chunk_size 0 in the calls below means density_hip_auto_chunk_for(algo, input_size); for Chameleon (density_hip_auto_chunk): a power of two between 64 KiB and 4 MiB, the largest that
- * still gives every CU of the device a chunk (a chunk is one work-group; small chunks restart the dictionary and cost ratio, every
- * chunk start costs a table clear: 10 MB -> 64 KiB, 100 MB -> 256 KiB, 256 MiB -> 1 MiB, >= 1 GiB -> 4 MiB). */
+/* chunk_size 0 in the calls below means density_hip_auto_chunk_for(algo, input_size); for Chameleon (density_hip_auto_chunk): a chunk is one work-group
+ * on one CU, small chunks restart the dictionary and cost ratio, every chunk start costs a table clear — so: 64 KiB up to 16 MiB of input, beyond
+ * that the fewest whole waves of 256 chunks of at most 4 MiB with the input spread evenly over them in whole 4 KiB rounds (10 MB -> 64 KiB,
+ * 100 MB -> 384 KiB = 255 chunks, 256 MiB -> 1 MiB, 1 GiB -> 4 MiB, 1.5 GiB -> 3 MiB = 512 chunks). */
 size_t density_hip_auto_chunk(size_t input_size);
 /* The same per algorithm, 64 KiB .. 1 MiB: Lion (one wave per chunk stream, memory-latency bound) takes the largest power of two that
  * still gives the device 2048 streams; Cheetah (decode passes: one chunk's chain of contexts per CU, in time proportional to the chunk)
