@@ -707,6 +707,7 @@ __global__ __launch_bounds__(64) void cheetah_decode_wave(const uint8_t* __restr
 // what travels along a chain of lanes on the same predictor slot; the dictionary is touched only by quads no entry predicted.
 // =================================================================================================================
 struct Row5 { uint32_t n[5]; };
+__device__ __forceinline__ uint32_t rlane32(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
 __device__ __forceinline__ Row5 row_load(const uint32_t* p) {
     Row5 r;
 #pragma unroll
@@ -754,7 +755,7 @@ __global__ __launch_bounds__(64) void lion_encode_wave(const uint8_t* __restrict
     Tables<DENSITY_HIP_LION> t;
     t.dict = reinterpret_cast<Pair*>(tables + slot * kTableBytes);
     t.pred = reinterpret_cast<uint32_t*>(tables + slot * kTableBytes + 65536ull * sizeof(Pair));
-    const bool act = lane < 16;
+    const bool act16 = lane < 16;
     const uint32_t below = (1u << (lane & 31u)) - 1u;
     for (uint64_t chunk = slot; chunk < n_chunks; chunk += n_slots) {
         const uint8_t* src = in + chunk * chunk_bytes;
@@ -776,41 +777,48 @@ __global__ __launch_bounds__(64) void lion_encode_wave(const uint8_t* __restrict
             pos = ts[0]; opos = ts[1]; last_hash = ts[2];
             guard.prev = ts[3]; guard.start = ts[4]; guard.counter = ts[5];
         }
-        uint32_t qnext = (act && pos + G::kBlock <= len) ? ld32u(src + pos + 4u * lane) : 0u;
+        // (Round 4.)  TWO blocks per step — lanes 0..15 the first, 16..31 the second — where the second is there and no hand-over boundary lies between them:
+        // a step is one gather of rows and pairs, their resolution across lanes and the stores, and costs the same latency for 32 quads as for 16 (the key
+        // matches and the chains of one slot work on 32 lanes: Cheetah's records are 32 quads).  Whether the second block is coded at all depends on the
+        // first record's length (codec.rs:35-37,68), which only the resolution gives: it is resolved on the assumption that it is, and dropped — its lanes store
+        // nothing, the slots it shares keep the first block's last writers — when the blow-up protection says otherwise; the next step then copies it.
+        auto window = [&](uint64_t at) -> uint32_t { return (lane < 32 && at + 4u * lane + 4u <= len) ? ld32u(src + at + 4u * lane) : 0u; };
+        uint32_t qwin = window(pos);                                             // the quads of the next two blocks
         bool may_hand_over = head_state && len >= 4ull * head_bytes, handed_over = false;   // (as cheetah_encode_wave)
         uint64_t last_copy_end = 0;
-        for (; pos + G::kBlock <= len; pos += G::kBlock) {
+        while (pos + G::kBlock <= len) {
             if (may_hand_over && pos >= head_bytes && (pos & 4095u) == 0) {
                 if (pos >= last_copy_end + head_calm && guard.penalty == 0) { handed_over = true; break; }
                 if (pos >= 4ull * head_bytes || pos >= len / 2) may_hand_over = false;   // raw copies this far in are not the cold start's: no hand-over
             }
-            const uint8_t* blk = src + pos;
             if (guard.block_is_copy()) {                                      // codec.rs:35-37
                 last_copy_end = pos + G::kBlock;
-                if (act) st32u(dst + opos + 4u * lane, qnext);
-                qnext = (act && pos + 2 * G::kBlock <= len) ? ld32u(blk + G::kBlock + 4u * lane) : 0u;
-                opos += G::kBlock;
+                if (act16) st32u(dst + opos + 4u * lane, qwin);
+                pos += G::kBlock; opos += G::kBlock;
+                qwin = window(pos);
                 guard.decay();
                 continue;
             }
-            const uint32_t q = qnext;
+            const bool can2 = pos + 2u * G::kBlock <= len && !(may_hand_over && ((pos + G::kBlock) & 4095u) == 0);
+            const uint32_t nact = can2 ? 32u : 16u;
+            const bool act = lane < nact;
+            const uint32_t q = qwin;
             const uint32_t h = hash16(q);
             const uint32_t hprev = bperm(lane ? lane - 1u : 0u, h);
             const uint32_t ps = lane == 0 ? last_hash : hprev;               // lion.rs:213,268
             tbl_drain();
             Row5 row = act ? row_load(t.pred + 5u * ps) : Row5{{0u, 0u, 0u, 0u, 0u}};
             const Pair e0 = act ? tbl_load_pair(t.dict + h) : Pair{0u, 0u};
-            qnext = (act && pos + 2 * G::kBlock <= len) ? ld32u(blk + G::kBlock + 4u * lane) : 0u;
+            const uint32_t qwin_next = window(pos + 4u * nact);                // (on the assumption that the step takes all its blocks)
             uint32_t da = e0.a, db = e0.b, pdirty = 0, ddirty = 0;
             uint32_t peq, deq;
             same_key_masks2(ps, act, h, act, lane, peq, deq);
             const uint32_t pbefore = peq & below, dbefore = deq & below;
             const uint32_t pprev = pbefore ? 31u - (uint32_t)__builtin_clz(pbefore) : 64u;
             const uint32_t dprev = dbefore ? 31u - (uint32_t)__builtin_clz(dbefore) : 64u;
-            const bool plast = act && (peq >> (lane & 31u) >> 1) == 0, dlast = act && (deq >> (lane & 31u) >> 1) == 0;
             uint32_t flag = 0;
             bool done = !act;
-            for (uint32_t round = 0; round < 16; ++round) {                   // (a chain has at most 16 links)
+            for (uint32_t round = 0; round < 32; ++round) {                   // (a chain has at most 32 links)
                 const uint32_t done_mask = (uint32_t)ballot64(done && act);
                 const bool pok = pprev == 64u || ((done_mask >> pprev) & 1u), dok = dprev == 64u || ((done_mask >> dprev) & 1u);
                 const bool ready = !done && pok && dok;
@@ -835,19 +843,43 @@ __global__ __launch_bounds__(64) void lion_encode_wave(const uint8_t* __restrict
                 if (ballot64(!done) == 0) break;
             }
             const uint32_t ilen = !act ? 0u : (flag == 0 ? 4u : (flag >= 6 ? 2u : 0u));
-            uint32_t items;
-            const uint32_t off = scan32(ilen, lane, items);
+            uint32_t both;
+            const uint32_t off = scan32(ilen, lane, both);
+            const uint32_t items1 = can2 ? rfl(bperm(16u, off)) : both;
+            const uint32_t rlen1 = G::kSig + items1;
+            Guard g2 = guard;
+            g2.update(rlen1 >= G::kBlock);                                        // codec.rs:68 for the first record ...
+            Guard g2c = g2;
+            const bool two = can2 && !g2c.block_is_copy();                        // ... and :35 for the block behind it
+            const uint32_t live = two ? 0xffffffffu : 0x0000ffffu;               // the lanes whose work stands
+            const bool mine = act && ((live >> (lane & 31u)) & 1u);
+            const bool plast = mine && ((peq & live) >> (lane & 31u) >> 1) == 0, dlast = mine && ((deq & live) >> (lane & 31u) >> 1) == 0;
             uint8_t* rec = dst + opos;
-            const uint64_t sig = spread16by3((uint32_t)ballot64(act && (flag & 1u))) | (spread16by3((uint32_t)ballot64(act && (flag & 2u))) << 1) |
-                                 (spread16by3((uint32_t)ballot64(act && (flag & 4u))) << 2);
+            const uint32_t f0 = (uint32_t)ballot64(act && (flag & 1u)), f1 = (uint32_t)ballot64(act && (flag & 2u)), f2 = (uint32_t)ballot64(act && (flag & 4u));
+            const uint64_t sig = spread16by3(f0) | (spread16by3(f1) << 1) | (spread16by3(f2) << 2);
             if (lane < 3) st16u(rec + 2u * lane, (uint32_t)(sig >> (16u * lane)) & 0xffffu);   // lion.rs:334-337: 6 bytes
-            if (ilen == 4) st32u(rec + G::kSig + off, q); else if (ilen == 2) st16u(rec + G::kSig + off, h);
+            if (two) {
+                const uint64_t sigb = spread16by3(f0 >> 16) | (spread16by3(f1 >> 16) << 1) | (spread16by3(f2 >> 16) << 2);
+                if (lane < 3) st16u(rec + rlen1 + 2u * lane, (uint32_t)(sigb >> (16u * lane)) & 0xffffu);
+            }
+            // (a lane of the second record: its items start one signature further on)
+            uint8_t* ip = rec + G::kSig + off + (lane >= 16 ? G::kSig : 0u);
+            if (mine) { if (ilen == 4) st32u(ip, q); else if (ilen == 2) st16u(ip, h); }
             if (plast && pdirty) row_store(t.pred + 5u * ps, row);
             if (dlast && ddirty) tbl_store_pair(t.dict + h, Pair{da, db});
-            last_hash = rfl(bperm(15u, h));
-            const uint32_t rlen = G::kSig + items;
-            guard.update(rlen >= G::kBlock);
-            opos += rlen;
+            if (two) {
+                last_hash = rfl(bperm(31u, h));
+                guard = g2c;
+                const uint32_t rlen2 = G::kSig + (both - items1);
+                guard.update(rlen2 >= G::kBlock);
+                opos += rlen1 + rlen2; pos += 2u * G::kBlock;
+                qwin = qwin_next;
+            } else {
+                last_hash = rfl(bperm(15u, h));
+                guard = g2;
+                opos += rlen1; pos += G::kBlock;
+                qwin = can2 ? window(pos) : qwin_next;                            // (the second block was resolved in vain: its quads again, as the next step's first)
+            }
         }
         tbl_drain();
         if (head_state) {
@@ -938,7 +970,7 @@ __global__ __launch_bounds__(64) void lion_decode_wave(const uint8_t* __restrict
     Tables<DENSITY_HIP_LION> t;
     t.dict = reinterpret_cast<Pair*>(tables + slot * kTableBytes);
     t.pred = reinterpret_cast<uint32_t*>(tables + slot * kTableBytes + 65536ull * sizeof(Pair));
-    const bool act = lane < 16;
+    const bool act16 = lane < 16;
     const uint32_t below = (1u << (lane & 31u)) - 1u;
     for (uint64_t chunk = slot; chunk < n_chunks; chunk += n_slots) {
         const uint8_t* src = in + offsets[chunk];
@@ -956,28 +988,58 @@ __global__ __launch_bounds__(64) void lion_decode_wave(const uint8_t* __restrict
         Guard guard;
         uint64_t ipos = 0, opos = 0;
         bool bad = false, done = false;
+        uint32_t ahead = 0;                                                       // (the register a touch-ahead load lands in: see below)
         while (elen - ipos >= kMaxRecord && cap - opos >= G::kBlock) {
             if (guard.block_is_copy()) {                                      // codec.rs:89-91
-                if (act) st32u(dst + opos + 4u * lane, ld32u(src + ipos + 4u * lane));
+                if (act16) st32u(dst + opos + 4u * lane, ld32u(src + ipos + 4u * lane));
                 ipos += G::kBlock; opos += G::kBlock;
                 guard.decay();
                 continue;
             }
+            // (Round 4.)  TWO records per step where the second one is whole, coded and has room: lanes 0..15 the first, 16..31 the second.  A step is a
+            // chain of dependent memory reads (signature, items, predicted runs, rows) that costs the same for 32 quads as for 16 — the key matches, the
+            // forwarding along chains of one slot and the repair walk all work on 32 lanes (Cheetah's records are 32 quads) — so this halves the number of chains.
             const uint8_t* rec = src + ipos;
             const uint64_t sig = ((uint64_t)ld32u(rec) | ((uint64_t)ld32u(rec + 4) << 32)) & 0xffffffffffffull;   // lion.rs:340-351
-            const uint32_t flag = act ? (uint32_t)(sig >> (3u * (lane & 15u))) & 7u : 1u;
-            const uint32_t ilen = !act ? 0u : (flag == 0 ? 4u : (flag >= 6 ? 2u : 0u));
+            uint32_t flag = act16 ? (uint32_t)(sig >> (3u * (lane & 15u))) & 7u : 1u;
+            uint32_t ilen = !act16 ? 0u : (flag == 0 ? 4u : (flag >= 6 ? 2u : 0u));
             uint32_t items;
-            const uint32_t off = scan32(ilen, lane, items);
+            uint32_t off = scan32(ilen, lane, items);
+            const uint32_t rlen1 = G::kSig + items;
+            Guard g2 = guard;
+            g2.update(rlen1 >= G::kBlock);                                        // codec.rs:98 for the first record ...
+            Guard g2c = g2;
+            const bool two = elen - ipos >= rlen1 + kMaxRecord && cap - opos >= 2u * G::kBlock && !g2c.block_is_copy();   // ... and :89 for the block behind it
+            const uint8_t* rec2 = rec + rlen1;
+            uint32_t items2 = 0;
+            if (two) {
+                const uint64_t sig2 = ((uint64_t)ld32u(rec2) | ((uint64_t)ld32u(rec2 + 4) << 32)) & 0xffffffffffffull;
+                if (lane >= 16 && lane < 32) { flag = (uint32_t)(sig2 >> (3u * (lane & 15u))) & 7u; ilen = flag == 0 ? 4u : (flag >= 6 ? 2u : 0u); }
+                uint32_t both;
+                off = scan32(ilen, lane, both);
+                items2 = both - items;
+            }
+            const uint32_t nact = two ? 32u : 16u;
+            const bool act = lane < nact;
+            const uint8_t* ibase = lane < 16 ? rec + G::kSig + off : rec2 + G::kSig + (off - items);
             uint32_t q = 0, h = 0;
-            if (ilen == 4) { q = ld32u(rec + G::kSig + off); h = hash16(q); } else if (ilen == 2) h = ld16u(rec + G::kSig + off);
+            if (ilen == 4) { q = ld32u(ibase); h = hash16(q); } else if (ilen == 2) h = ld16u(ibase);
             const bool dtouch = act && (flag == 0 || flag >= 6);              // touches the dictionary (lion.rs:85-186)
             const bool predicted = act && flag >= 1 && flag <= 5;
-            tbl_drain();
+            // (Round 4.)  The stream is read 50-70 bytes at a time, each record's place known only from the one before: nothing fetches it ahead, and
+            // the signature and the items were two dependent misses per record.  Two lanes touch the lines 512 and 640 bytes on, in the shadow of
+            // the table reads below (loads return in order: issued here, not in front of the signature load).  The touch's register is held — as an
+            // operand of the drain of the NEXT record, by which time it has long landed — so that nothing else lives where the load lands.
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(ahead) : : "memory");          // tbl_drain(): the previous record's table stores are in L2
+            {
+                const uint64_t far = ipos + 512u + 128u * (lane & 1u);
+                const uint8_t* pa = src + (far + 4 <= elen ? far : ipos);
+                if (lane < 2) asm volatile("global_load_dword %0, %1, off" : "=v"(ahead) : "v"(pa) : "memory");
+            }
             const Pair e0 = dtouch ? tbl_load_pair(t.dict + h) : Pair{0u, 0u};
             // ---- runs of predicted quads: one dependent read per round; speculation: nobody earlier in this record rewrote that row ----
             bool known = !predicted;
-            for (uint32_t round = 0; round < 16; ++round) {
+            for (uint32_t round = 0; round < 32; ++round) {
                 const uint32_t hp = bperm(lane ? lane - 1u : 0u, h);
                 const uint32_t kpv = bperm(lane ? lane - 1u : 0u, known ? 1u : 0u);
                 const bool kp = lane == 0 || kpv != 0;
@@ -991,6 +1053,7 @@ __global__ __launch_bounds__(64) void lion_decode_wave(const uint8_t* __restrict
             const uint32_t hprev = bperm(lane ? lane - 1u : 0u, h);
             const uint32_t ps = lane == 0 ? last_hash : hprev;
             Row5 row = act ? row_load(t.pred + 5u * ps) : Row5{{0u, 0u, 0u, 0u, 0u}};
+            const Row5 row_mem = row;                                             // as memory holds it (the repair below starts over from it)
             // ---- dictionary, in dependency order among the lanes that touch it ----
             uint32_t peq, deq;
             same_key_masks2(ps, act, h, dtouch, lane, peq, deq);
@@ -999,7 +1062,7 @@ __global__ __launch_bounds__(64) void lion_decode_wave(const uint8_t* __restrict
             const bool dlast = dtouch && (deq >> (lane & 31u) >> 1) == 0;
             uint32_t da = e0.a, db = e0.b, ddirty = 0;
             bool ddone = !dtouch;
-            for (uint32_t round = 0; round < 16; ++round) {
+            for (uint32_t round = 0; round < 32; ++round) {
                 const uint32_t done_mask = (uint32_t)ballot64(ddone && dtouch);
                 const bool ready = !ddone && (dprev == 64u || ((done_mask >> dprev) & 1u));
                 const uint32_t fda = bperm(dprev & 31u, da), fdb = bperm(dprev & 31u, db), fdd = bperm(dprev & 31u, ddirty);
@@ -1018,7 +1081,7 @@ __global__ __launch_bounds__(64) void lion_decode_wave(const uint8_t* __restrict
             const bool plast = act && (peq >> (lane & 31u) >> 1) == 0;
             uint32_t pdirty = 0;
             bool pdone = !act, wrong = false;
-            for (uint32_t round = 0; round < 16; ++round) {
+            for (uint32_t round = 0; round < 32; ++round) {
                 const uint32_t done_mask = (uint32_t)ballot64(pdone && act);
                 const bool ready = !pdone && (pprev == 64u || ((done_mask >> pprev) & 1u));
                 const Row5 frow = row_from_lane(pprev & 31u, row);
@@ -1038,25 +1101,68 @@ __global__ __launch_bounds__(64) void lion_decode_wave(const uint8_t* __restrict
                 }
                 if (ballot64(!pdone) == 0) break;
             }
+            uint32_t psf = ps;                                                    // the predictor slot my row is stored to
+            bool plastf = plast;
             if (ballot64(wrong) != 0) {
-                __threadfence();
-                if (lane == 0) { t.last_hash = last_hash; bad = lion_record_scalar(t, src, elen, ipos, dst, cap, opos, done, guard); last_hash = t.last_hash; }
-                __threadfence();
-                ipos = bcast64(ipos); opos = bcast64(opos); last_hash = rfl(last_hash);
-                bad = rfl(bad ? 1u : 0u) != 0; done = rfl(done ? 1u : 0u) != 0;
-                guard.penalty = rfl(guard.penalty); guard.start = rfl(guard.start); guard.prev = rfl(guard.prev); guard.counter = rfl(guard.counter);
-                if (bad || done) break;
-                continue;
+                // (Round 4.)  A speculation failed: a predicted quad read an entry that an earlier quad of this record has since moved.  Its real value —
+                // the entry of the row as forwarded — has another hash, so the quad behind it sits in another context than assumed, and so on.  Up to
+                // round 3 the whole record was decoded again by the scalar code on lane 0 (two dependent memory reads per quad: ≈24 µs, a fifth of the
+                // kernel's time on prose).  Now: ONE exact walk over the step's quads in stream order, in registers — every value wave-uniform — with rows
+                // forwarded between quads of one context, taken from the speculative gather where it was made at the right context, and read from
+                // memory only where the context turned out to be another one (lion.rs:85-186).
+                uint32_t ctx = last_hash;
+                uint32_t cxv = 0xffffffffu, dirtyv = 0;                           // per lane, once walked: my true context; my row differs from memory
+                Row5 rf = row_mem;
+#pragma nounroll
+                for (uint32_t i = 0; i < nact; ++i) {
+                    const uint32_t m = (uint32_t)ballot64(lane < i && cxv == ctx);
+                    Row5 r;
+                    uint32_t dirty = 0;
+                    if (m) {                                                      // the latest earlier quad of this context hands its row on
+                        const uint32_t j = 31u - (uint32_t)__builtin_clz(m);
+#pragma unroll
+                        for (int k = 0; k < 5; ++k) r.n[k] = rlane32(rf.n[k], j);
+                        dirty = rlane32(dirtyv, j);
+                    } else if (rlane32(ps, i) == ctx) {                           // nobody before it in this record: memory's row, gathered at the right place
+#pragma unroll
+                        for (int k = 0; k < 5; ++k) r.n[k] = rlane32(row_mem.n[k], i);
+                    } else {
+                        r = row_load(t.pred + 5u * ctx);
+                    }
+                    const uint32_t f = rlane32(flag, i);
+                    uint32_t qi, hi;
+                    if (f >= 1u && f <= 5u) {
+                        qi = r.n[0];
+#pragma unroll
+                        for (uint32_t k = 1; k < 5; ++k) qi = f == k + 1u ? r.n[k] : qi;
+                        hi = hash16(qi);
+                        if (f > 1u) { row_promote(r, f - 1u, qi); dirty = 1; }
+                    } else {
+                        qi = rlane32(q, i); hi = rlane32(h, i);                   // what the dictionary gave: no context in it
+                        row_promote(r, 4, qi); dirty = 1;
+                    }
+                    if (lane == i) { q = qi; h = hi; rf = r; cxv = ctx; dirtyv = dirty; }
+                    ctx = hi;
+                }
+                row = rf; pdirty = dirtyv; psf = cxv;
+                uint32_t peq2, deq2;
+                same_key_masks2(cxv, act, h, false, lane, peq2, deq2);
+                plastf = act && (peq2 >> (lane & 31u) >> 1) == 0;
             }
             if (act) st32u(dst + opos + 4u * lane, q);
-            if (plast && pdirty) row_store(t.pred + 5u * ps, row);
+            if (plastf && pdirty) row_store(t.pred + 5u * psf, row);
             if (dlast && ddirty) tbl_store_pair(t.dict + h, Pair{da, db});
-            last_hash = rfl(bperm(15u, h));
-            const uint32_t rlen = G::kSig + items;
-            guard.update(rlen >= G::kBlock);
-            ipos += rlen; opos += G::kBlock;
+            last_hash = rfl(bperm(nact - 1u, h));
+            if (two) {
+                guard = g2c;                                                      // (the first record's update and the second block's turn at :89 are in it)
+                guard.update(G::kSig + items2 >= G::kBlock);
+                ipos += rlen1 + G::kSig + items2; opos += 2u * G::kBlock;
+            } else {
+                guard = g2;
+                ipos += rlen1; opos += G::kBlock;
+            }
         }
-        tbl_drain();
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(ahead) : : "memory");              // tbl_drain(), and the last touch-ahead has landed before its register is anyone else's
         __threadfence();
         if (lane == 0) {                                                      // the rest: scalar code, codec.rs:102-123
             t.last_hash = last_hash;
