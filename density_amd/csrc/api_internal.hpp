@@ -64,10 +64,10 @@ inline size_t auto_chunk(size_t n, int algo = DENSITY_HIP_CHAMELEON) {
         if (c > (4u << 20)) c = 4u << 20;
         return c;
     }
-    // Lion: one wave per chunk stream, bound by memory latency per stream — the largest power of two that still gives the device 1024 streams
+    // Lion: one wave per chunk stream, bound by memory latency per stream — the largest power of two that still gives the device 700 streams (about three per CU)
     // (round 4, with two records per step: 100 MB in 128 KiB chunks runs as fast as round 3's 64 KiB chunks did, at ratio 1.41 instead of 1.28)
     size_t c = 1u << 20;
-    while (c > (64u << 10) && n / c < 1024) c >>= 1;
+    while (c > (64u << 10) && n / c < 700) c >>= 1;
     return c;
 }
 inline size_t normalise_chunk(size_t chunk, size_t n, int algo = DENSITY_HIP_CHAMELEON) { return chunk == 0 ? auto_chunk(n, algo) : chunk; }

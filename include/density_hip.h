@@ -125,7 +125,7 @@ typedef struct density_hip_header {
  * 100 MB -> 384 KiB = 255 chunks, 256 MiB -> 1 MiB, 1 GiB -> 4 MiB, 1.5 GiB -> 3 MiB = 512 chunks). */
 size_t density_hip_auto_chunk(size_t input_size);
 /* The same per algorithm, 64 KiB .. 1 MiB: Lion (one wave per chunk stream, memory-latency bound) takes the largest power of two that
- * still gives the device 1024 streams (100 MB -> 128 KiB); Cheetah (decode passes: one chunk's chain of contexts per CU, in time proportional to the chunk)
+ * still gives the device 700 streams, about three per CU (100 MB -> 128 KiB); Cheetah (decode passes: one chunk's chain of contexts per CU, in time proportional to the chunk)
  * one chunk per CU: the input over 256, rounded up to 4 KiB (100 MB -> 384 KiB). */
 size_t density_hip_auto_chunk_for(int algo, size_t input_size);
 

@@ -60,7 +60,7 @@ def test_container_bound_arithmetic():
 
 def test_auto_chunk_policy():
     """density_hip_auto_chunk_for (host arithmetic): Chameleon in whole waves of 256 chunks of at most 4 MiB, in whole 4 KiB rounds, 64 KiB up to
-    16 MiB of input; Cheetah one chunk per CU in 4 KiB trips between 64 KiB and 1 MiB; Lion the largest power of two with 1024 streams."""
+    16 MiB of input; Cheetah one chunk per CU in 4 KiB trips between 64 KiB and 1 MiB; Lion the largest power of two with 700 streams."""
     L = _lib.lib()
     want = {10_192_446: 65536, 16 << 20: 65536, 100_000_000: 393_216, 256 << 20: 1 << 20, 1 << 30: 4 << 20, 3 << 29: 3 << 20, 2 << 30: 4 << 20}
     for n, c in want.items():
