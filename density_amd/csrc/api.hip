@@ -472,6 +472,8 @@ void density_hip_shutdown(void) {
         for (Buffer* b : {&c->work, &c->stage_in, &c->stage_out, &c->seg}) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
         if (c->pin_sizes) (void)hipHostFree(c->pin_sizes);
         c->pin_sizes = nullptr; c->pin_sizes_cap = 0;
+        if (c->pin_meta) (void)hipHostFree(c->pin_meta);
+        c->pin_meta = nullptr; c->pin_meta_cap = 0;
         for (hipEvent_t ev : c->pipe_events) (void)hipEventDestroy(ev);
         c->pipe_events.clear();
         for (hipEvent_t ev : c->events) (void)hipEventDestroy(ev);

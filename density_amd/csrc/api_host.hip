@@ -4,6 +4,32 @@
 
 namespace density {
 namespace api {
+
+bool pipe_streams(DeviceCtx* c, uint32_t n_events) {
+    hipError_t e = hipSuccess;
+    if (!c->up) {
+        e = hipStreamCreateWithFlags(&c->up, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->down, hipStreamNonBlocking);
+        for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipStreamCreateWithFlags(&c->kern[i], hipStreamNonBlocking);
+    }
+    while (e == hipSuccess && c->pipe_events.size() < n_events) {
+        hipEvent_t ev;
+        e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        if (e == hipSuccess) c->pipe_events.push_back(ev);
+    }
+    if (e != hipSuccess) { set_error("pipelined host path: streams / events", e); return false; }
+    return true;
+}
+hipError_t pin_meta_ensure(DeviceCtx* c, size_t bytes) {
+    if (bytes <= c->pin_meta_cap) return hipSuccess;
+    if (c->pin_meta) (void)hipHostFree(c->pin_meta);
+    c->pin_meta = nullptr; c->pin_meta_cap = 0;
+    const size_t want = align_up(bytes + bytes / 2, 4096);
+    const hipError_t e = hipHostMalloc((void**)&c->pin_meta, want, hipHostMallocDefault);
+    if (e == hipSuccess) c->pin_meta_cap = want;
+    return e;
+}
+
 namespace {
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -16,16 +42,6 @@ namespace {
 // better than N / (N + E) x 56 = 35 GB/s; overlapped it is bound by the larger of the two.  Where pinning fails (memory that is
 // already registered, read-only mappings) the plain staged path below is taken.
 // ---------------------------------------------------------------------------------------------------------------
-struct PinnedInPlace {
-    void* p = nullptr;
-    PinnedInPlace(const void* q, size_t n) {
-        if (q && n && hipHostRegister(const_cast<void*>(q), n, hipHostRegisterDefault) == hipSuccess) p = const_cast<void*>(q);
-        else (void)hipGetLastError();
-    }
-    ~PinnedInPlace() { if (p) (void)hipHostUnregister(p); }
-    explicit operator bool() const { return p != nullptr; }
-};
-constexpr uint32_t kPipeMaxSlices = 48;
 // Slices of whole chunks.  A slice's kernel takes as long as ONE chunk takes (0.11 ms per MiB of chunk: chunks run side by side, a chunk is a
 // chain) and the kernels of different slices mostly queue up behind one another (the streams share a few hardware queues), so a slice
 // must be worth ~10 chunk lengths of transfer or the kernels, not the link, set the pace: a twelfth of the input, ten chunks, 2 MiB at least —
@@ -41,21 +57,6 @@ inline size_t pipe_slice_bytes(size_t total, size_t chunk) {
 inline bool pipe_wanted(int algo, size_t n, size_t chunk, size_t n_chunks) {
     if (algo != DENSITY_HIP_CHAMELEON || n_chunks < 4 || (g_variant & 512)) return false;
     return (g_variant & 256) || (n >= (32u << 20) && n >= 3 * pipe_slice_bytes(n, chunk));
-}
-bool pipe_streams(DeviceCtx* c, uint32_t n_events) {
-    hipError_t e = hipSuccess;
-    if (!c->up) {
-        e = hipStreamCreateWithFlags(&c->up, hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->down, hipStreamNonBlocking);
-        for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipStreamCreateWithFlags(&c->kern[i], hipStreamNonBlocking);
-    }
-    while (e == hipSuccess && c->pipe_events.size() < n_events) {
-        hipEvent_t ev;
-        e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
-        if (e == hipSuccess) c->pipe_events.push_back(ev);
-    }
-    if (e != hipSuccess) { set_error("pipelined host path: streams / events", e); return false; }
-    return true;
 }
 inline uint32_t pipe_slice_chunks(size_t total, size_t chunk, size_t n_chunks) {
     const size_t target = pipe_slice_bytes(total, chunk);
@@ -254,12 +255,12 @@ size_t density_hip_encode(int algo, const uint8_t* input, size_t input_size, uin
     hipError_t e = c->stage_in.ensure(input_size ? input_size : 1);
     if (e == hipSuccess) e = c->stage_out.ensure(bound);
     if (e == hipSuccess) e = c->work.ensure(plan_encode(algo, input_size, chunk_size).total);
-    if (e == hipSuccess && input_size) e = hipMemcpyAsync(c->stage_in.p, input, input_size, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && input_size) e = copy_host_side_pinned(c->stage_in.p, input, input_size, hipMemcpyHostToDevice, c->stream);
     if (e != hipSuccess) { set_error("staging (H2D)", e); return 0; }
     density_hip_header_t h;
     if (run_encode_container(c, algo, (const uint8_t*)c->stage_in.p, input_size, (uint8_t*)c->stage_out.p, bound, chunk_size, (uint8_t*)c->work.p, c->stream, &h) != DENSITY_HIP_OK) return 0;
     if (h.container_len > output_size) { set_error("output buffer too small"); return 0; }
-    e = hipMemcpy(output, c->stage_out.p, h.container_len, hipMemcpyDeviceToHost);
+    e = copy_host_side_pinned(output, c->stage_out.p, h.container_len, hipMemcpyDeviceToHost, c->stream);
     if (e != hipSuccess) { set_error("staging (D2H)", e); return 0; }
     return (size_t)h.container_len;
 }
@@ -290,11 +291,11 @@ size_t density_hip_decode(const uint8_t* container, size_t container_size, uint8
     hipError_t e = c->stage_in.ensure(h.container_len);
     if (e == hipSuccess) e = c->stage_out.ensure(h.total_len);
     if (e == hipSuccess) e = c->work.ensure(plan_decode(h.algo, h.n_chunks, h.chunk_size).total_with_passes);
-    if (e == hipSuccess) e = hipMemcpyAsync(c->stage_in.p, container, h.container_len, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = copy_host_side_pinned(c->stage_in.p, container, h.container_len, hipMemcpyHostToDevice, c->stream);
     if (e != hipSuccess) { set_error("staging (H2D)", e); return 0; }
     size_t produced = 0;
     if (run_decode_container(c, (const uint8_t*)c->stage_in.p, h.container_len, h, (uint8_t*)c->stage_out.p, h.total_len, (uint8_t*)c->work.p, c->stream, &produced, c->work.cap) != DENSITY_HIP_OK) return 0;
-    e = hipMemcpy(output, c->stage_out.p, produced, hipMemcpyDeviceToHost);
+    e = copy_host_side_pinned(output, c->stage_out.p, produced, hipMemcpyDeviceToHost, c->stream);
     if (e != hipSuccess) { set_error("staging (D2H)", e); return 0; }
     return produced;
 }

@@ -42,8 +42,7 @@ inline bool valid_algo(int algo) { return algo >= DENSITY_HIP_CHAMELEON && algo 
 // CUs (256) where that is possible without dropping below 64 KiB (small chunks restart the dictionary and cost ratio), and no finer than that
 // (every chunk start costs a table clear and a few in-order rounds): never above 4 MiB, the largest chunk the index-fed decoder takes.
 // 10 MB -> 64 KiB (156 chunks), 100 MB -> 384 KiB (255), 256 MiB -> 1 MiB, 1 GiB -> 4 MiB, 1.5 GiB -> 3 MiB (512).
-// Lion runs one WAVE per chunk stream and is bound by memory latency per stream, not by a CU's LDS: it wants eight streams per CU (2048)
-// and starts from 1 MiB.  Cheetah's decode passes (decode_passes.hip) walk one chunk per CU, in time proportional to the chunk: one
+// Lion runs one WAVE per chunk stream and is bound by memory latency per stream, not by a CU's LDS (below).  Cheetah's decode passes (decode_passes.hip) walk one chunk per CU, in time proportional to the chunk: one
 // chunk per CU exactly — the input over 256, up to whole 4 KiB trips of the encoder's passes — between 64 KiB and 1 MiB (100 MB -> 384 KiB:
 // ratio 1.67 where 64 KiB chunks gave 1.34, and a faster round trip).
 inline size_t auto_chunk(size_t n, int algo = DENSITY_HIP_CHAMELEON) {
@@ -105,6 +104,8 @@ struct DeviceCtx {
     std::vector<hipEvent_t> pipe_events;
     uint64_t* pin_sizes = nullptr;
     size_t pin_sizes_cap = 0;
+    uint8_t* pin_meta = nullptr;             // the pipelined stream calls: per segment sizes, offsets, states as the device reports them
+    size_t pin_meta_cap = 0;
     // profiling: event marks accumulated since the last density_hip_last_timings() (name == nullptr opens a call)
     std::vector<hipEvent_t> events;
     std::vector<const char*> names;
@@ -134,6 +135,41 @@ struct Profiler {
         (void)hipEventRecord(c->events[c->n_marks++], s);
     }
 };
+
+// A caller's buffer pinned in place for the duration of a call (hipHostRegister: microseconds on this platform, probes/host_register.hip), so that
+// copies from and to it are asynchronous.  Where pinning fails (memory that is already registered, read-only mappings) the staged paths are taken.
+struct PinnedInPlace {
+    void* p = nullptr;
+    PinnedInPlace(const void* q, size_t n) {
+        if (q && n && hipHostRegister(const_cast<void*>(q), n, hipHostRegisterDefault) == hipSuccess) p = const_cast<void*>(q);
+        else (void)hipGetLastError();
+    }
+    ~PinnedInPlace() { if (p) (void)hipHostUnregister(p); }
+    PinnedInPlace(const PinnedInPlace&) = delete;
+    PinnedInPlace& operator=(const PinnedInPlace&) = delete;
+    explicit operator bool() const { return p != nullptr; }
+};
+// One copy between the caller's memory and the device on stream s, complete on return.  A megabyte and more: the caller's side is pinned in place for
+// the copy's duration by US — never by the runtime's own pageable-copy path, which pins the caller's pages too but keeps what it pinned in a cache
+// of its own beyond the call; a later hipHostRegister of memory that has come to lie at such an address then maps stale pages (round 4: a GPU
+// write fault in the pipelined calls whenever a staged call on a since-freed buffer had gone before).
+inline hipError_t copy_host_side_pinned(void* dst, const void* src, size_t n, hipMemcpyKind kind, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    const void* host = kind == hipMemcpyHostToDevice ? src : dst;
+    if (n >= (1u << 20)) {
+        PinnedInPlace pin(host, n);
+        if (pin) {
+            const hipError_t e = hipMemcpyAsync(dst, src, n, kind, s), e2 = hipStreamSynchronize(s);
+            return e != hipSuccess ? e : e2;
+        }
+    }
+    const hipError_t e = hipMemcpyAsync(dst, src, n, kind, s), e2 = hipStreamSynchronize(s);
+    return e != hipSuccess ? e : e2;
+}
+constexpr uint32_t kPipeMaxSlices = 48;
+// the upload, download and kernel streams of the pipelined host-pointer calls and n_events events (api_host.hip)
+bool pipe_streams(DeviceCtx* c, uint32_t n_events);
+hipError_t pin_meta_ensure(DeviceCtx* c, size_t bytes);
 
 constexpr size_t kSerialSlots = 16384;   // concurrent chunk streams of the functional Cheetah/Lion kernels (one lane each; 12 / 28 GiB of tables when all are in use)
 constexpr size_t kSerialTableBudget = 8ull << 30;   // ... but never more than 8 GiB of tables (the count comes from an untrusted header on decode): Cheetah 10922 streams, Lion 4681

@@ -46,6 +46,8 @@ hipError_t launch_rotor_encode_seg(const uint8_t* d_in, uint64_t total, uint64_t
 hipError_t launch_rotor_lastwriters(const uint8_t* d_in, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_images, uint32_t* d_err, hipStream_t stream);
 // start images of chunks first+1 .. first+count: base image, then the last-writer images of chunks first+1 .. laid over it one after the other
 hipError_t launch_merge_images(const uint8_t* d_base, const uint8_t* d_lastwriters, uint8_t* d_start, uint32_t count, hipStream_t stream);
+// offsets[first + i] = *d_carry + sizes[first] + .. + sizes[first + i - 1]; *d_carry moves to the end of the last one
+hipError_t launch_scan_offsets(const uint64_t* d_sizes, uint32_t first, uint32_t count, uint64_t* d_carry, uint64_t* d_offsets, hipStream_t stream);
 // byte-granular gather of chunk streams (d_src + i * src_stride, sizes[i]) to d_dst + offsets[i]
 hipError_t launch_compact_bytes(const uint8_t* d_src, uint64_t src_stride, const uint64_t* d_sizes, const uint64_t* d_offsets, uint32_t n_chunks,
                                 uint8_t* d_dst, hipStream_t stream);
@@ -109,6 +111,8 @@ hipError_t launch_decode_passes(int algo, const uint8_t* d_in, const uint64_t* d
 uint64_t stream_parse_workspace(uint64_t E);
 hipError_t launch_stream_parse(const uint8_t* d_in, uint64_t E, uint64_t from_pos, uint8_t* d_ws, uint8_t* d_index, uint64_t index_cap, uint64_t* d_chunk_offset,
                                uint32_t chunk_blocks, uint32_t* d_pos32, uint32_t* d_info, hipStream_t stream);
+// offsets / sizes of segments [first, first + count) of a parsed stream from the parse's d_chunk_offset (`end` != ~0: where the range's last segment ends)
+hipError_t launch_seg_layout(const uint64_t* d_chunk_offset, uint32_t first, uint32_t count, uint64_t end, uint64_t* d_offsets, uint64_t* d_sizes, uint32_t* d_err, hipStream_t stream);
 
 // ---- container.hip ----
 // Exclusive scan of 16-byte-aligned chunk sizes -> payload offsets; writes the container header and the u32 size

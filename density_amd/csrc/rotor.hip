@@ -951,6 +951,15 @@ __global__ __launch_bounds__(256) void merge_images_kernel(const uint8_t* __rest
     }
 }
 
+// where the streams of segments [first, first + count) go: one behind the other from *carry on, which moves to their end (write_buffer.rs:29-31's
+// running total, a few dozen sizes at a time)
+__global__ void scan_offsets_kernel(const uint64_t* __restrict__ sizes, uint32_t first, uint32_t count, uint64_t* __restrict__ carry, uint64_t* __restrict__ offsets) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    uint64_t at = *carry;
+    for (uint32_t i = 0; i < count; ++i) { offsets[first + i] = at; at += sizes[first + i]; }
+    *carry = at;
+}
+
 // 16 bytes per lane: aligned stores, unaligned loads (the streams start at any even offset of the destination); head and tail by bytes
 __global__ __launch_bounds__(256) void compact_bytes_kernel(const uint8_t* __restrict__ src, uint64_t src_stride, const uint64_t* __restrict__ sizes,
                                                             const uint64_t* __restrict__ offsets, uint8_t* __restrict__ dst) {
@@ -1695,6 +1704,11 @@ hipError_t launch_merge_images(const uint8_t* d_base, const uint8_t* d_lastwrite
     hipError_t e = hipMemset2DAsync(d_start + kTableBytes, kSegImageBytes, 0, kZmapBytes, count, stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(merge_images_kernel, dim3(65536 / 256), dim3(256), 0, stream, d_base, d_lastwriters, d_start, count);
+    return hipGetLastError();
+}
+hipError_t launch_scan_offsets(const uint64_t* d_sizes, uint32_t first, uint32_t count, uint64_t* d_carry, uint64_t* d_offsets, hipStream_t stream) {
+    if (count == 0) return hipSuccess;
+    hipLaunchKernelGGL(scan_offsets_kernel, dim3(1), dim3(64), 0, stream, d_sizes, first, count, d_carry, d_offsets);
     return hipGetLastError();
 }
 hipError_t launch_compact_bytes(const uint8_t* d_src, uint64_t src_stride, const uint64_t* d_sizes, const uint64_t* d_offsets, uint32_t n_chunks,

@@ -23,7 +23,7 @@ namespace density {
 
 namespace {
 
-constexpr uint32_t kWin = 8192, kCand = kWin / 2, kEntries = 132, kEnd = 254, kGroup = 256;   // (8 KiB windows: 8 KiB of LDS each, 20 sweeps per CU in flight; 16 KiB and 4 KiB windows measured slower)
+constexpr uint32_t kWin = 8192, kCand = kWin / 2, kEntries = 132, kEnd = 254, kGroup = 256, kGroupSmall = 64;   // (8 KiB windows: 8 KiB of LDS each, 20 sweeps per CU in flight; 16 KiB and 4 KiB windows measured slower)
 constexpr uint32_t kHeadMaxBlocks = 4096;
 
 __device__ __forceinline__ uint64_t ld64u(const uint8_t* p) { return *reinterpret_cast<const u64_u*>(p); }
@@ -108,13 +108,13 @@ __global__ __launch_bounds__(64) void parse_windows_kernel(const uint8_t* __rest
 }
 
 // composition of the windows of one group: entry e of its first window -> (entry of the next group's first window, records)
-__global__ __launch_bounds__(64) void parse_groups_kernel(const uint8_t* __restrict__ T, const uint8_t* __restrict__ C, uint32_t n_windows,
+__global__ __launch_bounds__(64) void parse_groups_kernel(const uint8_t* __restrict__ T, const uint8_t* __restrict__ C, uint32_t n_windows, uint32_t group,
                                                           uint8_t* __restrict__ GT, uint32_t* __restrict__ GC) {
     extern __shared__ uint8_t gsm[];
     uint8_t* Ts = gsm;
-    uint8_t* Cs = gsm + kGroup * kEntries;
+    uint8_t* Cs = gsm + group * kEntries;
     const uint32_t lane = threadIdx.x, g = blockIdx.x;
-    const uint32_t w0 = g * kGroup, nw = n_windows - w0 < kGroup ? n_windows - w0 : kGroup;
+    const uint32_t w0 = g * group, nw = n_windows - w0 < group ? n_windows - w0 : group;
     for (uint32_t i = lane; i < nw * kEntries; i += 64) { Ts[i] = T[(uint64_t)w0 * kEntries + i]; Cs[i] = C[(uint64_t)w0 * kEntries + i]; }
     __syncthreads();
     for (uint32_t e = lane; e < kEntries; e += 64) {
@@ -138,14 +138,14 @@ __global__ void parse_top_kernel(const uint8_t* __restrict__ GT, const uint32_t*
     info[4] = base;                                                               // whole blocks of the stream
 }
 
-__global__ __launch_bounds__(64) void parse_entries_kernel(const uint8_t* __restrict__ T, const uint8_t* __restrict__ C, uint32_t n_windows,
+__global__ __launch_bounds__(64) void parse_entries_kernel(const uint8_t* __restrict__ T, const uint8_t* __restrict__ C, uint32_t n_windows, uint32_t group,
                                                            const uint8_t* __restrict__ gent, const uint32_t* __restrict__ gbase,
                                                            uint8_t* __restrict__ went, uint32_t* __restrict__ wbase) {
     extern __shared__ uint8_t gsm[];
     uint8_t* Ts = gsm;
-    uint8_t* Cs = gsm + kGroup * kEntries;
+    uint8_t* Cs = gsm + group * kEntries;
     const uint32_t lane = threadIdx.x, g = blockIdx.x;
-    const uint32_t w0 = g * kGroup, nw = n_windows - w0 < kGroup ? n_windows - w0 : kGroup;
+    const uint32_t w0 = g * group, nw = n_windows - w0 < group ? n_windows - w0 : group;
     for (uint32_t i = lane; i < nw * kEntries; i += 64) { Ts[i] = T[(uint64_t)w0 * kEntries + i]; Cs[i] = C[(uint64_t)w0 * kEntries + i]; }
     __syncthreads();
     if (lane == 0) {
@@ -157,23 +157,44 @@ __global__ __launch_bounds__(64) void parse_entries_kernel(const uint8_t* __rest
     }
 }
 
-// one lane per window: forward from the window's entry — block index, chunk offsets, the end of the whole blocks
+// one wave per window: forward from the window's entry — block index, chunk offsets, the end of the whole blocks.  The window's bytes go to LDS in one
+// sweep and lane 0 walks them there (a step is an LDS read, not a trip to memory: the walk of ~50 records was the longest kernel of the parse — and
+// the pipelined host call pays the parse's latency once per slice)
 __global__ __launch_bounds__(64) void parse_emit_kernel(const uint8_t* __restrict__ in, uint64_t E, uint32_t* __restrict__ info,
                                                         const uint8_t* __restrict__ went, const uint32_t* __restrict__ wbase, uint32_t n_windows,
                                                         uint8_t* __restrict__ index, uint64_t index_cap, uint64_t* __restrict__ chunk_offset, uint32_t chunk_blocks,
                                                         uint32_t* __restrict__ pos32) {
-    const uint32_t w = blockIdx.x * 64 + threadIdx.x;
+    typedef uint4 uint4_u __attribute__((aligned(1)));
+    __shared__ __attribute__((aligned(16))) uint8_t win[kWin + 16];
+    const uint32_t w = blockIdx.x, lane = threadIdx.x;
     if (w >= n_windows || info[0] == 0) return;
     uint32_t c = went[w];
     if (c == kEnd) return;
     const uint64_t p0 = ((uint64_t)info[3] << 32) | info[2];
     const uint64_t ws = p0 + (uint64_t)w * kWin;
+    for (uint32_t v = lane; v < (kWin + 16) / 16; v += 64) {
+        const uint64_t p = ws + 16ull * v;
+        uint4 x = make_uint4(0, 0, 0, 0);
+        if (p + 16 <= E) { const uint4_u* sp = reinterpret_cast<const uint4_u*>(in + p); x = make_uint4(sp->x, sp->y, sp->z, sp->w); }
+        else if (p < E) {
+            uint8_t t[16] = {};
+            for (uint32_t i = 0; i < 16 && p + i < E; ++i) t[i] = in[p + i];
+            x = *reinterpret_cast<const uint4*>(t);
+        }
+        *reinterpret_cast<uint4*>(win + 16u * v) = x;
+    }
+    __syncthreads();
+    if (lane != 0) return;
     uint32_t b = wbase[w];
     while (c < kCand) {
         const uint64_t p = ws + 2ull * c;
         uint32_t pc = 0;
         bool whole = p + kSig <= E;
-        if (whole) { pc = (uint32_t)__builtin_popcountll(ld64u(in + p)); whole = p + (kSig + kBlock - 2u * pc) <= E; }
+        if (whole) {
+            const uint16_t* h = reinterpret_cast<const uint16_t*>(win + 2u * c);
+            pc = (uint32_t)__builtin_popcount((uint32_t)h[0] | ((uint32_t)h[1] << 16)) + (uint32_t)__builtin_popcount((uint32_t)h[2] | ((uint32_t)h[3] << 16));
+            whole = p + (kSig + kBlock - 2u * pc) <= E;
+        }
         if (!whole || b >= index_cap) {                                           // the ragged end (or nothing at all) starts here
             info[5] = (uint32_t)p; info[6] = (uint32_t)(p >> 32);
             return;
@@ -199,16 +220,47 @@ __global__ __launch_bounds__(256) void parse_check_kernel(const uint8_t* __restr
     }
 }
 
+// where the last whole block starts (info[11]): a caller that parses a stream piece by piece resumes ONE block back, so that the head walk's fresh
+// FSM sees the record in front of the new piece (a pair of incompressible records across the seam must not be missed: the check above looks at pairs
+// from the head's end on, the head at pairs from its first block on)
+__global__ void parse_tail_kernel(uint32_t* __restrict__ info, const uint32_t* __restrict__ pos32, uint64_t index_cap) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const uint32_t whole = info[4];
+    info[11] = (info[0] != 0 && whole > 0 && whole <= index_cap) ? pos32[whole - 1] : 0u;
+}
+
+// offsets and sizes of segments [first, first + count) of a parsed stream: segment k starts at chunk_offset[k] (the stream's first at 0); the
+// last one of the range ends at `end` where that is given (the stream's end; a piece's parse that stopped on a segment boundary), else where its successor starts
+__global__ void seg_layout_kernel(const uint64_t* __restrict__ chunk_offset, uint32_t first, uint32_t count, uint64_t end, uint64_t* __restrict__ offsets,
+                                  uint64_t* __restrict__ sizes, uint32_t* __restrict__ err) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t k = first + i;
+    const uint64_t off = k ? chunk_offset[k] : 0ull;
+    const uint64_t next = (i + 1 < count || end == ~0ull) ? chunk_offset[k + 1] : end;
+    if (next <= off) { atomicOr(err, 1u); offsets[k] = off; sizes[k] = 0; return; }   // (cannot happen; never hand the kernels a broken layout)
+    offsets[k] = off; sizes[k] = next - off;
+}
+
 }  // namespace
 
+hipError_t launch_seg_layout(const uint64_t* d_chunk_offset, uint32_t first, uint32_t count, uint64_t end, uint64_t* d_offsets, uint64_t* d_sizes, uint32_t* d_err, hipStream_t stream) {
+    if (count == 0) return hipSuccess;
+    hipLaunchKernelGGL(seg_layout_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, d_chunk_offset, first, count, end, d_offsets, d_sizes, d_err);
+    return hipGetLastError();
+}
+
 uint64_t stream_parse_workspace(uint64_t E) {
-    const uint64_t nw = E / kWin + 2, ng = (nw + kGroup - 1) / kGroup;
+    const uint64_t nw = E / kWin + 2, ng = (nw + kGroupSmall - 1) / kGroupSmall;   // (sized for the finer grouping)
     return nw * kEntries * 2 + ng * kEntries * 5 + ng * 5 + nw * 5 + 4096;
 }
 
 hipError_t launch_stream_parse(const uint8_t* d_in, uint64_t E, uint64_t from_pos, uint8_t* d_ws, uint8_t* d_index, uint64_t index_cap, uint64_t* d_chunk_offset,
                                uint32_t chunk_blocks, uint32_t* d_pos32, uint32_t* d_info, hipStream_t stream) {
-    const uint32_t nw = (uint32_t)((E - from_pos) / kWin + 2), ng = (nw + kGroup - 1) / kGroup;   // (windows behind the head, which starts at or behind from_pos)
+    const uint32_t nw = (uint32_t)((E - from_pos) / kWin + 2);                       // (windows behind the head, which starts at or behind from_pos)
+    // groups of 256 windows for long stretches (the groups are walked in sequence by one lane: few of them), of 64 for short ones — a piece of a
+    // stream that is parsed slice by slice: the walk through a group's windows is what the two group kernels' time is made of
+    const uint32_t group = nw > 64u * kGroupSmall ? kGroup : kGroupSmall, ng = (nw + group - 1) / group;
     uint8_t* T = d_ws;
     uint8_t* C = T + (uint64_t)nw * kEntries;
     uint32_t* GC = reinterpret_cast<uint32_t*>((reinterpret_cast<uintptr_t>(C + (uint64_t)nw * kEntries) + 15) & ~(uintptr_t)15);
@@ -217,17 +269,18 @@ hipError_t launch_stream_parse(const uint8_t* d_in, uint64_t E, uint64_t from_po
     uint8_t* GT = reinterpret_cast<uint8_t*>(wbase + nw);
     uint8_t* gent = GT + (uint64_t)ng * kEntries;
     uint8_t* went = gent + ng;
-    const size_t group_lds = (size_t)kGroup * kEntries * 2;
+    const size_t group_lds = (size_t)group * kEntries * 2;
     hipError_t e = hipFuncSetAttribute((const void*)parse_groups_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)group_lds);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)parse_entries_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)group_lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(parse_head_kernel, dim3(1), dim3(64), 0, stream, d_in, E, d_index, index_cap, d_info, d_pos32, d_chunk_offset, chunk_blocks);
     hipLaunchKernelGGL(parse_windows_kernel, dim3(nw), dim3(64), 0, stream, d_in, E, d_info, T, C);
-    hipLaunchKernelGGL(parse_groups_kernel, dim3(ng), dim3(64), group_lds, stream, T, C, nw, GT, GC);
+    hipLaunchKernelGGL(parse_groups_kernel, dim3(ng), dim3(64), group_lds, stream, T, C, nw, group, GT, GC);
     hipLaunchKernelGGL(parse_top_kernel, dim3(1), dim3(64), 0, stream, GT, GC, ng, d_info, gent, gbase);
-    hipLaunchKernelGGL(parse_entries_kernel, dim3(ng), dim3(64), group_lds, stream, T, C, nw, gent, gbase, went, wbase);
-    hipLaunchKernelGGL(parse_emit_kernel, dim3((nw + 63) / 64), dim3(64), 0, stream, d_in, E, d_info, went, wbase, nw, d_index, index_cap, d_chunk_offset, chunk_blocks, d_pos32);
+    hipLaunchKernelGGL(parse_entries_kernel, dim3(ng), dim3(64), group_lds, stream, T, C, nw, group, gent, gbase, went, wbase);
+    hipLaunchKernelGGL(parse_emit_kernel, dim3(nw), dim3(64), 0, stream, d_in, E, d_info, went, wbase, nw, d_index, index_cap, d_chunk_offset, chunk_blocks, d_pos32);
     hipLaunchKernelGGL(parse_check_kernel, dim3(256), dim3(256), 0, stream, d_index, index_cap, d_info);
+    hipLaunchKernelGGL(parse_tail_kernel, dim3(1), dim3(64), 0, stream, d_info, d_pos32, index_cap);
     return hipGetLastError();
 }
 
