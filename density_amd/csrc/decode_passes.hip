@@ -37,6 +37,7 @@ namespace density {
 
 extern __shared__ __attribute__((aligned(16))) uint8_t pass_lds[];
 bool g_force_serial_decode = false;   // density_hip_set_kernel_variant(128): Cheetah containers on the one-wave decoder instead
+bool g_serial_parse = false;          // density_hip_set_kernel_variant(1024): the records of a chunk found by the one-wave walk alone (no window kernels)
 
 namespace {
 
@@ -70,10 +71,98 @@ __device__ __forceinline__ uint64_t chunk_cap(const PassArgs& a, uint64_t chunk)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// parse, in parallel (round 4): where the records of a CALM chunk stream start, without walking the stream from its first byte.
+// A record's length is in its signature (8 + 128 - 2 per MAP flag - 4 per predicted one: cheetah.rs:17-23), so every even offset p is a candidate
+// record start with a known successor, whether or not a record starts there; and as long as never two records in a row are incompressible
+// (protection_state.rs:38-47) there are no raw copies and the FSM stays at rest.  The chain of real record starts enters each window of 2 KiB at one
+// of 68 even offsets (a record is 8 .. 136 bytes long):
+//   head      the one-wave walk below, with the real FSM, over the chunk's first records — a fresh dictionary makes them incompressible, raw copies
+//             follow — until the FSM is at rest behind a record that was not incompressible: the windows count from there;
+//   windows   per window, a lane per entry: from entry e the chain leaves the window at offset x of the next one after n records (or stops: fewer
+//             than 136 bytes are left, the one-wave walk below takes over there), and whether it saw two incompressible records in a row;
+//   walk      per chunk, the one-wave walk below with the windows' tables in LDS: wherever it stands at a window's entry with the FSM at rest, the
+//             table says no pair lies ahead in this window and the record in front does not make one with its first, the window is taken in one step
+//             (its entry and first block number noted); everything else — the windows with raw copies in them, the last records, the ragged end,
+//             the checks — record by record as before;
+//   emit      per window that was taken in one step, from its entry: rec[] of its blocks.
+// (A chunk whose stream the tables have no room for, or that has no calm head, is walked whole.)  SURVEY.md §8: codec/codec.rs:82-126.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr uint32_t kPW = 2048, kPE = 68, kPStop = 127, kPNone = 255, kHeadMark = 0x5eed0002u, kHeadMaxBlocks = 512;
+constexpr uint32_t kPWinLds = kPW + 144;                                  // a window and what a record that starts in it may reach into the next
+__device__ __forceinline__ uint32_t record_bytes(const uint8_t* lds_at) {  // item bytes behind the signature at a 2-byte aligned LDS address
+    const uint16_t* h = reinterpret_cast<const uint16_t*>(lds_at);
+    const uint32_t s0 = (uint32_t)h[0] | ((uint32_t)h[1] << 16), s1 = (uint32_t)h[2] | ((uint32_t)h[3] << 16);
+    const uint32_t lo0 = s0 & 0x55555555u, hi0 = (s0 >> 1) & 0x55555555u, lo1 = s1 & 0x55555555u, hi1 = (s1 >> 1) & 0x55555555u;
+    return 4u * kRecQuads - 2u * (uint32_t)(__builtin_popcount(lo0 | hi0) + __builtin_popcount(lo1 | hi1)) - 2u * (uint32_t)(__builtin_popcount(lo0 & hi0) + __builtin_popcount(lo1 & hi1));
+}
+__device__ __forceinline__ void stage_window(uint8_t* win, const uint8_t* src, uint32_t wstart, uint32_t elen, uint32_t tid, uint32_t threads) {
+    typedef uint4 uint4_u __attribute__((aligned(1)));
+    for (uint32_t v = tid; v < kPWinLds / 16; v += threads) {
+        const uint32_t p = wstart + 16u * v;
+        uint4 x = make_uint4(0, 0, 0, 0);
+        if (p + 16u <= elen) { const uint4_u* sp = reinterpret_cast<const uint4_u*>(src + p); x = make_uint4(sp->x, sp->y, sp->z, sp->w); }
+        else if (p < elen) {
+            uint8_t t[16] = {};
+            for (uint32_t i = 0; i < 16 && p + i < elen; ++i) t[i] = src[p + i];
+            x = *reinterpret_cast<const uint4*>(t);
+        }
+        *reinterpret_cast<uint4*>(win + 16u * v) = x;
+    }
+    __syncthreads();
+}
+// T[(chunk * wpc + w) * kPE + e]: exit [0,7) (kPStop: the chain stopped inside the window) | records [7,17) | where it stopped, from the window's start [17,29)
+// | first record incompressible [29] | last one [30] | two in a row [31]
+__global__ __launch_bounds__(128) void cheetah_parse_windows(PassArgs a, uint32_t wpc, uint32_t* __restrict__ T, uint8_t* __restrict__ went) {
+    __shared__ __attribute__((aligned(16))) uint8_t win[kPWinLds];
+    const uint32_t e = threadIdx.x, w = blockIdx.x;                           // (two waves: the second one's four lanes take entries 64 .. 67)
+    const uint64_t chunk = blockIdx.y;
+    if (e == 0) went[chunk * wpc + w] = (uint8_t)kPNone;
+    const uint64_t elen64 = a.sizes[chunk];
+    if (elen64 >= 0x7fffff00ull) return;
+    const ChunkInfo head = a.info[chunk];
+    if (head.pad1 != kHeadMark) return;                                       // (no calm head: the one-wave walk takes the whole chunk)
+    const uint32_t elen = (uint32_t)elen64;
+    const uint64_t wstart64 = (uint64_t)head.produced + (uint64_t)w * kPW;    // windows count from where the head walk stopped
+    if (wstart64 >= elen) return;
+    const uint32_t wstart = (uint32_t)wstart64;
+    const uint32_t hot_end = elen >= kSigBytes + kRecBytes ? elen - (kSigBytes + kRecBytes) + 1u : 0u;   // record starts below this have a whole record's room behind them (codec.rs:88)
+    stage_window(win, a.in + a.offsets[chunk], wstart, elen, e, 128);
+    if (e >= kPE) return;
+    uint32_t pos = 2u * e, cnt = 0, first = 0, last = 0, pair = 0, stop = 0;
+    while (pos < kPW) {
+        if (wstart + pos >= hot_end) { stop = 1; break; }
+        const uint32_t bytes = record_bytes(win + pos);
+        const uint32_t inc = kSigBytes + bytes >= kRecBytes ? 1u : 0u;           // codec.rs:98
+        if (cnt == 0) first = inc; else pair |= inc & last;
+        last = inc; ++cnt;
+        pos += kSigBytes + bytes;
+    }
+    T[(chunk * wpc + w) * kPE + e] = (stop ? kPStop : (pos - kPW) / 2u) | (cnt << 7) | ((stop ? pos : 0u) << 17) | (first << 29) | (last << 30) | (pair << 31);
+}
+__global__ __launch_bounds__(64) void cheetah_parse_emit(PassArgs a, uint32_t wpc, const uint8_t* __restrict__ went, const uint32_t* __restrict__ wbase) {
+    __shared__ __attribute__((aligned(16))) uint8_t win[kPWinLds];
+    const uint32_t lane = threadIdx.x, w = blockIdx.x;
+    const uint64_t chunk = blockIdx.y;
+    const uint32_t entry = went[chunk * wpc + w];
+    if (entry == kPNone) return;                                              // (walked record by record, or not at all)
+    const uint32_t elen = (uint32_t)a.sizes[chunk], wstart = a.info[chunk].pad1 + w * kPW;   // (pad1: where the chunk's windows count from, left by the walk)
+    stage_window(win, a.in + a.offsets[chunk], wstart, elen, lane, 64);
+    if (lane != 0) return;
+    uint32_t* rec = a.rec + chunk * (a.out_stride / kRecBytes);
+    uint32_t b = wbase[chunk * wpc + w], pos = 2u * entry;
+    while (pos < kPW) {                                                       // (a window that is taken in one step holds whole records only, and its chain leaves it)
+        rec[b++] = wstart + pos;
+        pos += kSigBytes + record_bytes(win + pos);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // parse: Codec::decode's walk over the records (codec/codec.rs:82-126) without decoding them
 // ---------------------------------------------------------------------------------------------------------------
 constexpr uint32_t kWin = 8192, kWinStride = kWin - 64;                   // bytes of stream per LDS window; windows overlap by 64 bytes (a signature + slack)
-__global__ __launch_bounds__(64) void cheetah_parse(PassArgs a) {
+// mode 0: the whole chunk | 1: from the head on with the windows' tables (the whole chunk where there are none) | 2: the head alone
+__global__ __launch_bounds__(64) void cheetah_parse(PassArgs a, uint32_t mode, uint32_t wpc, uint32_t table_lds, const uint32_t* __restrict__ T, uint8_t* __restrict__ went,
+                                                    uint32_t* __restrict__ wbase) {
     __shared__ __attribute__((aligned(16))) uint8_t win[2][kWin];
     const uint32_t lane = threadIdx.x;
     const uint64_t chunk = blockIdx.x;
@@ -108,6 +197,25 @@ __global__ __launch_bounds__(64) void cheetah_parse(PassArgs a) {
     fetch(0); land(0); fetch(1);
     // record positions are collected 64 at a time in a register (lane b % 64) and stored together
     uint32_t recv = 0;
+    bool tables = false;
+    uint32_t p0 = 0, nwin = 0;
+    const uint32_t* Ts = reinterpret_cast<const uint32_t*>(pass_lds);
+    if (mode == 1 && !ci.bad) {                                           // the head walk and the window kernels have been over this chunk
+        const ChunkInfo head = a.info[chunk];
+        if (head.pad1 == kHeadMark && head.produced < elen) {
+            p0 = head.produced;
+            nwin = (elen - p0 + kPW - 1) / kPW;
+            tables = nwin <= wpc && (uint64_t)nwin * kPE * 4 <= table_lds;
+        }
+        if (tables) {
+            uint32_t* Tw = reinterpret_cast<uint32_t*>(pass_lds);
+            for (uint32_t i = lane; i < nwin * kPE; i += 64) Tw[i] = T[chunk * wpc * kPE + i];
+            __syncthreads();
+            b = head.blocks; ip = p0; op = b * kRecBytes;
+            g.counter = b;                                                // at rest (no penalty, start 1) behind a record that was not incompressible
+            if ((b & 63u) != 0 && lane < (b & 63u)) recv = rec[(b & ~63u) + lane];   // the positions of the group that is being filled
+        }
+    }
     auto put = [&](uint32_t blk, uint32_t value) {
         recv = writelane(recv, value, blk & 63u);
         if ((blk & 63u) == 63u && (blk & ~63u) + lane < max_blocks) rec[(blk & ~63u) + lane] = recv;   // (never into the next chunk's positions)
@@ -128,9 +236,28 @@ __global__ __launch_bounds__(64) void cheetah_parse(PassArgs a) {
         return (at & 2u) ? (((uint64_t)((d1 >> 16) | (d2 << 16)) << 32) | ((d0 >> 16) | (d1 << 16))) : (((uint64_t)d1 << 32) | d0);
     };
     const uint32_t full_blocks = (uint32_t)(cap / kRecBytes);             // blocks of 128 decoded bytes the output has room for
+    bool head_ok = false;
     while (!ci.bad && ip < elen) {
+        if (mode == 2) {                                                  // the head: until the FSM is at rest behind a record that was not incompressible
+            if (b >= 2 && g.penalty == 0 && g.start == 1 && g.prev == 0) { head_ok = true; break; }
+            if (b >= kHeadMaxBlocks) break;
+        }
+        if (tables && g.penalty == 0 && g.start == 1 && ip >= p0) {       // at a window's entry with the FSM at rest: the whole window in one step?
+            const uint32_t rel = ip - p0, w = rel / kPW, off = rel - w * kPW;
+            if (off < 2u * kPE && w < nwin) {
+                const uint32_t t = rfl(Ts[w * kPE + off / 2u]), cnt = (t >> 7) & 0x3ffu, ex = t & 127u;
+                if (cnt != 0 && ex != kPStop && (t >> 31) == 0 && (g.prev & (t >> 29) & 1u) == 0 && b + cnt <= full_blocks) {
+                    if ((b & 63u) != 0 && lane < (b & 63u)) rec[(b & ~63u) + lane] = recv;   // what has been collected of the group so far (`emit` fills in behind it)
+                    if (lane == 0) { went[chunk * wpc + w] = (uint8_t)(off / 2u); wbase[chunk * wpc + w] = b; }
+                    b += cnt; op += cnt * kRecBytes; g.counter += cnt;
+                    ip = p0 + (w + 1u) * kPW + 2u * ex;
+                    g.prev = (t >> 30) & 1u;
+                    continue;
+                }
+            }
+        }
         window_for(ip);
-        {   // The common case in as few (scalar) instructions as it takes — a lone wave issues one instruction every 4-5 cycles: records that
+        if (mode == 0 || (mode == 1 && !tables)) {   // The common case in as few (scalar) instructions as it takes — a lone wave issues one instruction every 4-5 cycles: records that
             // are whole (codec.rs:88: 136 bytes are left), whose signature lies in this window, with the blow-up protection at rest (no
             // penalty, penalty start 1: protection_state.rs:19-27 then only counts) and room in the output.
             const uint32_t wend = (wk + 1u) * kWinStride - misalign;       // stream offsets below this have their 12 bytes in the window
@@ -208,7 +335,13 @@ __global__ __launch_bounds__(64) void cheetah_parse(PassArgs a) {
         g.update(kSigBytes + bytes >= kRecBytes);
     }
     if ((b & 63u) != 0 && lane < (b & 63u)) rec[(b & ~63u) + lane] = recv;   // the positions not yet stored
-    ci.blocks = b; ci.produced = op;
+    if (mode == 2) {                                                      // (what is wrong with a chunk is the last walk's to say)
+        ChunkInfo h{};
+        h.blocks = b; h.produced = ip; h.pad1 = head_ok ? kHeadMark : 0u;
+        if (lane == 0) a.info[chunk] = h;
+        return;
+    }
+    ci.blocks = b; ci.produced = op; ci.pad1 = p0;
     if (lane == 0) {
         a.info[chunk] = ci;
         if (ci.bad) atomicOr(a.err, kErrFormat);
@@ -610,7 +743,24 @@ hipError_t launch_decode_passes(int algo, const uint8_t* d_in, const uint64_t* d
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)cheetah_pass<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pass_lds_bytes());
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)cheetah_walk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWalkLds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(cheetah_parse, dim3(n_chunks), dim3(64), 0, stream, a);
+    // the records of calm stretches are found by the window kernels (their tables live where the descriptors and contexts will: nothing else is in use yet)
+    const uint64_t slot_bound = out_stride + out_stride / kRecBytes * kSigBytes + kSigBytes;
+    const uint32_t wpc = (uint32_t)((slot_bound + kPW - 1) / kPW);
+    const bool windows = !g_serial_parse && out_stride >= (64u << 10) && (uint64_t)wpc * kPE * 4 <= out_stride && (uint64_t)wpc * 8 <= out_stride / 2;
+    if (windows) {
+        uint32_t* T = a.desc;
+        uint32_t* wbase = reinterpret_cast<uint32_t*>(a.ctx);
+        uint8_t* went = reinterpret_cast<uint8_t*>(wbase + (uint64_t)n_chunks * wpc);
+        const uint32_t table_lds = (uint32_t)std::min<uint64_t>((uint64_t)wpc * kPE * 4, 140u * 1024);   // (+ the walk's own 16 KiB of stream windows)
+        e = hipFuncSetAttribute((const void*)cheetah_parse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)table_lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(cheetah_parse, dim3(n_chunks), dim3(64), 0, stream, a, 2u, 0u, 0u, (const uint32_t*)nullptr, (uint8_t*)nullptr, (uint32_t*)nullptr);
+        hipLaunchKernelGGL(cheetah_parse_windows, dim3(wpc, n_chunks), dim3(128), 0, stream, a, wpc, T, went);
+        hipLaunchKernelGGL(cheetah_parse, dim3(n_chunks), dim3(64), table_lds, stream, a, 1u, wpc, table_lds, (const uint32_t*)T, went, wbase);
+        hipLaunchKernelGGL(cheetah_parse_emit, dim3(wpc, n_chunks), dim3(64), 0, stream, a, wpc, (const uint8_t*)went, (const uint32_t*)wbase);
+    } else {
+        hipLaunchKernelGGL(cheetah_parse, dim3(n_chunks), dim3(64), 0, stream, a, 0u, 0u, 0u, (const uint32_t*)nullptr, (uint8_t*)nullptr, (uint32_t*)nullptr);
+    }
     const uint64_t pairs = (uint64_t)n_chunks * (blocks_per_chunk / 2);
     hipLaunchKernelGGL(cheetah_prepare, dim3((uint32_t)((pairs + 3) / 4)), dim3(256), 0, stream, a, blocks_per_chunk);
     hipLaunchKernelGGL(cheetah_pass<0>, dim3(2 * n_chunks), dim3(kPassWaves * 64), pass_lds_bytes(), stream, a);

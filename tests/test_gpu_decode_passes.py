@@ -34,9 +34,10 @@ def cpu_container(data, chunk, algo=ALGO, algo_id=1):
 
 
 def decode_both(raw, n):
-    """(passes result, one-wave result): each ('ok', bytes) or ('error',)"""
+    """(passes result, one-wave result): each ('ok', bytes) or ('error',).  The passes run twice — records found by the window kernels (default) and
+    by the one-wave walk alone (variant 1024) — and must agree with each other before they are compared with anything else."""
     res = []
-    for variant in (0, 128):
+    for variant in (0, 1024, 128):
         container.set_kernel_variant(variant)
         out = np.zeros(max(n, 1), dtype=np.uint8)
         try:
@@ -45,7 +46,8 @@ def decode_both(raw, n):
         except DecodeError:
             res.append(("error",))
     container.set_kernel_variant(0)
-    return res
+    assert res[0] == res[1], "window parse and one-wave parse disagree"
+    return [res[0], res[2]]
 
 
 KINDS = ["prose", "mixed", "random", "zeros", "rep", "binaryish", "samehash", "patchy", "pairs"]
