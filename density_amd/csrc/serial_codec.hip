@@ -15,6 +15,7 @@
 namespace density {
 
 bool g_force_lane_codec = false;   // density_hip_set_kernel_variant(16): Cheetah on the one-lane-per-stream kernels (cross-check)
+bool g_lion_two_records = false;   // density_hip_set_kernel_variant(2048): Lion's decoder two records per step (lion_decode_wave) instead of four
 
 namespace {
 
@@ -1187,6 +1188,261 @@ __global__ __launch_bounds__(64) void lion_decode_wave(const uint8_t* __restrict
     }
 }
 
+// ---- round 4, second step: FOUR records per step (the whole wave: lanes 16r .. 16r+15 take record r) ----
+// What a step costs is its chain of dependent memory reads, not its lanes; where a record's successor starts follows from its signature alone
+// (4 bytes per PLAIN flag, 2 per dictionary flag: lion.rs:317-325), so the four signatures are a chain of four reads of lines the touch-ahead
+// has brought in, and everything behind them — items, dictionary pairs, runs of predicted quads, rows, the key matches, the repair walk — is done
+// once for 64 quads.  Same semantics lane for lane as lion_decode_wave above (kept: kernel variant 2048, and the cross-check of this one).
+__device__ __forceinline__ uint64_t same_key_mask64(uint32_t key, bool on) {
+    uint64_t eq = ~0ull;
+#pragma unroll
+    for (uint32_t b = 0; b < 16; ++b) {
+        const bool bit = (key >> b) & 1u;
+        const uint64_t plane = ballot64(bit && on);
+        eq &= bit ? plane : ~plane;
+    }
+    return eq & ballot64(on);
+}
+__device__ __forceinline__ uint32_t lion_item_bytes(uint64_t sig) {                  // of a 48-bit signature: 4 per flag 0, 2 per flag 6 / 7, none per predicted one
+    constexpr uint64_t kLow = 0x0000249249249249ull;                                // bit 0 of each of the 16 three-bit flags
+    const uint64_t b0 = sig & kLow, b1 = (sig >> 1) & kLow, b2 = (sig >> 2) & kLow;
+    return 4u * (uint32_t)__builtin_popcountll(~(b0 | b1 | b2) & kLow) + 2u * (uint32_t)__builtin_popcountll(b2 & b1);
+}
+__device__ __forceinline__ uint64_t lion_sig_at(const uint8_t* p) {                  // lion.rs:340-351, as a scalar
+    return (((uint64_t)rfl(ld32u(p + 4)) << 32) | rfl(ld32u(p))) & 0xffffffffffffull;
+}
+__global__ __launch_bounds__(64) void lion_decode_wave4(const uint8_t* __restrict__ in, const uint64_t* __restrict__ offsets,
+                                                        const uint64_t* __restrict__ sizes, uint32_t n_chunks,
+                                                        uint8_t* __restrict__ out, uint64_t out_stride, uint64_t out_total,
+                                                        uint32_t exact, uint64_t* __restrict__ produced, uint32_t* __restrict__ err,
+                                                        uint8_t* __restrict__ tables, uint32_t n_slots) {
+    using G = Geo<DENSITY_HIP_LION>;
+    const uint32_t slot = blockIdx.x;
+    const uint32_t lane = threadIdx.x;
+    if (slot >= n_slots) return;
+    constexpr uint64_t kTableBytes = 65536ull * (sizeof(Pair) + 4ull * G::kPredWords);
+    constexpr uint32_t kMaxRecord = 8 + G::kBlock;                            // 6 + 16 x 4, and the signature is fetched as 8 bytes
+    Tables<DENSITY_HIP_LION> t;
+    t.dict = reinterpret_cast<Pair*>(tables + slot * kTableBytes);
+    t.pred = reinterpret_cast<uint32_t*>(tables + slot * kTableBytes + 65536ull * sizeof(Pair));
+    const uint32_t myrec = lane >> 4, k16 = lane & 15u;
+    const uint64_t below = (1ull << lane) - 1ull;
+    for (uint64_t chunk = slot; chunk < n_chunks; chunk += n_slots) {
+        const uint8_t* src = in + offsets[chunk];
+        const uint64_t elen = sizes[chunk];
+        uint8_t* dst = out + chunk * out_stride;
+        const uint64_t room_all = out_total - chunk * out_stride;
+        const uint64_t cap = room_all < out_stride ? room_all : out_stride;
+        if (chunk != slot) {
+            uint4* p = reinterpret_cast<uint4*>(tables + slot * kTableBytes);
+            const uint4 z = make_uint4(0, 0, 0, 0);
+            for (uint64_t i = lane; i < kTableBytes / 16; i += 64) p[i] = z;
+            __threadfence();
+        }
+        uint32_t last_hash = 0;
+        Guard guard;
+        uint64_t ipos = 0, opos = 0;
+        bool bad = false, done = false;
+        uint32_t ahead = 0;                                                       // (the register a touch-ahead load lands in)
+        while (elen - ipos >= kMaxRecord && cap - opos >= G::kBlock) {
+            if (guard.block_is_copy()) {                                      // codec.rs:89-91
+                if (lane < 16) st32u(dst + opos + 4u * lane, ld32u(src + ipos + 4u * lane));
+                ipos += G::kBlock; opos += G::kBlock;
+                guard.decay();
+                continue;
+            }
+            // the step's records: the first, and up to three more while each is whole, has room and the FSM lets it be coded (codec.rs:88-99)
+            uint64_t sg0 = lion_sig_at(src + ipos), sg1 = 0, sg2 = 0, sg3 = 0;
+            uint32_t at1 = 0, at2 = 0, at3 = 0;                                    // where records 1..3 start, from ipos
+            uint32_t nrec = 1;
+            Guard g = guard;
+            uint32_t len = G::kSig + lion_item_bytes(sg0);                        // stream bytes of the step so far
+            g.update(len >= G::kBlock);                                           // codec.rs:98
+            {
+                Guard gc = g;
+                if (elen - ipos - len >= kMaxRecord && cap - opos >= 2u * G::kBlock && !gc.block_is_copy()) {
+                    g = gc; at1 = len; sg1 = lion_sig_at(src + ipos + len);
+                    const uint32_t rl = G::kSig + lion_item_bytes(sg1);
+                    g.update(rl >= G::kBlock); len += rl; nrec = 2;
+                }
+            }
+            if (nrec == 2) {
+                Guard gc = g;
+                if (elen - ipos - len >= kMaxRecord && cap - opos >= 3u * G::kBlock && !gc.block_is_copy()) {
+                    g = gc; at2 = len; sg2 = lion_sig_at(src + ipos + len);
+                    const uint32_t rl = G::kSig + lion_item_bytes(sg2);
+                    g.update(rl >= G::kBlock); len += rl; nrec = 3;
+                }
+            }
+            if (nrec == 3) {
+                Guard gc = g;
+                if (elen - ipos - len >= kMaxRecord && cap - opos >= 4u * G::kBlock && !gc.block_is_copy()) {
+                    g = gc; at3 = len; sg3 = lion_sig_at(src + ipos + len);
+                    const uint32_t rl = G::kSig + lion_item_bytes(sg3);
+                    g.update(rl >= G::kBlock); len += rl; nrec = 4;
+                }
+            }
+            const uint32_t nact = 16u * nrec;
+            const bool act = lane < nact;
+            const uint64_t sig = myrec == 0 ? sg0 : myrec == 1 ? sg1 : myrec == 2 ? sg2 : sg3;
+            const uint32_t at = myrec == 0 ? 0u : myrec == 1 ? at1 : myrec == 2 ? at2 : at3;
+            const uint32_t flag = act ? (uint32_t)(sig >> (3u * k16)) & 7u : 1u;
+            const uint32_t ilen = !act ? 0u : (flag == 0 ? 4u : (flag >= 6 ? 2u : 0u));
+            uint32_t incl = ilen;                                                 // where my item lies behind my record's signature: a sum over the lanes of my row of 16
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xf, 0xf, true);   // row_shr:1
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xf, 0xf, true);   // row_shr:2
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xf, 0xf, true);   // row_shr:4
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xf, 0xf, true);   // row_shr:8
+            const uint8_t* ibase = src + ipos + at + G::kSig + (incl - ilen);
+            uint32_t q = 0, h = 0;
+            if (ilen == 4) { q = ld32u(ibase); h = hash16(q); } else if (ilen == 2) h = ld16u(ibase);
+            const bool dtouch = act && (flag == 0 || flag >= 6);              // touches the dictionary (lion.rs:85-186)
+            const bool predicted = act && flag >= 1 && flag <= 5;
+            // the previous step's table stores are in L2; four lanes touch the stream lines half a KiB on (see lion_decode_wave)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(ahead) : : "memory");
+            {
+                const uint64_t far = ipos + 512u + 128u * (lane & 3u);
+                const uint8_t* pa = src + (far + 4 <= elen ? far : ipos);
+                if (lane < 4) asm volatile("global_load_dword %0, %1, off" : "=v"(ahead) : "v"(pa) : "memory");
+            }
+            const Pair e0 = dtouch ? tbl_load_pair(t.dict + h) : Pair{0u, 0u};
+            // ---- runs of predicted quads: one dependent read per round; speculation: nobody earlier in this step rewrote that row ----
+            bool known = !predicted;
+            for (uint32_t round = 0; round < 64; ++round) {
+                const uint32_t hp = bperm(lane ? lane - 1u : 0u, h);
+                const uint32_t kpv = bperm(lane ? lane - 1u : 0u, known ? 1u : 0u);
+                const bool kp = lane == 0 || kpv != 0;
+                if (!known && kp) {
+                    q = tbl_load32(t.pred + 5u * (lane == 0 ? last_hash : hp) + (flag - 1u));
+                    h = hash16(q);
+                    known = true;
+                }
+                if (ballot64(!known) == 0) break;
+            }
+            const uint32_t hprev = bperm(lane ? lane - 1u : 0u, h);
+            const uint32_t ps = lane == 0 ? last_hash : hprev;
+            Row5 row = act ? row_load(t.pred + 5u * ps) : Row5{{0u, 0u, 0u, 0u, 0u}};
+            const Row5 row_mem = row;                                             // as memory holds it (the repair below starts over from it)
+            // ---- dictionary, in dependency order among the lanes that touch it ----
+            const uint64_t peq = same_key_mask64(ps, act), deq = same_key_mask64(h, dtouch);
+            const uint64_t dbefore = deq & below;
+            const uint32_t dprev = dbefore ? 63u - (uint32_t)__builtin_clzll(dbefore) : 64u;
+            const bool dlast = dtouch && ((deq >> lane) >> 1) == 0;
+            uint32_t da = e0.a, db = e0.b, ddirty = 0;
+            bool ddone = !dtouch;
+            for (uint32_t round = 0; round < 64; ++round) {
+                const uint64_t done_mask = ballot64(ddone && dtouch);
+                const bool ready = !ddone && (dprev == 64u || ((done_mask >> (dprev & 63u)) & 1ull));
+                const uint32_t fda = bperm(dprev & 63u, da), fdb = bperm(dprev & 63u, db), fdd = bperm(dprev & 63u, ddirty);
+                if (ready) {
+                    if (dprev != 64u) { da = fda; db = fdb; ddirty = fdd; }
+                    if (flag == 0) { db = da; da = q; ddirty = 1; }
+                    else if (flag == 6) q = da;
+                    else { q = db; db = da; da = q; ddirty = 1; }
+                    ddone = true;
+                }
+                if (ballot64(!ddone) == 0) break;
+            }
+            // ---- predictor rows, in dependency order (every quad rewrites its row unless it hit the front entry) ----
+            const uint64_t pbefore = peq & below;
+            const uint32_t pprev = pbefore ? 63u - (uint32_t)__builtin_clzll(pbefore) : 64u;
+            const bool plast = act && ((peq >> lane) >> 1) == 0;
+            uint32_t pdirty = 0;
+            bool pdone = !act, wrong = false;
+            for (uint32_t round = 0; round < 64; ++round) {
+                const uint64_t done_mask = ballot64(pdone && act);
+                const bool ready = !pdone && (pprev == 64u || ((done_mask >> (pprev & 63u)) & 1ull));
+                const Row5 frow = row_from_lane(pprev & 63u, row);
+                const uint32_t fpd = bperm(pprev & 63u, pdirty);
+                if (ready) {
+                    if (pprev != 64u) { row = frow; pdirty = fpd; }
+                    if (predicted) {
+                        uint32_t cur = row.n[0];
+#pragma unroll
+                        for (uint32_t k = 1; k < 5; ++k) cur = flag == k + 1u ? row.n[k] : cur;
+                        wrong = cur != q;                                     // the row as it really stands does not hold what the speculation read
+                        if (flag > 1) { row_promote(row, flag - 1u, q); pdirty = 1; }
+                    } else {
+                        row_promote(row, 4, q); pdirty = 1;                   // lion.rs:50-57
+                    }
+                    pdone = true;
+                }
+                if (ballot64(!pdone) == 0) break;
+            }
+            uint32_t psf = ps;                                                    // the predictor slot my row is stored to
+            bool plastf = plast;
+            if (ballot64(wrong) != 0) {
+                // the exact walk over the step's quads in stream order, in registers (see lion_decode_wave)
+                uint32_t ctx = last_hash;
+                uint32_t cxv = 0xffffffffu, dirtyv = 0;                           // per lane, once walked: my true context; my row differs from memory
+                Row5 rf = row_mem;
+#pragma nounroll
+                for (uint32_t i = 0; i < nact; ++i) {
+                    const uint64_t m = ballot64(lane < i && cxv == ctx);
+                    Row5 r;
+                    uint32_t dirty = 0;
+                    if (m) {                                                      // the latest earlier quad of this context hands its row on
+                        const uint32_t j = 63u - (uint32_t)__builtin_clzll(m);
+#pragma unroll
+                        for (int k = 0; k < 5; ++k) r.n[k] = rlane32(rf.n[k], j);
+                        dirty = rlane32(dirtyv, j);
+                    } else if (rlane32(ps, i) == ctx) {                           // nobody before it in this step: memory's row, gathered at the right place
+#pragma unroll
+                        for (int k = 0; k < 5; ++k) r.n[k] = rlane32(row_mem.n[k], i);
+                    } else {
+                        r = row_load(t.pred + 5u * ctx);
+                    }
+                    const uint32_t f = rlane32(flag, i);
+                    uint32_t qi, hi;
+                    if (f >= 1u && f <= 5u) {
+                        qi = r.n[0];
+#pragma unroll
+                        for (uint32_t k = 1; k < 5; ++k) qi = f == k + 1u ? r.n[k] : qi;
+                        hi = hash16(qi);
+                        if (f > 1u) { row_promote(r, f - 1u, qi); dirty = 1; }
+                    } else {
+                        qi = rlane32(q, i); hi = rlane32(h, i);                   // what the dictionary gave: no context in it
+                        row_promote(r, 4, qi); dirty = 1;
+                    }
+                    if (lane == i) { q = qi; h = hi; rf = r; cxv = ctx; dirtyv = dirty; }
+                    ctx = hi;
+                }
+                row = rf; pdirty = dirtyv; psf = cxv;
+                const uint64_t peq2 = same_key_mask64(cxv, act);
+                plastf = act && ((peq2 >> lane) >> 1) == 0;
+            }
+            if (act) st32u(dst + opos + 4u * lane, q);
+            if (plastf && pdirty) row_store(t.pred + 5u * psf, row);
+            if (dlast && ddirty) tbl_store_pair(t.dict + h, Pair{da, db});
+            last_hash = rlane32(h, nact - 1u);
+            guard = g;
+            ipos += len; opos += (uint64_t)nrec * G::kBlock;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(ahead) : : "memory");              // tbl_drain(), and the last touch-ahead has landed before its register is anyone else's
+        __threadfence();
+        if (lane == 0) {                                                      // the rest: scalar code, codec.rs:102-123
+            t.last_hash = last_hash;
+            while (ipos < elen && !bad && !done) {
+                const uint64_t rem = elen - ipos;
+                if (guard.block_is_copy()) {
+                    const uint32_t take = rem > G::kBlock ? G::kBlock : (uint32_t)rem;
+                    if (opos + take > cap) { bad = true; break; }
+                    for (uint32_t i = 0; i < take; ++i) dst[opos + i] = src[ipos + i];
+                    ipos += take; opos += take;
+                    if (rem <= G::kBlock) break;
+                    guard.decay();
+                    continue;
+                }
+                bad = lion_record_scalar(t, src, elen, ipos, dst, cap, opos, done, guard);
+            }
+            if (exact && !bad && opos != cap) bad = true;
+            produced[chunk] = opos;
+            if (bad) atomicOr(err, 1u);
+        }
+        __threadfence();
+    }
+}
+
 }  // namespace
 
 uint64_t serial_table_bytes(int algo) { return 65536ull * (sizeof(Pair) + 4ull * (algo == DENSITY_HIP_LION ? 5 : 1)); }
@@ -1246,6 +1502,8 @@ hipError_t launch_serial_decode(int algo, const uint8_t* d_in, const uint64_t* d
         hipLaunchKernelGGL(cheetah_decode_wave, dim3(n_slots), dim3(64), 0, stream, d_in, d_offsets, d_sizes, n_chunks, d_out, out_stride, out_total, exact ? 1u : 0u, d_produced, d_err, d_tables, n_slots);
     else if (algo == DENSITY_HIP_CHEETAH)
         hipLaunchKernelGGL(serial_decode_chunks<DENSITY_HIP_CHEETAH>, dim3(blocks), dim3(64), 0, stream, d_in, d_offsets, d_sizes, n_chunks, d_out, out_stride, out_total, exact ? 1u : 0u, d_produced, d_err, d_tables, n_slots);
+    else if (!g_force_lane_codec && !g_lion_two_records)
+        hipLaunchKernelGGL(lion_decode_wave4, dim3(n_slots), dim3(64), 0, stream, d_in, d_offsets, d_sizes, n_chunks, d_out, out_stride, out_total, exact ? 1u : 0u, d_produced, d_err, d_tables, n_slots);
     else if (!g_force_lane_codec)
         hipLaunchKernelGGL(lion_decode_wave, dim3(n_slots), dim3(64), 0, stream, d_in, d_offsets, d_sizes, n_chunks, d_out, out_stride, out_total, exact ? 1u : 0u, d_produced, d_err, d_tables, n_slots);
     else

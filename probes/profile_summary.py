@@ -76,7 +76,7 @@ if os.path.exists(f"{src}/ta_sq.txt"):
     shutil.copy(f"{src}/ta_sq.txt", f"profiles/{tag}_ta_sq_counters.txt")
 if os.path.exists(f"{src}/vmem_width.txt"):
     shutil.copy(f"{src}/vmem_width.txt", f"profiles/{tag}_probe_vmem_width.log")
-for extra in ("packed", "cheetah"):
+for extra in ("packed", "cheetah", "lion"):
     m = glob.glob(f"{src}/stats_{extra}/**/*_kernel_stats.csv", recursive=True)
     if m:
         shutil.copy(m[0], f"profiles/{tag}_{extra}_kernel_stats.csv")
