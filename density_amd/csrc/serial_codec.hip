@@ -741,6 +741,16 @@ __device__ __forceinline__ uint64_t spread16by3(uint32_t x16) {
     return x;
 }
 
+__device__ __forceinline__ uint64_t same_key_mask64(uint32_t key, bool on) {
+    uint64_t eq = ~0ull;
+#pragma unroll
+    for (uint32_t b = 0; b < 16; ++b) {
+        const bool bit = (key >> b) & 1u;
+        const uint64_t plane = ballot64(bit && on);
+        eq &= bit ? plane : ~plane;
+    }
+    return eq & ballot64(on);
+}
 __global__ __launch_bounds__(64) void lion_encode_wave(const uint8_t* __restrict__ in, uint64_t total, uint64_t chunk_bytes,
                                                        uint32_t n_chunks, uint8_t* __restrict__ out, uint64_t out_stride,
                                                        uint64_t* __restrict__ sizes, uint8_t* __restrict__ tables, uint32_t n_slots,
@@ -881,6 +891,192 @@ __global__ __launch_bounds__(64) void lion_encode_wave(const uint8_t* __restrict
                 opos += rlen1; pos += G::kBlock;
                 qwin = can2 ? window(pos) : qwin_next;                            // (the second block was resolved in vain: its quads again, as the next step's first)
             }
+        }
+        tbl_drain();
+        if (head_state) {
+            if (lane == 0) {
+                head_state[8 * chunk + 0] = (uint32_t)opos;
+                head_state[8 * chunk + 1] = last_hash;
+                head_state[8 * chunk + 2] = (guard.penalty ? 1u : 0u) | (guard.prev ? 2u : 0u);
+                head_state[8 * chunk + 3] = handed_over ? 0u : 2u;             // 2: the chunk is finished, nothing for the passes
+                head_state[8 * chunk + 4] = guard.start;
+                head_state[8 * chunk + 5] = guard.counter;
+                head_state[8 * chunk + 6] = (uint32_t)pos;                    // where the passes take over
+            }
+            if (handed_over) continue;
+        }
+        if (pos < len) {                                                      // the ragged last block: scalar code, lane 0
+            __threadfence();
+            if (lane == 0) {
+                t.last_hash = last_hash;
+                const uint32_t blen = (uint32_t)(len - pos);
+                const uint8_t* blk = src + pos;
+                if (guard.block_is_copy()) {
+                    for (uint32_t i = 0; i < blen; ++i) dst[opos + i] = blk[i];
+                    opos += blen;
+                } else {
+                    uint8_t* rec = dst + opos;
+                    uint64_t o = G::kSig, sig = 0;
+                    const uint32_t nq = blen >> 2;
+                    for (uint32_t k = 0; k < nq; ++k) {
+                        uint32_t item = 0, il = 0;
+                        const uint32_t flag = enc_quad(t, ld32u(blk + 4u * k), item, il);
+                        sig |= (uint64_t)flag << (G::kFlagBits * k);
+                        if (il == 2) st16u(rec + o, item); else if (il == 4) st32u(rec + o, item);
+                        o += il;
+                    }
+                    for (uint32_t i = 4u * nq; i < blen; ++i) rec[o++] = blk[i];
+                    store_sig<DENSITY_HIP_LION>(rec, sig);
+                    opos += o;
+                }
+            }
+            opos = bcast64(opos);
+            __threadfence();
+        }
+        if (lane == 0) sizes[chunk] = opos;
+    }
+}
+
+
+__global__ __launch_bounds__(64) void lion_encode_wave4(const uint8_t* __restrict__ in, uint64_t total, uint64_t chunk_bytes,
+                                                       uint32_t n_chunks, uint8_t* __restrict__ out, uint64_t out_stride,
+                                                       uint64_t* __restrict__ sizes, uint8_t* __restrict__ tables, uint32_t n_slots,
+                                                       const uint32_t* __restrict__ only, uint32_t* __restrict__ head_state, uint32_t head_bytes,
+                                                       uint32_t head_calm, const uint32_t* __restrict__ tail_state) {
+    // only / head_state / tail_state: as cheetah_encode_wave (the chunks handed back by, the heads before and the ragged ends behind the
+    // exchange passes of exchange_stages.hip)
+    using G = Geo<DENSITY_HIP_LION>;
+    const uint32_t slot = blockIdx.x;
+    const uint32_t lane = threadIdx.x;
+    if (slot >= n_slots) return;
+    constexpr uint64_t kTableBytes = 65536ull * (sizeof(Pair) + 4ull * G::kPredWords);
+    Tables<DENSITY_HIP_LION> t;
+    t.dict = reinterpret_cast<Pair*>(tables + slot * kTableBytes);
+    t.pred = reinterpret_cast<uint32_t*>(tables + slot * kTableBytes + 65536ull * sizeof(Pair));
+    const bool act16 = lane < 16;
+    const uint32_t myrec = lane >> 4;
+    const uint64_t below = (1ull << lane) - 1ull;
+    for (uint64_t chunk = slot; chunk < n_chunks; chunk += n_slots) {
+        const uint8_t* src = in + chunk * chunk_bytes;
+        const uint64_t len = (total - chunk * chunk_bytes) < chunk_bytes ? (total - chunk * chunk_bytes) : chunk_bytes;
+        uint8_t* dst = out + chunk * out_stride;
+        if (only && !only[chunk]) continue;
+        if (tail_state && !tail_state[8 * chunk + 6]) continue;
+        if ((chunk != slot || only || head_state) && !tail_state) {
+            uint4* p = reinterpret_cast<uint4*>(tables + slot * kTableBytes);
+            const uint4 z = make_uint4(0, 0, 0, 0);
+            for (uint64_t i = lane; i < kTableBytes / 16; i += 64) p[i] = z;
+            __threadfence();
+        }
+        uint32_t last_hash = 0;
+        Guard guard;
+        uint64_t opos = 0, pos = 0;
+        if (tail_state) {
+            const uint32_t* ts = tail_state + 8 * chunk;
+            pos = ts[0]; opos = ts[1]; last_hash = ts[2];
+            guard.prev = ts[3]; guard.start = ts[4]; guard.counter = ts[5];
+        }
+        // FOUR blocks per step (the whole wave: lanes 16r .. 16r+15 take block r) where they are there and no hand-over boundary lies between them; the
+        // scheme of lion_encode_wave above — every block behind the first is resolved on the assumption that it is coded, and the blocks from the first
+        // one the blow-up protection wants copied on are dropped: their lanes store nothing, the slots they share keep the last writers of the blocks that
+        // stand (`live`), the next step starts with the dropped block.
+        auto window = [&](uint64_t at) -> uint32_t { return (at + 4u * lane + 4u <= len) ? ld32u(src + at + 4u * lane) : 0u; };
+        uint32_t qwin = window(pos);                                             // the quads of the next four blocks
+        bool may_hand_over = head_state && len >= 4ull * head_bytes, handed_over = false;   // (as cheetah_encode_wave)
+        uint64_t last_copy_end = 0;
+        while (pos + G::kBlock <= len) {
+            if (may_hand_over && pos >= head_bytes && (pos & 4095u) == 0) {
+                if (pos >= last_copy_end + head_calm && guard.penalty == 0) { handed_over = true; break; }
+                if (pos >= 4ull * head_bytes || pos >= len / 2) may_hand_over = false;   // raw copies this far in are not the cold start's: no hand-over
+            }
+            if (guard.block_is_copy()) {                                      // codec.rs:35-37
+                last_copy_end = pos + G::kBlock;
+                if (act16) st32u(dst + opos + 4u * lane, qwin);
+                pos += G::kBlock; opos += G::kBlock;
+                qwin = window(pos);
+                guard.decay();
+                continue;
+            }
+            uint32_t nblk = 1;                                                    // blocks the step takes on: whole ones, up to a hand-over boundary
+            while (nblk < 4u && pos + (nblk + 1u) * G::kBlock <= len && !(may_hand_over && ((pos + nblk * G::kBlock) & 4095u) == 0)) ++nblk;
+            const uint32_t nact = 16u * nblk;
+            const bool act = lane < nact;
+            const uint32_t q = qwin;
+            const uint32_t h = hash16(q);
+            const uint32_t hprev = bperm(lane ? lane - 1u : 0u, h);
+            const uint32_t ps = lane == 0 ? last_hash : hprev;               // lion.rs:213,268
+            tbl_drain();
+            Row5 row = act ? row_load(t.pred + 5u * ps) : Row5{{0u, 0u, 0u, 0u, 0u}};
+            const Pair e0 = act ? tbl_load_pair(t.dict + h) : Pair{0u, 0u};
+            const uint32_t qwin_next = window(pos + 4u * nact);                // (on the assumption that the step takes all its blocks)
+            uint32_t da = e0.a, db = e0.b, pdirty = 0, ddirty = 0;
+            const uint64_t peq = same_key_mask64(ps, act), deq = same_key_mask64(h, act);
+            const uint64_t pbefore = peq & below, dbefore = deq & below;
+            const uint32_t pprev = pbefore ? 63u - (uint32_t)__builtin_clzll(pbefore) : 64u;
+            const uint32_t dprev = dbefore ? 63u - (uint32_t)__builtin_clzll(dbefore) : 64u;
+            uint32_t flag = 0;
+            bool done = !act;
+            for (uint32_t round = 0; round < 64; ++round) {                   // (a chain has at most 64 links)
+                const uint64_t done_mask = ballot64(done && act);
+                const bool pok = pprev == 64u || ((done_mask >> (pprev & 63u)) & 1ull), dok = dprev == 64u || ((done_mask >> (dprev & 63u)) & 1ull);
+                const bool ready = !done && pok && dok;
+                const Row5 frow = row_from_lane(pprev & 63u, row);
+                const uint32_t fpd = bperm(pprev & 63u, pdirty);
+                const uint32_t fda = bperm(dprev & 63u, da), fdb = bperm(dprev & 63u, db), fdd = bperm(dprev & 63u, ddirty);
+                if (ready) {
+                    if (pprev != 64u) { row = frow; pdirty = fpd; }
+                    if (dprev != 64u) { da = fda; db = fdb; ddirty = fdd; }
+                    if (row.n[0] == q) flag = 1;                              // lion.rs:211-270
+                    else if (row.n[1] == q) { flag = 2; row_promote(row, 1, q); pdirty = 1; }
+                    else if (row.n[2] == q) { flag = 3; row_promote(row, 2, q); pdirty = 1; }
+                    else if (row.n[3] == q) { flag = 4; row_promote(row, 3, q); pdirty = 1; }
+                    else {
+                        if (row.n[4] == q) flag = 5;
+                        else if (da == q) flag = 6;
+                        else { flag = db == q ? 7u : 0u; db = da; da = q; ddirty = 1; }
+                        row_promote(row, 4, q); pdirty = 1;                   // shift_predictions (a hit on the last entry included)
+                    }
+                    done = true;
+                }
+                if (ballot64(!done) == 0) break;
+            }
+            const uint32_t ilen = !act ? 0u : (flag == 0 ? 4u : (flag >= 6 ? 2u : 0u));
+            uint32_t incl = ilen;                                                 // item bytes of my record up to and with mine: a sum over the lanes of my row of 16
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xf, 0xf, true);   // row_shr:1
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xf, 0xf, true);   // row_shr:2
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xf, 0xf, true);   // row_shr:4
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xf, 0xf, true);   // row_shr:8
+            const uint32_t rl0 = G::kSig + rlane32(incl, 15), rl1 = G::kSig + rlane32(incl, 31), rl2 = G::kSig + rlane32(incl, 47), rl3 = G::kSig + rlane32(incl, 63);
+            // which blocks stand: codec.rs:68 for a record, :35 for the block behind it
+            Guard g = guard;
+            g.update(rl0 >= G::kBlock);
+            uint32_t nlive = 1;
+            if (nblk > 1) { Guard gc = g; if (!gc.block_is_copy()) { g = gc; g.update(rl1 >= G::kBlock); nlive = 2; } }
+            if (nblk > 2 && nlive == 2) { Guard gc = g; if (!gc.block_is_copy()) { g = gc; g.update(rl2 >= G::kBlock); nlive = 3; } }
+            if (nblk > 3 && nlive == 3) { Guard gc = g; if (!gc.block_is_copy()) { g = gc; g.update(rl3 >= G::kBlock); nlive = 4; } }
+            const uint64_t live = nlive == 4 ? ~0ull : (1ull << (16u * nlive)) - 1ull;   // the lanes whose work stands
+            const bool mine = act && myrec < nlive;
+            const bool plast = mine && (((peq & live) >> lane) >> 1) == 0, dlast = mine && (((deq & live) >> lane) >> 1) == 0;
+            uint8_t* rec = dst + opos;
+            const uint32_t at1 = rl0, at2 = rl0 + rl1, at3 = rl0 + rl1 + rl2;      // where records 1..3 start behind `rec`
+            const uint64_t f0 = ballot64(act && (flag & 1u)), f1 = ballot64(act && (flag & 2u)), f2 = ballot64(act && (flag & 4u));
+            {   // lion.rs:334-337: 6 bytes per signature; lanes 3r .. 3r+2 store record r's
+                const uint32_t r = lane / 3u, part = lane - 3u * r;
+                const uint32_t sh = 16u * (r & 3u);
+                const uint64_t sig = spread16by3((uint32_t)(f0 >> sh)) | (spread16by3((uint32_t)(f1 >> sh)) << 1) | (spread16by3((uint32_t)(f2 >> sh)) << 2);
+                const uint32_t at = r == 0 ? 0u : r == 1 ? at1 : r == 2 ? at2 : at3;
+                if (lane < 3u * nlive) st16u(rec + at + 2u * part, (uint32_t)(sig >> (16u * part)) & 0xffffu);
+            }
+            const uint32_t myat = myrec == 0 ? 0u : myrec == 1 ? at1 : myrec == 2 ? at2 : at3;
+            uint8_t* ip = rec + myat + G::kSig + (incl - ilen);
+            if (mine) { if (ilen == 4) st32u(ip, q); else if (ilen == 2) st16u(ip, h); }
+            if (plast && pdirty) row_store(t.pred + 5u * ps, row);
+            if (dlast && ddirty) tbl_store_pair(t.dict + h, Pair{da, db});
+            last_hash = rlane32(h, 16u * nlive - 1u);
+            guard = g;
+            opos += nlive == 1 ? rl0 : nlive == 2 ? at2 : nlive == 3 ? at3 : at3 + rl3;
+            pos += (uint64_t)nlive * G::kBlock;
+            qwin = nlive == nblk ? qwin_next : window(pos);                       // (blocks resolved in vain: their quads again, from the next step's first on)
         }
         tbl_drain();
         if (head_state) {
@@ -1193,16 +1389,6 @@ __global__ __launch_bounds__(64) void lion_decode_wave(const uint8_t* __restrict
 // (4 bytes per PLAIN flag, 2 per dictionary flag: lion.rs:317-325), so the four signatures are a chain of four reads of lines the touch-ahead
 // has brought in, and everything behind them — items, dictionary pairs, runs of predicted quads, rows, the key matches, the repair walk — is done
 // once for 64 quads.  Same semantics lane for lane as lion_decode_wave above (kept: kernel variant 2048, and the cross-check of this one).
-__device__ __forceinline__ uint64_t same_key_mask64(uint32_t key, bool on) {
-    uint64_t eq = ~0ull;
-#pragma unroll
-    for (uint32_t b = 0; b < 16; ++b) {
-        const bool bit = (key >> b) & 1u;
-        const uint64_t plane = ballot64(bit && on);
-        eq &= bit ? plane : ~plane;
-    }
-    return eq & ballot64(on);
-}
 __device__ __forceinline__ uint32_t lion_item_bytes(uint64_t sig) {                  // of a 48-bit signature: 4 per flag 0, 2 per flag 6 / 7, none per predicted one
     constexpr uint64_t kLow = 0x0000249249249249ull;                                // bit 0 of each of the 16 three-bit flags
     const uint64_t b0 = sig & kLow, b1 = (sig >> 1) & kLow, b2 = (sig >> 2) & kLow;
@@ -1458,7 +1644,7 @@ hipError_t launch_serial_encode(int algo, const uint8_t* d_in, uint64_t total, u
     else if (algo == DENSITY_HIP_CHEETAH)
         hipLaunchKernelGGL(serial_encode_chunks<DENSITY_HIP_CHEETAH>, dim3(blocks), dim3(64), 0, stream, d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, n_slots);
     else if (!g_force_lane_codec)
-        hipLaunchKernelGGL(lion_encode_wave, dim3(n_slots), dim3(64), 0, stream, d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, n_slots,
+        hipLaunchKernelGGL(g_lion_two_records ? lion_encode_wave : lion_encode_wave4, dim3(n_slots), dim3(64), 0, stream, d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, n_slots,
                            (const uint32_t*)nullptr, (uint32_t*)nullptr, 0u, 0u, (const uint32_t*)nullptr);
     else
         hipLaunchKernelGGL(serial_encode_chunks<DENSITY_HIP_LION>, dim3(blocks), dim3(64), 0, stream, d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, n_slots);
@@ -1469,7 +1655,7 @@ hipError_t launch_serial_encode(int algo, const uint8_t* d_in, uint64_t total, u
 hipError_t launch_wave_encode_only(int algo, const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_out, uint64_t out_stride,
                                    uint64_t* d_sizes, uint8_t* d_tables, uint32_t n_slots, const uint32_t* d_only, hipStream_t stream) {
     if (n_chunks == 0) return hipSuccess;
-    auto kernel = algo == DENSITY_HIP_CHEETAH ? cheetah_encode_wave : lion_encode_wave;
+    auto kernel = algo == DENSITY_HIP_CHEETAH ? cheetah_encode_wave : g_lion_two_records ? lion_encode_wave : lion_encode_wave4;
     hipLaunchKernelGGL(kernel, dim3(n_slots), dim3(64), 0, stream, d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, n_slots, d_only,
                        (uint32_t*)nullptr, 0u, 0u, (const uint32_t*)nullptr);
     return hipGetLastError();
@@ -1477,7 +1663,7 @@ hipError_t launch_wave_encode_only(int algo, const uint8_t* d_in, uint64_t total
 hipError_t launch_wave_encode_heads(int algo, const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_out, uint64_t out_stride,
                                     uint64_t* d_sizes, uint8_t* d_tables, uint32_t* d_head_state, uint32_t head_bytes, uint32_t head_calm, hipStream_t stream) {
     if (n_chunks == 0) return hipSuccess;
-    auto kernel = algo == DENSITY_HIP_CHEETAH ? cheetah_encode_wave : lion_encode_wave;
+    auto kernel = algo == DENSITY_HIP_CHEETAH ? cheetah_encode_wave : g_lion_two_records ? lion_encode_wave : lion_encode_wave4;
     hipLaunchKernelGGL(kernel, dim3(n_chunks), dim3(64), 0, stream, d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, n_chunks,
                        (const uint32_t*)nullptr, d_head_state, head_bytes, head_calm, (const uint32_t*)nullptr);
     return hipGetLastError();
@@ -1485,7 +1671,7 @@ hipError_t launch_wave_encode_heads(int algo, const uint8_t* d_in, uint64_t tota
 hipError_t launch_wave_encode_tails(int algo, const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_out, uint64_t out_stride,
                                     uint64_t* d_sizes, uint8_t* d_tables, const uint32_t* d_tail_state, hipStream_t stream) {
     if (n_chunks == 0) return hipSuccess;
-    auto kernel = algo == DENSITY_HIP_CHEETAH ? cheetah_encode_wave : lion_encode_wave;
+    auto kernel = algo == DENSITY_HIP_CHEETAH ? cheetah_encode_wave : g_lion_two_records ? lion_encode_wave : lion_encode_wave4;
     hipLaunchKernelGGL(kernel, dim3(n_chunks), dim3(64), 0, stream, d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, n_chunks,
                        (const uint32_t*)nullptr, (uint32_t*)nullptr, 0u, 0u, d_tail_state);
     return hipGetLastError();
