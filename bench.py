@@ -119,7 +119,8 @@ def host_api_rates(algo, host, chunk, sample_bytes):
     out["reference_symbols"] = {"encode_MBps": round(n / t_e / 1e6, 1), "decode_MBps": round(n / t_d / 1e6, 1),
                                 "round_trip_MBps": round(n / (t_e + t_d) / 1e6, 1), "timing": "median of 3 warm calls",
                                 "note": "ONE reference stream; H2D + kernels + D2H.  Chameleon encode of >= 4 MiB runs in parallel segments and is still the "
-                                        "reference's stream byte for byte; decode of >= 2 MiB runs in parallel segments too (unless it is mostly raw copies)"}
+                                        "reference's stream byte for byte; decode of >= 2 MiB runs in parallel segments too (unless it is mostly raw copies); "
+                                        "from 32 MiB (encode) / 16 MiB of stream (decode) on the transfers run in slices beside the kernels"}
     if algo == "chameleon":
         # the same single stream with the buffers already on the device (density_hip_stream_encode_device): what the segments buy
         import ctypes
