@@ -381,6 +381,12 @@ int run_stream_decode(DeviceCtx* c, int algo, const uint8_t* d_in, size_t n, uin
 }
 
 // ---- host-pointer front ends ----
+// (experiments: the number of slices of the pipelined calls below)
+inline size_t slices_from_env(const char* name, size_t fallback) {
+    const char* v = getenv(name);
+    const long k = v ? atol(v) : 0;
+    return k >= 3 && k <= (long)kPipeMaxSlices ? (size_t)k : fallback;
+}
 inline double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // chameleon_encode() of a long stream with the transfers beside the kernels.  The caller's buffers are pinned in place; the input goes up in slices
@@ -407,7 +413,8 @@ size_t host_stream_encode_pipelined(DeviceCtx* c, const uint8_t* in, size_t n, u
     if (e == hipSuccess) e = L.setup(c, n, s);
     if (e != hipSuccess) { (void)hipGetLastError(); return 0; }                   // (the staged path reports what it cannot have either)
     const size_t S = L.S, img = kSegImageBytes;
-    size_t per = (std::max<size_t>(n / 12, 2u << 20) + L.C - 1) / L.C;
+    const size_t want_slices = slices_from_env("DENSITY_HIP_ENCODE_SLICES", 12);
+    size_t per = (std::max<size_t>(n / want_slices, 2u << 20) + L.C - 1) / L.C;
     while ((S + per - 1) / per > kPipeMaxSlices) ++per;
     const uint32_t slices = (uint32_t)((S + per - 1) / per);
     if (slices < 3 || !pipe_streams(c, 2 * slices) || pin_meta_ensure(c, S * 16 + 64) != hipSuccess) { (void)hipGetLastError(); return 0; }
@@ -516,8 +523,10 @@ size_t host_stream_decode_pipelined(DeviceCtx* c, const uint8_t* in, size_t E, u
     hipError_t e;
     if (!D.setup(c, E, cap, &e, 1024)) { (void)hipGetLastError(); return 0; }
     const size_t kCB = D.kChunkBlocks, kCBy = D.kChunkBytes, img = kSegImageBytes;
-    // (few slices: each pays the latency of the parse's kernels once, ~0.1 ms, whatever its length)
-    const size_t slice = (std::max<size_t>((E + 4) / 5, 4u << 20) + 255) & ~(size_t)255;
+    // (few slices: each pays the latency of the parse's kernels once, ≈0.2 ms, whatever its length — about 10 MiB of stream per slice, eight slices at
+    // most: 64 MiB of text in 4 slices 37 GB/s, in 8 28; 256 MiB in 8 slices 45, in 3 39)
+    const size_t want_slices = slices_from_env("DENSITY_HIP_DECODE_SLICES", std::min<size_t>(8, std::max<size_t>(3, E / (10u << 20))));
+    const size_t slice = (std::max<size_t>((E + want_slices - 1) / want_slices, 4u << 20) + 255) & ~(size_t)255;
     const uint32_t slices = (uint32_t)((E + slice - 1) / slice);
     if (slices < 3 || slices > kPipeMaxSlices) return 0;
     PinnedInPlace pin_in(in, E), pin_out(out, bound);
