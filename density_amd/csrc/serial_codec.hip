@@ -15,7 +15,6 @@
 namespace density {
 
 bool g_force_lane_codec = false;   // density_hip_set_kernel_variant(16): Cheetah on the one-lane-per-stream kernels (cross-check)
-bool g_lion_two_records = false;   // density_hip_set_kernel_variant(2048): Lion's decoder two records per step (lion_decode_wave) instead of four
 
 namespace {
 
@@ -767,193 +766,6 @@ __global__ __launch_bounds__(64) void lion_encode_wave(const uint8_t* __restrict
     t.dict = reinterpret_cast<Pair*>(tables + slot * kTableBytes);
     t.pred = reinterpret_cast<uint32_t*>(tables + slot * kTableBytes + 65536ull * sizeof(Pair));
     const bool act16 = lane < 16;
-    const uint32_t below = (1u << (lane & 31u)) - 1u;
-    for (uint64_t chunk = slot; chunk < n_chunks; chunk += n_slots) {
-        const uint8_t* src = in + chunk * chunk_bytes;
-        const uint64_t len = (total - chunk * chunk_bytes) < chunk_bytes ? (total - chunk * chunk_bytes) : chunk_bytes;
-        uint8_t* dst = out + chunk * out_stride;
-        if (only && !only[chunk]) continue;
-        if (tail_state && !tail_state[8 * chunk + 6]) continue;
-        if ((chunk != slot || only || head_state) && !tail_state) {
-            uint4* p = reinterpret_cast<uint4*>(tables + slot * kTableBytes);
-            const uint4 z = make_uint4(0, 0, 0, 0);
-            for (uint64_t i = lane; i < kTableBytes / 16; i += 64) p[i] = z;
-            __threadfence();
-        }
-        uint32_t last_hash = 0;
-        Guard guard;
-        uint64_t opos = 0, pos = 0;
-        if (tail_state) {
-            const uint32_t* ts = tail_state + 8 * chunk;
-            pos = ts[0]; opos = ts[1]; last_hash = ts[2];
-            guard.prev = ts[3]; guard.start = ts[4]; guard.counter = ts[5];
-        }
-        // (Round 4.)  TWO blocks per step — lanes 0..15 the first, 16..31 the second — where the second is there and no hand-over boundary lies between them:
-        // a step is one gather of rows and pairs, their resolution across lanes and the stores, and costs the same latency for 32 quads as for 16 (the key
-        // matches and the chains of one slot work on 32 lanes: Cheetah's records are 32 quads).  Whether the second block is coded at all depends on the
-        // first record's length (codec.rs:35-37,68), which only the resolution gives: it is resolved on the assumption that it is, and dropped — its lanes store
-        // nothing, the slots it shares keep the first block's last writers — when the blow-up protection says otherwise; the next step then copies it.
-        auto window = [&](uint64_t at) -> uint32_t { return (lane < 32 && at + 4u * lane + 4u <= len) ? ld32u(src + at + 4u * lane) : 0u; };
-        uint32_t qwin = window(pos);                                             // the quads of the next two blocks
-        bool may_hand_over = head_state && len >= 4ull * head_bytes, handed_over = false;   // (as cheetah_encode_wave)
-        uint64_t last_copy_end = 0;
-        while (pos + G::kBlock <= len) {
-            if (may_hand_over && pos >= head_bytes && (pos & 4095u) == 0) {
-                if (pos >= last_copy_end + head_calm && guard.penalty == 0) { handed_over = true; break; }
-                if (pos >= 4ull * head_bytes || pos >= len / 2) may_hand_over = false;   // raw copies this far in are not the cold start's: no hand-over
-            }
-            if (guard.block_is_copy()) {                                      // codec.rs:35-37
-                last_copy_end = pos + G::kBlock;
-                if (act16) st32u(dst + opos + 4u * lane, qwin);
-                pos += G::kBlock; opos += G::kBlock;
-                qwin = window(pos);
-                guard.decay();
-                continue;
-            }
-            const bool can2 = pos + 2u * G::kBlock <= len && !(may_hand_over && ((pos + G::kBlock) & 4095u) == 0);
-            const uint32_t nact = can2 ? 32u : 16u;
-            const bool act = lane < nact;
-            const uint32_t q = qwin;
-            const uint32_t h = hash16(q);
-            const uint32_t hprev = bperm(lane ? lane - 1u : 0u, h);
-            const uint32_t ps = lane == 0 ? last_hash : hprev;               // lion.rs:213,268
-            tbl_drain();
-            Row5 row = act ? row_load(t.pred + 5u * ps) : Row5{{0u, 0u, 0u, 0u, 0u}};
-            const Pair e0 = act ? tbl_load_pair(t.dict + h) : Pair{0u, 0u};
-            const uint32_t qwin_next = window(pos + 4u * nact);                // (on the assumption that the step takes all its blocks)
-            uint32_t da = e0.a, db = e0.b, pdirty = 0, ddirty = 0;
-            uint32_t peq, deq;
-            same_key_masks2(ps, act, h, act, lane, peq, deq);
-            const uint32_t pbefore = peq & below, dbefore = deq & below;
-            const uint32_t pprev = pbefore ? 31u - (uint32_t)__builtin_clz(pbefore) : 64u;
-            const uint32_t dprev = dbefore ? 31u - (uint32_t)__builtin_clz(dbefore) : 64u;
-            uint32_t flag = 0;
-            bool done = !act;
-            for (uint32_t round = 0; round < 32; ++round) {                   // (a chain has at most 32 links)
-                const uint32_t done_mask = (uint32_t)ballot64(done && act);
-                const bool pok = pprev == 64u || ((done_mask >> pprev) & 1u), dok = dprev == 64u || ((done_mask >> dprev) & 1u);
-                const bool ready = !done && pok && dok;
-                const Row5 frow = row_from_lane(pprev & 31u, row);
-                const uint32_t fpd = bperm(pprev & 31u, pdirty);
-                const uint32_t fda = bperm(dprev & 31u, da), fdb = bperm(dprev & 31u, db), fdd = bperm(dprev & 31u, ddirty);
-                if (ready) {
-                    if (pprev != 64u) { row = frow; pdirty = fpd; }
-                    if (dprev != 64u) { da = fda; db = fdb; ddirty = fdd; }
-                    if (row.n[0] == q) flag = 1;                              // lion.rs:211-270
-                    else if (row.n[1] == q) { flag = 2; row_promote(row, 1, q); pdirty = 1; }
-                    else if (row.n[2] == q) { flag = 3; row_promote(row, 2, q); pdirty = 1; }
-                    else if (row.n[3] == q) { flag = 4; row_promote(row, 3, q); pdirty = 1; }
-                    else {
-                        if (row.n[4] == q) flag = 5;
-                        else if (da == q) flag = 6;
-                        else { flag = db == q ? 7u : 0u; db = da; da = q; ddirty = 1; }
-                        row_promote(row, 4, q); pdirty = 1;                   // shift_predictions (a hit on the last entry included)
-                    }
-                    done = true;
-                }
-                if (ballot64(!done) == 0) break;
-            }
-            const uint32_t ilen = !act ? 0u : (flag == 0 ? 4u : (flag >= 6 ? 2u : 0u));
-            uint32_t both;
-            const uint32_t off = scan32(ilen, lane, both);
-            const uint32_t items1 = can2 ? rfl(bperm(16u, off)) : both;
-            const uint32_t rlen1 = G::kSig + items1;
-            Guard g2 = guard;
-            g2.update(rlen1 >= G::kBlock);                                        // codec.rs:68 for the first record ...
-            Guard g2c = g2;
-            const bool two = can2 && !g2c.block_is_copy();                        // ... and :35 for the block behind it
-            const uint32_t live = two ? 0xffffffffu : 0x0000ffffu;               // the lanes whose work stands
-            const bool mine = act && ((live >> (lane & 31u)) & 1u);
-            const bool plast = mine && ((peq & live) >> (lane & 31u) >> 1) == 0, dlast = mine && ((deq & live) >> (lane & 31u) >> 1) == 0;
-            uint8_t* rec = dst + opos;
-            const uint32_t f0 = (uint32_t)ballot64(act && (flag & 1u)), f1 = (uint32_t)ballot64(act && (flag & 2u)), f2 = (uint32_t)ballot64(act && (flag & 4u));
-            const uint64_t sig = spread16by3(f0) | (spread16by3(f1) << 1) | (spread16by3(f2) << 2);
-            if (lane < 3) st16u(rec + 2u * lane, (uint32_t)(sig >> (16u * lane)) & 0xffffu);   // lion.rs:334-337: 6 bytes
-            if (two) {
-                const uint64_t sigb = spread16by3(f0 >> 16) | (spread16by3(f1 >> 16) << 1) | (spread16by3(f2 >> 16) << 2);
-                if (lane < 3) st16u(rec + rlen1 + 2u * lane, (uint32_t)(sigb >> (16u * lane)) & 0xffffu);
-            }
-            // (a lane of the second record: its items start one signature further on)
-            uint8_t* ip = rec + G::kSig + off + (lane >= 16 ? G::kSig : 0u);
-            if (mine) { if (ilen == 4) st32u(ip, q); else if (ilen == 2) st16u(ip, h); }
-            if (plast && pdirty) row_store(t.pred + 5u * ps, row);
-            if (dlast && ddirty) tbl_store_pair(t.dict + h, Pair{da, db});
-            if (two) {
-                last_hash = rfl(bperm(31u, h));
-                guard = g2c;
-                const uint32_t rlen2 = G::kSig + (both - items1);
-                guard.update(rlen2 >= G::kBlock);
-                opos += rlen1 + rlen2; pos += 2u * G::kBlock;
-                qwin = qwin_next;
-            } else {
-                last_hash = rfl(bperm(15u, h));
-                guard = g2;
-                opos += rlen1; pos += G::kBlock;
-                qwin = can2 ? window(pos) : qwin_next;                            // (the second block was resolved in vain: its quads again, as the next step's first)
-            }
-        }
-        tbl_drain();
-        if (head_state) {
-            if (lane == 0) {
-                head_state[8 * chunk + 0] = (uint32_t)opos;
-                head_state[8 * chunk + 1] = last_hash;
-                head_state[8 * chunk + 2] = (guard.penalty ? 1u : 0u) | (guard.prev ? 2u : 0u);
-                head_state[8 * chunk + 3] = handed_over ? 0u : 2u;             // 2: the chunk is finished, nothing for the passes
-                head_state[8 * chunk + 4] = guard.start;
-                head_state[8 * chunk + 5] = guard.counter;
-                head_state[8 * chunk + 6] = (uint32_t)pos;                    // where the passes take over
-            }
-            if (handed_over) continue;
-        }
-        if (pos < len) {                                                      // the ragged last block: scalar code, lane 0
-            __threadfence();
-            if (lane == 0) {
-                t.last_hash = last_hash;
-                const uint32_t blen = (uint32_t)(len - pos);
-                const uint8_t* blk = src + pos;
-                if (guard.block_is_copy()) {
-                    for (uint32_t i = 0; i < blen; ++i) dst[opos + i] = blk[i];
-                    opos += blen;
-                } else {
-                    uint8_t* rec = dst + opos;
-                    uint64_t o = G::kSig, sig = 0;
-                    const uint32_t nq = blen >> 2;
-                    for (uint32_t k = 0; k < nq; ++k) {
-                        uint32_t item = 0, il = 0;
-                        const uint32_t flag = enc_quad(t, ld32u(blk + 4u * k), item, il);
-                        sig |= (uint64_t)flag << (G::kFlagBits * k);
-                        if (il == 2) st16u(rec + o, item); else if (il == 4) st32u(rec + o, item);
-                        o += il;
-                    }
-                    for (uint32_t i = 4u * nq; i < blen; ++i) rec[o++] = blk[i];
-                    store_sig<DENSITY_HIP_LION>(rec, sig);
-                    opos += o;
-                }
-            }
-            opos = bcast64(opos);
-            __threadfence();
-        }
-        if (lane == 0) sizes[chunk] = opos;
-    }
-}
-
-
-__global__ __launch_bounds__(64) void lion_encode_wave4(const uint8_t* __restrict__ in, uint64_t total, uint64_t chunk_bytes,
-                                                       uint32_t n_chunks, uint8_t* __restrict__ out, uint64_t out_stride,
-                                                       uint64_t* __restrict__ sizes, uint8_t* __restrict__ tables, uint32_t n_slots,
-                                                       const uint32_t* __restrict__ only, uint32_t* __restrict__ head_state, uint32_t head_bytes,
-                                                       uint32_t head_calm, const uint32_t* __restrict__ tail_state) {
-    // only / head_state / tail_state: as cheetah_encode_wave (the chunks handed back by, the heads before and the ragged ends behind the
-    // exchange passes of exchange_stages.hip)
-    using G = Geo<DENSITY_HIP_LION>;
-    const uint32_t slot = blockIdx.x;
-    const uint32_t lane = threadIdx.x;
-    if (slot >= n_slots) return;
-    constexpr uint64_t kTableBytes = 65536ull * (sizeof(Pair) + 4ull * G::kPredWords);
-    Tables<DENSITY_HIP_LION> t;
-    t.dict = reinterpret_cast<Pair*>(tables + slot * kTableBytes);
-    t.pred = reinterpret_cast<uint32_t*>(tables + slot * kTableBytes + 65536ull * sizeof(Pair));
-    const bool act16 = lane < 16;
     const uint32_t myrec = lane >> 4;
     const uint64_t below = (1ull << lane) - 1ull;
     for (uint64_t chunk = slot; chunk < n_chunks; chunk += n_slots) {
@@ -976,10 +788,12 @@ __global__ __launch_bounds__(64) void lion_encode_wave4(const uint8_t* __restric
             pos = ts[0]; opos = ts[1]; last_hash = ts[2];
             guard.prev = ts[3]; guard.start = ts[4]; guard.counter = ts[5];
         }
-        // FOUR blocks per step (the whole wave: lanes 16r .. 16r+15 take block r) where they are there and no hand-over boundary lies between them; the
-        // scheme of lion_encode_wave above — every block behind the first is resolved on the assumption that it is coded, and the blocks from the first
-        // one the blow-up protection wants copied on are dropped: their lanes store nothing, the slots they share keep the last writers of the blocks that
-        // stand (`live`), the next step starts with the dropped block.
+        // (Round 4.)  FOUR blocks per step — the whole wave, lanes 16r .. 16r+15 take block r — where they are there and no hand-over boundary lies between
+        // them: a step is one gather of rows and pairs, their resolution across lanes and the stores, and costs the same latency for 64 quads as for 16 (the
+        // key matches and the chains of one slot work on 64 lanes as they did on 16).  Whether a block behind the first is coded at all depends on the length
+        // of the record in front of it (codec.rs:35-37,68), which only the resolution gives: it is resolved on the assumption that it is, and the blocks from
+        // the first one the blow-up protection wants copied on are dropped — their lanes store nothing, the slots they share keep the last writers of the
+        // blocks that stand (`live`) — and the next step starts with the dropped block.
         auto window = [&](uint64_t at) -> uint32_t { return (at + 4u * lane + 4u <= len) ? ld32u(src + at + 4u * lane) : 0u; };
         uint32_t qwin = window(pos);                                             // the quads of the next four blocks
         bool may_hand_over = head_state && len >= 4ull * head_bytes, handed_over = false;   // (as cheetah_encode_wave)
@@ -1153,242 +967,11 @@ __device__ __forceinline__ bool lion_record_scalar(Tables<DENSITY_HIP_LION>& t, 
     return false;
 }
 
-__global__ __launch_bounds__(64) void lion_decode_wave(const uint8_t* __restrict__ in, const uint64_t* __restrict__ offsets,
-                                                       const uint64_t* __restrict__ sizes, uint32_t n_chunks,
-                                                       uint8_t* __restrict__ out, uint64_t out_stride, uint64_t out_total,
-                                                       uint32_t exact, uint64_t* __restrict__ produced, uint32_t* __restrict__ err,
-                                                       uint8_t* __restrict__ tables, uint32_t n_slots) {
-    using G = Geo<DENSITY_HIP_LION>;
-    const uint32_t slot = blockIdx.x;
-    const uint32_t lane = threadIdx.x;
-    if (slot >= n_slots) return;
-    constexpr uint64_t kTableBytes = 65536ull * (sizeof(Pair) + 4ull * G::kPredWords);
-    constexpr uint32_t kMaxRecord = 8 + G::kBlock;                            // 6 + 16 x 4, and the signature is fetched as 8 bytes
-    Tables<DENSITY_HIP_LION> t;
-    t.dict = reinterpret_cast<Pair*>(tables + slot * kTableBytes);
-    t.pred = reinterpret_cast<uint32_t*>(tables + slot * kTableBytes + 65536ull * sizeof(Pair));
-    const bool act16 = lane < 16;
-    const uint32_t below = (1u << (lane & 31u)) - 1u;
-    for (uint64_t chunk = slot; chunk < n_chunks; chunk += n_slots) {
-        const uint8_t* src = in + offsets[chunk];
-        const uint64_t elen = sizes[chunk];
-        uint8_t* dst = out + chunk * out_stride;
-        const uint64_t room_all = out_total - chunk * out_stride;
-        const uint64_t cap = room_all < out_stride ? room_all : out_stride;
-        if (chunk != slot) {
-            uint4* p = reinterpret_cast<uint4*>(tables + slot * kTableBytes);
-            const uint4 z = make_uint4(0, 0, 0, 0);
-            for (uint64_t i = lane; i < kTableBytes / 16; i += 64) p[i] = z;
-            __threadfence();
-        }
-        uint32_t last_hash = 0;
-        Guard guard;
-        uint64_t ipos = 0, opos = 0;
-        bool bad = false, done = false;
-        uint32_t ahead = 0;                                                       // (the register a touch-ahead load lands in: see below)
-        while (elen - ipos >= kMaxRecord && cap - opos >= G::kBlock) {
-            if (guard.block_is_copy()) {                                      // codec.rs:89-91
-                if (act16) st32u(dst + opos + 4u * lane, ld32u(src + ipos + 4u * lane));
-                ipos += G::kBlock; opos += G::kBlock;
-                guard.decay();
-                continue;
-            }
-            // (Round 4.)  TWO records per step where the second one is whole, coded and has room: lanes 0..15 the first, 16..31 the second.  A step is a
-            // chain of dependent memory reads (signature, items, predicted runs, rows) that costs the same for 32 quads as for 16 — the key matches, the
-            // forwarding along chains of one slot and the repair walk all work on 32 lanes (Cheetah's records are 32 quads) — so this halves the number of chains.
-            const uint8_t* rec = src + ipos;
-            const uint64_t sig = ((uint64_t)ld32u(rec) | ((uint64_t)ld32u(rec + 4) << 32)) & 0xffffffffffffull;   // lion.rs:340-351
-            uint32_t flag = act16 ? (uint32_t)(sig >> (3u * (lane & 15u))) & 7u : 1u;
-            uint32_t ilen = !act16 ? 0u : (flag == 0 ? 4u : (flag >= 6 ? 2u : 0u));
-            uint32_t items;
-            uint32_t off = scan32(ilen, lane, items);
-            const uint32_t rlen1 = G::kSig + items;
-            Guard g2 = guard;
-            g2.update(rlen1 >= G::kBlock);                                        // codec.rs:98 for the first record ...
-            Guard g2c = g2;
-            const bool two = elen - ipos >= rlen1 + kMaxRecord && cap - opos >= 2u * G::kBlock && !g2c.block_is_copy();   // ... and :89 for the block behind it
-            const uint8_t* rec2 = rec + rlen1;
-            uint32_t items2 = 0;
-            if (two) {
-                const uint64_t sig2 = ((uint64_t)ld32u(rec2) | ((uint64_t)ld32u(rec2 + 4) << 32)) & 0xffffffffffffull;
-                if (lane >= 16 && lane < 32) { flag = (uint32_t)(sig2 >> (3u * (lane & 15u))) & 7u; ilen = flag == 0 ? 4u : (flag >= 6 ? 2u : 0u); }
-                uint32_t both;
-                off = scan32(ilen, lane, both);
-                items2 = both - items;
-            }
-            const uint32_t nact = two ? 32u : 16u;
-            const bool act = lane < nact;
-            const uint8_t* ibase = lane < 16 ? rec + G::kSig + off : rec2 + G::kSig + (off - items);
-            uint32_t q = 0, h = 0;
-            if (ilen == 4) { q = ld32u(ibase); h = hash16(q); } else if (ilen == 2) h = ld16u(ibase);
-            const bool dtouch = act && (flag == 0 || flag >= 6);              // touches the dictionary (lion.rs:85-186)
-            const bool predicted = act && flag >= 1 && flag <= 5;
-            // (Round 4.)  The stream is read 50-70 bytes at a time, each record's place known only from the one before: nothing fetches it ahead, and
-            // the signature and the items were two dependent misses per record.  Two lanes touch the lines 512 and 640 bytes on, in the shadow of
-            // the table reads below (loads return in order: issued here, not in front of the signature load).  The touch's register is held — as an
-            // operand of the drain of the NEXT record, by which time it has long landed — so that nothing else lives where the load lands.
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(ahead) : : "memory");          // tbl_drain(): the previous record's table stores are in L2
-            {
-                const uint64_t far = ipos + 512u + 128u * (lane & 1u);
-                const uint8_t* pa = src + (far + 4 <= elen ? far : ipos);
-                if (lane < 2) asm volatile("global_load_dword %0, %1, off" : "=v"(ahead) : "v"(pa) : "memory");
-            }
-            const Pair e0 = dtouch ? tbl_load_pair(t.dict + h) : Pair{0u, 0u};
-            // ---- runs of predicted quads: one dependent read per round; speculation: nobody earlier in this record rewrote that row ----
-            bool known = !predicted;
-            for (uint32_t round = 0; round < 32; ++round) {
-                const uint32_t hp = bperm(lane ? lane - 1u : 0u, h);
-                const uint32_t kpv = bperm(lane ? lane - 1u : 0u, known ? 1u : 0u);
-                const bool kp = lane == 0 || kpv != 0;
-                if (!known && kp) {
-                    q = tbl_load32(t.pred + 5u * (lane == 0 ? last_hash : hp) + (flag - 1u));
-                    h = hash16(q);
-                    known = true;
-                }
-                if (ballot64(!known) == 0) break;
-            }
-            const uint32_t hprev = bperm(lane ? lane - 1u : 0u, h);
-            const uint32_t ps = lane == 0 ? last_hash : hprev;
-            Row5 row = act ? row_load(t.pred + 5u * ps) : Row5{{0u, 0u, 0u, 0u, 0u}};
-            const Row5 row_mem = row;                                             // as memory holds it (the repair below starts over from it)
-            // ---- dictionary, in dependency order among the lanes that touch it ----
-            uint32_t peq, deq;
-            same_key_masks2(ps, act, h, dtouch, lane, peq, deq);
-            const uint32_t dbefore = deq & below;
-            const uint32_t dprev = dbefore ? 31u - (uint32_t)__builtin_clz(dbefore) : 64u;
-            const bool dlast = dtouch && (deq >> (lane & 31u) >> 1) == 0;
-            uint32_t da = e0.a, db = e0.b, ddirty = 0;
-            bool ddone = !dtouch;
-            for (uint32_t round = 0; round < 32; ++round) {
-                const uint32_t done_mask = (uint32_t)ballot64(ddone && dtouch);
-                const bool ready = !ddone && (dprev == 64u || ((done_mask >> dprev) & 1u));
-                const uint32_t fda = bperm(dprev & 31u, da), fdb = bperm(dprev & 31u, db), fdd = bperm(dprev & 31u, ddirty);
-                if (ready) {
-                    if (dprev != 64u) { da = fda; db = fdb; ddirty = fdd; }
-                    if (flag == 0) { db = da; da = q; ddirty = 1; }
-                    else if (flag == 6) q = da;
-                    else { q = db; db = da; da = q; ddirty = 1; }
-                    ddone = true;
-                }
-                if (ballot64(!ddone) == 0) break;
-            }
-            // ---- predictor rows, in dependency order (every quad rewrites its row unless it hit the front entry) ----
-            const uint32_t pbefore = peq & below;
-            const uint32_t pprev = pbefore ? 31u - (uint32_t)__builtin_clz(pbefore) : 64u;
-            const bool plast = act && (peq >> (lane & 31u) >> 1) == 0;
-            uint32_t pdirty = 0;
-            bool pdone = !act, wrong = false;
-            for (uint32_t round = 0; round < 32; ++round) {
-                const uint32_t done_mask = (uint32_t)ballot64(pdone && act);
-                const bool ready = !pdone && (pprev == 64u || ((done_mask >> pprev) & 1u));
-                const Row5 frow = row_from_lane(pprev & 31u, row);
-                const uint32_t fpd = bperm(pprev & 31u, pdirty);
-                if (ready) {
-                    if (pprev != 64u) { row = frow; pdirty = fpd; }
-                    if (predicted) {
-                        uint32_t cur = row.n[0];
-#pragma unroll
-                        for (uint32_t k = 1; k < 5; ++k) cur = flag == k + 1u ? row.n[k] : cur;
-                        wrong = cur != q;                                     // the row as it really stands does not hold what the speculation read
-                        if (flag > 1) { row_promote(row, flag - 1u, q); pdirty = 1; }
-                    } else {
-                        row_promote(row, 4, q); pdirty = 1;                   // lion.rs:50-57
-                    }
-                    pdone = true;
-                }
-                if (ballot64(!pdone) == 0) break;
-            }
-            uint32_t psf = ps;                                                    // the predictor slot my row is stored to
-            bool plastf = plast;
-            if (ballot64(wrong) != 0) {
-                // (Round 4.)  A speculation failed: a predicted quad read an entry that an earlier quad of this record has since moved.  Its real value —
-                // the entry of the row as forwarded — has another hash, so the quad behind it sits in another context than assumed, and so on.  Up to
-                // round 3 the whole record was decoded again by the scalar code on lane 0 (two dependent memory reads per quad: ≈24 µs, a fifth of the
-                // kernel's time on prose).  Now: ONE exact walk over the step's quads in stream order, in registers — every value wave-uniform — with rows
-                // forwarded between quads of one context, taken from the speculative gather where it was made at the right context, and read from
-                // memory only where the context turned out to be another one (lion.rs:85-186).
-                uint32_t ctx = last_hash;
-                uint32_t cxv = 0xffffffffu, dirtyv = 0;                           // per lane, once walked: my true context; my row differs from memory
-                Row5 rf = row_mem;
-#pragma nounroll
-                for (uint32_t i = 0; i < nact; ++i) {
-                    const uint32_t m = (uint32_t)ballot64(lane < i && cxv == ctx);
-                    Row5 r;
-                    uint32_t dirty = 0;
-                    if (m) {                                                      // the latest earlier quad of this context hands its row on
-                        const uint32_t j = 31u - (uint32_t)__builtin_clz(m);
-#pragma unroll
-                        for (int k = 0; k < 5; ++k) r.n[k] = rlane32(rf.n[k], j);
-                        dirty = rlane32(dirtyv, j);
-                    } else if (rlane32(ps, i) == ctx) {                           // nobody before it in this record: memory's row, gathered at the right place
-#pragma unroll
-                        for (int k = 0; k < 5; ++k) r.n[k] = rlane32(row_mem.n[k], i);
-                    } else {
-                        r = row_load(t.pred + 5u * ctx);
-                    }
-                    const uint32_t f = rlane32(flag, i);
-                    uint32_t qi, hi;
-                    if (f >= 1u && f <= 5u) {
-                        qi = r.n[0];
-#pragma unroll
-                        for (uint32_t k = 1; k < 5; ++k) qi = f == k + 1u ? r.n[k] : qi;
-                        hi = hash16(qi);
-                        if (f > 1u) { row_promote(r, f - 1u, qi); dirty = 1; }
-                    } else {
-                        qi = rlane32(q, i); hi = rlane32(h, i);                   // what the dictionary gave: no context in it
-                        row_promote(r, 4, qi); dirty = 1;
-                    }
-                    if (lane == i) { q = qi; h = hi; rf = r; cxv = ctx; dirtyv = dirty; }
-                    ctx = hi;
-                }
-                row = rf; pdirty = dirtyv; psf = cxv;
-                uint32_t peq2, deq2;
-                same_key_masks2(cxv, act, h, false, lane, peq2, deq2);
-                plastf = act && (peq2 >> (lane & 31u) >> 1) == 0;
-            }
-            if (act) st32u(dst + opos + 4u * lane, q);
-            if (plastf && pdirty) row_store(t.pred + 5u * psf, row);
-            if (dlast && ddirty) tbl_store_pair(t.dict + h, Pair{da, db});
-            last_hash = rfl(bperm(nact - 1u, h));
-            if (two) {
-                guard = g2c;                                                      // (the first record's update and the second block's turn at :89 are in it)
-                guard.update(G::kSig + items2 >= G::kBlock);
-                ipos += rlen1 + G::kSig + items2; opos += 2u * G::kBlock;
-            } else {
-                guard = g2;
-                ipos += rlen1; opos += G::kBlock;
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(ahead) : : "memory");              // tbl_drain(), and the last touch-ahead has landed before its register is anyone else's
-        __threadfence();
-        if (lane == 0) {                                                      // the rest: scalar code, codec.rs:102-123
-            t.last_hash = last_hash;
-            while (ipos < elen && !bad && !done) {
-                const uint64_t rem = elen - ipos;
-                if (guard.block_is_copy()) {
-                    const uint32_t take = rem > G::kBlock ? G::kBlock : (uint32_t)rem;
-                    if (opos + take > cap) { bad = true; break; }
-                    for (uint32_t i = 0; i < take; ++i) dst[opos + i] = src[ipos + i];
-                    ipos += take; opos += take;
-                    if (rem <= G::kBlock) break;
-                    guard.decay();
-                    continue;
-                }
-                bad = lion_record_scalar(t, src, elen, ipos, dst, cap, opos, done, guard);
-            }
-            if (exact && !bad && opos != cap) bad = true;
-            produced[chunk] = opos;
-            if (bad) atomicOr(err, 1u);
-        }
-        __threadfence();
-    }
-}
-
-// ---- round 4, second step: FOUR records per step (the whole wave: lanes 16r .. 16r+15 take record r) ----
-// What a step costs is its chain of dependent memory reads, not its lanes; where a record's successor starts follows from its signature alone
-// (4 bytes per PLAIN flag, 2 per dictionary flag: lion.rs:317-325), so the four signatures are a chain of four reads of lines the touch-ahead
-// has brought in, and everything behind them — items, dictionary pairs, runs of predicted quads, rows, the key matches, the repair walk — is done
-// once for 64 quads.  Same semantics lane for lane as lion_decode_wave above (kept: kernel variant 2048, and the cross-check of this one).
+// ---- round 4: FOUR records per step (the whole wave: lanes 16r .. 16r+15 take record r) ----
+// What a step costs is its chain of dependent memory reads — signature, items, one table read per link of a run of predicted quads, the rows — not its
+// lanes; where a record's successor starts follows from its signature alone (4 bytes per PLAIN flag, 2 per dictionary flag: lion.rs:317-325), so the four
+// signatures are a chain of four reads of lines the touch-ahead has brought in, and everything behind them — items, dictionary pairs, runs of predicted
+// quads, rows, the key matches, the repair walk — is done once for 64 quads.
 __device__ __forceinline__ uint32_t lion_item_bytes(uint64_t sig) {                  // of a 48-bit signature: 4 per flag 0, 2 per flag 6 / 7, none per predicted one
     constexpr uint64_t kLow = 0x0000249249249249ull;                                // bit 0 of each of the 16 three-bit flags
     const uint64_t b0 = sig & kLow, b1 = (sig >> 1) & kLow, b2 = (sig >> 2) & kLow;
@@ -1397,7 +980,7 @@ __device__ __forceinline__ uint32_t lion_item_bytes(uint64_t sig) {             
 __device__ __forceinline__ uint64_t lion_sig_at(const uint8_t* p) {                  // lion.rs:340-351, as a scalar
     return (((uint64_t)rfl(ld32u(p + 4)) << 32) | rfl(ld32u(p))) & 0xffffffffffffull;
 }
-__global__ __launch_bounds__(64) void lion_decode_wave4(const uint8_t* __restrict__ in, const uint64_t* __restrict__ offsets,
+__global__ __launch_bounds__(64) void lion_decode_wave(const uint8_t* __restrict__ in, const uint64_t* __restrict__ offsets,
                                                         const uint64_t* __restrict__ sizes, uint32_t n_chunks,
                                                         uint8_t* __restrict__ out, uint64_t out_stride, uint64_t out_total,
                                                         uint32_t exact, uint64_t* __restrict__ produced, uint32_t* __restrict__ err,
@@ -1484,7 +1067,10 @@ __global__ __launch_bounds__(64) void lion_decode_wave4(const uint8_t* __restric
             if (ilen == 4) { q = ld32u(ibase); h = hash16(q); } else if (ilen == 2) h = ld16u(ibase);
             const bool dtouch = act && (flag == 0 || flag >= 6);              // touches the dictionary (lion.rs:85-186)
             const bool predicted = act && flag >= 1 && flag <= 5;
-            // the previous step's table stores are in L2; four lanes touch the stream lines half a KiB on (see lion_decode_wave)
+            // The stream is read 50-70 bytes at a time, each record's place known only from the one before: nothing fetches it ahead, and the signature and
+            // the items were two dependent misses per record.  Four lanes touch the lines half a KiB on, in the shadow of the table reads below (loads
+            // return in order: issued here, not in front of the signature loads).  The touch's register is held — as an operand of the drain of the NEXT
+            // step, by which time it has long landed — so that nothing else lives where the load lands.  (The drain: the previous step's table stores are in L2.)
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(ahead) : : "memory");
             {
                 const uint64_t far = ipos + 512u + 128u * (lane & 3u);
@@ -1558,7 +1144,12 @@ __global__ __launch_bounds__(64) void lion_decode_wave4(const uint8_t* __restric
             uint32_t psf = ps;                                                    // the predictor slot my row is stored to
             bool plastf = plast;
             if (ballot64(wrong) != 0) {
-                // the exact walk over the step's quads in stream order, in registers (see lion_decode_wave)
+                // A speculation failed: a predicted quad read an entry that an earlier quad of this step has since moved.  Its real value — the entry of the
+                // row as forwarded — has another hash, so the quad behind it sits in another context than assumed, and so on.  Up to round 3 the whole record
+                // was decoded again by the scalar code on lane 0 (two dependent memory reads per quad: a fifth of the kernel's time on prose).  Now: ONE
+                // exact walk over the step's quads in stream order, in registers — every value wave-uniform — with rows forwarded between quads of one
+                // context, taken from the speculative gather where it was made at the right context, and read from memory only where the context turned
+                // out to be another one (lion.rs:85-186).
                 uint32_t ctx = last_hash;
                 uint32_t cxv = 0xffffffffu, dirtyv = 0;                           // per lane, once walked: my true context; my row differs from memory
                 Row5 rf = row_mem;
@@ -1644,7 +1235,7 @@ hipError_t launch_serial_encode(int algo, const uint8_t* d_in, uint64_t total, u
     else if (algo == DENSITY_HIP_CHEETAH)
         hipLaunchKernelGGL(serial_encode_chunks<DENSITY_HIP_CHEETAH>, dim3(blocks), dim3(64), 0, stream, d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, n_slots);
     else if (!g_force_lane_codec)
-        hipLaunchKernelGGL(g_lion_two_records ? lion_encode_wave : lion_encode_wave4, dim3(n_slots), dim3(64), 0, stream, d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, n_slots,
+        hipLaunchKernelGGL(lion_encode_wave, dim3(n_slots), dim3(64), 0, stream, d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, n_slots,
                            (const uint32_t*)nullptr, (uint32_t*)nullptr, 0u, 0u, (const uint32_t*)nullptr);
     else
         hipLaunchKernelGGL(serial_encode_chunks<DENSITY_HIP_LION>, dim3(blocks), dim3(64), 0, stream, d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, n_slots);
@@ -1655,7 +1246,7 @@ hipError_t launch_serial_encode(int algo, const uint8_t* d_in, uint64_t total, u
 hipError_t launch_wave_encode_only(int algo, const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_out, uint64_t out_stride,
                                    uint64_t* d_sizes, uint8_t* d_tables, uint32_t n_slots, const uint32_t* d_only, hipStream_t stream) {
     if (n_chunks == 0) return hipSuccess;
-    auto kernel = algo == DENSITY_HIP_CHEETAH ? cheetah_encode_wave : g_lion_two_records ? lion_encode_wave : lion_encode_wave4;
+    auto kernel = algo == DENSITY_HIP_CHEETAH ? cheetah_encode_wave : lion_encode_wave;
     hipLaunchKernelGGL(kernel, dim3(n_slots), dim3(64), 0, stream, d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, n_slots, d_only,
                        (uint32_t*)nullptr, 0u, 0u, (const uint32_t*)nullptr);
     return hipGetLastError();
@@ -1663,7 +1254,7 @@ hipError_t launch_wave_encode_only(int algo, const uint8_t* d_in, uint64_t total
 hipError_t launch_wave_encode_heads(int algo, const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_out, uint64_t out_stride,
                                     uint64_t* d_sizes, uint8_t* d_tables, uint32_t* d_head_state, uint32_t head_bytes, uint32_t head_calm, hipStream_t stream) {
     if (n_chunks == 0) return hipSuccess;
-    auto kernel = algo == DENSITY_HIP_CHEETAH ? cheetah_encode_wave : g_lion_two_records ? lion_encode_wave : lion_encode_wave4;
+    auto kernel = algo == DENSITY_HIP_CHEETAH ? cheetah_encode_wave : lion_encode_wave;
     hipLaunchKernelGGL(kernel, dim3(n_chunks), dim3(64), 0, stream, d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, n_chunks,
                        (const uint32_t*)nullptr, d_head_state, head_bytes, head_calm, (const uint32_t*)nullptr);
     return hipGetLastError();
@@ -1671,7 +1262,7 @@ hipError_t launch_wave_encode_heads(int algo, const uint8_t* d_in, uint64_t tota
 hipError_t launch_wave_encode_tails(int algo, const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_out, uint64_t out_stride,
                                     uint64_t* d_sizes, uint8_t* d_tables, const uint32_t* d_tail_state, hipStream_t stream) {
     if (n_chunks == 0) return hipSuccess;
-    auto kernel = algo == DENSITY_HIP_CHEETAH ? cheetah_encode_wave : g_lion_two_records ? lion_encode_wave : lion_encode_wave4;
+    auto kernel = algo == DENSITY_HIP_CHEETAH ? cheetah_encode_wave : lion_encode_wave;
     hipLaunchKernelGGL(kernel, dim3(n_chunks), dim3(64), 0, stream, d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, n_chunks,
                        (const uint32_t*)nullptr, (uint32_t*)nullptr, 0u, 0u, d_tail_state);
     return hipGetLastError();
@@ -1688,8 +1279,6 @@ hipError_t launch_serial_decode(int algo, const uint8_t* d_in, const uint64_t* d
         hipLaunchKernelGGL(cheetah_decode_wave, dim3(n_slots), dim3(64), 0, stream, d_in, d_offsets, d_sizes, n_chunks, d_out, out_stride, out_total, exact ? 1u : 0u, d_produced, d_err, d_tables, n_slots);
     else if (algo == DENSITY_HIP_CHEETAH)
         hipLaunchKernelGGL(serial_decode_chunks<DENSITY_HIP_CHEETAH>, dim3(blocks), dim3(64), 0, stream, d_in, d_offsets, d_sizes, n_chunks, d_out, out_stride, out_total, exact ? 1u : 0u, d_produced, d_err, d_tables, n_slots);
-    else if (!g_force_lane_codec && !g_lion_two_records)
-        hipLaunchKernelGGL(lion_decode_wave4, dim3(n_slots), dim3(64), 0, stream, d_in, d_offsets, d_sizes, n_chunks, d_out, out_stride, out_total, exact ? 1u : 0u, d_produced, d_err, d_tables, n_slots);
     else if (!g_force_lane_codec)
         hipLaunchKernelGGL(lion_decode_wave, dim3(n_slots), dim3(64), 0, stream, d_in, d_offsets, d_sizes, n_chunks, d_out, out_stride, out_total, exact ? 1u : 0u, d_produced, d_err, d_tables, n_slots);
     else
