@@ -1,11 +1,11 @@
 """Turns the output of probes/profile_round.sh into profiles/rNN_{kernel_stats,pmc_fetch,pmc_write}.csv, rNN_pmc_summary.json,
 rNN_lds_counters.txt and rNN_phase_profile.txt."""
-import csv, json, collections, re, shutil, sys, glob
+import csv, json, collections, os, re, shutil, sys, glob
 src, tag = sys.argv[1], sys.argv[2]          # e.g. gpurun_out/prof r02
 def one(pattern):
-    m = glob.glob(pattern, recursive=True)
-    assert len(m) == 1, (pattern, m)
-    return m[0]
+    m = glob.glob(pattern, recursive=True)   # (gpurun merges a call's files into what earlier calls left: the newest is this call's)
+    assert m, pattern
+    return max(m, key=os.path.getmtime)
 KERNEL = r"(chameleon_encode_rot|chameleon_decode_rot|chameleon_\w+_chunks_pipe|compact_kernel|layout_\w+_kernel|selftest_kernel|rotor_selftest_kernel|read4|read16|write4|write2)"
 def avg(path, counter):
     acc = collections.defaultdict(list)
