@@ -150,13 +150,15 @@ struct PinnedInPlace {
     explicit operator bool() const { return p != nullptr; }
 };
 // One copy between the caller's memory and the device on stream s, complete on return.  A megabyte and more: the caller's side is pinned in place for
-// the copy's duration by US — never by the runtime's own pageable-copy path, which pins the caller's pages too but keeps what it pinned in a cache
-// of its own beyond the call; a later hipHostRegister of memory that has come to lie at such an address then maps stale pages (round 4: a GPU
-// write fault in the pipelined calls whenever a staged call on a since-freed buffer had gone before).
+// the copy's duration by US — never by the runtime's own pageable-copy path, which pins the caller's pages too and keeps the pin in a cache of its own
+// (the last eight per queue) beyond the call.  A later hipHostRegister of the same buffer over a LARGER extent is then answered with the cached pin's
+// pages and no more: the pages behind them are not mapped, and the first access faults the GPU (round 4: "memory access fault ... write access to a
+// read-only page" on the last page of an output buffer — a staged decode had brought down a few bytes less into it than the pipelined call that
+// followed registered; DENSITY_HIP_RAW_STAGED=1 brings the old copies back, tools/gpu_host_stream_sequence.py walks the sequence).
 inline hipError_t copy_host_side_pinned(void* dst, const void* src, size_t n, hipMemcpyKind kind, hipStream_t s) {
     if (n == 0) return hipSuccess;
     const void* host = kind == hipMemcpyHostToDevice ? src : dst;
-    if (n >= (1u << 20)) {
+    if (n >= (1u << 20) && !getenv("DENSITY_HIP_RAW_STAGED")) {      // (the environment switch: the round-4 fault's reproducer, tools/gpu_host_stream_sequence.py)
         PinnedInPlace pin(host, n);
         if (pin) {
             const hipError_t e = hipMemcpyAsync(dst, src, n, kind, s), e2 = hipStreamSynchronize(s);
