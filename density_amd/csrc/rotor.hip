@@ -50,6 +50,9 @@ constexpr uint32_t kNone = 0xffffffffu;
 // sync block (bytes from its base): D line {D, A}; O line {O, A', P0, P1}; a 256-byte sink for the idle lanes of a token write;
 // 16 words "rounds whose zero-entry-map phase this wave has finished" (decoder); 16 words "the round of this wave that is about to mark the map" (decoder)
 constexpr uint32_t kSyD = 0, kSyO = 16, kSyZ = 32, kSyEnd = 48, kSySink = 64, kSyZdone = 64 + 256, kSyWsum = 64 + 256 + 64, kSyZset = 64 + 256 + 64 + 64, kSyBytes = 64 + 256 + 64 + 64 + 64;
+// (encoder: the words of the decoder's zero-entry chain hold the memo of FSM predictions instead — 8 entries of {state, raw-copy blocks, end state, -})
+constexpr uint32_t kSyMemo = kSyZdone, kMemoEntries = 8;
+static_assert(kSyMemo + 16u * kMemoEntries <= kSyBytes, "memo inside the sync block");
 // encoder LDS: table | zero-entry map | sync
 constexpr uint32_t kEncZmap = kTableBytes, kEncSync = kTableBytes + kZmapBytes, kEncStage = kEncSync + kSyBytes;
 // (encoder staging: two arrays of up to 16 blocks x 64 lanes for the rolled loops of the rare paths — rollback, in-order rounds, zero-entry
@@ -83,6 +86,10 @@ __device__ __forceinline__ u32x4 lds_peek4(uint32_t addr) {
     u32x4 v;
     asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
     return v;
+}
+// two consecutive 16-byte lines in one round trip (the D line and the O line of the sync block)
+__device__ __forceinline__ void lds_peek4x2(uint32_t addr, u32x4& a, u32x4& b) {
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)" : "=&v"(a), "=&v"(b) : "v"(addr) : "memory");
 }
 __device__ __forceinline__ uint32_t lds_peek1(uint32_t addr) {
     uint32_t v;
@@ -266,6 +273,40 @@ __device__ __forceinline__ void exchange_tied<16>(uint32_t (&ra)[16], const uint
     if (!token_after_answers) asm volatile(DENSITY_ROT_X16 "ds_write_b32 %48, %49\n\ts_waitcnt lgkmcnt(0)" DENSITY_ROT_X16_OPS);
     else asm volatile(DENSITY_ROT_X16 "s_waitcnt lgkmcnt(0)\n\tds_write_b32 %48, %49" DENSITY_ROT_X16_OPS);
 }
+// The exchanges of an ORDERED round (encoder, below) in one statement: block j's is skipped if bit j of `idle` is set (a final block, a predicted
+// raw copy); no token behind them.
+#define DENSITY_ROT_XC16 \
+    "s_bitcmp1_b32 %[idle], 0\n\ts_cbranch_scc1 .Lskip0_%=\n\tds_mskor_rtn_b32 %0, %0, %16, %32\n.Lskip0_%=:\n\t" \
+    "s_bitcmp1_b32 %[idle], 1\n\ts_cbranch_scc1 .Lskip1_%=\n\tds_mskor_rtn_b32 %1, %1, %17, %33\n.Lskip1_%=:\n\t" \
+    "s_bitcmp1_b32 %[idle], 2\n\ts_cbranch_scc1 .Lskip2_%=\n\tds_mskor_rtn_b32 %2, %2, %18, %34\n.Lskip2_%=:\n\t" \
+    "s_bitcmp1_b32 %[idle], 3\n\ts_cbranch_scc1 .Lskip3_%=\n\tds_mskor_rtn_b32 %3, %3, %19, %35\n.Lskip3_%=:\n\t" \
+    "s_bitcmp1_b32 %[idle], 4\n\ts_cbranch_scc1 .Lskip4_%=\n\tds_mskor_rtn_b32 %4, %4, %20, %36\n.Lskip4_%=:\n\t" \
+    "s_bitcmp1_b32 %[idle], 5\n\ts_cbranch_scc1 .Lskip5_%=\n\tds_mskor_rtn_b32 %5, %5, %21, %37\n.Lskip5_%=:\n\t" \
+    "s_bitcmp1_b32 %[idle], 6\n\ts_cbranch_scc1 .Lskip6_%=\n\tds_mskor_rtn_b32 %6, %6, %22, %38\n.Lskip6_%=:\n\t" \
+    "s_bitcmp1_b32 %[idle], 7\n\ts_cbranch_scc1 .Lskip7_%=\n\tds_mskor_rtn_b32 %7, %7, %23, %39\n.Lskip7_%=:\n\t" \
+    "s_bitcmp1_b32 %[idle], 8\n\ts_cbranch_scc1 .Lskip8_%=\n\tds_mskor_rtn_b32 %8, %8, %24, %40\n.Lskip8_%=:\n\t" \
+    "s_bitcmp1_b32 %[idle], 9\n\ts_cbranch_scc1 .Lskip9_%=\n\tds_mskor_rtn_b32 %9, %9, %25, %41\n.Lskip9_%=:\n\t" \
+    "s_bitcmp1_b32 %[idle], 10\n\ts_cbranch_scc1 .Lskip10_%=\n\tds_mskor_rtn_b32 %10, %10, %26, %42\n.Lskip10_%=:\n\t" \
+    "s_bitcmp1_b32 %[idle], 11\n\ts_cbranch_scc1 .Lskip11_%=\n\tds_mskor_rtn_b32 %11, %11, %27, %43\n.Lskip11_%=:\n\t" \
+    "s_bitcmp1_b32 %[idle], 12\n\ts_cbranch_scc1 .Lskip12_%=\n\tds_mskor_rtn_b32 %12, %12, %28, %44\n.Lskip12_%=:\n\t" \
+    "s_bitcmp1_b32 %[idle], 13\n\ts_cbranch_scc1 .Lskip13_%=\n\tds_mskor_rtn_b32 %13, %13, %29, %45\n.Lskip13_%=:\n\t" \
+    "s_bitcmp1_b32 %[idle], 14\n\ts_cbranch_scc1 .Lskip14_%=\n\tds_mskor_rtn_b32 %14, %14, %30, %46\n.Lskip14_%=:\n\t" \
+    "s_bitcmp1_b32 %[idle], 15\n\ts_cbranch_scc1 .Lskip15_%=\n\tds_mskor_rtn_b32 %15, %15, %31, %47\n.Lskip15_%=:\n\t"
+template <int R>
+__device__ __forceinline__ void exchange_some(uint32_t (&ra)[R], const uint32_t (&mask)[R], const uint32_t (&val)[R], uint32_t idle) {
+    // (one statement per block WITH its wait: an answer still in flight at the end of a conditional statement would be the compiler's to copy)
+#pragma unroll
+    for (uint32_t j = 0; j < (uint32_t)R; ++j) {
+        if (!((idle >> j) & 1u)) asm volatile("ds_mskor_rtn_b32 %0, %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "+v"(ra[j]) : "v"(mask[j]), "v"(val[j]) : "memory");
+    }
+}
+template <>
+__device__ __forceinline__ void exchange_some<16>(uint32_t (&ra)[16], const uint32_t (&mask)[16], const uint32_t (&val)[16], uint32_t idle) {
+    asm volatile(DENSITY_ROT_XC16 "s_waitcnt lgkmcnt(0)"
+                 : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(ra[4]), "+v"(ra[5]), "+v"(ra[6]), "+v"(ra[7]), "+v"(ra[8]), "+v"(ra[9]), "+v"(ra[10]), "+v"(ra[11]), "+v"(ra[12]), "+v"(ra[13]), "+v"(ra[14]), "+v"(ra[15])
+                 : "v"(mask[0]), "v"(mask[1]), "v"(mask[2]), "v"(mask[3]), "v"(mask[4]), "v"(mask[5]), "v"(mask[6]), "v"(mask[7]), "v"(mask[8]), "v"(mask[9]), "v"(mask[10]), "v"(mask[11]), "v"(mask[12]), "v"(mask[13]), "v"(mask[14]), "v"(mask[15]), "v"(val[0]), "v"(val[1]), "v"(val[2]), "v"(val[3]), "v"(val[4]), "v"(val[5]), "v"(val[6]), "v"(val[7]), "v"(val[8]), "v"(val[9]), "v"(val[10]), "v"(val[11]), "v"(val[12]), "v"(val[13]), "v"(val[14]), "v"(val[15]), [idle] "s"(idle)
+                 : "memory", "scc");
+}
 // (keeps a set of operands from being scheduled past this point, i.e. into the critical section behind the token wait)
 template <int R>
 __device__ __forceinline__ void pin_operands(uint32_t (&ra)[R], uint32_t (&mask)[R], uint32_t (&val)[R]) {
@@ -287,9 +328,65 @@ __device__ __forceinline__ Guard unpack_guard(uint32_t w) {
     return g;
 }
 
-// Every spin is bounded: a wave that polls one token ~4 M times in a row (>= 0.2 s; a legitimate wait is microseconds) declares the
-// work-group dead — error bit 16 for the host, a poison value in the token words so that the other waves leave too — instead of
-// hanging the device.  Nothing should ever get here; it turns a protocol bug into an error code.
+// The FSM of an ORDERED round (below), protection_state.rs:19-47 on packed states (pack_guard), wave-uniform (scalar registers).
+// fsm_verify: blocks j0..R-1 from the state `st` in front of block j0; every block's raw-copy status must be bit j of `raw_old` (what the last
+// exchange assumed), a coded block is incompressible iff bit j of `inc` (its signature).  Returns the first block that is not what was assumed
+// (R: none; then `state` is the state behind the round), the state in front of it and whether it is a raw copy — a raw copy where none was
+// expected starts an incompressible stretch, a coded block where a copy was expected ends one.
+template <int R>
+__device__ __forceinline__ uint32_t fsm_verify(uint32_t st, uint32_t j0, uint32_t inc, uint32_t raw_old, uint32_t& state, uint32_t& is_copy) {
+    Guard g = unpack_guard(st);
+    is_copy = 0;
+    uint32_t j = j0;
+#pragma nounroll
+    for (; j < (uint32_t)R; ++j) {
+        const uint32_t copy = g.penalty != 0 ? 1u : 0u;                            // (what block_is_copy will say: the halving in it does not change that)
+        if (copy != ((raw_old >> j) & 1u)) { is_copy = copy; break; }
+        (void)g.block_is_copy();                                                   // codec.rs:35
+        if (copy) g.decay();                                                       // codec.rs:36-37
+        else g.update((inc >> j) & 1u);                                            // codec.rs:68
+    }
+    state = pack_guard(g);
+    return j;
+}
+// fsm_predict: the raw-copy blocks among j0..R-1 (`raw`: bits below j0 as given) and the state behind the round if every coded block from j0
+// on is incompressible (`storm`) or none is — the FSM is then a function of its state alone, taken run by run instead of block by block:
+// a run of raw copies (penalty blocks, protection_state.rs:30-35), one coded block that triggers the next (:38-47), ...; `start` is halved at
+// the one block of the stretch whose counter is a multiple of 16 (:19-27: before that block's own decay or trigger).
+template <int R>
+__device__ __forceinline__ void fsm_predict(uint32_t st, uint32_t j0, uint32_t storm, uint32_t raw_below, uint32_t& raw, uint32_t& end_state) {
+    uint32_t p = st & 0xffu, s = ((st >> 8) & 0xffu) + 1u, v = (st >> 16) & 1u, c = (st >> 17) & 15u;
+    uint32_t j = j0;
+    raw = raw_below & ((1u << j0) - 1u);
+#pragma nounroll
+    while (j < (uint32_t)R) {
+        const uint32_t kh = (16u - c) & 15u;                                       // blocks in front of the next halving point
+        if (p) {                                                                   // a run of raw copies
+            uint32_t L = (uint32_t)R - j;
+            L = p < L ? p : L;
+            raw |= ((1u << L) - 1u) << j;
+            if (kh < L && s > 1u) s >>= 1;
+            c = (c + L) & 15u; p -= L; j += L;
+            if (p == 0) s = (s + 1u) & 0xffu;
+        } else if (storm) {                                                        // one coded, incompressible block
+            if (kh == 0 && s > 1u) s >>= 1;
+            c = (c + 1u) & 15u; ++j;
+            if (v) p = s;
+            v = 1;
+        } else {                                                                   // coded blocks to the round's end, none of them incompressible
+            const uint32_t n = (uint32_t)R - j;
+            if (kh < n && s > 1u) s >>= 1;
+            c = (c + n) & 15u; j = (uint32_t)R; v = 0;
+        }
+    }
+    end_state = (p & 0xffu) | (((s - 1u) & 0xffu) << 8) | (v << 16) | (c << 17);
+}
+
+// ordered rounds without unrest before the encoder speculates ACROSS rounds again: 2, and 2 more (at most 7) with every abort the chunk has seen —
+// its count, up to 3, rides in bits 24..25 of the commit payload.  (Same box, round 5: leaving after 2 quiet rounds is as fast as round 4's library
+// on text at 1 GiB and 6 % faster at 10 MB — the cold start of every 64 KiB chunk is ordered rounds now, not block-by-block walks —, waiting for
+// 6 always costs text 1.3 % / 10 % / 13 % at 1 GiB / 100 MB / 10 MB; data that flips every few KiB aborts a work-group per flip when it leaves early.)
+__device__ __forceinline__ uint32_t quiet_rounds(uint32_t P1) { const uint32_t q = 2u + 2u * ((P1 >> 24) & 3u); return q > 7u ? 7u : q; }
 constexpr uint32_t kSpinLimit = 1u << 22, kPoison = 0xfffffffeu, kErrWatchdog = 16u;
 __device__ __forceinline__ void wave_exit() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_endpgm" ::: "memory"); }
 __device__ __forceinline__ void watchdog(uint32_t& spins, uint32_t sync_base, uint32_t* err, uint32_t lane) {
@@ -316,13 +413,14 @@ struct PhaseClock<false> {
     __device__ __forceinline__ void stamp(uint32_t, uint32_t, uint32_t) {}
     __device__ __forceinline__ void note(uint32_t, uint32_t, uint32_t) {}
     __device__ __forceinline__ void flush(uint32_t, uint32_t) {}
+    __device__ __forceinline__ void count(int, uint32_t) {}
 };
 template <>
 struct PhaseClock<true> {
-    uint64_t* out; uint64_t t0 = 0; uint64_t ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t* out; uint64_t t0 = 0; uint32_t ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // (32-bit sums: the profiling instances are as short of registers as the shipped ones)
     __device__ __forceinline__ explicit PhaseClock(uint64_t* o) : out(o) {}
     __device__ __forceinline__ void start() { if (out) t0 = __builtin_readcyclecounter(); }
-    __device__ __forceinline__ void mark(int k) { if (out) { const uint64_t t = __builtin_readcyclecounter(); ph[k] += t - t0; t0 = t; } }
+    __device__ __forceinline__ void mark(int k) { if (out) { const uint64_t t = __builtin_readcyclecounter(); ph[k] += (uint32_t)(t - t0); t0 = t; } }
     // per-round time stamps of the D chain (rounds < kProfRounds): 0 = started polling, 1 = token seen, 2 = exchanges + token done, 3 = round finished
     __device__ __forceinline__ void stamp(uint32_t r, uint32_t what, uint32_t lane) {
         if (out && r < kProfRounds && lane == 0) out[128 + 4 * r + what] = __builtin_readcyclecounter();
@@ -332,6 +430,8 @@ struct PhaseClock<true> {
         if (out && r < kProfRounds && lane == 0) out[128 + 4 * kProfRounds + r] = v;
     }
     __device__ __forceinline__ void flush(uint32_t wave, uint32_t lane) { if (out && lane == 0) for (int k = 0; k < 8; ++k) out[8 * wave + k] = ph[k]; }
+    // event counters of work-group 0 (encoder: 0 fast rounds committed, 1 ordered rounds that held, 2 ordered rounds taken back, 3 rounds walked in order, 4 aborts raised)
+    __device__ __forceinline__ void count(int k, uint32_t lane) { if (out && lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(out + 128 + 5 * kProfRounds + k), 1ull); }
 };
 
 // Waiting for a token.  The wave whose turn is next (or next but one) polls in a loop of five instructions; waves further away sleep
@@ -407,6 +507,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
             *reinterpret_cast<uint4*>(smem + kEncSync + kSyO) = make_uint4(0u, kNone, 0u, g0 & 0x7fffffffu);
             if (lds_addr(smem) != 0 && err) atomicOr(err, kErrWatchdog);           // (cannot happen: see above)
         }
+        if (threadIdx.x < kMemoEntries) *reinterpret_cast<uint4*>(smem + kEncSync + kSyMemo + 16u * threadIdx.x) = make_uint4(kNone, 0u, 0u, 0u);
     }
     __syncthreads();
 
@@ -534,10 +635,12 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
     // undo the exchanges of this wave's round, last block first: the lowest lane of a slot holds the pre-block entry, so the
     // answers go back lane-reversed in ONE ds_write_b16 per block (ascending lane service order: the highest physical lane =
     // the lowest original lane wins)
-    auto rollback_round = [&]() {
+    // (`skip`: blocks of the round that exchanged nothing — the raw copies an ordered round predicted, below)
+    auto rollback_round = [&](uint32_t skip = 0u) {
         park(0, q); park(1, ra);                                                  // (a rolled loop: this path is rare, its code must not weigh on the common one)
 #pragma nounroll
         for (int j = (int)R - 1; j >= 0; --j) {
+            if ((skip >> j) & 1u) continue;
             const uint32_t P = parked(0, (uint32_t)j) * kHashMul, srj = parked(1, (uint32_t)j);
             const uint32_t hi = (P >> 16) & 1u;                                    // 1: the slot is the upper half of its dword
             const uint32_t a16 = ((P >> 15) & 0x1fffcu) + 2u * hi;
@@ -572,13 +675,18 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
     } else {
         load_round(q, wave);
     }
+    uint32_t poll_tries = 16;                                                     // polls for the FAST token before a look at the whole D line: few while this wave's rounds are ordered ones
     for (uint32_t r = wave; r < nrounds; r += W) {
         clk.start();
         __builtin_amdgcn_s_setprio(1);                                   // (see the priorities note at the exchange)
         uint32_t slo = 0, shi = 0;                                                // lane j: the signature of block j (codec.rs:24-26)
         uint32_t copy_mask = 0, opos = 0;
         bool fast_commit = false, prefetched = false;
-      for (;;) {   // (re-entered after an abort: the answers have replaced the addresses, so the operands are made again)
+        // an ORDERED round (below): its commit payload, and how far it is final — blocks below it_j0, the FSM state in front of it_j0, the raw-copy
+        // blocks (final below it_j0, predicted from there on), the prediction and the state behind the round if it holds
+        uint32_t P0 = 0, P1 = 0, it_j0 = kNone, it_state = 0, it_raw = 0, it_mode = 0, it_end = 0;
+        bool have_turn = false;
+      for (;;) {   // (re-entered after an abort, and by an ordered round whose prediction failed: the answers have replaced the addresses, so the operands are made again)
         uint32_t zmin = 0xffffffffu;
 #pragma unroll
         for (uint32_t j = 0; j < R; ++j) {
@@ -600,7 +708,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
             }
         }
         const bool zero_round = zblocks != 0;
-        const uint32_t tokaddr = lane == 0 ? sy + kSyD : sy + kSySink + 4u * lane;
+        uint32_t tokaddr = lane == 0 ? sy + kSyD : sy + kSySink + 4u * lane;
         uint32_t tokval = (r + 1u) << 1;                                          // (in its register before the wait, like the operands)
         asm volatile("" : "+v"(tokval));
         pin_operands<R>(ra, mask, val);                                           // complete before the wait for the token
@@ -610,8 +718,26 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
         __builtin_amdgcn_s_setprio(2);
         {
             // ---- D chain: wait for this round's turn ----
-            uint32_t slow;
+            uint32_t slow = 1;
+            bool got_payload = false;
+            if (!have_turn)
             for (uint32_t spins = 0;;) {
+                if (poll_tries != 16) {
+                    // this wave's last round was an ordered one: most likely this one is too, and then it needs the commit payload as well —
+                    // the D line and the O line in one look instead of one after the other
+                    u32x4 dl, ol;
+                    lds_peek4x2(sy + kSyD, dl, ol);
+                    const uint32_t D = rfl(dl.x), A = rfl(dl.y);
+                    if (__builtin_expect(A != kNone, 0)) { if (A == kPoison) wave_exit(); abort_sync(false, 0); continue; }
+                    if ((D >> 1) == r) {
+                        slow = D & 1u;
+                        if (slow && rfl(ol.x) == r) { P0 = rfl(ol.z); P1 = rfl(ol.w); got_payload = true; }
+                        break;
+                    }
+                    backoff(r - (D >> 1));
+                    watchdog(spins, sy, err, lane);
+                    continue;
+                }
                 if (poll_word(sy + kSyD, r << 1, 16)) { slow = 0; break; }         // the common hand-off: fast token for this round
                 const u32x2 v = lds_peek2(sy + kSyD);
                 const uint32_t D = rfl(v.x), A = rfl(v.y);
@@ -677,7 +803,6 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
                 if (!kKeepQuads) load_round(q, r);                        // the quads again (from L2): not kept across the wait for the token
                 clk.mark(3);
                 // ---- O chain: commit ----
-                uint32_t P0, P1;
                 bool aborted = false;
                 for (uint32_t spins = 0;;) {
                     u32x4 v = lds_peek4(sy + kSyO);
@@ -721,7 +846,9 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
                             if ((flipped >> j) & 1u) zmap.clear((pick<R>(q, j) * kHashMul) >> 16);
                         }
                     }
-                    if (lane == 0) { lds_poke(sy + kSyD + 4, r); lds_poke(sy + kSyO + 4, r); }
+                    // (the chunk's abort count, for the ordered rounds' patience: this wave holds the commit token, the payload is its to amend)
+                    if (lane == 0) { lds_poke(sy + kSyO + 12, ((P1 >> 24) & 3u) < 3u ? P1 + 0x01000000u : P1); lds_poke(sy + kSyD + 4, r); lds_poke(sy + kSyO + 4, r); }
+                    clk.count(4, lane);
                     abort_sync(true, r);
                     continue;
                 }
@@ -734,7 +861,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
                     for (uint32_t j = 0; j < R; ++j) (void)g.block_is_copy();        // no block was a copy: bookkeeping only (:19-27)
                     g.penalty = ((t >> (R - 1)) & 1u) ? g.start : 0u;
                     g.prev = (inc >> (R - 1)) & 1u;
-                    g_out = pack_guard(g);
+                    g_out = pack_guard(g) | (P1 & 0x03000000u);
                 }
                 opos = P0;
                 if (lane == 0) {
@@ -746,25 +873,121 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
                 fast_commit = true;
                 if (kKeepQuads && !prefetched && r + W < nrounds) prefetch_quads<R, W>(src + (uint64_t)(r + W) * (R * kBlock) + 4u * lane);   // next round's quads: in flight behind the commit, landed by the end of the emit
                 clk.mark(4);
+                clk.count(0, lane);
+                poll_tries = 16;
                 break;
             }
-            // ---- in-order round: wait until everything before it is final, then walk the blocks with the FSM ----
-            uint32_t P0, P1;
-            bool aborted = false;
-            for (uint32_t spins = 0;;) {
-                const u32x4 v = lds_peek4(sy + kSyO);
-                const uint32_t O = rfl(v.x), A = rfl(v.y);
-                if (O == r) { P0 = rfl(v.z); P1 = rfl(v.w); break; }
-                if (A != kNone) { if (A == kPoison) wave_exit(); abort_sync(false, 0); aborted = true; break; }
-                backoff(r - O);
-                watchdog(spins, sy, err, lane);
-            }
-            if (aborted) continue;
-            if (!kKeepQuads) load_round(q, r);                                    // (as in the fast path: the quads are not kept across the waits)
-            Guard g = unpack_guard(P1);
-            uint32_t sum = 0, unrest = 0;
-            copy_mask = 0;
+            // ---- ordered round (round 5): everything before it is final first, then the round in batches ----
+            // A round behind an abort or behind unrest does not speculate ACROSS rounds: it waits for its commit payload, so the FSM state at its
+            // first block is known.  INSIDE the round the raw-copy blocks are predicted — calm state: none; inside an incompressible stretch
+            // (penalty running, or the last coded block incompressible): every coded block incompressible, which makes the FSM a function of its
+            // state alone (protection_state.rs:19-47) —, the blocks predicted coded exchange in one go like a fast round's, and the FSM walked over
+            // the signatures they produce must arrive at the predicted raw blocks: by induction, block by block, the round is then exactly the
+            // sequential one.  Where it does not — block jm — everything below jm IS final; this wave takes back its exchanges from jm on (nobody
+            // has seen them: the dictionary token leaves only with the commit), predicts again from the exact state at jm — the other way round:
+            // a raw copy where none was expected starts an incompressible stretch, a coded block where a copy was expected ends one — and
+            // exchanges the rest of the round again; jm only grows.  No barrier, no other wave involved: data that flips between compressible and
+            // incompressible every few KiB costs a round a second batch, not an abort of the work-group per flip; incompressible data runs in
+            // batches too.
+            bool ordered = false;
             {
+                if (!have_turn) {
+                    bool aborted = false;
+                    if (!got_payload)
+                    for (uint32_t spins = 0;;) {
+                        const u32x4 v = lds_peek4(sy + kSyO);
+                        const uint32_t O = rfl(v.x), A = rfl(v.y);
+                        if (O == r) { P0 = rfl(v.z); P1 = rfl(v.w); break; }
+                        if (A != kNone) { if (A == kPoison) wave_exit(); abort_sync(false, 0); aborted = true; break; }
+                        backoff(r - O);
+                        watchdog(spins, sy, err, lane);
+                    }
+                    if (aborted) continue;
+                    have_turn = true;
+                    if (!kKeepQuads) load_round(q, r);                            // (as in the fast path: the quads are not kept across the waits)
+                    // (a fresh chunk's first round is the cold start — raw copies for certain, nothing to predict —, and the rare zero-entry quads
+                    // are settled block by block: those rounds are walked in order, below)
+                    if (!zero_round && !(r == 0 && !seg.init_images)) {
+                        it_j0 = 0; it_state = P1 & 0x1fffffu; it_raw = 0;
+                        it_end = (it_state & ~0x1e0000u) | ((((it_state >> 17) + R) & 15u) << 17);   // (calm, start == 1, no incompressible block: only the counter moves)
+                        it_mode = (P1 & 0x100ffu) != 0 ? 1u : 0u;                    // penalty running or the last coded block incompressible
+                        if ((P1 & 0x1ffffu) != 0) {                                // (calm, start == 1: no raw copy while no block is incompressible, only the counter moves: the check below)
+                            // Inside an incompressible stretch the state in front of a round repeats with a period of a few rounds (the counter moves
+                            // by R = 16 a round, penalty and start go round a short cycle), and the prediction is a function of that state alone: a
+                            // memo of eight in the sync block, touched only by the holder of the commit token, saves the walk — a few hundred scalar
+                            // instructions in the one place where every later round waits.
+                            const u32x4 e = lds_peek4(sy + kSyMemo + 16u * (lane & (kMemoEntries - 1u)));   // lane l: entry l mod 8; the round's number picks the one to replace
+                            const uint64_t found = ballot64(e.x == it_state);
+                            if (it_mode && found) {
+                                const uint32_t l0 = (uint32_t)__builtin_ctzll(found);
+                                it_raw = rlane(e.y, l0); it_end = rlane(e.z, l0);
+                            } else {
+                                fsm_predict<R>(it_state, 0u, it_mode, 0u, it_raw, it_end);
+                                if (it_mode && lane == 0) { const u32x4 v = {it_state, it_raw, it_end, 0u}; asm volatile("ds_write_b128 %0, %1" ::"v"(sy + kSyMemo + 16u * (r & (kMemoEntries - 1u))), "v"(v) : "memory"); }
+                            }
+                        }
+                    }
+                }
+                ordered = it_j0 != kNone;
+                if (ordered) {
+                }
+            }
+            bool batched = false;
+            uint32_t osum = 0, ounrest = 0;
+            Guard og;
+            if (ordered) {
+                // only the blocks from it_j0 on that are predicted coded exchange (final blocks and raw copies — codec.rs:35-37 — touch no state); no
+                // token behind them: it leaves with the commit
+                const uint32_t keep_lo = slo, keep_hi = shi;                       // (final blocks keep their signatures)
+                exchange_some<R>(ra, mask, val, rfl(it_raw | ((1u << it_j0) - 1u)));
+#pragma unroll
+                for (uint32_t j = 0; j < R; ++j) {                                // chameleon.rs:90-99 (an idle block's "signature" is never looked at)
+                    const uint64_t sg = ballot64(((ra[j] ^ val[j]) & mask[j]) == 0);
+                    slo = lane == j ? (uint32_t)sg : slo;
+                    shi = lane == j ? (uint32_t)(sg >> 32) : shi;
+                }
+                // ---- do the signatures lead the FSM to the predicted raw copies? ----
+                {
+                    const uint32_t below = (1u << it_j0) - 1u, all = (1u << R) - 1u;
+                    slo = lane < it_j0 ? keep_lo : slo;                            // (final blocks keep their signatures; theirs of this pass are of idle lanes)
+                    shi = lane < it_j0 ? keep_hi : shi;
+                    const uint32_t nh2 = (uint32_t)(__builtin_popcount(slo) + __builtin_popcount(shi));
+                    const uint32_t inc_all = (uint32_t)ballot64(lane < R && nh2 <= 4u) & ~it_raw;   // codec.rs:68, coded blocks
+                    const uint32_t coded_new = all & ~it_raw & ~below;
+                    bool done = ((inc_all ^ (it_mode ? all : 0u)) & coded_new) == 0;   // every block behaved as predicted: the prediction's end state stands
+                    if (!done) {
+                        uint32_t sm, mm;
+                        const uint32_t jm = fsm_verify<R>(it_state, it_j0, inc_all, it_raw, sm, mm);
+                        if (jm == (uint32_t)R) { done = true; it_end = sm; }          // (single incompressible blocks in a calm round: no raw copy came of them)
+                        else {
+                            clk.count(2, lane);
+                            rollback_round(it_raw | ((1u << jm) - 1u));             // the exchanges from jm on, last block first
+                            uint32_t raw_new;
+                            fsm_predict<R>(sm, jm, mm, it_raw, raw_new, it_end);
+                            it_raw = raw_new; it_j0 = jm; it_state = sm; it_mode = mm;
+                            continue;
+                        }
+                    }
+                    batched = true;
+                    clk.count(1, lane);
+                    og = unpack_guard(it_end);
+                    uint32_t acc = ((it_raw >> lane) & 1u) ? kBlock : kSig + kBlock - 2u * nh2;              // lane j < R: bytes of block j
+                    acc = lane < R ? acc : 0u;
+                    acc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc, 0x111, 0xf, 0xf, true);     // row_shr:1
+                    acc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc, 0x112, 0xf, 0xf, true);     // row_shr:2
+                    acc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc, 0x114, 0xf, 0xf, true);     // row_shr:4
+                    acc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc, 0x118, 0xf, 0xf, true);     // row_shr:8
+                    osum = rlane_u(acc, 15);
+                    ounrest = inc_all != 0 ? 1u : 0u;
+                }
+            }
+            // ---- in-order round: everything before it is final (the wait above); walk the blocks with the FSM ----
+            Guard g = batched ? og : unpack_guard(P1);
+            uint32_t sum = osum, unrest = ounrest;
+            copy_mask = batched ? it_raw : 0u;
+            if (!batched) {
+                clk.count(3, lane);
+                slo = 0; shi = 0;
                 park(0, q);                                                       // (a rolled loop, as in rollback_round)
 #pragma nounroll
                 for (uint32_t j = 0; j < R; ++j) {
@@ -783,13 +1006,18 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
             }
             opos = P0;
             if (seg.raw_blocks && copy_mask && lane == 0) atomicAdd(seg.raw_blocks + chunk, (uint32_t)__builtin_popcount(copy_mask));
-            const uint32_t stay_slow = (g.penalty | copy_mask | unrest) != 0 ? 1u : 0u;   // back to speculation only after a round without an incompressible or raw block
+            // back to speculation ACROSS rounds only after quiet_rounds() rounds in a row without an incompressible or raw block (the count rides in
+            // bits 21..23 of the commit payload): a mis-speculated fast round costs a work-group barrier and the roll-back of every round that ran
+            // ahead — dozens of ordered rounds' worth
+            const uint32_t streak = (g.penalty | copy_mask | unrest) != 0 ? 0u : (((P1 >> 21) & 7u) < 7u ? ((P1 >> 21) & 7u) + 1u : 7u);
+            const uint32_t stay_slow = streak < quiet_rounds(P1) ? 1u : 0u;
             if (lane == 0) {
-                lds_poke2(sy + kSyO + 8, opos + sum, pack_guard(g));
+                lds_poke2(sy + kSyO + 8, opos + sum, pack_guard(g) | (streak << 21) | (P1 & 0x03000000u));
                 lds_poke(sy + kSyO, r + 1u);
                 lds_poke(sy + kSyD, ((r + 1u) << 1) | stay_slow);
             }
             if (kKeepQuads && !prefetched && r + W < nrounds) prefetch_quads<R, W>(src + (uint64_t)(r + W) * (R * kBlock) + 4u * lane);   // (as behind a fast commit)
+            poll_tries = 2;
             clk.mark(7);
             break;
         }
@@ -801,15 +1029,16 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
         if (__builtin_expect(copy_mask == 0, 1)) {
             emit_round_coded(opos, idx ? idx + (uint64_t)r * R : nullptr, slo, shi);
         } else {
+            // (unrolled since round 5 — ordered rounds made incompressible data a common case: the rolled loop picked every block's quads out of
+            // the registers by a chain of selects, ten thousand cycles a round)
             uint8_t* rec = dst + opos;
-#pragma nounroll
+            if (idx && lane < R) idx[(uint64_t)r * R + lane] = (uint8_t)(((copy_mask >> lane) & 1u) ? kIdxCopy : (uint32_t)(__builtin_popcount(slo) + __builtin_popcount(shi)));
+#pragma unroll
             for (uint32_t j = 0; j < R; ++j) {
                 const bool raw = (copy_mask >> j) & 1u;
-                const uint64_t sg = ((uint64_t)rlane(shi, j) << 32) | rlane(slo, j);
-                const uint32_t nh = (uint32_t)__builtin_popcountll(sg);
-                emit_block(rec, pick<R>(q, j), sg, raw);
-                if (idx && lane == 0) idx[(uint64_t)r * R + j] = (uint8_t)(raw ? kIdxCopy : nh);
-                rec += raw ? kBlock : kSig + kBlock - 2u * nh;
+                const uint64_t sg = ((uint64_t)rlane_u(shi, (int)j) << 32) | rlane_u(slo, (int)j);
+                emit_block(rec, q[j], sg, raw);
+                rec += raw ? kBlock : kSig + kBlock - 2u * (uint32_t)__builtin_popcountll(sg);
             }
         }
         if (kKeepQuads) {
@@ -1318,6 +1547,18 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
         // ---- zero-entry map, in stream order (rare: stored entries are salted).  A round with no such quad only reports "done"; one that
         // has any first waits until every earlier round has reported (wave w' owns the rounds = w' mod W). ----
         if (__builtin_expect(marks || zany != 0, 0)) {
+          if (!marks) {
+            // (round 5) Slot 0 needs no map: its entry 0 IS the zero quad, written or not (chameleon.rs:41,88-100), so a record whose MAP lanes all
+            // name slot 0 — zero pages, the zero quads of low-entropy data — has nothing to ask, whatever it read.  Such records are dropped here
+            // (all-zero input used to take every record of every round through the select chains below); a record with a MAP lane on another
+            // slot stays in and is looked at exactly.
+            uint32_t real = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < R; ++j) real |= (ballot64(((hit_mask >> j) & 1u) != 0 && (itemc[j] & 0xffffu) != 0) != 0 ? 1u : 0u) << j;
+            zrec &= real;
+            if (zrec == 0) zany = 0;
+          }
+          if (marks || zany != 0) {
             clk.note(x, 1, lane);
             for (uint32_t spins = 0;;) {
                 const uint32_t wv = lane % W;
@@ -1397,6 +1638,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
                 }
             }
             }
+          }
         }
         if (lane == 0) {
             if (marks) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); lds_poke(sy + kSyZset + 4u * wave, 0u); }   // (behind the marks: LDS operations of a wave execute in order; in L2: ZmapGlobal::set consumed the atomics' answers)
@@ -1534,7 +1776,7 @@ __global__ __launch_bounds__(kRotThreads) void rotor_selftest_kernel(uint32_t* _
 // ---------------------------------------------------------------------------------------------------------------
 namespace {
 // DENSITY_HIP_PROF=1: per-wave, per-phase cycle accounting of work-group 0, printed to stderr after every launch (synchronises)
-constexpr size_t kProfWords = 128 + 5 * kProfRounds;
+constexpr size_t kProfWords = 128 + 5 * kProfRounds + 8;
 uint64_t* rot_prof_buffer() {
     static uint64_t* buf = nullptr;
     if (!getenv("DENSITY_HIP_PROF")) return nullptr;
@@ -1552,6 +1794,11 @@ void rot_prof_report(const char* what, const char* phases, uint64_t* buf, hipStr
         if (FILE* f = fopen(path, "wb")) { fwrite(h, sizeof(uint64_t), kProfWords, f); fclose(f); }
     }
     fprintf(stderr, "[density_hip prof] %s work-group 0, kcycles per wave by phase (%s)\n", what, phases);
+    {
+        const uint64_t* c = h + 128 + 5 * kProfRounds;
+        fprintf(stderr, "[density_hip prof]   events: fast rounds %llu, ordered rounds held %llu / taken back %llu, rounds walked in order %llu, aborts raised %llu\n",
+                (unsigned long long)c[0], (unsigned long long)c[1], (unsigned long long)c[2], (unsigned long long)c[3], (unsigned long long)c[4]);
+    }
     for (int w = 0; w < 16; ++w) {
         uint64_t tot = 0;
         for (int k = 0; k < 8; ++k) tot += h[8 * w + k];

@@ -10,7 +10,8 @@ from density_amd import container, _lib
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 tree_path = _lib.LIB_PATH
 libs = [("tree", tree_path)] + [(n, os.path.join(ROOT, "probes", "variants", f"lib_{n}.so")) for n in sys.argv[2:]]
-n, chunk = 1 << 30, 4 << 20
+n = int(os.environ.get("DENSITY_AB_BYTES", 1 << 30))                       # (DENSITY_AB_BYTES: another size at its automatic chunk, e.g. 10000000)
+chunk = (4 << 20) if n == 1 << 30 else int(_lib.lib().density_hip_auto_chunk_for(0, n))
 x = torch.from_numpy(datagen.rep_text(n)).cuda()
 cap = container.container_bound_slotted("chameleon", n, chunk)
 cont = torch.empty(cap, dtype=torch.uint8, device="cuda"); scratch = torch.empty(cap, dtype=torch.uint8, device="cuda"); back = torch.empty(n, dtype=torch.uint8, device="cuda")
