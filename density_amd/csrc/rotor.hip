@@ -1481,7 +1481,20 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
         // A round that will MARK the zero-entry map (a PLAIN quad whose entry is 0: about four per 4 MiB of text) says so before its exchanges:
         // rounds behind it that only LOOK a slot up in the map (every recurrence of such a quad: one round in 25) then wait for nothing but
         // earlier rounds that have said so — almost never — instead of for every earlier round to finish.
-        const bool marks = zplain != 0;
+        // (round 5) ... unless it is the ZERO quad, whose entry 0 in slot 0 is no candidate (a 0 there IS the zero quad, written or not): the first
+        // zero quad behind anything else that hashed to slot 0 — once per incompressible patch of mixed data — used to announce a mark, and a
+        // marking round waits for every earlier round to be through.  Looked at exactly, in a rare branch (a last-writers pass does mark slot 0:
+        // there the mark says "written").
+        uint64_t zreal = zplain;
+        if (__builtin_expect(zplain != 0, 0) && !seg.lastwriters_only) {
+            zreal = 0;
+#pragma nounroll
+            for (uint32_t j = 0; j < R; ++j) {                                    // (rolled, over select chains, like every rare path of this kernel)
+                const uint32_t it = pick<R>(itemc, j), P = it * kHashMul;
+                zreal |= ballot64(!((hitsc >> j) & 1u) && ((coded_mask >> j) & 1u) && (P >> 16) != 0 && stored_entry(it, P) == 0);
+            }
+        }
+        const bool marks = zreal != 0;
         if (__builtin_expect(marks, 0)) { if (lane == 0) lds_poke(sy + kSyZset + 4u * wave, x + 1u); }
         if (__builtin_expect(mc.copy_mask != 0, 0)) {
             // raw-copy records (codec.rs:89-91) touch no state: their lanes read a harmless conflict-free word instead
@@ -1548,13 +1561,17 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
         // has any first waits until every earlier round has reported (wave w' owns the rounds = w' mod W). ----
         if (__builtin_expect(marks || zany != 0, 0)) {
           if (!marks) {
-            // (round 5) Slot 0 needs no map: its entry 0 IS the zero quad, written or not (chameleon.rs:41,88-100), so a record whose MAP lanes all
-            // name slot 0 — zero pages, the zero quads of low-entropy data — has nothing to ask, whatever it read.  Such records are dropped here
-            // (all-zero input used to take every record of every round through the select chains below); a record with a MAP lane on another
-            // slot stays in and is looked at exactly.
+            // (round 5) Slot 0 needs no map: its entry 0 IS the zero quad, written or not (chameleon.rs:41,88-100) — and the zero quad is the
+            // commonest quad of real data (zero pages, padding).  Its MAP lanes read 0 like a candidate's, so all-zero input took every record
+            // of every round through the select chains below, low-entropy data every other round.  Here, still in the rare branch (rounds
+            // without any 0 read never get here), the candidates are made exact again: a MAP lane that read 0 — its quad is the one an entry of
+            // 0 stands for in its slot, entry -> quad being one-to-one per slot — in a slot other than 0.
             uint32_t real = 0;
-#pragma unroll
-            for (uint32_t j = 0; j < R; ++j) real |= (ballot64(((hit_mask >> j) & 1u) != 0 && (itemc[j] & 0xffffu) != 0) != 0 ? 1u : 0u) << j;
+            for (uint32_t zb = zrec; zb; zb &= zb - 1u) {                         // (rolled, over select chains)
+                const uint32_t j = (uint32_t)__builtin_ctz(zb);
+                const uint32_t h = pick<R>(itemc, j) & 0xffffu;
+                real |= (ballot64(((hit_mask >> j) & 1u) != 0 && h != 0 && pick<R>(ra, j) == entry_to_quad(h, 0)) != 0 ? 1u : 0u) << j;
+            }
             zrec &= real;
             if (zrec == 0) zany = 0;
           }
