@@ -91,5 +91,15 @@ def lib():
     return _lib
 
 
+def use_debug_build():
+    """Profiling / tuning tools only: switch this process to libdensity_hip_debug.so (-DDENSITY_HIP_DEBUG: the one build that reads DENSITY_HIP_PROF,
+    DENSITY_HIP_TUNE, ... from the environment), building it if it is not there.  Call before the first lib()."""
+    global _lib, LIB_PATH
+    from . import build
+    LIB_PATH = build.build(debug=True)
+    _lib = None
+    return lib()
+
+
 def last_error():
     return lib().density_hip_last_error().decode()

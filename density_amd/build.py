@@ -7,6 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdensity_hip.so")
+LIB_DEBUG = os.path.join(HERE, "libdensity_hip_debug.so")      # -DDENSITY_HIP_DEBUG: the only build that reads tuning / diagnostic switches from the environment
 SOURCES = ["api.hip", "api_stream.hip", "api_host.hip", "chameleon.hip", "rotor.hip", "container.hip", "serial_codec.hip", "stream_parse.hip", "exchange_stages.hip", "decode_passes.hip", "placement.hip"]
 HEADERS = ["api_internal.hpp", "common.hpp", "chameleon_dev.hpp", "kernels.hpp", os.path.join("..", "..", "include", "density_hip.h")]
 
@@ -25,18 +26,21 @@ def kernels_id():
     return h.hexdigest()[:12]
 
 
-def needs_build():
-    if not os.path.exists(LIB):
+def needs_build(lib=LIB):
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
 
 
-def build(force=False, verbose=False):
-    if not force and not needs_build():
+def build(force=False, verbose=False, debug=False):
+    """The shipped library; debug=True: libdensity_hip_debug.so, the same sources with -DDENSITY_HIP_DEBUG (profiling / tuning tools load it through
+    density_amd._lib.use_debug_build(); nothing in tests/, bench.py or __graft_entry__ does)."""
+    LIB = LIB_DEBUG if debug else globals()["LIB"]
+    if not force and not needs_build(LIB):
         return LIB
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-value",
-           f'-DDENSITY_HIP_KERNELS_ID="{kernels_id()}"', "-o", LIB] + [os.path.join(CSRC, f) for f in SOURCES]
+           f'-DDENSITY_HIP_KERNELS_ID="{kernels_id()}"'] + (["-DDENSITY_HIP_DEBUG"] if debug else []) + ["-o", LIB] + [os.path.join(CSRC, f) for f in SOURCES]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)
@@ -51,4 +55,4 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    print(build(force=True, verbose=True, debug="--debug" in sys.argv))

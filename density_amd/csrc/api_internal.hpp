@@ -138,11 +138,27 @@ struct Profiler {
 
 // A caller's buffer pinned in place for the duration of a call (hipHostRegister: microseconds on this platform, probes/host_register.hip), so that
 // copies from and to it are asynchronous.  Where pinning fails (memory that is already registered, read-only mappings) the staged paths are taken.
+// What a successful registration is worth: the runtime keeps pins of its own pageable copies in a cache, and a register over a larger extent of a
+// buffer it has such a pin for can "succeed" with the cached pin's pages and no more — the pages behind them stay unmapped and the first access
+// faults the GPU (round 4).  Round 5 looked for a check (probes/host_register_trap.hip, profiles/r05_probe_host_register_trap.txt): for a clean and
+// for a suspect registration alike hipHostGetDevicePointer translates the first and the last byte, hipMemGetAddressRange reports base 0 and the
+// full span, hipPointerGetAttributes the same type and pointers — nothing the API says tells them apart, and the minimal sequence (a pageable copy
+// of part of a buffer, then the register) does not fault by itself.  So the defence stays where round 4 put it: THIS library never lets the runtime
+// pin a caller's memory (copy_host_side_pinned below), and the translation of both ends is checked because it is free.  A caller whose OTHER
+// libraries copy part of a buffer pageably and then hand us the whole of it can still meet the runtime's cache; bounce buffers of our own would
+// close that at the price of a CPU copy of every byte (10 GB/s against the 40-50 the pipelined calls move).
 struct PinnedInPlace {
     void* p = nullptr;
     PinnedInPlace(const void* q, size_t n) {
-        if (q && n && hipHostRegister(const_cast<void*>(q), n, hipHostRegisterDefault) == hipSuccess) p = const_cast<void*>(q);
-        else (void)hipGetLastError();
+        if (!q || !n) return;
+        void* host = const_cast<void*>(q);
+        if (hipHostRegister(host, n, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return; }
+        void *d0 = nullptr, *d1 = nullptr;
+        const bool whole = hipHostGetDevicePointer(&d0, host, 0) == hipSuccess &&
+                           hipHostGetDevicePointer(&d1, static_cast<uint8_t*>(host) + (n - 1), 0) == hipSuccess &&
+                           static_cast<uint8_t*>(d1) - static_cast<uint8_t*>(d0) == (ptrdiff_t)(n - 1);
+        if (whole) p = host;
+        else { (void)hipGetLastError(); (void)hipHostUnregister(host); (void)hipGetLastError(); }
     }
     ~PinnedInPlace() { if (p) (void)hipHostUnregister(p); }
     PinnedInPlace(const PinnedInPlace&) = delete;
@@ -154,11 +170,11 @@ struct PinnedInPlace {
 // (the last eight per queue) beyond the call.  A later hipHostRegister of the same buffer over a LARGER extent is then answered with the cached pin's
 // pages and no more: the pages behind them are not mapped, and the first access faults the GPU (round 4: "memory access fault ... write access to a
 // read-only page" on the last page of an output buffer — a staged decode had brought down a few bytes less into it than the pipelined call that
-// followed registered; DENSITY_HIP_RAW_STAGED=1 brings the old copies back, tools/gpu_host_stream_sequence.py walks the sequence).
+// followed registered; in a DENSITY_HIP_DEBUG build DENSITY_HIP_RAW_STAGED=1 brings the old copies back, tools/gpu_host_stream_sequence.py walks the sequence).
 inline hipError_t copy_host_side_pinned(void* dst, const void* src, size_t n, hipMemcpyKind kind, hipStream_t s) {
     if (n == 0) return hipSuccess;
     const void* host = kind == hipMemcpyHostToDevice ? src : dst;
-    if (n >= (1u << 20) && !getenv("DENSITY_HIP_RAW_STAGED")) {      // (the environment switch: the round-4 fault's reproducer, tools/gpu_host_stream_sequence.py)
+    if (n >= (1u << 20) && !debug_env("DENSITY_HIP_RAW_STAGED")) {      // (the switch — debug builds only — is the round-4 fault's reproducer, tools/gpu_host_stream_sequence.py)
         PinnedInPlace pin(host, n);
         if (pin) {
             const hipError_t e = hipMemcpyAsync(dst, src, n, kind, s), e2 = hipStreamSynchronize(s);

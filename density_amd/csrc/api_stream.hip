@@ -122,7 +122,7 @@ hipError_t seg_encode_passes(const SegEncode& L, const uint8_t* d_in, size_t fir
 }
 
 int run_stream_encode_segmented(DeviceCtx* c, const uint8_t* d_in, size_t n, uint8_t* d_out, hipStream_t s, size_t* size_out) {
-    const bool trace = getenv("DENSITY_HIP_PROF") != nullptr;
+    const bool trace = debug_env("DENSITY_HIP_PROF") != nullptr;
     SegEncode L;
     hipError_t e = L.setup(c, n, s);
     if (e != hipSuccess) { set_error("workspace allocation (segmented stream encode)", e); return DENSITY_HIP_ERR_RUNTIME; }
@@ -252,7 +252,7 @@ int run_stream_decode_segmented(DeviceCtx* c, const uint8_t* d_in, size_t E, uin
     uint8_t *base = D.base, *d_index = D.d_index;
     uint32_t *d_pos32 = D.d_pos32, *d_info = D.d_info, *d_err = D.d_err;
     uint64_t *d_chunk_offset = D.d_chunk_offset, *d_offsets = D.d_offsets, *d_sizes = D.d_sizes, *d_produced = D.d_produced;
-    const bool trace = getenv("DENSITY_HIP_PROF") != nullptr;
+    const bool trace = debug_env("DENSITY_HIP_PROF") != nullptr;
     e = hipMemsetAsync(d_chunk_offset, 0, (max_chunks + 2) * sizeof(uint64_t), s);
     if (e == hipSuccess) e = hipMemsetAsync(d_info, 0, 18 * sizeof(uint32_t), s);
     // Parse.  A pair of incompressible records behind the head means raw copies follow: the parse is final up to that pair, the head walk
@@ -383,7 +383,7 @@ int run_stream_decode(DeviceCtx* c, int algo, const uint8_t* d_in, size_t n, uin
 // ---- host-pointer front ends ----
 // (experiments: the number of slices of the pipelined calls below)
 inline size_t slices_from_env(const char* name, size_t fallback) {
-    const char* v = getenv(name);
+    const char* v = debug_env(name);
     const long k = v ? atol(v) : 0;
     return k >= 3 && k <= (long)kPipeMaxSlices ? (size_t)k : fallback;
 }
@@ -402,7 +402,7 @@ size_t host_stream_encode_pipelined(DeviceCtx* c, const uint8_t* in, size_t n, u
     *handled = false;
     const size_t safe = safe_size(DENSITY_HIP_CHAMELEON, n);
     if (n < kPipeMinStream || n >= (64ull << 30) || (g_variant & (5 | 512)) || g_rotor_unsafe || cap < safe) return 0;
-    const bool trace = getenv("DENSITY_HIP_PROF") != nullptr;
+    const bool trace = debug_env("DENSITY_HIP_PROF") != nullptr;
     const double t0 = trace ? now_ms() : 0;
     PinnedInPlace pin_in(in, n), pin_out(out, safe);
     if (!pin_in || !pin_out) return 0;
@@ -514,8 +514,11 @@ size_t host_stream_encode_pipelined(DeviceCtx* c, const uint8_t* in, size_t n, u
 // so far, and the segments that are now whole are decoded: last writers from empty dictionaries, start images laid over the image carried on from the
 // slice in front, the real pass, and their output on its way down while later slices are still coming up.  Anything but a calm stream that fits — raw
 // copies, a parse that finds no calm head, an error flag — drops the attempt: `handled` stays false and the staged call gives the verdict.
-size_t host_stream_decode_pipelined(DeviceCtx* c, const uint8_t* in, size_t E, uint8_t* out, size_t cap, bool* handled) {
+// `uploaded`: set when the attempt was dropped AFTER the whole stream had gone up — it is in c->stage_in then, and the staged call that follows decodes
+// it from there instead of sending it again (streams that turn out not to be calm late: raw copies in the last slice, an incompressible pair).
+size_t host_stream_decode_pipelined(DeviceCtx* c, const uint8_t* in, size_t E, uint8_t* out, size_t cap, bool* handled, bool* uploaded) {
     *handled = false;
+    *uploaded = false;
     if (E < kPipeMinStream / 2 || E >= (1ull << 32) || (g_variant & (5 | 512)) || g_rotor_unsafe || cap == 0) return 0;
     cap = std::min<size_t>(cap, (E / 136 + 2) * 256);                              // what the stream can decode to: 256 bytes per record of 136 bytes and more
     const size_t bound = cap;
@@ -535,7 +538,7 @@ size_t host_stream_decode_pipelined(DeviceCtx* c, const uint8_t* in, size_t E, u
     e = c->stage_in.ensure(E);
     if (e == hipSuccess) e = c->stage_out.ensure(bound);
     if (e != hipSuccess) { (void)hipGetLastError(); return 0; }
-    const bool trace = getenv("DENSITY_HIP_PROF") != nullptr;
+    const bool trace = debug_env("DENSITY_HIP_PROF") != nullptr;
     const double t0 = trace ? now_ms() : 0;
     uint8_t* d_in = (uint8_t*)c->stage_in.p;
     uint8_t* d_out = (uint8_t*)c->stage_out.p;
@@ -641,7 +644,7 @@ size_t host_stream_decode_pipelined(DeviceCtx* c, const uint8_t* in, size_t E, u
     const hipError_t e1 = hipStreamSynchronize(c->up), e2 = hipStreamSynchronize(s), e2b = hipStreamSynchronize(q), e3 = hipStreamSynchronize(c->down);
     if (e == hipSuccess) e = e1 != hipSuccess ? e1 : e2 != hipSuccess ? e2 : e2b != hipSuccess ? e2b : e3;
     if (e != hipSuccess) { (void)hipGetLastError(); return 0; }                   // (handled stays false: the staged call reports what is wrong)
-    if (give_up) { if (trace) fprintf(stderr, "[density_hip prof]   -> staged path\n"); return 0; }
+    if (give_up) { *uploaded = true; if (trace) fprintf(stderr, "[density_hip prof]   -> staged path (the stream stays where it is: on the device)\n"); return 0; }
     if (trace) fprintf(stderr, "[density_hip prof]   %zu segments of %zu bytes, all down at %.3f ms\n", n_chunks, kCBy, now_ms() - t0);
     *handled = true;
     ++g_stream_stats[2];
@@ -660,16 +663,17 @@ size_t host_stream_codec(int algo, bool encode, const uint8_t* in, size_t n, uin
         const size_t r = host_stream_encode_pipelined(c, in, n, out, cap, &handled);
         if (handled) return r;
     }
+    bool uploaded = false;
     if (!encode && algo == DENSITY_HIP_CHAMELEON) {
         bool handled = false;
-        const size_t r = host_stream_decode_pipelined(c, in, n, out, cap, &handled);
+        const size_t r = host_stream_decode_pipelined(c, in, n, out, cap, &handled, &uploaded);
         if (handled) return r;
     }
     const size_t dev_cap = encode ? safe_size(algo, n) : cap;
     hipError_t e = c->stage_in.ensure(n);
     if (e == hipSuccess) e = c->stage_out.ensure(dev_cap ? dev_cap : 1);
     if (e == hipSuccess) e = c->work.ensure(plan_decode(algo, 1).total + kAlign);
-    if (e == hipSuccess) e = copy_host_side_pinned(c->stage_in.p, in, n, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && !uploaded) e = copy_host_side_pinned(c->stage_in.p, in, n, hipMemcpyHostToDevice, c->stream);
     if (e != hipSuccess) { set_error("staging (H2D)", e); return 0; }
     size_t produced = 0;
     const int rc = encode ? run_stream_encode(c, algo, (const uint8_t*)c->stage_in.p, n, (uint8_t*)c->stage_out.p, dev_cap, (uint8_t*)c->work.p, c->stream, &produced)

@@ -1270,7 +1270,7 @@ namespace {
 // DENSITY_HIP_PROF=1: per-wave cycle accounting of work-group 0, printed to stderr after every pipelined launch (synchronises)
 uint64_t* prof_buffer() {
     static uint64_t* buf = nullptr;
-    if (!getenv("DENSITY_HIP_PROF")) return nullptr;
+    if (!debug_env("DENSITY_HIP_PROF")) return nullptr;
     if (!buf && hipMalloc((void**)&buf, 72 * sizeof(uint64_t)) != hipSuccess) buf = nullptr;
     if (buf) (void)hipMemset(buf, 0, 72 * sizeof(uint64_t));
     return buf;
@@ -1305,7 +1305,7 @@ hipError_t launch_chameleon_encode(const uint8_t* d_in, uint64_t total, uint64_t
         e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytesPipe + 64);
         if (e != hipSuccess) return e;
 #ifdef DENSITY_HIP_DEBUG
-        const uint32_t dbg = getenv("DENSITY_HIP_DBG") ? (uint32_t)atoi(getenv("DENSITY_HIP_DBG")) : 0u;   // stage-idling switches: debug builds only
+        const uint32_t dbg = debug_env("DENSITY_HIP_DBG") ? (uint32_t)atoi(debug_env("DENSITY_HIP_DBG")) : 0u;   // stage-idling switches: debug builds only
 #else
         const uint32_t dbg = 0u;
 #endif
@@ -1334,7 +1334,7 @@ hipError_t launch_chameleon_decode(const uint8_t* d_in, const uint64_t* d_offset
         e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytesDec + 64);
         if (e != hipSuccess) return e;
 #ifdef DENSITY_HIP_DEBUG
-        const uint32_t dbg = getenv("DENSITY_HIP_DBG") ? (uint32_t)atoi(getenv("DENSITY_HIP_DBG")) : 0u;   // stage-idling switches: debug builds only
+        const uint32_t dbg = debug_env("DENSITY_HIP_DBG") ? (uint32_t)atoi(debug_env("DENSITY_HIP_DBG")) : 0u;   // stage-idling switches: debug builds only
 #else
         const uint32_t dbg = 0u;
 #endif

@@ -705,7 +705,7 @@ bool decode_pass_eligible(int algo, const uint8_t* d_out, uint32_t n_chunks, uin
     // Where the passes win: from 64 KiB chunks on (measured, 100 MB of prose, decode ms passes / one wave per stream: 64 KiB 3.2 / 3.6,
     // 128 KiB 3.3 / 4.2, 256 KiB 4.4 / 6.2, 512 KiB 5.2 / 10.5, 1 MiB 9.8 / 20.2); shorter chunks have less to parse than the passes have to
     // set up.  DENSITY_HIP_PASS_MIN (bytes; tuning runs) moves the threshold.
-    static const uint64_t min_chunk = getenv("DENSITY_HIP_PASS_MIN") ? (uint64_t)atoll(getenv("DENSITY_HIP_PASS_MIN")) : 64ull * 1024;
+    static const uint64_t min_chunk = debug_env("DENSITY_HIP_PASS_MIN") ? (uint64_t)atoll(debug_env("DENSITY_HIP_PASS_MIN")) : 64ull * 1024;
     const uint64_t per_chunk = n_chunks == 1 ? out_total : out_stride;
     return per_chunk >= min_chunk && per_chunk >= 65536 && per_chunk < (1ull << 31);
 }
@@ -746,7 +746,8 @@ hipError_t launch_decode_passes(int algo, const uint8_t* d_in, const uint64_t* d
     // the records of calm stretches are found by the window kernels (their tables live where the descriptors and contexts will: nothing else is in use yet)
     const uint64_t slot_bound = out_stride + out_stride / kRecBytes * kSigBytes + kSigBytes;
     const uint32_t wpc = (uint32_t)((slot_bound + kPW - 1) / kPW);
-    const bool windows = !g_serial_parse && out_stride >= (64u << 10) && (uint64_t)wpc * kPE * 4 <= out_stride && (uint64_t)wpc * 8 <= out_stride / 2;
+    // (the window kernels put the chunk on the grid's y axis: at most 65535 chunks — 4 GiB and more in 64 KiB chunks take the one-wave parse)
+    const bool windows = !g_serial_parse && n_chunks <= 65535u && out_stride >= (64u << 10) && (uint64_t)wpc * kPE * 4 <= out_stride && (uint64_t)wpc * 8 <= out_stride / 2;
     if (windows) {
         uint32_t* T = a.desc;
         uint32_t* wbase = reinterpret_cast<uint32_t*>(a.ctx);
@@ -756,6 +757,7 @@ hipError_t launch_decode_passes(int algo, const uint8_t* d_in, const uint64_t* d
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(cheetah_parse, dim3(n_chunks), dim3(64), 0, stream, a, 2u, 0u, 0u, (const uint32_t*)nullptr, (uint8_t*)nullptr, (uint32_t*)nullptr);
         hipLaunchKernelGGL(cheetah_parse_windows, dim3(wpc, n_chunks), dim3(128), 0, stream, a, wpc, T, went);
+        if ((e = hipGetLastError()) != hipSuccess) return e;                      // (the walk below reads what these kernels wrote)
         hipLaunchKernelGGL(cheetah_parse, dim3(n_chunks), dim3(64), table_lds, stream, a, 1u, wpc, table_lds, (const uint32_t*)T, went, wbase);
         hipLaunchKernelGGL(cheetah_parse_emit, dim3(wpc, n_chunks), dim3(64), 0, stream, a, wpc, (const uint8_t*)went, (const uint32_t*)wbase);
     } else {

@@ -465,7 +465,7 @@ bool stage_encode_eligible(int algo, const uint8_t* d_in, uint64_t total, uint64
     // against 13.1 on the one-wave kernel, Lion (seven stages, 48 KiB heads) 29.9 against 20.3; on 100 MB in 96 chunks 0.9 / 3.4 against 11.4 / 24.2.
     // Round 4 (Lion's one-wave encoder takes four blocks per step now): 100 MB in 96 / 191 chunks 2.3 / 2.4 ms in passes against 10.6 / 5.4, in 381 chunks
     // (two rounds of work-groups per stage) 5.7 against 3.0 — Lion's passes up to one work-group per CU.
-    static const uint32_t most_override = getenv("DENSITY_HIP_STAGE_MOST") ? (uint32_t)atoi(getenv("DENSITY_HIP_STAGE_MOST")) : 0u;   // (tuning runs)
+    static const uint32_t most_override = debug_env("DENSITY_HIP_STAGE_MOST") ? (uint32_t)atoi(debug_env("DENSITY_HIP_STAGE_MOST")) : 0u;   // (tuning runs)
     const uint32_t most = most_override ? most_override : algo == DENSITY_HIP_CHEETAH ? 4096u : 256u;
     // (chunk bases must be whole 256-byte blocks; ONE chunk — a reference stream — may have any length: its ragged end is the in-order kernel's)
     return !g_force_lane_codec && !g_force_wave_codec && !g_rotor_unsafe && n_chunks != 0 && n_chunks <= most && (uintptr_t)d_in % 4 == 0 &&

@@ -2,10 +2,22 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/density_hip.h"
 
 namespace density {
+
+// Tuning and diagnostic switches come from the environment only in a DENSITY_HIP_DEBUG build (python -m density_amd.build --debug ->
+// libdensity_hip_debug.so; tools/build_variant.sh): the shipped library has no environment interface.
+inline const char* debug_env(const char* name) {
+#ifdef DENSITY_HIP_DEBUG
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
 
 // ---- chameleon.hip ----
 extern bool g_force_simple;   // density_hip_set_kernel_variant(1)

@@ -1796,7 +1796,7 @@ namespace {
 constexpr size_t kProfWords = 128 + 5 * kProfRounds + 8;
 uint64_t* rot_prof_buffer() {
     static uint64_t* buf = nullptr;
-    if (!getenv("DENSITY_HIP_PROF")) return nullptr;
+    if (!debug_env("DENSITY_HIP_PROF")) return nullptr;
     if (!buf && hipMalloc((void**)&buf, kProfWords * sizeof(uint64_t)) != hipSuccess) buf = nullptr;
     if (buf) { (void)hipDeviceSynchronize(); (void)hipMemset(buf, 0, kProfWords * sizeof(uint64_t)); (void)hipDeviceSynchronize(); }
     return buf;
@@ -1805,7 +1805,7 @@ void rot_prof_report(const char* what, const char* phases, uint64_t* buf, hipStr
     if (!buf) return;
     static uint64_t h[kProfWords];
     if (hipStreamSynchronize(stream) != hipSuccess || hipMemcpy(h, buf, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return;
-    if (const char* dump = getenv("DENSITY_HIP_PROF_DUMP")) {                     // raw buffer, for offline analysis: <prefix>.<encode|decode>.bin
+    if (const char* dump = debug_env("DENSITY_HIP_PROF_DUMP")) {                     // raw buffer, for offline analysis: <prefix>.<encode|decode>.bin
         char path[512];
         snprintf(path, sizeof(path), "%s.%s.bin", dump, what);
         if (FILE* f = fopen(path, "wb")) { fwrite(h, sizeof(uint64_t), kProfWords, f); fclose(f); }
@@ -1870,13 +1870,13 @@ void rot_prof_report(const char* what, const char* phases, uint64_t* buf, hipStr
 // how long the decoder's waiting waves sleep (units of 64 cycles): per hand-off still to come (bits 8..11 of the kernel's flags) and once the token has
 // reached the predecessor (bits 16..19); DENSITY_HIP_NAP="far,near" overrides (tuning runs)
 uint32_t decode_naps(uint32_t round_len) {
-    static const char* env = getenv("DENSITY_HIP_NAP");
+    static const char* env = debug_env("DENSITY_HIP_NAP");
     uint32_t far_ = round_len >= 16 ? 5u : 5u, near_ = round_len >= 16 ? 3u : 3u;
     if (env) { unsigned a = 0, b = 0; if (sscanf(env, "%u,%u", &a, &b) == 2) { far_ = a & 15u; near_ = b & 15u; } }
     return (far_ << 8) | (near_ << 16);
 }
 uint32_t rot_tune() {
-    static const uint32_t t = getenv("DENSITY_HIP_TUNE") ? (uint32_t)atoi(getenv("DENSITY_HIP_TUNE")) : 0u;   // read once: bit 0 = token after answers
+    static const uint32_t t = debug_env("DENSITY_HIP_TUNE") ? (uint32_t)atoi(debug_env("DENSITY_HIP_TUNE")) : 0u;   // read once: bit 0 = token after answers
     return t;
 }
 }  // namespace

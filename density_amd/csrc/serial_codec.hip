@@ -1012,7 +1012,7 @@ __global__ __launch_bounds__(64) void lion_decode_wave(const uint8_t* __restrict
         Guard guard;
         uint64_t ipos = 0, opos = 0;
         bool bad = false, done = false;
-        uint32_t ahead = 0;                                                       // (the register a touch-ahead load lands in)
+        uint32_t ahead = 0;                                                       // (a touch-ahead load's value: never looked at)
         while (elen - ipos >= kMaxRecord && cap - opos >= G::kBlock) {
             if (guard.block_is_copy()) {                                      // codec.rs:89-91
                 if (lane < 16) st32u(dst + opos + 4u * lane, ld32u(src + ipos + 4u * lane));
@@ -1071,11 +1071,14 @@ __global__ __launch_bounds__(64) void lion_decode_wave(const uint8_t* __restrict
             // the items were two dependent misses per record.  Four lanes touch the lines half a KiB on, in the shadow of the table reads below (loads
             // return in order: issued here, not in front of the signature loads).  The touch's register is held — as an operand of the drain of the NEXT
             // step, by which time it has long landed — so that nothing else lives where the load lands.  (The drain: the previous step's table stores are in L2.)
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(ahead) : : "memory");
+            // (Round 5: the touch is a load the COMPILER sees — until now a hand-issued one into a C variable, which nothing kept the register allocator
+            // from copying or re-using between this statement and the next step's wait.  Its only use is the next step's empty statement below, so
+            // the compiler waits for it there, by itself, and nowhere earlier.)
+            asm volatile("s_waitcnt vmcnt(0)" : : "v"(ahead) : "memory");
             {
                 const uint64_t far = ipos + 512u + 128u * (lane & 3u);
                 const uint8_t* pa = src + (far + 4 <= elen ? far : ipos);
-                if (lane < 4) asm volatile("global_load_dword %0, %1, off" : "=v"(ahead) : "v"(pa) : "memory");
+                ahead = lane < 4 ? ld32u(pa) : 0u;
             }
             const Pair e0 = dtouch ? tbl_load_pair(t.dict + h) : Pair{0u, 0u};
             // ---- runs of predicted quads: one dependent read per round; speculation: nobody earlier in this step rewrote that row ----
@@ -1195,7 +1198,7 @@ __global__ __launch_bounds__(64) void lion_decode_wave(const uint8_t* __restrict
             guard = g;
             ipos += len; opos += (uint64_t)nrec * G::kBlock;
         }
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(ahead) : : "memory");              // tbl_drain(), and the last touch-ahead has landed before its register is anyone else's
+        asm volatile("s_waitcnt vmcnt(0)" : : "v"(ahead) : "memory");                // tbl_drain() (the last touch-ahead is consumed here)
         __threadfence();
         if (lane == 0) {                                                      // the rest: scalar code, codec.rs:102-123
             t.last_hash = last_hash;

@@ -6,7 +6,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch, datagen
 import bench
-from density_amd import container
+from density_amd import container, _lib
+if any(k.startswith("DENSITY_HIP_") for k in os.environ): _lib.use_debug_build()   # (switches are read by the debug build only)
 mib = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 kinds = sys.argv[2].split(",") if len(sys.argv) > 2 else ["text", "zeros", "random", "mixed"]
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 5

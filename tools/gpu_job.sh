@@ -1,7 +1,7 @@
 #!/bin/bash
 # The round's ONE GPU job script (rewritten per call; git history keeps the versions): gpurun -- 'bash tools/gpu_job.sh'
-# r5r: exact slot-0 filter in the decoder.s rare branch: whole GPU suite, A/B against round 4's library, data kinds
-T=gpurun_out/r5r; mkdir -p $T; export TMPDIR=/tmp
-timeout 1500 python -m pytest tests -m gpu -x -q > $T/pytest.log 2>&1; echo "pytest rc=$?"; tail -3 $T/pytest.log
-timeout 400 python tools/gpu_variants.py 10 r04 2>&1 | grep -v amdgpu.ids | tee $T/ab_1g.txt
-timeout 600 python tools/gpu_data_kinds.py 2>&1 | grep -v amdgpu.ids | tee $T/kinds.txt
+# r5u: probes/host_register_trap.hip: what tells a registration answered from the runtime's pin cache from a clean one
+T=gpurun_out/r5u; mkdir -p $T; export TMPDIR=/tmp
+cd probes && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o host_register_trap host_register_trap.hip 2>&1 | tail -3; cd ..
+timeout 120 ./probes/host_register_trap 2>&1 | tee $T/trap.txt
+timeout 120 ./probes/host_register_trap touch 2>&1 | tail -3 | tee $T/trap_touch.txt
