@@ -60,6 +60,9 @@ SYMBOLS.update({
     "density_hip_decode_device": (_I, [_VP, _SZ, ctypes.POINTER(Header), _VP, _SZ, _VP, _SZ, _VP, ctypes.POINTER(_SZ)]),
     "density_hip_container_bound_slotted": (_SZ, [_I, _SZ, _SZ]),
     "density_hip_encode_device_slotted": (_I, [_I, _VP, _SZ, _VP, _SZ, _SZ, _VP, _SZ, _VP, ctypes.POINTER(Header)]),
+    "density_hip_container_bound_paged": (_SZ, [_I, _SZ, _SZ]),
+    "density_hip_paged_pages_per_chunk": (_SZ, [_SZ]),
+    "density_hip_encode_device_paged": (_I, [_I, _VP, _SZ, _VP, _SZ, _SZ, _VP, _SZ, _VP, ctypes.POINTER(Header)]),
     "density_hip_pack_device": (_I, [_VP, _SZ, ctypes.POINTER(Header), _VP, _SZ, _VP, _SZ, _VP, ctypes.POINTER(Header)]),
     "density_hip_stream_encode_device": (_I, [_I, _VP, _SZ, _VP, _SZ, _VP, ctypes.POINTER(_SZ)]),
     "density_hip_stream_decode_device": (_I, [_I, _VP, _SZ, _VP, _SZ, _VP, ctypes.POINTER(_SZ)]),

@@ -43,6 +43,8 @@ def parse_header(raw32):
 
 FLAG_BLOCK_INDEX = 1
 FLAG_SLOTTED = 2
+FLAG_PAGED = 4
+PAGE_BYTES = 65536
 
 
 def slot_stride(algo, chunk_size):
@@ -69,6 +71,23 @@ def chunk_payloads(container):
     off = (32 + 4 * h.n_chunks + 15) // 16 * 16
     if h.flags & FLAG_BLOCK_INDEX:
         off = (off + (h.total_len + 255) // 256 + 15) // 16 * 16
+    if h.flags & FLAG_PAGED:
+        # a chunk's stream = the used bytes of its pages, in directory order (include/density_hip.h): what a CPU reader does before it calls the crate
+        ppc = int(_lib.lib().density_hip_paged_pages_per_chunk(h.chunk_size))
+        pages_base = (off + 16 * (ppc + 1) * h.n_chunks + 255) // 256 * 256
+        out = []
+        for i, s in enumerate(sizes):
+            d = off + 16 * (ppc + 1) * i
+            n_pages = int.from_bytes(b[d:d + 4], "little")
+            parts = []
+            for k in range(n_pages):
+                e = d + 16 * (k + 1)
+                page, used = int.from_bytes(b[e:e + 4], "little"), int.from_bytes(b[e + 8:e + 12], "little")
+                parts.append(b[pages_base + page * PAGE_BYTES:pages_base + page * PAGE_BYTES + used])
+            stream = b"".join(parts)
+            assert len(stream) == s, f"chunk {i}: the directory's bytes ({len(stream)}) are not the size table's ({s})"
+            out.append(stream)
+        return h, out
     out = []
     stride = slot_stride(_lib.ALGO_NAMES[h.algo], h.chunk_size) if h.flags & FLAG_SLOTTED else 0
     for i, s in enumerate(sizes):
@@ -103,6 +122,20 @@ def encode_device_slotted(algo, d_in, n, d_out, cap, chunk_size=0, stream=0, wor
     hdr = _lib.Header() if want_header else None
     rc = _lib.lib().density_hip_encode_device_slotted(_lib.ALGO_IDS[algo], d_in, n, d_out, cap, chunk_size, workspace[0], workspace[1], stream,
                                                       ctypes.byref(hdr) if want_header else None)
+    _check(rc, EncodeError)
+    return hdr
+
+
+def container_bound_paged(algo, n, chunk_size=0):
+    return int(_lib.lib().density_hip_container_bound_paged(_lib.ALGO_IDS[algo], n, chunk_size))
+
+
+def encode_device_paged(algo, d_in, n, d_out, cap, chunk_size=0, stream=0, workspace=(0, 0), want_header=True):
+    """As encode_device, but wire-ready WITHOUT a stitch pass: the streams in pages taken from one counter (DENSITY_HIP_FLAG_PAGED; what the paged form
+    is not for comes out slotted: see the header's flags)."""
+    hdr = _lib.Header() if want_header else None
+    rc = _lib.lib().density_hip_encode_device_paged(_lib.ALGO_IDS[algo], d_in, n, d_out, cap, chunk_size, workspace[0], workspace[1], stream,
+                                                    ctypes.byref(hdr) if want_header else None)
     _check(rc, EncodeError)
     return hdr
 

@@ -128,11 +128,24 @@ size_t container_bound_slotted(int algo, size_t n, size_t chunk) {
     return bound;
 }
 
+// a paged container: every chunk as many pages as its worst case needs (they are taken as the streams grow: a container of text ends far below this)
+size_t container_bound_paged(int algo, size_t n, size_t chunk) {
+    if (!paged_eligible(algo, n, chunk)) return container_bound_slotted(algo, n, chunk);
+    const size_t nc = chunk_count(n, chunk);
+    return paged_pages_base(nc, n, chunk) + nc * (size_t)paged_pages_per_chunk(chunk) * kPageBytes;
+}
+
 int check_header(const density_hip_header_t& h, size_t container_size) {
     if (h.magic != DENSITY_HIP_MAGIC || h.version != 1 || !valid_algo(h.algo)) return DENSITY_HIP_ERR_FORMAT;
     if (!valid_chunk(h.chunk_size)) return DENSITY_HIP_ERR_FORMAT;
     if (h.n_chunks != chunk_count(h.total_len, h.chunk_size)) return DENSITY_HIP_ERR_FORMAT;
-    if (h.flags & ~(DENSITY_HIP_FLAG_BLOCK_INDEX | DENSITY_HIP_FLAG_SLOTTED)) return DENSITY_HIP_ERR_FORMAT;
+    if (h.flags & ~(DENSITY_HIP_FLAG_BLOCK_INDEX | DENSITY_HIP_FLAG_SLOTTED | DENSITY_HIP_FLAG_PAGED)) return DENSITY_HIP_ERR_FORMAT;
+    if (h.flags & DENSITY_HIP_FLAG_PAGED) {                                        // pages: Chameleon with its block index, whole pages behind the directory
+        if (h.algo != DENSITY_HIP_CHAMELEON || (h.flags & (DENSITY_HIP_FLAG_BLOCK_INDEX | DENSITY_HIP_FLAG_SLOTTED)) != DENSITY_HIP_FLAG_BLOCK_INDEX) return DENSITY_HIP_ERR_FORMAT;
+        const size_t pb = paged_pages_base(h.n_chunks, h.total_len, h.chunk_size);
+        if (h.container_len > container_size || h.container_len < pb || (h.container_len - pb) % kPageBytes != 0 || h.container_len - pb >= (1ull << 32)) return DENSITY_HIP_ERR_FORMAT;
+        return DENSITY_HIP_OK;
+    }
     if (h.container_len > container_size || h.container_len < payload_base(h.n_chunks, h.total_len, h.flags & DENSITY_HIP_FLAG_BLOCK_INDEX)) return DENSITY_HIP_ERR_FORMAT;
     return DENSITY_HIP_OK;
 }
@@ -140,11 +153,12 @@ int check_header(const density_hip_header_t& h, size_t container_size) {
 // ---- device-side drivers (ctx already acquired; `ws` points at a workspace of sufficient size) ----
 
 int run_encode_container(DeviceCtx* c, int algo, const uint8_t* d_in, size_t n, uint8_t* d_out, size_t cap, size_t chunk,
-                         uint8_t* ws, hipStream_t s, density_hip_header_t* header_out, bool slotted) {
+                         uint8_t* ws, hipStream_t s, density_hip_header_t* header_out, bool slotted, bool paged) {
     const EncodePlan p = plan_encode(algo, n, chunk);
     if (p.n_chunks > 0xffffffffull) { set_error("too many chunks"); return DENSITY_HIP_ERR_ARGUMENT; }
     if (p.n_chunks <= 1) slotted = false;                                              // (one chunk encodes straight into place either way)
-    if (cap < (slotted ? container_bound_slotted(algo, n, chunk) : container_bound(algo, n, chunk))) { set_error("output capacity below density_hip_container_bound()"); return DENSITY_HIP_ERR_CAPACITY; }
+    if (paged && !(paged_eligible(algo, n, chunk) && rotor_encode_eligible(d_in, n, chunk, (uint32_t)p.n_chunks) && !g_rotor_unsafe && !(g_variant & 5))) { paged = false; slotted = p.n_chunks > 1; }   // (what the paged form is not for: the slotted one)
+    if (cap < (paged ? container_bound_paged(algo, n, chunk) : slotted ? container_bound_slotted(algo, n, chunk) : container_bound(algo, n, chunk))) { set_error("output capacity below density_hip_container_bound()"); return DENSITY_HIP_ERR_CAPACITY; }
     uint32_t* d_err = reinterpret_cast<uint32_t*>(ws + p.off_err);
     uint64_t* d_sizes = reinterpret_cast<uint64_t*>(ws + p.off_sizes);
     uint64_t* d_offsets = reinterpret_cast<uint64_t*>(ws + p.off_offsets);
@@ -160,7 +174,21 @@ int run_encode_container(DeviceCtx* c, int algo, const uint8_t* d_in, size_t n, 
     Profiler prof(c, s);
     hipError_t e = hipMemsetAsync(d_err, 0, sizeof(uint32_t), s);
     if (e != hipSuccess) { set_error("hipMemsetAsync", e); return DENSITY_HIP_ERR_RUNTIME; }
-    if (p.n_chunks == 1) {
+    if (paged) {
+        // Paged container (round 5): the wire form WITHOUT a stitch.  The encode kernel places the streams itself, page by page (64 KiB, from one
+        // counter, in the order the chunks ask for them): dense but for the unused tails of the pages, and a chunk's stream is its pages' used bytes
+        // in directory order.  write_buffer.rs:29-31's running total lives in the directory.
+        hdr.flags = DENSITY_HIP_FLAG_BLOCK_INDEX | DENSITY_HIP_FLAG_PAGED;
+        const uint64_t dir_base = paged_dir_base(p.n_chunks, n), pages_base = paged_pages_base(p.n_chunks, n, chunk);
+        const uint32_t ppc = paged_pages_per_chunk(chunk);
+        uint32_t* d_counter = d_err + 4;
+        e = hipMemsetAsync(d_counter, 0, sizeof(uint32_t), s);
+        if (e == hipSuccess) e = launch_rotor_encode_paged(d_in, n, chunk, (uint32_t)p.n_chunks, d_out + pages_base, (uint32_t)std::min<uint64_t>((cap - pages_base) / kPageBytes, 0xffffu),
+                                                         d_counter, reinterpret_cast<uint32_t*>(d_out + dir_base), page_dir_words(ppc), d_sizes, d_index, d_err, s);
+        prof.mark(encode_kernel_name(algo));
+        if (e == hipSuccess) e = launch_layout_encode_paged(d_sizes, (uint32_t)p.n_chunks, hdr, dir_base, dir_base + paged_dir_bytes(p.n_chunks, chunk), pages_base, d_out, cap, d_counter, d_err, s);
+        prof.mark("layout_encode");
+    } else if (p.n_chunks == 1) {
         // single chunk: its stream goes straight to its final place, no stitch pass
         e = codec_encode(algo, d_in, n, chunk, 1, d_out + pbase, 0, d_sizes, d_index, ws + p.off_tables, d_zmap, p.total > p.off_stage ? ws + p.off_stage : nullptr, d_err, s);
         prof.mark(encode_kernel_name(algo));
@@ -361,6 +389,30 @@ int density_hip_encode_device_slotted(int algo, const void* d_input, size_t inpu
     else { hipError_t e = c->work.ensure(need); if (e != hipSuccess) { set_error("workspace allocation", e); return DENSITY_HIP_ERR_RUNTIME; } ws = (uint8_t*)c->work.p; }
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     return run_encode_container(c, algo, (const uint8_t*)d_input, input_size, (uint8_t*)d_output, output_capacity, chunk_size, ws, s, header_out, true);
+}
+
+int density_hip_encode_device_paged(int algo, const void* d_input, size_t input_size, void* d_output, size_t output_capacity,
+                                    size_t chunk_size, void* d_workspace, size_t workspace_size, void* stream,
+                                    density_hip_header_t* header_out) {
+    g_last_error.clear();
+    chunk_size = normalise_chunk(chunk_size, input_size, algo);
+    if (!valid_algo(algo) || !valid_chunk(chunk_size) || (!d_input && input_size) || !d_output) { set_error("bad argument"); return DENSITY_HIP_ERR_ARGUMENT; }
+    DeviceCtx* c = acquire_ctx();
+    if (!c) return DENSITY_HIP_ERR_RUNTIME;
+    std::lock_guard<std::mutex> lk(c->mu);
+    const size_t need = plan_encode(algo, input_size, chunk_size).total;
+    uint8_t* ws = (uint8_t*)d_workspace;
+    if (ws) { if (workspace_size < need) { set_error("workspace too small"); return DENSITY_HIP_ERR_CAPACITY; } }
+    else { hipError_t e = c->work.ensure(need); if (e != hipSuccess) { set_error("workspace allocation", e); return DENSITY_HIP_ERR_RUNTIME; } ws = (uint8_t*)c->work.p; }
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    return run_encode_container(c, algo, (const uint8_t*)d_input, input_size, (uint8_t*)d_output, output_capacity, chunk_size, ws, s, header_out, false, true);
+}
+size_t density_hip_paged_pages_per_chunk(size_t chunk_size) { return valid_chunk(chunk_size) ? paged_pages_per_chunk(chunk_size) : 0; }
+size_t density_hip_container_bound_paged(int algo, size_t input_size, size_t chunk_size) {
+    if (!valid_algo(algo)) return 0;
+    chunk_size = normalise_chunk(chunk_size, input_size, algo);
+    if (!valid_chunk(chunk_size)) return 0;
+    return container_bound_paged(algo, input_size, chunk_size);
 }
 
 size_t density_hip_container_bound_slotted(int algo, size_t input_size, size_t chunk_size) {

@@ -76,6 +76,18 @@ inline size_t index_base(size_t n_chunks) { return align_up(sizeof(density_hip_h
 inline size_t index_bytes(size_t total_len, bool with_index) { return with_index ? (total_len + 255) / 256 : 0; }
 inline size_t payload_base(size_t n_chunks, size_t total_len, bool with_index) { return align_up(index_base(n_chunks) + index_bytes(total_len, with_index), 16); }
 inline bool want_index(int algo) { return algo == DENSITY_HIP_CHAMELEON && !(g_variant & 2); }
+// paged container (DENSITY_HIP_FLAG_PAGED): behind the block index the page directory (per chunk: 16 bytes {n_pages}, then 16 bytes per page), then,
+// on the next page-size boundary of the container, the pages
+inline size_t paged_dir_base(size_t n_chunks, size_t total_len) { return payload_base(n_chunks, total_len, true); }
+inline uint32_t paged_pages_per_chunk(size_t chunk) { return pages_per_chunk(safe_size(DENSITY_HIP_CHAMELEON, chunk)); }
+inline size_t paged_dir_bytes(size_t n_chunks, size_t chunk) { return 4 * (size_t)page_dir_words(paged_pages_per_chunk(chunk)) * n_chunks; }
+inline size_t paged_pages_base(size_t n_chunks, size_t total_len, size_t chunk) { return align_up(paged_dir_base(n_chunks, total_len) + paged_dir_bytes(n_chunks, chunk), kAlign); }
+// what the paged form is for: Chameleon, chunks of 1 MiB and more (a chunk's last page is half empty on average: 3 % of a MiB of text), 32-bit positions
+inline bool paged_eligible(int algo, size_t n, size_t chunk) {
+    const size_t nc = chunk_count(n, chunk);
+    return algo == DENSITY_HIP_CHAMELEON && want_index(algo) && nc > 1 && chunk >= (1u << 20) && (uint64_t)nc * paged_pages_per_chunk(chunk) * kPageBytes < (1ull << 32);
+}
+size_t container_bound_paged(int algo, size_t n, size_t chunk);
 inline size_t slot_stride(int algo, size_t chunk) { return align_up(safe_size(algo, chunk), kAlign); }
 
 struct Buffer {
@@ -224,7 +236,7 @@ int check_header(const density_hip_header_t& h, size_t container_size);
 
 // device-side drivers of the container (api.hip; ctx already acquired; `ws` points at a workspace of sufficient size)
 int run_encode_container(DeviceCtx* c, int algo, const uint8_t* d_in, size_t n, uint8_t* d_out, size_t cap, size_t chunk,
-                         uint8_t* ws, hipStream_t s, density_hip_header_t* header_out, bool slotted = false);
+                         uint8_t* ws, hipStream_t s, density_hip_header_t* header_out, bool slotted = false, bool paged = false);
 int run_decode_container(DeviceCtx* c, const uint8_t* d_in, size_t container_size, const density_hip_header_t& h, uint8_t* d_out,
                          size_t cap, uint8_t* ws, hipStream_t s, size_t* decoded_out, size_t ws_size = 0);
 // ... of one reference stream (api_stream.hip)

@@ -118,6 +118,25 @@ __global__ __launch_bounds__(kScanThreads) void layout_encode_batch_kernel(const
     }
 }
 
+// A PAGED container's front matter: size table, header (its length: the pages the encoder took from the counter), zeroed gaps.  The directory and the
+// pages were written by the encode kernel itself.
+__global__ __launch_bounds__(kScanThreads) void layout_encode_paged_kernel(const uint64_t* __restrict__ sizes, uint32_t n, density_hip_header_t hdr, uint64_t dir_base,
+                                                                           uint64_t dir_end, uint64_t pages_base, uint8_t* __restrict__ container, uint64_t capacity,
+                                                                           const uint32_t* __restrict__ page_counter, uint32_t* __restrict__ err) {
+    uint32_t* table = reinterpret_cast<uint32_t*>(container + kHeaderBytes);
+    for (uint32_t i = threadIdx.x; i < n; i += kScanThreads) table[i] = (uint32_t)sizes[i];
+    if (threadIdx.x == 0) {
+        hdr.container_len = pages_base + (uint64_t)*page_counter * kPageBytes;
+        *reinterpret_cast<density_hip_header_t*>(container) = hdr;
+        if (hdr.container_len > capacity) atomicOr(err, 2u);
+    }
+    const uint64_t table_end = kHeaderBytes + 4ull * n, ibase = (table_end + 15) / 16 * 16;
+    const uint64_t iend = ibase + (hdr.total_len + 255) / 256;
+    if (threadIdx.x < ibase - table_end) container[table_end + threadIdx.x] = 0;
+    if (threadIdx.x >= 32 && threadIdx.x - 32 < dir_base - iend) container[iend + threadIdx.x - 32] = 0;
+    for (uint64_t i = dir_end + threadIdx.x; i < pages_base; i += kScanThreads) container[i] = 0;
+}
+
 __global__ __launch_bounds__(kScanThreads) void layout_decode_kernel(const uint8_t* __restrict__ container, uint64_t container_size,
                                                                      uint32_t n, uint64_t base, uint64_t* __restrict__ sizes,
                                                                      uint64_t* __restrict__ offsets, uint64_t* __restrict__ end_scratch,
@@ -204,6 +223,12 @@ hipError_t launch_layout_encode(const uint64_t* d_sizes, uint32_t n_chunks, dens
     // d_offsets has n_chunks + 1 entries; the extra one is scratch for the end offset
     hipLaunchKernelGGL(layout_encode_kernel, dim3(1), dim3(kScanThreads), 0, stream, d_sizes, n_chunks, hdr, payload_base, d_container, capacity,
                        d_offsets, d_offsets + n_chunks, d_err, slot_stride);
+    return hipGetLastError();
+}
+
+hipError_t launch_layout_encode_paged(const uint64_t* d_sizes, uint32_t n_chunks, density_hip_header_t hdr, uint64_t dir_base, uint64_t dir_end, uint64_t pages_base, uint8_t* d_container,
+                                      uint64_t capacity, const uint32_t* d_page_counter, uint32_t* d_err, hipStream_t stream) {
+    hipLaunchKernelGGL(layout_encode_paged_kernel, dim3(1), dim3(kScanThreads), 0, stream, d_sizes, n_chunks, hdr, dir_base, dir_end, pages_base, d_container, capacity, d_page_counter, d_err);
     return hipGetLastError();
 }
 

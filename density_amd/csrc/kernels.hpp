@@ -37,7 +37,16 @@ hipError_t launch_chameleon_decode(const uint8_t* d_in, const uint64_t* d_offset
 constexpr uint32_t kZmapWordsPerChunk = 2048, kMaxPipelinedChunks = 16384;
 
 // ---- rotor.hip (Chameleon wave-rotation kernels: the default encode / index-fed decode path) ----
+// pages of a paged container: 64 KiB — a round of 16 blocks is at most 4224 bytes, so a page's unused tail is below 7 % and 2 % on average
+constexpr uint32_t kPageShift = 16, kPageBytes = 1u << kPageShift;
+// pages one chunk can need (a page is left when the next round's records do not fit: at most a round's worth unused per page), and the words of
+// its directory
+__host__ __device__ inline uint32_t pages_per_chunk(uint64_t worst_stream_bytes) { return (uint32_t)(worst_stream_bytes / (kPageBytes - 4352u)) + 2u; }
+__host__ __device__ inline uint32_t page_dir_words(uint32_t pages) { return 4u * (pages + 1u); }
 bool rotor_encode_eligible(const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks);
+// the rotation encoder writing a PAGED container's pages (d_pages: page 0) and directory; d_page_counter zeroed by the caller
+hipError_t launch_rotor_encode_paged(const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_pages, uint32_t page_limit,
+                                     uint32_t* d_page_counter, uint32_t* d_dir, uint32_t dir_words, uint64_t* d_sizes, uint8_t* d_index, uint32_t* d_err, hipStream_t stream);
 hipError_t launch_rotor_encode(const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_out, uint64_t out_stride,
                                uint64_t* d_sizes, uint8_t* d_index, uint32_t* d_err, hipStream_t stream);
 // Whole-stream-exact encoding in segments (api.hip::run_stream_encode_segmented): a chunk may start from a given dictionary image
@@ -49,6 +58,11 @@ struct SegArgs {
     uint8_t* final_images = nullptr;        // per chunk: the dictionary image after the chunk
     uint32_t* final_guard = nullptr;        // per chunk: the FSM state after the chunk's last whole block
     uint32_t* raw_blocks = nullptr;         // per chunk: number of raw-copy blocks (pre-zeroed by the caller)
+    // paged container (round 5, include/density_hip.h DENSITY_HIP_FLAG_PAGED): the streams live in pages of kPageBytes taken from one counter
+    uint32_t* page_counter = nullptr;       // encoder: the next free page of the output
+    uint32_t* page_dir = nullptr;           // per chunk page_dir_words words: {n_pages, 0, 0, 0}, then per page {page, first block, bytes used, 0}
+    uint32_t page_dir_words = 0;
+    uint32_t page_limit = 0;                // pages the output has room for (encoder) / the container holds (decoder)
     uint32_t lastwriters_only = 0;          // decoder: a pass that is run for its final dictionary alone — MAP quads are not looked up (their
                                             // slots are mostly empty in a dictionary that starts empty, and every empty read is a zero-entry question)
 };
@@ -133,6 +147,8 @@ hipError_t launch_seg_layout(const uint64_t* d_chunk_offset, uint32_t first, uin
 // slot_stride != 0: a slotted container (DENSITY_HIP_FLAG_SLOTTED): payload i stays in its slot at payload_base + i * slot_stride
 hipError_t launch_layout_encode(const uint64_t* d_sizes, uint32_t n_chunks, density_hip_header_t hdr, uint64_t payload_base, uint8_t* d_container,
                                 uint64_t capacity, uint64_t* d_offsets, uint32_t* d_err, hipStream_t stream, uint64_t slot_stride = 0);
+hipError_t launch_layout_encode_paged(const uint64_t* d_sizes, uint32_t n_chunks, density_hip_header_t hdr, uint64_t dir_base, uint64_t dir_end, uint64_t pages_base, uint8_t* d_container,
+                                      uint64_t capacity, const uint32_t* d_page_counter, uint32_t* d_err, hipStream_t stream);
 // The same for a slice of the chunks (batched encode): offsets continue from *d_carry, which is left at the slice's end.
 hipError_t launch_layout_encode_batch(const uint64_t* d_sizes, uint32_t first, uint32_t count, bool is_first, bool is_last, density_hip_header_t hdr,
                                       uint64_t payload_base, uint8_t* d_container, uint64_t capacity, uint64_t* d_offsets, uint64_t* d_carry, uint32_t* d_err,

@@ -52,6 +52,7 @@ constexpr uint32_t kNone = 0xffffffffu;
 constexpr uint32_t kSyD = 0, kSyO = 16, kSyZ = 32, kSyEnd = 48, kSySink = 64, kSyZdone = 64 + 256, kSyWsum = 64 + 256 + 64, kSyZset = 64 + 256 + 64 + 64, kSyBytes = 64 + 256 + 64 + 64 + 64;
 // (encoder: the words of the decoder's zero-entry chain hold the memo of FSM predictions instead — 8 entries of {state, raw-copy blocks, end state, -})
 constexpr uint32_t kSyMemo = kSyZdone, kMemoEntries = 8;
+constexpr uint32_t kSyPage = kSyZ;                                             // (PAGED encoder: 16 bytes of page state, the commit token's holder's)
 static_assert(kSyMemo + 16u * kMemoEntries <= kSyBytes, "memo inside the sync block");
 // encoder LDS: table | zero-entry map | sync
 constexpr uint32_t kEncZmap = kTableBytes, kEncSync = kTableBytes + kZmapBytes, kEncStage = kEncSync + kSyBytes;
@@ -471,7 +472,7 @@ __device__ __forceinline__ bool poll_word(uint32_t addr, uint32_t want, uint32_t
 // ---------------------------------------------------------------------------------------------------------------
 // encode: Codec::encode / encode_block (codec/codec.rs:34-80), Chameleon::encode_quad (chameleon.rs:88-100)
 // ---------------------------------------------------------------------------------------------------------------
-template <int R, int W, bool kProf, bool KEEP = (W == 8), bool EARLY = false>
+template <int R, int W, bool kProf, bool KEEP = (W == 8), bool EARLY = false, bool PAGED = false>
 __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __restrict__ in, uint64_t total, uint64_t chunk_bytes,
                                                                    uint8_t* __restrict__ out, uint64_t out_stride, uint64_t* __restrict__ sizes,
                                                                    uint8_t* __restrict__ index, uint32_t* __restrict__ err, SegArgs seg,
@@ -486,10 +487,13 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
     PhaseClock<kProf> clk(blockIdx.x == 0 ? prof : nullptr);   // phases: 0 hash, 1 D wait, 2 exchange, 3 signatures, 4 O wait + commit, 5 load wait, 6 emit, 7 in-order rounds
     const uint8_t* src = in + chunk * chunk_bytes;
     const uint64_t len = (total - chunk * chunk_bytes) < chunk_bytes ? (total - chunk * chunk_bytes) : chunk_bytes;
-    uint8_t* dst = out + chunk * out_stride;
+    // PAGED (round 5): no slot per chunk — `out` is page 0 of the container, stream positions are absolute offsets from it, and the stream moves to
+    // a fresh page (one shared counter) whenever a round's records would not fit the rest of its page (below: page_place)
+    uint8_t* dst = PAGED ? out : out + chunk * out_stride;
     uint8_t* idx = index ? index + chunk * (chunk_bytes / kBlock) : nullptr;     // this chunk's slice of the block index
     const uint32_t nfull = (uint32_t)(len / kBlock);                              // whole blocks (the launcher bounds len)
-    const uint32_t nrounds = nfull / R;                                            // whole rounds: these rotate; the rest (< R blocks + a ragged one) is the epilogue
+    const uint32_t nrounds = nfull / R;
+    uint32_t* dir = PAGED ? seg.page_dir + chunk * seg.page_dir_words : nullptr;   // this chunk's page directory                                            // whole rounds: these rotate; the rest (< R blocks + a ragged one) is the epilogue
     // the table sits at LDS address 0 (this kernel has no static LDS): slot addresses need no base
     const uint32_t sy = kEncSync;
     const ZmapLds zmap{kEncZmap};
@@ -503,8 +507,16 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
         for (uint32_t i = threadIdx.x; i < (kTableBytes + kZmapBytes) / 16; i += W * 64) p[i] = image ? image[i] : z;
         if (threadIdx.x == 0) {
             const uint32_t g0 = seg.init_guard ? seg.init_guard[chunk] : pack_guard(Guard{});
+            uint32_t pos0 = 0;
+            if (PAGED) {                                                          // this chunk's first page and its spare: {page base, stream bytes in earlier pages, spare page, pages so far}
+                const uint32_t pg = atomicAdd(seg.page_counter, 2u);
+                if (pg + 2u > seg.page_limit && err) atomicOr(err, 2u);           // (cannot happen: the launcher's bound is every chunk's worst case)
+                pos0 = pg << kPageShift;
+                *reinterpret_cast<uint4*>(smem + kEncSync + kSyPage) = make_uint4(pos0, 0u, pg + 1u, 1u);
+                *reinterpret_cast<uint4*>(dir + 4) = make_uint4(pg, 0u, 0u, 0u);
+            }
             *reinterpret_cast<uint4*>(smem + kEncSync + kSyD) = make_uint4((g0 >> 31) ? 0u : 1u, kNone, 0u, 0u);
-            *reinterpret_cast<uint4*>(smem + kEncSync + kSyO) = make_uint4(0u, kNone, 0u, g0 & 0x7fffffffu);
+            *reinterpret_cast<uint4*>(smem + kEncSync + kSyO) = make_uint4(0u, kNone, pos0, g0 & 0x7fffffffu);
             if (lds_addr(smem) != 0 && err) atomicOr(err, kErrWatchdog);           // (cannot happen: see above)
         }
         if (threadIdx.x < kMemoEntries) *reinterpret_cast<uint4*>(smem + kEncSync + kSyMemo + 16u * threadIdx.x) = make_uint4(kNone, 0u, 0u, 0u);
@@ -668,6 +680,34 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
         wg_barrier();
     };
 
+    // PAGED: where a round of `need` bytes goes whose turn it is at stream position `pos` — there, if it ends INSIDE the page (strictly: a position on
+    // a page boundary is then always a fresh page's start), else at the start of the spare page, which becomes the stream's page (io/write_buffer.rs:
+    // 29-31's running total moves on in the directory instead: bytes used per page).  Called by the holder of the commit token only; `refill`: the
+    // spare was taken, a new one is fetched once the tokens have been passed on.
+    bool refill = false;
+    auto page_place = [&](uint32_t pos, uint32_t need, uint32_t first_block) -> uint32_t {
+        if (__builtin_expect((pos & (kPageBytes - 1u)) + need < kPageBytes, 1)) return pos;
+        const u32x4 st = lds_peek4(sy + kSyPage);
+        const uint32_t base = rfl(st.x), before = rfl(st.y), count = rfl(st.w);
+        uint32_t spare = rfl(st.z);
+        if (spare == kNone) spare = rfl(lane == 0 ? atomicAdd(seg.page_counter, 1u) : 0u);          // (the refill has not come back yet: rare)
+        if (spare >= seg.page_limit) { if (err && lane == 0) atomicOr(err, 2u); spare = seg.page_limit - 1u; }   // (cannot happen, see above; never write past the output)
+        if (lane == 0) {
+            dir[4u * count + 2u] = pos - base;                                    // bytes of stream in the page that is left
+            *reinterpret_cast<uint4*>(dir + 4u * (count + 1u)) = make_uint4(spare, first_block, 0u, 0u);
+            const u32x4 v = {spare << kPageShift, before + (pos - base), kNone, count + 1u};
+            asm volatile("ds_write_b128 %0, %1" ::"v"(sy + kSyPage), "v"(v) : "memory");
+        }
+        refill = true;
+        return spare << kPageShift;
+    };
+    auto page_refill = [&]() {
+        if (lane == 0) { const uint32_t pg = atomicAdd(seg.page_counter, 1u); lds_poke(sy + kSyPage + 8u, pg); }
+        refill = false;
+    };
+    // (the last whole round also keeps room for what follows it on one wave: the blocks of the partial round and the ragged block — so that no page
+    // starts inside the decoder's in-order tail)
+    const uint32_t tail_need = PAGED ? (nfull - nrounds * R + 1u) * (kSig + kBlock) : 0u;
     if (kKeepQuads) {
         // (by hand like every later fetch: a load the compiler can see ahead of the loop would make it wait, at the top of every
         // iteration, until all but a few of the previous round's record stores have been acknowledged)
@@ -863,7 +903,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
                     g.prev = (inc >> (R - 1)) & 1u;
                     g_out = pack_guard(g) | (P1 & 0x03000000u);
                 }
-                opos = P0;
+                opos = PAGED ? page_place(P0, sum + (r + 1u == nrounds ? tail_need : 0u), r * R) : P0;
                 if (lane == 0) {
                     lds_poke2(sy + kSyO + 8, opos + sum, g_out);
                     lds_poke(sy + kSyO, r + 1u);
@@ -871,6 +911,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
                 copy_mask = 0;
                 __builtin_amdgcn_s_setprio(0);
                 fast_commit = true;
+                if (PAGED && refill) page_refill();
                 if (kKeepQuads && !prefetched && r + W < nrounds) prefetch_quads<R, W>(src + (uint64_t)(r + W) * (R * kBlock) + 4u * lane);   // next round's quads: in flight behind the commit, landed by the end of the emit
                 clk.mark(4);
                 clk.count(0, lane);
@@ -1004,7 +1045,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
                     sum += raw ? kBlock : kSig + kBlock - 2u * (uint32_t)__builtin_popcountll(sg);
                 }
             }
-            opos = P0;
+            opos = PAGED ? page_place(P0, sum + (r + 1u == nrounds ? tail_need : 0u), r * R) : P0;
             if (seg.raw_blocks && copy_mask && lane == 0) atomicAdd(seg.raw_blocks + chunk, (uint32_t)__builtin_popcount(copy_mask));
             // back to speculation ACROSS rounds only after quiet_rounds() rounds in a row without an incompressible or raw block (the count rides in
             // bits 21..23 of the commit payload): a mis-speculated fast round costs a work-group barrier and the roll-back of every round that ran
@@ -1018,6 +1059,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
             }
             if (kKeepQuads && !prefetched && r + W < nrounds) prefetch_quads<R, W>(src + (uint64_t)(r + W) * (R * kBlock) + 4u * lane);   // (as behind a fast commit)
             poll_tries = 2;
+            if (PAGED && refill) page_refill();
             clk.mark(7);
             break;
         }
@@ -1085,6 +1127,15 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
         }
         if (seg.final_guard && lane == 0) seg.final_guard[chunk] = pack_guard(g) | (g.penalty == 0 ? 0x80000000u : 0u);   // (a segment that is not the stream's last ends on a whole block; bit 31: the next one may start speculating)
         const uint64_t end = encode_ragged_block(src, len, nfull, dst, opos, g, idx, 0u, zmap, lane);
+        if (PAGED) {                                                              // the stream's length is the bytes used over its pages; the last page's share and the count go into the directory
+            const u32x4 st = lds_peek4(sy + kSyPage);
+            const uint32_t base = rfl(st.x), before = rfl(st.y), count = rfl(st.w);
+            if (lane == 0) {
+                dir[4u * count + 2u] = (uint32_t)end - base;
+                *reinterpret_cast<uint4*>(dir) = make_uint4(count, 0u, 0u, 0u);
+                sizes[chunk] = (uint64_t)before + ((uint32_t)end - base);
+            }
+        } else
         if (lane == 0) sizes[chunk] = end;
     }
     if (seg.final_images) {                                                        // the dictionary as this chunk leaves it
@@ -1903,6 +1954,16 @@ hipError_t launch_rotor_encode(const uint8_t* d_in, uint64_t total, uint64_t chu
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3(n_chunks), dim3(waves * 64), kEncLds, stream, d_in, total, chunk_bytes, d_out, out_stride, d_sizes, d_index, d_err, SegArgs{}, prof);
     rot_prof_report("encode", "hash | D wait | exchange | signatures | O wait+commit | load wait | emit | in-order rounds", prof, stream, waves);
+    return hipGetLastError();
+}
+hipError_t launch_rotor_encode_paged(const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_pages, uint32_t page_limit,
+                                     uint32_t* d_page_counter, uint32_t* d_dir, uint32_t dir_words, uint64_t* d_sizes, uint8_t* d_index, uint32_t* d_err, hipStream_t stream) {
+    auto kernel = chameleon_encode_rot<16, 8, false, true, true, true>;
+    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEncLds);
+    if (e != hipSuccess) return e;
+    SegArgs pg;
+    pg.page_counter = d_page_counter; pg.page_dir = d_dir; pg.page_dir_words = dir_words; pg.page_limit = page_limit;
+    hipLaunchKernelGGL(kernel, dim3(n_chunks), dim3(512), kEncLds, stream, d_in, total, chunk_bytes, d_pages, (uint64_t)0, d_sizes, d_index, d_err, pg, (uint64_t*)nullptr);
     return hipGetLastError();
 }
 bool rotor_decode_eligible(const uint8_t* d_out, uint32_t n_chunks, uint64_t out_stride, uint64_t out_total, const uint8_t* d_index, const uint32_t* d_zmap) {

@@ -105,6 +105,18 @@ enum {
  * equivalent until the sizes exist) is left to the moment the container leaves the device — density_hip_pack_device(), or the
  * host-pointer density_hip_encode(), which always returns the packed form. */
 #define DENSITY_HIP_FLAG_SLOTTED 2u
+/* Paged container (round 5; Chameleon, with the block index): the wire form WITHOUT a stitch pass.  The encoder places the streams itself, in
+ * pages of DENSITY_HIP_PAGE_BYTES taken from one counter as the chunks ask for them: a chunk's stream leaves a page when the records of its next
+ * round of 16 blocks (4 KiB of input, at most 4224 bytes) would not end inside it, so page changes fall on multiples of 16 blocks and a page's
+ * unused tail is at most a round (2 % of a page on text).  Layout behind the block index:
+ *     (16-byte aligned)   page directory, per chunk 16 * (1 + P) bytes, P = density_hip_paged_pages_per_chunk(chunk_size):
+ *                             {u32 n_pages, 0, 0, 0}, then per page of the chunk, in stream order,
+ *                             {u32 page, u32 first input block of the chunk coded there, u32 bytes of stream in the page, 0}
+ *     (256-byte aligned)  page 0, page 1, ...   (container_len = this base + DENSITY_HIP_PAGE_BYTES * pages in use)
+ * Chunk i's reference stream = the first `bytes` of each of its pages, concatenated; the u32 size table holds the sum.  A CPU reader does that and
+ * calls the crate; density_hip_decode_device() reads the pages in place. */
+#define DENSITY_HIP_FLAG_PAGED 4u
+#define DENSITY_HIP_PAGE_BYTES 65536u
 #define DENSITY_HIP_MAGIC 0x31434844u /* "DHC1" */
 #define DENSITY_HIP_DEFAULT_CHUNK (1u << 20)
 
@@ -168,6 +180,14 @@ size_t density_hip_container_bound_slotted(int algo, size_t input_size, size_t c
 int density_hip_encode_device_slotted(int algo, const void* d_input, size_t input_size, void* d_output, size_t output_capacity,
                                       size_t chunk_size, void* d_workspace, size_t workspace_size, void* stream,
                                       density_hip_header_t* header_out);
+/* The same as a PAGED container (DENSITY_HIP_FLAG_PAGED above): wire-ready without a stitch pass.  Chameleon inputs of two and more chunks of 1 MiB and
+ * more and less than about 3 GiB; anything else comes out slotted, as from density_hip_encode_device_slotted() — the header's flags say which.
+ * `output_capacity` must be at least density_hip_container_bound_paged() (the pages every chunk could need; text ends far below it). */
+size_t density_hip_container_bound_paged(int algo, size_t input_size, size_t chunk_size);
+size_t density_hip_paged_pages_per_chunk(size_t chunk_size);
+int density_hip_encode_device_paged(int algo, const void* d_input, size_t input_size, void* d_output, size_t output_capacity,
+                                    size_t chunk_size, void* d_workspace, size_t workspace_size, void* stream,
+                                    density_hip_header_t* header_out);
 /* Slotted (or packed) container -> packed container: byte for byte what density_hip_encode_device() writes for the same input.  Workspace as for
  * decode.  With header_out == NULL the call is asynchronous and reports nothing about the container it was given (a size table that does not
  * fit its slots or the container leaves the output unwritten): pass header_out to have it validated. */

@@ -88,7 +88,7 @@ def main():
     total = bad = 0
     for name, body in funcs.items():
         # every encoder instance with kept quads (last template argument): 8 waves stage in v(256-R)..v255, 12 waves in v(168-R)..v167
-        m = re.match(r"^_ZN7density20chameleon_encode_rotILi(\d+)ELi(\d+)ELb[01]ELb1ELb[01]EE", name)
+        m = re.match(r"^_ZN7density20chameleon_encode_rotILi(\d+)ELi(\d+)ELb[01]ELb1ELb[01]ELb[01]EE", name)   # (<R, W, kProf, KEEP, EARLY, PAGED>)
         if not m:
             continue
         g, b = check_function(name, int(m.group(1)), body, 256 if int(m.group(2)) == 8 else 168)
