@@ -269,11 +269,26 @@ int run_decode_container(DeviceCtx* c, const uint8_t* d_in, size_t container_siz
     hipError_t e = hipMemsetAsync(d_err, 0, sizeof(uint32_t), s);
     const bool with_index = h.flags & DENSITY_HIP_FLAG_BLOCK_INDEX;
     const uint8_t* d_index = with_index ? d_in + index_base(h.n_chunks) : nullptr;
+    if (h.flags & DENSITY_HIP_FLAG_PAGED) {
+        // the pages are read where they lie: the rotation decoder turns stream positions into page offsets through the chunk's directory
+        uint32_t* d_zmap = zmap_bytes(h.algo, h.n_chunks) ? reinterpret_cast<uint32_t*>(ws + p.off_zmap) : nullptr;
+        const size_t dir_base = paged_dir_base(h.n_chunks, h.total_len), pages_base = paged_pages_base(h.n_chunks, h.total_len, h.chunk_size);
+        if (g_rotor_unsafe || !rotor_decode_eligible(d_out, h.n_chunks, h.chunk_size, h.total_len, d_index, d_zmap) || (uintptr_t)(d_in + pages_base) % 4 != 0) {
+            set_error("a paged container needs the rotation decoder (chunks of at most 4 MiB, 4-byte aligned buffers)"); return DENSITY_HIP_ERR_UNSUPPORTED;
+        }
+        if (e == hipSuccess) e = launch_layout_decode_paged(d_in, h.n_chunks, d_sizes, d_offsets, s);
+        prof.mark("layout_decode");
+        if (e == hipSuccess) e = launch_rotor_decode_paged(d_in + pages_base, d_offsets, d_sizes, h.n_chunks, d_out, h.chunk_size, h.total_len, d_index,
+                                                         reinterpret_cast<const uint32_t*>(d_in + dir_base), page_dir_words(paged_pages_per_chunk(h.chunk_size)),
+                                                         (uint32_t)((h.container_len - pages_base) / kPageBytes), d_zmap, d_produced, d_err, s);
+        prof.mark(decode_kernel_name(h.algo));
+    } else {
     if (e == hipSuccess) e = launch_layout_decode(d_in, container_size, h.n_chunks, payload_base(h.n_chunks, h.total_len, with_index), d_sizes, d_offsets, d_err, s,
                                                   (h.flags & DENSITY_HIP_FLAG_SLOTTED) ? slot_stride(h.algo, h.chunk_size) : 0);
     prof.mark("layout_decode");
     if (e == hipSuccess) e = codec_decode(h.algo, d_in, d_offsets, d_sizes, h.n_chunks, d_out, h.chunk_size, h.total_len, true, d_index, d_produced, d_err, ws + p.off_tables, zmap_bytes(h.algo, h.n_chunks) ? reinterpret_cast<uint32_t*>(ws + p.off_zmap) : nullptr, s, d_pass);
     prof.mark(decode_kernel_name(h.algo));
+    }
     if (e != hipSuccess) { set_error("kernel launch (decode)", e); return DENSITY_HIP_ERR_RUNTIME; }
     if (decoded_out) {
         uint32_t h_err = 0;

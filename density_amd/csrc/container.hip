@@ -232,6 +232,16 @@ hipError_t launch_layout_encode_paged(const uint64_t* d_sizes, uint32_t n_chunks
     return hipGetLastError();
 }
 
+// PAGED container, decode side: the streams' lengths from the u32 table; every chunk reads from page 0 on (the kernel follows the directory)
+__global__ __launch_bounds__(kScanThreads) void layout_decode_paged_kernel(const uint8_t* __restrict__ container, uint32_t n, uint64_t* __restrict__ sizes, uint64_t* __restrict__ offsets) {
+    const uint32_t* table = reinterpret_cast<const uint32_t*>(container + kHeaderBytes);
+    for (uint32_t i = threadIdx.x; i < n; i += kScanThreads) { sizes[i] = table[i]; offsets[i] = 0; }
+}
+hipError_t launch_layout_decode_paged(const uint8_t* d_container, uint32_t n_chunks, uint64_t* d_sizes, uint64_t* d_offsets, hipStream_t stream) {
+    hipLaunchKernelGGL(layout_decode_paged_kernel, dim3(1), dim3(kScanThreads), 0, stream, d_container, n_chunks, d_sizes, d_offsets);
+    return hipGetLastError();
+}
+
 hipError_t launch_layout_encode_batch(const uint64_t* d_sizes, uint32_t first, uint32_t count, bool is_first, bool is_last, density_hip_header_t hdr,
                                       uint64_t payload_base, uint8_t* d_container, uint64_t capacity, uint64_t* d_offsets, uint64_t* d_carry, uint32_t* d_err,
                                       hipStream_t stream) {

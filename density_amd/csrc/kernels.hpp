@@ -147,8 +147,13 @@ hipError_t launch_seg_layout(const uint64_t* d_chunk_offset, uint32_t first, uin
 // slot_stride != 0: a slotted container (DENSITY_HIP_FLAG_SLOTTED): payload i stays in its slot at payload_base + i * slot_stride
 hipError_t launch_layout_encode(const uint64_t* d_sizes, uint32_t n_chunks, density_hip_header_t hdr, uint64_t payload_base, uint8_t* d_container,
                                 uint64_t capacity, uint64_t* d_offsets, uint32_t* d_err, hipStream_t stream, uint64_t slot_stride = 0);
+// the rotation decoder on a PAGED container: d_pages = page 0 (d_offsets: all zero), d_sizes the streams' lengths, the directory beside them
+hipError_t launch_rotor_decode_paged(const uint8_t* d_pages, const uint64_t* d_offsets, const uint64_t* d_sizes, uint32_t n_chunks, uint8_t* d_out, uint64_t out_stride,
+                                     uint64_t out_total, const uint8_t* d_index, const uint32_t* d_dir, uint32_t dir_words, uint32_t n_pages, uint32_t* d_zmap,
+                                     uint64_t* d_produced, uint32_t* d_err, hipStream_t stream);
 hipError_t launch_layout_encode_paged(const uint64_t* d_sizes, uint32_t n_chunks, density_hip_header_t hdr, uint64_t dir_base, uint64_t dir_end, uint64_t pages_base, uint8_t* d_container,
                                       uint64_t capacity, const uint32_t* d_page_counter, uint32_t* d_err, hipStream_t stream);
+hipError_t launch_layout_decode_paged(const uint8_t* d_container, uint32_t n_chunks, uint64_t* d_sizes, uint64_t* d_offsets, hipStream_t stream);
 // The same for a slice of the chunks (batched encode): offsets continue from *d_carry, which is left at the slice's end.
 hipError_t launch_layout_encode_batch(const uint64_t* d_sizes, uint32_t first, uint32_t count, bool is_first, bool is_last, density_hip_header_t hdr,
                                       uint64_t payload_base, uint8_t* d_container, uint64_t capacity, uint64_t* d_offsets, uint64_t* d_carry, uint32_t* d_err,

@@ -69,6 +69,11 @@ constexpr bool dec_zmap_in_lds(uint32_t R) { return kDecPos + dec_pos_bytes(R) +
 constexpr uint32_t dec_zmap_at(uint32_t R) { return kDecPos + dec_pos_bytes(R); }
 constexpr uint32_t dec_sync_at(uint32_t R) { return dec_zmap_at(R) + (dec_zmap_in_lds(R) ? kZmapBytes : 0u); }
 constexpr uint32_t dec_lds_bytes(uint32_t R) { return dec_sync_at(R) + kSyBytes; }
+// PAGED decoder: behind the sync block, per page of the chunk its first block and what turns a stream position into an offset from page 0
+constexpr uint32_t kDecMaxPages = 96;
+constexpr uint32_t dec_pages_at(uint32_t R) { return dec_lds_bytes(R); }
+constexpr uint32_t dec_lds_bytes_paged(uint32_t R) { return dec_lds_bytes(R) + 8u * kDecMaxPages; }
+static_assert(dec_lds_bytes_paged(12) <= 160u * 1024u, "LDS budget of the paged decoder");
 static_assert(kEncLds <= 160u * 1024u && dec_lds_bytes(8) <= 160u * 1024u && dec_lds_bytes(12) <= 160u * 1024u && dec_lds_bytes(16) <= 160u * 1024u, "LDS budget");
 static_assert(dec_zmap_in_lds(12) && !dec_zmap_in_lds(8), "where the decoder's zero-entry map lives");
 
@@ -1315,7 +1320,7 @@ __device__ __forceinline__ bool index_fsm_consistent(const uint8_t* ix, uint32_t
     return L == s || (L < s && i + L == nblk);
 }
 
-template <int R, int W, bool kProf>
+template <int R, int W, bool kProf, bool PAGED = false>
 __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __restrict__ in, const uint64_t* __restrict__ offsets,
                                                               const uint64_t* __restrict__ sizes, uint8_t* __restrict__ out,
                                                               uint64_t out_stride, uint64_t out_total, uint32_t flags,
@@ -1417,6 +1422,52 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
         }
     }
     __syncthreads();
+    // ---- PAGED (round 5): the stream lives in pages (include/density_hip.h); positions so far are positions in the STREAM.  The chunk's directory is
+    // checked against them — a page starts at a multiple of 16 blocks, pages follow one another in block order, the stream position of a page's first
+    // block is the bytes of the pages before it, no page holds more than a page, every page lies inside the container — and then every round's
+    // position is turned into an offset from page 0; bit 0 (record positions are even) marks the rounds a page change falls into. ----
+    uint32_t* pg_first = reinterpret_cast<uint32_t*>(smem + dec_pages_at(R));
+    uint32_t* pg_delta = pg_first + kDecMaxPages;
+    uint32_t n_pages = 0;
+    if constexpr (PAGED) {
+        const uint32_t* dirp = seg.page_dir + chunk * seg.page_dir_words;
+        n_pages = rfl(dirp[0]);
+        const bool dir_ok = n_pages >= 1 && n_pages <= kDecMaxPages && 4u * (n_pages + 1u) <= seg.page_dir_words;
+        if (!dir_ok) n_pages = 0;
+        uint32_t used = 0, page = 0, first = 0;
+        if (threadIdx.x < n_pages) { const uint4 e = *reinterpret_cast<const uint4*>(dirp + 4u * (threadIdx.x + 1u)); page = e.x; first = e.y; used = e.z; pg_first[threadIdx.x] = first; pg_delta[threadIdx.x] = used; }
+        if (threadIdx.x == 0) *reinterpret_cast<uint32_t*>(smem + dSync + kSyEnd + 8) = 0u;   // (the verdict word)
+        __syncthreads();
+        uint32_t before = 0;
+        if (threadIdx.x < n_pages) {
+            const uint32_t k = threadIdx.x;
+            for (uint32_t m = 0; m < k; ++m) before += pg_delta[m];               // bytes of stream in the pages before this one
+            bool ok = page < seg.page_limit && used <= kPageBytes && first % 16u == 0 && first < nblk && (k == 0 ? first == 0 : first > pg_first[k - 1]);
+            if (ok) {
+                // the stream position of block `first`: the position of its round and the index entries in front of it inside the round
+                uint32_t at = *reinterpret_cast<const uint32_t*>(smem + kDecPos + (first / R) * 4u);
+                for (uint32_t b = first / R * R; b < first; ++b) { const uint32_t ent = smem[kDecIdx + b]; at += (ent & kIdxCopy) ? kBlock : kSig + kBlock - 2u * (ent & 0x7fu); }
+                ok = at == before;
+            }
+            if (!ok) bad_index = 1;
+        }
+        if (!dir_ok) bad_index = 1;
+        if (bad_index) atomicOr(reinterpret_cast<uint32_t*>(smem + dSync + kSyEnd + 8), 1u);
+        __syncthreads();
+        if (threadIdx.x < n_pages) pg_delta[threadIdx.x] = (page << kPageShift) - before;
+        const bool dead = *reinterpret_cast<const uint32_t*>(smem + dSync + kSyEnd + 8) != 0;   // a directory (or index) that lies: nothing is read through it
+        __syncthreads();
+        for (uint32_t x = threadIdx.x; x <= kRotMaxBlocks / R; x += kThreads) {
+            const uint32_t b = x * R;
+            uint32_t lo = 0, hi = n_pages ? n_pages - 1u : 0u;                     // the last page whose first block is <= b
+            while (lo < hi) { const uint32_t mid = (lo + hi + 1u) >> 1; if (pg_first[mid] <= b) lo = mid; else hi = mid - 1u; }
+            uint32_t* slot = reinterpret_cast<uint32_t*>(smem + kDecPos + x * 4u);
+            const bool change = lo + 1u < n_pages && pg_first[lo + 1u] < b + R;
+            *slot = dead ? 0u : (*slot + pg_delta[lo]) | (change ? 1u : 0u);
+        }
+        if (dead) { if (threadIdx.x == 0) { atomicOr(err, 8u); *reinterpret_cast<uint64_t*>(smem + dSync + kSyEnd) = 0; } }   // no record is followed: the in-order tail reports the rest
+        __syncthreads();
+    }
     const uint64_t end_key = *reinterpret_cast<const uint64_t*>(smem + dSync + kSyEnd);
     const uint32_t nvalid = rfl((uint32_t)(end_key >> 33));                      // records [0, nvalid) are complete and followed by more data
     const uint32_t npr = nvalid / R;                                              // whole rounds: these rotate; the rest (< R records + the ragged end) is the epilogue
@@ -1431,14 +1482,24 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
     auto stage_a = [&](uint32_t xr, Meta& m) {                                   // positions of round x; signatures requested
         const uint32_t x = xr < npr ? xr : npr - 1u;
         const uint32_t e = smem[kDecIdx + x * R + (lane < R ? lane : 0u)];        // lane j < R: entry of record j
-        const uint32_t base = rfl(lds_peek1(kDecPos + x * 4u));
+        uint32_t base = rfl(lds_peek1(kDecPos + x * 4u));
         const uint32_t mylen = (e & kIdxCopy) ? kBlock : kSig + kBlock - 2u * (e & 0x7fu);
+        uint32_t hop = 0;                                                         // PAGED: what the records behind a page change inside this round are further on
+        if constexpr (PAGED) {
+            if (__builtin_expect(base & 1u, 0)) {                                 // (a page change falls into this round: some forty times per 4 MiB chunk)
+                uint32_t k = 0;
+                while (k + 1u < n_pages && pg_first[k + 1u] <= x * R) ++k;        // the page of the round's first record; the next one starts inside the round
+                const uint32_t j0 = pg_first[k + 1u] - x * R;
+                hop = lane >= j0 ? pg_delta[k + 1u] - pg_delta[k] : 0u;
+                base &= ~1u;
+            }
+        }
         uint32_t incl = mylen;                                                    // prefix within rows of 16 lanes
         incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xf, 0xf, true);   // row_shr:1
         incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xf, 0xf, true);   // row_shr:2
         incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xf, 0xf, true);   // row_shr:4
         if (R > 8) incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xf, 0xf, true);   // row_shr:8
-        m.posv = base + incl - mylen;
+        m.posv = base + incl - mylen + hop;
         m.copy_mask = (uint32_t)ballot64((e & kIdxCopy) != 0 && lane < R);
         m.sgv = *reinterpret_cast<const u32x2_u*>(src + ((lane < R && !(e & kIdxCopy)) ? m.posv : base));   // codec.rs:28-31 (idle lanes: any valid address)
         m.cnt = e & 0x7fu;                                                        // the entry's MAP count: checked against the signature in stage B
@@ -1733,8 +1794,17 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
     // from the index standing in for the FSM — then the ragged end of the stream (codec.rs:102-123) ----
     if (wave == 0) {
         Guard g;
-        uint64_t ip = npr * R < nvalid ? rfl(lds_peek1(kDecPos + npr * 4u)) : (uint32_t)end_key, op = (uint64_t)npr * R * kBlock;
+        // (PAGED: no page starts inside this tail — the encoder keeps room for it in the last round's page —, so one offset turns its stream positions
+        // into offsets from page 0; a directory that says otherwise is malformed)
+        uint32_t tail_delta = 0;
         bool bad = false;
+        if constexpr (PAGED) {
+            if (n_pages == 0 || *reinterpret_cast<const uint32_t*>(smem + dSync + kSyEnd + 8) != 0 || pg_first[n_pages - 1u] > npr * R) bad = true;
+            else tail_delta = pg_delta[n_pages - 1u];
+        }
+        const uint32_t end_at = (uint32_t)end_key + tail_delta;
+        const uint64_t elen_at = elen64 + tail_delta;
+        uint64_t ip = npr * R < nvalid ? (rfl(lds_peek1(kDecPos + npr * 4u)) & (PAGED ? ~1u : ~0u)) : end_at, op = (uint64_t)npr * R * kBlock;
         for (uint32_t i = npr * R; i < nvalid && !bad; ++i) {
             const uint32_t ent = smem[kDecIdx + i];
             const uint64_t rec_end = ip + ((ent & kIdxCopy) ? kBlock : kSig + kBlock - 2u * (ent & 0x7fu));
@@ -1742,8 +1812,8 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
             bad = !decode_in_order(src, rec_end, dst, cap, g, ip, op, 0u, zmap, lane, seg.lastwriters_only != 0) || ip != rec_end;
         }
         g.penalty = (uint32_t)(end_key >> 32) & 1u; g.start = 1; g.prev = 0; g.counter = 1;    // the stopping block's raw-copy flag is all that is left of the FSM
-        if (!bad && (ip != (uint32_t)end_key || op != (uint64_t)nvalid * kBlock)) bad = true;
-        if (!bad) bad = !decode_in_order(src, elen64, dst, cap, g, ip, op, 0u, zmap, lane, seg.lastwriters_only != 0);
+        if (!bad && (ip != end_at || op != (uint64_t)nvalid * kBlock)) bad = true;
+        if (!bad) bad = !decode_in_order(src, elen_at, dst, cap, g, ip, op, 0u, zmap, lane, seg.lastwriters_only != 0);
         if (exact && !bad && op != cap) bad = true;
         if (lane == 0) {
             produced[chunk] = op;
@@ -2000,6 +2070,19 @@ hipError_t launch_rotor_decode(const uint8_t* d_in, const uint64_t* d_offsets, c
     hipLaunchKernelGGL(kernel, dim3(n_chunks), dim3(waves * 64), lds, stream, d_in, d_offsets, d_sizes, d_out, out_stride, out_total,
                        (exact ? 1u : 0u) | naps, d_index, d_zmap, d_produced, d_err, SegArgs{}, prof);
     rot_prof_report("decode", "stage A | stage B | operands | D wait | exchange | quads | Z chain | stores", prof, stream, waves);
+    return hipGetLastError();
+}
+hipError_t launch_rotor_decode_paged(const uint8_t* d_pages, const uint64_t* d_offsets, const uint64_t* d_sizes, uint32_t n_chunks, uint8_t* d_out, uint64_t out_stride,
+                                     uint64_t out_total, const uint8_t* d_index, const uint32_t* d_dir, uint32_t dir_words, uint32_t n_pages, uint32_t* d_zmap,
+                                     uint64_t* d_produced, uint32_t* d_err, hipStream_t stream) {
+    auto kernel = chameleon_decode_rot<12, 12, false, true>;
+    const uint32_t lds = dec_lds_bytes_paged(12);
+    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    SegArgs pg;
+    pg.page_dir = const_cast<uint32_t*>(d_dir); pg.page_dir_words = dir_words; pg.page_limit = n_pages;
+    hipLaunchKernelGGL(kernel, dim3(n_chunks), dim3(768), lds, stream, d_pages, d_offsets, d_sizes, d_out, out_stride, out_total, 1u | decode_naps(12), d_index, d_zmap,
+                       d_produced, d_err, pg, (uint64_t*)nullptr);
     return hipGetLastError();
 }
 hipError_t launch_rotor_selftest(uint32_t* d_fail, hipStream_t stream) {

@@ -49,3 +49,44 @@ def test_paged_streams_are_the_oracles(kind, n, chunk):
             page, first = int.from_bytes(b[e:e + 4], "little"), int.from_bytes(b[e + 4:e + 8], "little")
             assert first % 16 == 0 and page not in seen
             seen.add(page)
+
+
+@pytest.mark.parametrize("kind,n,chunk", [("rep-text", 64 << 20, 4 << 20), ("mixed", 24 << 20, 1 << 20), ("random", 16 << 20, 2 << 20),
+                                           ("zeros", 16 << 20, 1 << 20), ("rep-text", (32 << 20) + 12345, 4 << 20), ("prose", 40 << 20, 3 << 20)])
+def test_paged_container_decodes_in_place(kind, n, chunk):
+    import torch
+    from density_amd import container
+    host = datagen.rep_text(n) if kind == "rep-text" else datagen.by_kind(kind, n, seed=12)
+    x, cont, hdr = _encode_paged(host, chunk)
+    assert hdr.flags & container.FLAG_PAGED
+    back = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    assert container.decode_device(cont.data_ptr(), hdr.container_len, back.data_ptr(), n, header=hdr) == n
+    assert torch.equal(back, x)
+    # ... and from a copy at another address, with the header read from the blob (what arrives over a wire)
+    blob = cont[:hdr.container_len].clone()
+    back.zero_()
+    assert container.decode_device(blob.data_ptr(), hdr.container_len, back.data_ptr(), n) == n
+    assert torch.equal(back, x)
+
+
+def test_a_lying_page_directory_is_a_format_error():
+    import torch
+    from density_amd import container, _lib
+    from density_amd.codec import DecodeError
+    n, chunk = 16 << 20, 2 << 20
+    host = datagen.rep_text(n)
+    x, cont, hdr = _encode_paged(host, chunk)
+    blob = cont[:hdr.container_len].cpu().numpy().copy()
+    off = (32 + 4 * hdr.n_chunks + 15) // 16 * 16
+    off = (off + (n + 255) // 256 + 15) // 16 * 16
+    ppc = int(_lib.lib().density_hip_paged_pages_per_chunk(chunk))
+    back = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    def entry(c, k): return off + 16 * (ppc + 1) * c + 16 * (k + 1)
+    for what, at, value in [("page beyond the container", entry(1, 1), 0x7fff), ("first block off the grid", entry(2, 1) + 4, 24), ("bytes used too many", entry(3, 0) + 8, 65536 + 2),
+                            ("bytes used shifted", entry(0, 0) + 8, None), ("no pages", off + 16 * (ppc + 1) * 4, 0), ("too many pages", off + 16 * (ppc + 1) * 5, 200)]:
+        bad = blob.copy()
+        v = int.from_bytes(bad[at:at + 4].tobytes(), "little") - 2 if value is None else value
+        bad[at:at + 4] = np.frombuffer(int(v).to_bytes(4, "little"), dtype=np.uint8)
+        d = torch.from_numpy(bad).cuda()
+        with pytest.raises(DecodeError):
+            container.decode_device(d.data_ptr(), bad.size, back.data_ptr(), n)

@@ -1,5 +1,5 @@
 #!/bin/bash
 # The round's ONE GPU job script (rewritten per call; git history keeps the versions): gpurun -- 'bash tools/gpu_job.sh'
-# r5v: paged container, encoder side: streams == oracle after CPU reassembly
-T=gpurun_out/r5v; mkdir -p $T; export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_gpu_paged.py -m gpu -x -q > $T/pytest.log 2>&1; echo "pytest rc=$?"; tail -15 $T/pytest.log
+# r5w: the three container forms side by side on the headline workload
+T=gpurun_out/r5w; mkdir -p $T; export TMPDIR=/tmp
+timeout 600 python tools/gpu_forms.py 10 2>&1 | grep -v amdgpu.ids | tee $T/forms.txt
