@@ -31,6 +31,47 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s meas
 METRIC = "MB/s encode+decode (round-trip) per GPU + compression ratio, dickens/enwik8"
 
 
+def cpu_all_cores(src, chunk, algo, gpu_payloads=None):
+    """All host cores, one chunk per task (ctypes releases the GIL): what a chunked CPU build of the same container does (SURVEY.md 8d "N-thread run over
+    the same chunks").  Every chunk it encodes is compared with the GPU's stream of that chunk when `gpu_payloads` is given."""
+    from oracle import pyoracle
+    try:
+        from concurrent.futures import ThreadPoolExecutor
+        n = src.size
+        dec = np.empty(n, dtype=np.uint8)
+        ncpu = os.cpu_count() or 1
+        nchunks = (n + chunk - 1) // chunk
+        ccap = pyoracle.safe_encode_buffer_size(algo, chunk)
+        encs = np.empty((nchunks, ccap), dtype=np.uint8)
+        sizes = [0] * nchunks
+
+        def enc_task(i):
+            ln = min(chunk, n - i * chunk)
+            sizes[i] = pyoracle.encode_into(algo, src.ctypes.data + i * chunk, ln, encs[i].ctypes.data, ccap)
+
+        def dec_task(i):
+            ln = min(chunk, n - i * chunk)
+            pyoracle.decode_into(algo, encs[i].ctypes.data, sizes[i], dec.ctypes.data + i * chunk, ln)
+
+        with ThreadPoolExecutor(ncpu) as ex:
+            list(ex.map(enc_task, range(nchunks))); list(ex.map(dec_task, range(nchunks)))     # warm (pages of the buffers, the pool's threads)
+            t0 = time.perf_counter(); list(ex.map(enc_task, range(nchunks))); t1 = time.perf_counter()
+            list(ex.map(dec_task, range(nchunks))); t2 = time.perf_counter()
+        assert np.array_equal(dec, src)
+        out = {"value": round(n / (t2 - t0) / 1e6, 1), "unit": "MB/s", "cores": ncpu, "encode_MBps": round(n / (t1 - t0) / 1e6, 1), "decode_MBps": round(n / (t2 - t1) / 1e6, 1),
+               "ratio_chunked": round(n / sum(sizes), 4), "chunk": chunk, "n_chunks": nchunks,
+               "sample": f"{n} B in {nchunks} chunks of {chunk} B, one chunk per task on a pool of {ncpu} threads, C restatement (oracle/density_oracle.c)"}
+        if gpu_payloads is not None:
+            bad = [i for i in range(min(nchunks, len(gpu_payloads))) if bytes(encs[i][:sizes[i]]) != gpu_payloads[i]]
+            assert not bad, f"GPU chunk streams differ from the oracle: chunks {bad[:8]}"
+            out["gpu_chunks_compared_bit_exact"] = min(nchunks, len(gpu_payloads))
+        return out
+    except AssertionError:
+        raise
+    except Exception as ex:  # pragma: no cover
+        return {"error": str(ex)}
+
+
 def cpu_baseline(host, chunk, sample_bytes, algo="chameleon", reps=25, gpu_payloads=None):
     """Times the CPU oracle (C restatement of the Rust reference, single thread like the reference's bench) on a bounded
     sample of the same workload.  Checker/baseline only — never part of the measured GPU path.  `gpu_payloads`: the GPU's chunk
@@ -61,38 +102,7 @@ def cpu_baseline(host, chunk, sample_bytes, algo="chameleon", reps=25, gpu_paylo
            "encode_MBps": round(n / med_e / 1e6, 1), "decode_MBps": round(n / med_d / 1e6, 1),
            "fastest": {"value": round(n / (best_e + best_d) / 1e6, 1), "encode_MBps": round(n / best_e / 1e6, 1), "decode_MBps": round(n / best_d / 1e6, 1)},
            "ratio_whole_stream": round(n / esize, 4)}
-    # all host cores, one chunk per task (ctypes releases the GIL): what a chunked CPU build of the same container does
-    try:
-        from concurrent.futures import ThreadPoolExecutor
-        ncpu = os.cpu_count() or 1
-        nchunks = (n + chunk - 1) // chunk
-        ccap = pyoracle.safe_encode_buffer_size(algo, chunk)
-        encs = np.empty((nchunks, ccap), dtype=np.uint8)
-        sizes = [0] * nchunks
-
-        def enc_task(i):
-            ln = min(chunk, n - i * chunk)
-            sizes[i] = pyoracle.encode_into(algo, src.ctypes.data + i * chunk, ln, encs[i].ctypes.data, ccap)
-
-        def dec_task(i):
-            ln = min(chunk, n - i * chunk)
-            pyoracle.decode_into(algo, encs[i].ctypes.data, sizes[i], dec.ctypes.data + i * chunk, ln)
-
-        with ThreadPoolExecutor(ncpu) as ex:
-            list(ex.map(enc_task, range(nchunks)))     # warm
-            t0 = time.perf_counter(); list(ex.map(enc_task, range(nchunks))); t1 = time.perf_counter()
-            list(ex.map(dec_task, range(nchunks))); t2 = time.perf_counter()
-        assert np.array_equal(dec, src)
-        out["all_cores"] = {"value": round(n / (t2 - t0) / 1e6, 1), "unit": "MB/s", "cores": ncpu,
-                            "ratio_chunked": round(n / sum(sizes), 4), "chunk": chunk}
-        if gpu_payloads is not None:
-            bad = [i for i in range(nchunks) if bytes(encs[i][:sizes[i]]) != gpu_payloads[i]]
-            assert not bad, f"GPU chunk streams differ from the oracle: chunks {bad[:8]}"
-            out["all_cores"]["gpu_chunks_compared_bit_exact"] = nchunks
-    except AssertionError:
-        raise
-    except Exception as ex:  # pragma: no cover
-        out["all_cores"] = {"error": str(ex)}
+    out["all_cores"] = cpu_all_cores(src, chunk, algo, gpu_payloads)
     return out
 
 
@@ -252,7 +262,7 @@ def settle(step, ms):
     return n
 
 
-def other_config(container, algo, label, host, steps=3, warmup=1, cpu_sample=32 << 20, chunk=0, settle_ms=0.0):
+def other_config(container, algo, label, host, steps=3, warmup=1, cpu_sample=32 << 20, chunk=0, settle_ms=0.0, all_cores=False):
     """One of BASELINE's other configurations, measured like the headline workload (device-resident container encode + decode, HIP events
     around every kernel) with a bounded CPU sample beside it.  Returns a dict for the `other_configs` list of the bench line."""
     import torch
@@ -311,9 +321,12 @@ def other_config(container, algo, label, host, steps=3, warmup=1, cpu_sample=32 
     nchk = max(m // chunk, 1)
     bad = [i for i in range(min(nchk, len(payloads))) if payloads[i] != pyoracle.encode(algo, host[i * chunk:(i + 1) * chunk])]
     assert not bad, f"{algo}: GPU chunk streams differ from the oracle: {bad[:8]}"
+    # ... and on all host cores over the SAME chunks (the whole buffer, every chunk held against the GPU's stream of it)
+    cores = cpu_all_cores(np.ascontiguousarray(host), chunk, algo, gpu_payloads=payloads) if all_cores else None
     return {"config": label, "algorithm": algo, "bytes": int(n), "chunk_bytes": int(chunk), "n_chunks": int(hdr.n_chunks),
             "value": round(n * steps / dt / 1e6, 1), "unit": "MB/s", "steps": steps, "ms_per_step": round(dt / steps * 1e3, 4),
             "compression_ratio": round(n / E, 4), "encoded_bytes": E,
+            "container_form": "slotted (the packed size stated)",
             "encode_ms": round(t_enc, 4), "decode_ms": round(t_dec, 4), "kernel_ms": {k: round(v, 4) for k, v in tot.items()},
             "residency": "HBM-bound" if 2 * n > (256 << 20) else "cache-resident (fits the 256 MiB Infinity Cache)",
             "roofline": {"encode": roofline_entry(f"{algo} encode (all kernels of the direction)", n + E, t_enc),
@@ -322,7 +335,7 @@ def other_config(container, algo, label, host, steps=3, warmup=1, cpu_sample=32 
                              "encode_MBps": round(m / (c1 - c0) / 1e6, 1), "decode_MBps": round(m / (c2 - c1) / 1e6, 1),
                              "ratio_whole_stream": round(m / es, 4),
                              "sample": f"first {m >> 20} MiB, whole-stream {algo} encode+decode, 1 thread, C restatement of density-rs 0.16.6",
-                             "gpu_chunks_compared_bit_exact": int(min(nchk, len(payloads)))}}
+                             "gpu_chunks_compared_bit_exact": int(min(nchk, len(payloads))), "all_cores": cores}}
 
 
 def strict_stream_leg(host, x, steps=5, label=None):
@@ -428,7 +441,8 @@ def main():
     ap.add_argument("--no-sweep", action="store_true", help="skip the size sweep (profiling runs: only the headline workload's launches)")
     ap.add_argument("--no-extra", action="store_true", help="skip the other_configs legs (configs 3/4, strict stream): only the headline workload")
     ap.add_argument("--no-gpu", action="store_true", help="dry mode: launcher + distributed bookkeeping on CPU/gloo (tests)")
-    ap.add_argument("--packed", action="store_true", help="time the packed container (encode + stitch pass + decode) instead of the slotted one")
+    ap.add_argument("--packed", action="store_true", help="time the packed container (encode + stitch pass + decode) instead of the paged one")
+    ap.add_argument("--slotted", action="store_true", help="time the slotted container (rounds 3-4's `value`: no stitch, not wire-ready) instead of the paged one")
     ap.add_argument("--concat", action="store_true", help="also time the optional gather-to-rank-0 stitch (N > 1)")
     ap.add_argument("--variant", type=int, default=0, help="kernel variant bit mask (density_hip_set_kernel_variant): 0 = default")
     ap.add_argument("--algo", default="chameleon", choices=["chameleon", "cheetah", "lion"],
@@ -477,19 +491,20 @@ def main():
         host = datagen.prose(n, seed=0xD1B54A32D192ED03 + rank)
     x = torch.from_numpy(host).cuda()
     algo = args.algo
-    cap = container.container_bound_slotted(algo, n, chunk)
+    cap = max(container.container_bound_slotted(algo, n, chunk), container.container_bound_paged(algo, n, chunk))
     cont = torch.empty(cap, dtype=torch.uint8, device="cuda")
     back = torch.empty(n, dtype=torch.uint8, device="cuda")
     ws_size = max(int(density_ws(container, n, chunk, args.algo)), 1)
     ws = torch.empty(ws_size, dtype=torch.uint8, device="cuda")
     stream = torch.cuda.current_stream()
     s = stream.cuda_stream
-    # The timed container is the SLOTTED form (include/density_hip.h: every chunk stream stays in the slot the encoder wrote it to, the
-    # decoder reads it there; same chunk streams, same size table, same block index) unless --packed: the packed wire form costs one more
-    # pass over every encoded byte (the stitch), which the library leaves to the moment a container leaves the device
-    # (density_hip_pack_device).  Both forms are checked here, and the packed form's time is reported beside `value` (`packed_container`).
-    slotted = not args.packed
-    enc_dev = container.encode_device_slotted if slotted else container.encode_device
+    # The timed container is the PAGED form (include/density_hip.h DENSITY_HIP_FLAG_PAGED; round 5): the encoder places every chunk stream itself, in
+    # 64 KiB pages taken from one counter, so what it leaves in HBM IS the wire blob (header + tables + page directory + pages in use) — two codec
+    # launches, no stitch pass — and the decoder reads the pages in place.  `value`, `encoded_bytes` and `compression_ratio` describe THOSE bytes.
+    # --slotted times rounds 3-4's form (worst-case slots, not wire-ready), --packed the packed form (encode + stitch + decode); both are also measured
+    # for a few steps beside the headline (`slotted_container`, `packed_container`).
+    form = "packed" if args.packed else ("slotted" if args.slotted else "paged")
+    enc_dev = {"packed": container.encode_device, "slotted": container.encode_device_slotted, "paged": container.encode_device_paged}[form]
 
     # correctness before any timing: decode(encode(x)) == x, and chunk streams equal to the oracle's (all of the CPU sample's chunks are
     # compared in cpu_baseline; here a spread of chunks so that --no-cpu runs are checked too)
@@ -500,20 +515,29 @@ def main():
     _, payloads = container.chunk_payloads(raw)
     for i in sorted(set([0, hdr_p.n_chunks // 3, hdr_p.n_chunks - 1])):
         assert payloads[i] == pyoracle.encode(algo, host[i * chunk:(i + 1) * chunk]), f"chunk {i} differs from the oracle"
-    E = int(hdr_p.container_len)                       # encoded bytes = the packed container (what leaves the device): the algorithmic E
+    E = int(hdr_p.container_len)                       # the PACKED container: the algorithmic E of the roofline (the fewest bytes the streams + tables can take)
     hdr, Ec = hdr_p, E
-    if slotted:
-        # the slotted form: decodes to the input, and packing it gives the packed container byte for byte
-        packed_ref = cont[:E].clone()
+    packed_ref = cont[:E].clone()
+    if form != "packed":
+        # the timed form: decodes to the input, and its chunk streams — read the way a CPU reader of the container reads them (slots / page
+        # directory: container.chunk_payloads) — are byte for byte the packed container's, i.e. the oracle's
         back.zero_()
-        hdr = container.encode_device_slotted(algo, x.data_ptr(), n, cont.data_ptr(), cap, chunk, stream=s, workspace=(ws.data_ptr(), ws_size))
+        hdr = enc_dev(algo, x.data_ptr(), n, cont.data_ptr(), cap, chunk, stream=s, workspace=(ws.data_ptr(), ws_size))
         Ec = int(hdr.container_len)
+        if form == "paged" and not (hdr.flags & container.FLAG_PAGED):
+            form = "slotted"                            # shapes the paged form is not for come out slotted (the header says so)
         got = container.decode_device(cont.data_ptr(), Ec, back.data_ptr(), n, header=hdr, stream=s, workspace=(ws.data_ptr(), ws_size))
-        assert got == n and torch.equal(back, x), "round trip mismatch (slotted container)"
-        repacked = torch.empty(cap, dtype=torch.uint8, device="cuda")
-        hr = container.pack_device(cont.data_ptr(), Ec, repacked.data_ptr(), cap, header=hdr, stream=s, workspace=(ws.data_ptr(), ws_size))
-        assert hr.container_len == E and torch.equal(repacked[:E], packed_ref), "pack(slotted) differs from the packed container"
-        del repacked, packed_ref
+        assert got == n and torch.equal(back, x), f"round trip mismatch ({form} container)"
+        _, payloads_f = container.chunk_payloads(cont[:Ec].cpu().numpy())
+        assert payloads_f == payloads, f"the {form} container's chunk streams differ from the packed container's"
+        del payloads_f
+        if form == "slotted":
+            repacked = torch.empty(cap, dtype=torch.uint8, device="cuda")
+            hr = container.pack_device(cont.data_ptr(), Ec, repacked.data_ptr(), cap, header=hdr, stream=s, workspace=(ws.data_ptr(), ws_size))
+            assert hr.container_len == E and torch.equal(repacked[:E], packed_ref), "pack(slotted) differs from the packed container"
+            del repacked
+    # the bytes `value` is about: what has to leave the device for the container to be decodable elsewhere
+    wire_bytes = Ec if form in ("paged", "packed") else E
     del raw
 
     def step():
@@ -546,18 +570,21 @@ def main():
         per_rank_ms = [float(v.item()) / args.steps * 1e3 for v in all_t]
         dt = max(float(v.item()) for v in all_t)
     assert torch.equal(back, x), "round trip mismatch after timed steps"
-    packed_cmp = None
-    if slotted and not args.no_extra:
-        # the same round trip through the packed container (stitch pass included), a few steps, for the record
-        def pstep():
-            container.encode_device(algo, x.data_ptr(), n, cont.data_ptr(), cap, chunk, stream=s, workspace=(ws.data_ptr(), ws_size), want_header=False)
-            container.decode_device(cont.data_ptr(), E, back.data_ptr(), n, header=hdr_p, stream=s, workspace=(ws.data_ptr(), ws_size), sync=False)
-        settle(pstep, args.settle_ms / 2)
-        pstep(); torch.cuda.synchronize()
+    # the other container forms through the same round trip, a few steps each, for the record (never `value`)
+    def side_form(fname):
+        fenc = {"packed": container.encode_device, "slotted": container.encode_device_slotted, "paged": container.encode_device_paged}[fname]
+        fh = fenc(algo, x.data_ptr(), n, cont.data_ptr(), cap, chunk, stream=s, workspace=(ws.data_ptr(), ws_size))
+        flen = int(fh.container_len)
+
+        def fstep():
+            fenc(algo, x.data_ptr(), n, cont.data_ptr(), cap, chunk, stream=s, workspace=(ws.data_ptr(), ws_size), want_header=False)
+            container.decode_device(cont.data_ptr(), flen, back.data_ptr(), n, header=fh, stream=s, workspace=(ws.data_ptr(), ws_size), sync=False)
+        settle(fstep, args.settle_ms / 2)
+        fstep(); torch.cuda.synchronize()
         container.set_profiling(True); container.last_timings()
         tp0 = time.perf_counter()
         for _ in range(5):
-            pstep()
+            fstep()
         torch.cuda.synchronize()
         dtp = (time.perf_counter() - tp0) / 5
         pk = {}
@@ -565,22 +592,24 @@ def main():
             pk[name] = pk.get(name, 0.0) + ms / 5
         container.set_profiling(False)
         assert torch.equal(back, x)
-        packed_cmp = {"value": round(n / dtp / 1e6, 1), "unit": "MB/s", "ms_per_step": round(dtp * 1e3, 4), "kernel_ms": {k: round(v, 4) for k, v in pk.items()},
-                      "whole_path_hbm_frac": round(2.0 * (n + E) / dtp / 1e9 / HBM_PEAK_GBS, 5),
-                      "note": "encode + stitch (compact: 2E bytes, none of them algorithmic) + decode of the packed container; the bytes are what density_hip_pack_device makes of the slotted one"}
-        # restore the slotted container for the multi-GPU bookkeeping below
-        enc_dev(algo, x.data_ptr(), n, cont.data_ptr(), cap, chunk, stream=s, workspace=(ws.data_ptr(), ws_size), want_header=False)
-        torch.cuda.synchronize()
+        notes = {"packed": "encode + stitch (compact: 2E bytes, none of them algorithmic) + decode of the packed container: the densest wire form",
+                 "slotted": "rounds 3-4's `value`: chunk streams left in worst-case slots (1.03 x N of address space), not wire-ready until density_hip_pack_device",
+                 "paged": "streams in 64 KiB pages from one counter: wire-ready without a stitch"}
+        return {"value": round(n_gpus * n / dtp / 1e6, 1), "unit": "MB/s", "ms_per_step": round(dtp * 1e3, 4), "kernel_ms": {k: round(v, 4) for k, v in pk.items()},
+                "whole_path_hbm_frac": round(2.0 * (n + E) / dtp / 1e9 / HBM_PEAK_GBS, 5), "container_bytes": flen,
+                "wire_ready": fname != "slotted", "note": notes[fname]}
+    side = {}
+    if not args.no_extra:
+        for fname in ("packed", "slotted", "paged"):
+            if fname != form and not (fname == "paged" and form == "slotted" and not args.slotted):
+                side[fname] = side_form(fname)
+    packed_cmp = side.get("packed")
 
-    # the path's only collective: all-gather of per-shard (chunks, payload bytes) -> offsets in the global container
+    # the path's only collective: all-gather of per-shard (chunks, payload bytes) -> offsets in the global container.  The bookkeeping below is done
+    # on the PACKED form of this rank's container (parallel.py's layout arithmetic is the packed one; a paged shard is wire-ready as it stands and
+    # would travel as one blob per rank)
     from density_amd import parallel
-    if slotted and hdr.flags & container.FLAG_SLOTTED:
-        # export: the packed wire form of this rank's container (what the size all-gather and the optional concat describe / move)
-        packed_local = torch.empty(container.container_bound(algo, n, chunk), dtype=torch.uint8, device="cuda")
-        container.pack_device(cont.data_ptr(), Ec, packed_local.data_ptr(), packed_local.numel(), header=hdr, stream=s, workspace=(ws.data_ptr(), ws_size))
-        local_cont = packed_local[:E]
-    else:
-        local_cont = cont[:E]
+    local_cont = packed_ref
     hdr_l, table_l, index_l, payload_l = parallel.parse_local(local_cont)
     if use_pg:
         torch.cuda.synchronize(); tg0 = time.perf_counter()
@@ -661,17 +690,24 @@ def main():
             "config": {"workload": f"{algo} {label}, {n >> 20} MiB per GPU, device-resident container encode+decode, chunk {chunk >> 10} KiB, {residency}",
                        "algorithm": algo, "bytes_per_gpu": n, "chunk_bytes": chunk, "n_chunks": int(hdr.n_chunks),
                        "parallelism": f"chunk-sharded x{n_gpus}, no data-path collective"},
-            "compression_ratio": round(n / E, 4),
-            "encoded_bytes": E,
-            "value_packed": (round(n_gpus * packed_cmp["value"], 1) if packed_cmp else None),
+            "compression_ratio": round(n / wire_bytes, 4),
+            "encoded_bytes": int(wire_bytes),
+            "compression_ratio_packed": round(n / E, 4), "encoded_bytes_packed": E,
+            "value_packed": (packed_cmp["value"] if packed_cmp else None),
             "whole_path_hbm_frac_packed": (packed_cmp["whole_path_hbm_frac"] if packed_cmp else None),
-            "value_definition": ("`value`: the round trip through the SLOTTED device-resident container (two codec launches, no stitch; its encoded form spans "
-                                 "1.03 x N of address space until packed); `value_packed`: the same round trip through the PACKED wire container "
-                                 "(encode + stitch + decode), whose size `compression_ratio` / `encoded_bytes` state.  Rounds 1-2 quoted the packed form as `value`."),
+            "value_slotted": (side["slotted"]["value"] if "slotted" in side else None),
+            "value_definition": {"paged": "`value`: the round trip through the PAGED device-resident container — two codec launches, no stitch pass, and what the encoder leaves "
+                                          "in HBM is the wire blob (`encoded_bytes` = its length, `compression_ratio` = N over it: the same bytes `value` is timed on).  "
+                                          "`value_packed`: the same through the PACKED container (encode + stitch + decode; `encoded_bytes_packed`, the densest form); "
+                                          "`value_slotted`: rounds 3-4's `value` (slots of the worst case, not wire-ready).  The roofline's algorithmic E is the packed size.",
+                                 "slotted": "`value`: the round trip through the SLOTTED device-resident container (two codec launches, no stitch; its encoded form spans "
+                                            "1.03 x N of address space until packed: `encoded_bytes` states the packed size)",
+                                 "packed": "`value`: the round trip through the PACKED container (encode + stitch + decode)"}[form],
             "kernels_id": kernels_id,
-            "container_form": ("slotted: chunk streams left in their slots, read there by the decoder; the stitch into the packed wire form is density_hip_pack_device's, "
-                               "at export" if slotted and (hdr.flags & container.FLAG_SLOTTED) else "packed"),
+            "container_form": form,
             "packed_container": packed_cmp,
+            "slotted_container": side.get("slotted"),
+            "paged_container": side.get("paged"),
             "encode_ms": round(t_enc, 4), "decode_ms": round(t_dec, 4),
             "per_rank_ms_per_step": [round(v, 4) for v in per_rank_ms],
             "kernel_ms": {k: round(v, 4) for k, v in tot.items()},
@@ -680,7 +716,12 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": int(alg_launch), "kernel_avg_ms": round(avg[dom], 4),
-                         "launches_per_step": round(launches.get(dom, 1.0), 2)},
+                         "launches_per_step": round(launches.get(dom, 1.0), 2),
+                         # the whole timed step against the same roofline: 2 (N + E) algorithmic bytes over ms_per_step, for the timed form and for the others
+                         "whole_path": {"form": form, "frac": round((2.0 * (n + E)) / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "value": round(n_gpus * n * args.steps / dt / 1e6, 1),
+                                        "frac_packed": (packed_cmp["whole_path_hbm_frac"] if packed_cmp else None), "value_packed": (packed_cmp["value"] if packed_cmp else None),
+                                        "frac_slotted": (side["slotted"]["whole_path_hbm_frac"] if "slotted" in side else None),
+                                        "value_slotted": (side["slotted"]["value"] if "slotted" in side else None)}},
             "multi_gpu": {"process_group": ("nccl (RCCL)" if use_pg else None), "size_gather_ms": round(gather_ms, 3),
                           "concat_to_rank0_ms": (round(concat_ms, 3) if concat_ms is not None else None), "concat_decodes_to_input": concat_checked,
                           "global_container_bytes": int(glob["container_len"])},
@@ -718,7 +759,7 @@ def main():
             prose = datagen.prose(100_000_000, seed=0xD1B54A32D192ED03)
             for a, lbl in (("cheetah", "3: Cheetah on synth-prose-100M (enwik8 stand-in: 100,000,000 B of non-periodic synthetic prose)"),
                            ("lion", "4: Lion on synth-prose-100M (enwik8 stand-in: 100,000,000 B of non-periodic synthetic prose)")):
-                extra.append(other_config(container, a, lbl, prose, settle_ms=args.settle_ms))
+                extra.append(other_config(container, a, lbl, prose, settle_ms=args.settle_ms, all_cores=True))
             result["other_configs"] = extra
         print(json.dumps(result))
     if use_pg:
