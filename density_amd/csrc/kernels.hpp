@@ -87,6 +87,8 @@ hipError_t launch_rotor_decode(const uint8_t* d_in, const uint64_t* d_offsets, c
                                uint64_t* d_produced, uint32_t* d_err, hipStream_t stream);
 // LDS assumptions of the rotation kernels (ordered exchange lane order, token hand-off behind the exchanges, lane-reversed rollback)
 hipError_t launch_rotor_selftest(uint32_t* d_fail, hipStream_t stream);
+constexpr bool kRotorSplitDefault = false;   // which rotation encoder ships: the split one (8 chain + 8 emit waves, rotor.hip) or the 8-wave one
+extern bool g_rotor_split;     // density_hip_set_kernel_variant(2048): the OTHER rotation encoder than kRotorSplitDefault (A/B runs, cross-checks)
 extern bool g_force_pipeline;  // density_hip_set_kernel_variant(4): the 16-wave role pipelines of chameleon.hip instead
 extern bool g_exchange_unsafe, g_rotor_unsafe;   // start-up self-test verdicts (api.hip::acquire_ctx)
 

@@ -74,6 +74,14 @@ constexpr uint32_t kDecMaxPages = 96;
 constexpr uint32_t dec_pages_at(uint32_t R) { return dec_lds_bytes(R); }
 constexpr uint32_t dec_lds_bytes_paged(uint32_t R) { return dec_lds_bytes(R) + 8u * kDecMaxPages; }
 static_assert(dec_lds_bytes_paged(12) <= 160u * 1024u, "LDS budget of the paged decoder");
+// SPLIT encoder (round 5): eight CHAIN waves (hash, exchange, signatures, commit) and eight EMIT waves.  Behind the staging area:
+// the quad ring — three rounds of 16 blocks x 64 lanes (or four of 12), filled by the emit waves (which load the input and keep the quads for the emit),
+// drained by the chain waves —, its words {ready[3], -, freed[3], -}, and one mail box per pair of waves: the signatures of a committed round
+// (lane j's 8 bytes), then {sequence word, stream position, -, -}, then {taken, -, -, -}
+constexpr uint32_t kEncRing = kEncLds, kEncRingSync = kEncRing + 12288u, kEncMbox = kEncRingSync + 32u, kMboxBytes = 160u;
+constexpr uint32_t ring_slots(uint32_t R) { return 12288u / (R * 256u); }          // 3 rounds of 16 blocks, 4 of 12
+constexpr uint32_t kEncLdsSplit = kEncMbox + 8u * kMboxBytes;
+static_assert(kEncLdsSplit <= 160u * 1024u && kEncRing % 16u == 0, "LDS budget of the split encoder");
 static_assert(kEncLds <= 160u * 1024u && dec_lds_bytes(8) <= 160u * 1024u && dec_lds_bytes(12) <= 160u * 1024u && dec_lds_bytes(16) <= 160u * 1024u, "LDS budget");
 static_assert(dec_zmap_in_lds(12) && !dec_zmap_in_lds(8), "where the decoder's zero-entry map lives");
 
@@ -105,6 +113,9 @@ __device__ __forceinline__ uint32_t lds_peek1(uint32_t addr) {
 __device__ __forceinline__ uint32_t rlane_u(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
 __device__ __forceinline__ uint32_t rlane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
 __device__ __forceinline__ void lds_poke(uint32_t addr, uint32_t v) { asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
+// the same at a compile-time offset from a base register (16-bit field): R addresses from ONE register — per-lane addresses that differ by constants would
+// otherwise be hoisted out of the round loop one register each, rare paths included, and sit on the common path's register budget
+#define DENSITY_LDS_POKE_AT(base, off, v) asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(base), "v"(v), "n"(off) : "memory")
 __device__ __forceinline__ void lds_poke2(uint32_t addr, uint32_t a, uint32_t b) {
     const u32x2 v = {a, b};
     asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
@@ -477,13 +488,16 @@ __device__ __forceinline__ bool poll_word(uint32_t addr, uint32_t want, uint32_t
 // ---------------------------------------------------------------------------------------------------------------
 // encode: Codec::encode / encode_block (codec/codec.rs:34-80), Chameleon::encode_quad (chameleon.rs:88-100)
 // ---------------------------------------------------------------------------------------------------------------
-template <int R, int W, bool kProf, bool KEEP = (W == 8), bool EARLY = false, bool PAGED = false>
-__global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __restrict__ in, uint64_t total, uint64_t chunk_bytes,
+template <int R, int W, bool kProf, bool KEEP = (W == 8), bool EARLY = false, bool PAGED = false, bool SPLIT = false>
+__global__ __launch_bounds__(SPLIT ? 2 * W * 64 : W * 64) void chameleon_encode_rot(const uint8_t* __restrict__ in, uint64_t total, uint64_t chunk_bytes,
                                                                    uint8_t* __restrict__ out, uint64_t out_stride, uint64_t* __restrict__ sizes,
                                                                    uint8_t* __restrict__ index, uint32_t* __restrict__ err, SegArgs seg,
                                                                    uint64_t* __restrict__ prof) {
     static_assert((R == 8 || R == 12 || R == 16) && (W == 8 || W == 12 || W == 16), "round = 8, 12 or 16 blocks; 8, 12 or 16 waves");
     static_assert(!KEEP || (R == 16 && W == 8), "kept quads: staging registers exist for rounds of 16 on 8 waves (12 waves: the compiler needs them itself, DESIGN.md 4.3)");
+    static_assert(!SPLIT || ((R == 16 || R == 12) && W == 8 && !KEEP && !EARLY), "split encoder: rounds of 12 or 16, 8 chain + 8 emit waves, quads from the ring (no hand-fetched loads)");
+    constexpr uint32_t kRingSlots = ring_slots(R), kSlotBytes = R * 256u;
+    constexpr uint32_t kThreads = SPLIT ? 2u * W * 64u : W * 64u;
     // (rounds of 16 on 16 waves fit the 128 registers a wave then has because nothing but the exchange operands is kept across the wait for the
     // dictionary token: the quads themselves are loaded again — from L2 — once the exchanges are out)
     const uint32_t lane = threadIdx.x & 63u;
@@ -509,7 +523,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
         uint4* p = reinterpret_cast<uint4*>(smem);
         const uint4 z = make_uint4(0, 0, 0, 0);
         const uint4* image = seg.init_images ? reinterpret_cast<const uint4*>(seg.init_images + chunk * kSegImageBytes) : nullptr;
-        for (uint32_t i = threadIdx.x; i < (kTableBytes + kZmapBytes) / 16; i += W * 64) p[i] = image ? image[i] : z;
+        for (uint32_t i = threadIdx.x; i < (kTableBytes + kZmapBytes) / 16; i += kThreads) p[i] = image ? image[i] : z;
         if (threadIdx.x == 0) {
             const uint32_t g0 = seg.init_guard ? seg.init_guard[chunk] : pack_guard(Guard{});
             uint32_t pos0 = 0;
@@ -525,12 +539,17 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
             if (lds_addr(smem) != 0 && err) atomicOr(err, kErrWatchdog);           // (cannot happen: see above)
         }
         if (threadIdx.x < kMemoEntries) *reinterpret_cast<uint4*>(smem + kEncSync + kSyMemo + 16u * threadIdx.x) = make_uint4(kNone, 0u, 0u, 0u);
+        if (SPLIT) {                                                              // ring words and mail boxes: nothing filled, nothing drained, nothing posted, nothing taken
+            if (threadIdx.x < 2) *reinterpret_cast<uint4*>(smem + kEncRingSync + 16u * threadIdx.x) = z;
+            if (threadIdx.x >= 64 && threadIdx.x < 64 + 16) *reinterpret_cast<uint4*>(smem + kEncMbox + kMboxBytes * ((threadIdx.x - 64) >> 1) + 128u + 16u * (threadIdx.x & 1u)) = z;
+        }
     }
     __syncthreads();
 
     // 8 waves have 256 registers each: the quads stay in registers across the waits and the next round's are fetched a round ahead;
     // 12 and 16 waves load them again instead
-    constexpr bool kKeepQuads = KEEP;
+    constexpr bool kKeepQuads = KEEP;                                             // (split: a chain wave takes its quads from the ring and keeps them only up to the exchange operands — the rare paths that want them again load them from L2, like the 12- and 16-wave geometries)
+    uint32_t cur_round = 0;                                                       // (split: the round whose quads such a path loads)
     constexpr bool kKeepHash = KEEP && W == 8;                                    // (12 waves have 168 registers each: the hash product is made again for the emit)
     uint32_t q[R], hp[R];                                                         // hp: the quads' hash products (kept with them)
 #pragma unroll
@@ -541,6 +560,13 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
 #pragma unroll
             for (uint32_t j = 0; j < R; ++j) d[j] = *reinterpret_cast<const uint32_t*>(p + j * kBlock + 4u * lane);
         }
+    };
+    // (split, rare paths of a chain wave: the round's quads again, unconditionally — a guarded load would keep the old values alive across the common path)
+    // Every such path loads into an array of ITS OWN (one merged with `q` would have the compiler keep two sets of quads alive in the common path).
+    auto reload_quads = [&](uint32_t (&t)[R], uint32_t r) {
+        const uint8_t* p = src + (uint64_t)r * (R * kBlock);
+#pragma unroll
+        for (uint32_t j = 0; j < R; ++j) t[j] = *reinterpret_cast<const uint32_t*>(p + j * kBlock + 4u * lane);
     };
     // quad -> exchange operands {dword address, half mask, entry << 16*half} (chameleon.rs:89, chameleon_dev.hpp)
     auto operands = [&](uint32_t qv, uint32_t& a, uint32_t& m, uint32_t& v, uint32_t* keep = nullptr) {
@@ -566,8 +592,10 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
     // what the rolled loops of the rare paths index instead of registers (a dynamically indexed register array would live in scratch
     // memory, whose loads the compiler waits for at the top of every round, common path included)
     auto park = [&](uint32_t which, const uint32_t (&a)[R]) {
+        uint32_t base = kEncStage + which * 4096u + 4u * lane;
+        asm volatile("" : "+v"(base));                                            // (made here, on the rare path: not an invariant of the round loop)
 #pragma unroll
-        for (uint32_t j = 0; j < R; ++j) lds_poke(kEncStage + which * 4096u + j * 256u + 4u * lane, a[j]);
+        for (uint32_t j = 0; j < R; ++j) DENSITY_LDS_POKE_AT(base, j * 256u, a[j]);
     };
     auto parked = [&](uint32_t which, uint32_t j) -> uint32_t { return lds_peek1(kEncStage + which * 4096u + j * 256u + 4u * lane); };
     auto block_in_order = [&](Guard& g, uint32_t qv, uint32_t& a, uint32_t m, uint32_t v, uint64_t& sg, bool& raw) {
@@ -589,7 +617,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
     // store each (lane j: record j, offsets by a DPP prefix over the record lengths); per block the MAP lanes store the 2-byte slot
     // index (the upper half of the hash product), the PLAIN lanes the quad, through an SGPR base (io/write_buffer.rs:13-27).
     const uint32_t minus_2lane = 0u - 2u * lane;
-    auto emit_round_coded = [&](uint32_t pos0, uint8_t* idxp, uint32_t slo, uint32_t shi) {
+    auto emit_round_coded = [&](const uint32_t (&qq)[R], uint32_t pos0, uint8_t* idxp, uint32_t slo, uint32_t shi) {
         const uint32_t nhv = (uint32_t)(__builtin_popcount(slo) + __builtin_popcount(shi));
         const uint32_t lenv = kSig + kBlock - 2u * nhv;
         uint32_t incl = lenv;                                                                 // prefix within a row of 16 lanes
@@ -615,7 +643,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
             const uint32_t pos = rlane_u(itemsv, (int)j);                         // (one read instead of a scalar running sum: popcount, shift, subtract, add)
             // the item's place: 4*lane - 2*(MAP lanes below) from the record's items on — the signature itself is the mask that is counted (no
             // complement to make), the count seeded with -2*lane, times -2 and added in one instruction
-            const uint32_t P = kKeepHash ? hp[j] : q[j] * kHashMul;               // (the hash is the MAP item: chameleon.rs:92)
+            const uint32_t P = kKeepHash ? hp[j] : qq[j] * kHashMul;              // (the hash is the MAP item: chameleon.rs:92)
             if (j + 1 < R) {
                 const uint32_t nsig = rlane_u(slo, (int)j + 1);                    // the next record's first bytes: its signature's low word
                 uint32_t val, off;
@@ -631,7 +659,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
                     "v_cndmask_b32 %[v], %[q], %[v], vcc\n\t"                         // PLAIN lanes: the quad
                     "global_store_dword %[o], %[v], %[dst]"
                     : [v] "=&v"(val), [o] "=&v"(off)
-                    : [P] "v"(P), [q] "v"(q[j]), [sg] "s"(sg), [sl] "s"((uint32_t)sg), [sh] "s"((uint32_t)(sg >> 32)), [ln] "v"(minus_2lane), [pos] "s"(pos),
+                    : [P] "v"(P), [q] "v"(qq[j]), [sg] "s"(sg), [sl] "s"((uint32_t)sg), [sh] "s"((uint32_t)(sg >> 32)), [ln] "v"(minus_2lane), [pos] "s"(pos),
                       [ns] "s"(nsig), [sel] "s"(0x05040302u), [dst] "s"(dst)
                     : "memory", "vcc");
             } else {
@@ -643,7 +671,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
                     "s_not_b64 exec, exec\n\t"
                     "global_store_short_d16_hi %0, %1, %3\n\t"
                     "s_mov_b64 exec, -1"
-                    ::"v"(off), "v"(P), "v"(q[j]), "s"(dst), "s"(plain) : "memory", "scc");
+                    ::"v"(off), "v"(P), "v"(qq[j]), "s"(dst), "s"(plain) : "memory", "scc");
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -654,7 +682,8 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
     // the lowest original lane wins)
     // (`skip`: blocks of the round that exchanged nothing — the raw copies an ordered round predicted, below)
     auto rollback_round = [&](uint32_t skip = 0u) {
-        park(0, q); park(1, ra);                                                  // (a rolled loop: this path is rare, its code must not weigh on the common one)
+        if constexpr (SPLIT) { uint32_t t[R]; reload_quads(t, cur_round); park(0, t); } else park(0, q);
+        park(1, ra);                                                  // (a rolled loop: this path is rare, its code must not weigh on the common one)
 #pragma nounroll
         for (int j = (int)R - 1; j >= 0; --j) {
             if ((skip >> j) & 1u) continue;
@@ -713,17 +742,130 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
     // (the last whole round also keeps room for what follows it on one wave: the blocks of the partial round and the ragged block — so that no page
     // starts inside the decoder's in-order tail)
     const uint32_t tail_need = PAGED ? (nfull - nrounds * R + 1u) * (kSig + kBlock) : 0u;
-    if (kKeepQuads) {
+    // ---- SPLIT: the ring and the mail boxes (constants above) ----
+    // Every spin of either role looks for a raised abort — the work-group barrier of the protocol counts all sixteen waves; an emit wave never holds an
+    // uncommitted round, a chain wave none at these places — and for the watchdog's poison.
+    auto join_abort = [&]() {
+        const u32x2 v = lds_peek2(sy + kSyD);
+        const uint32_t A = rfl(v.y);
+        if (__builtin_expect(A != kNone, 0)) { if (A == kPoison) wave_exit(); abort_sync(false, 0); }
+    };
+    // chain wave: round r's quads out of the ring (its LDS reads execute in issue order: whoever sees the `freed` word may overwrite the slot)
+    auto ring_take = [&](uint32_t (&d)[R], uint32_t r) {
+        const uint32_t slot = r % kRingSlots;
+        for (uint32_t spins = 0; !poll_word(kEncRingSync + 4u * slot, r + 1u, 4);) { join_abort(); __builtin_amdgcn_s_sleep(1); watchdog(spins, sy, err, lane); }
+        const uint32_t at = kEncRing + slot * kSlotBytes + 4u * lane;
+        // (one statement, issue to wait: an answer of an asynchronous LDS read exists for the compiler only when the statement ends)
+        if constexpr (R == 16) asm volatile("ds_read_b32 %0, %16 offset:0\n\t"
+                     "ds_read_b32 %1, %16 offset:256\n\t"
+                     "ds_read_b32 %2, %16 offset:512\n\t"
+                     "ds_read_b32 %3, %16 offset:768\n\t"
+                     "ds_read_b32 %4, %16 offset:1024\n\t"
+                     "ds_read_b32 %5, %16 offset:1280\n\t"
+                     "ds_read_b32 %6, %16 offset:1536\n\t"
+                     "ds_read_b32 %7, %16 offset:1792\n\t"
+                     "ds_read_b32 %8, %16 offset:2048\n\t"
+                     "ds_read_b32 %9, %16 offset:2304\n\t"
+                     "ds_read_b32 %10, %16 offset:2560\n\t"
+                     "ds_read_b32 %11, %16 offset:2816\n\t"
+                     "ds_read_b32 %12, %16 offset:3072\n\t"
+                     "ds_read_b32 %13, %16 offset:3328\n\t"
+                     "ds_read_b32 %14, %16 offset:3584\n\t"
+                     "ds_read_b32 %15, %16 offset:3840\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6]), "=&v"(d[7]), "=&v"(d[8]), "=&v"(d[9]), "=&v"(d[10]), "=&v"(d[11]), "=&v"(d[12]), "=&v"(d[13]), "=&v"(d[14]), "=&v"(d[15])
+                     : "v"(at) : "memory");
+        if constexpr (R == 12) asm volatile("ds_read_b32 %0, %12 offset:0\n\t"
+                     "ds_read_b32 %1, %12 offset:256\n\t"
+                     "ds_read_b32 %2, %12 offset:512\n\t"
+                     "ds_read_b32 %3, %12 offset:768\n\t"
+                     "ds_read_b32 %4, %12 offset:1024\n\t"
+                     "ds_read_b32 %5, %12 offset:1280\n\t"
+                     "ds_read_b32 %6, %12 offset:1536\n\t"
+                     "ds_read_b32 %7, %12 offset:1792\n\t"
+                     "ds_read_b32 %8, %12 offset:2048\n\t"
+                     "ds_read_b32 %9, %12 offset:2304\n\t"
+                     "ds_read_b32 %10, %12 offset:2560\n\t"
+                     "ds_read_b32 %11, %12 offset:2816\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6]), "=&v"(d[7]), "=&v"(d[8]), "=&v"(d[9]), "=&v"(d[10]), "=&v"(d[11])
+                     : "v"(at) : "memory");
+        if (lane == 0) lds_poke(kEncRingSync + 16u + 4u * slot, r + 1u);
+    };
+    // emit wave: round r's quads into the ring, once the chain wave of round r - kRingSlots has drained the slot
+    auto ring_put = [&](const uint32_t (&d)[R], uint32_t r) {
+        const uint32_t slot = r % kRingSlots;
+        if (r >= kRingSlots)
+            for (uint32_t spins = 0; !poll_word(kEncRingSync + 16u + 4u * slot, r + 1u - kRingSlots, 2);) { join_abort(); __builtin_amdgcn_s_sleep(4); watchdog(spins, sy, err, lane); }
+        const uint32_t base = kEncRing + slot * kSlotBytes + 4u * lane;
+#pragma unroll
+        for (uint32_t j = 0; j < R; ++j) DENSITY_LDS_POKE_AT(base, j * 256u, d[j]);
+        if (lane == 0) lds_poke(kEncRingSync + 4u * slot, r + 1u);
+    };
+    // chain wave `wave`, round r committed: its signatures and stream position to the partner (`skip`: the chain wave wrote the round out itself —
+    // rounds with raw-copy blocks); the box is free once the partner has taken the pair's previous round
+    auto mbox_post = [&](uint32_t r, uint32_t pos, uint32_t lo, uint32_t hi, uint32_t skip) {
+        const uint32_t mb = kEncMbox + kMboxBytes * wave;
+        if (r >= (uint32_t)W)
+            for (uint32_t spins = 0; !poll_word(mb + 144u, r + 1u - W, 2);) { join_abort(); __builtin_amdgcn_s_sleep(1); watchdog(spins, sy, err, lane); }
+        if (lane < R) lds_poke2(mb + 8u * lane, lo, hi);
+        if (lane == 0) { lds_poke(mb + 132u, pos); lds_poke(mb + 128u, ((r + 1u) << 1) | skip); }
+    };
+    auto mbox_wait = [&](uint32_t e, uint32_t r, uint32_t& pos, uint32_t& lo, uint32_t& hi) -> bool {
+        const uint32_t mb = kEncMbox + kMboxBytes * e;
+        uint32_t seq;
+        for (uint32_t spins = 0;;) {
+            seq = rfl(lds_peek1(mb + 128u));
+            if ((seq >> 1) == r + 1u) break;
+            join_abort(); __builtin_amdgcn_s_sleep(4); watchdog(spins, sy, err, lane);
+        }
+        pos = rfl(lds_peek1(mb + 132u));
+        const u32x2 sg = lds_peek2(mb + 8u * (lane < R ? lane : 0u));
+        lo = lane < R ? sg.x : 0u; hi = lane < R ? sg.y : 0u;
+        if (lane == 0) lds_poke(mb + 144u, r + 1u);
+        return (seq & 1u) != 0;
+    };
+    if (SPLIT && wave >= (uint32_t)W) {
+        // ---- emit wave e: loads the rounds e, e + 8, ... (plain loads: nothing else of this wave waits on the memory queue), hands their quads to the
+        // chain wave e through the ring — a round ahead of the one it is about to write out — and writes a round's records once the chain wave has
+        // committed it (mail box).  Two register sets: the round waiting for its commit and the next one.
+        __builtin_amdgcn_s_setprio(0);
+        const uint32_t e = wave - W;
+        uint32_t qa[R], qb[R];
+#pragma unroll
+        for (uint32_t j = 0; j < R; ++j) { qa[j] = 0; qb[j] = 0; }
+        load_round(qa, e);
+        if (e < nrounds) ring_put(qa, e);
+        load_round(qb, e + W);
+        auto step = [&](uint32_t (&cur)[R], uint32_t (&nxt)[R], uint32_t r) {
+            clk.start();
+            if (r + W < nrounds) ring_put(nxt, r + W);
+            clk.mark(1);
+            uint32_t pos, lo, hi;
+            const bool skip = mbox_wait(e, r, pos, lo, hi);
+            clk.mark(4);
+            if (!skip) emit_round_coded(cur, pos, idx ? idx + (uint64_t)r * R : nullptr, lo, hi);
+            clk.mark(6);
+            load_round(cur, r + 2u * W);
+            clk.mark(5);
+        };
+        for (uint32_t r = e; r < nrounds; r += 2u * W) {
+            step(qa, qb, r);
+            if (r + W < nrounds) step(qb, qa, r + W);
+        }
+    } else {
+    if constexpr (KEEP) {
         // (by hand like every later fetch: a load the compiler can see ahead of the loop would make it wait, at the top of every
         // iteration, until all but a few of the previous round's record stores have been acknowledged)
         if (wave < nrounds) { prefetch_quads<R, W>(src + (uint64_t)wave * (R * kBlock) + 4u * lane); quads_landed<R, W, true>(q); }
-    } else {
+    } else if (!SPLIT) {
         load_round(q, wave);
     }
     uint32_t poll_tries = 16;                                                     // polls for the FAST token before a look at the whole D line: few while this wave's rounds are ordered ones
     for (uint32_t r = wave; r < nrounds; r += W) {
         clk.start();
         __builtin_amdgcn_s_setprio(1);                                   // (see the priorities note at the exchange)
+        if (SPLIT) { cur_round = r; ring_take(q, r); clk.mark(5); }
         uint32_t slo = 0, shi = 0;                                                // lane j: the signature of block j (codec.rs:24-26)
         uint32_t copy_mask = 0, opos = 0;
         bool fast_commit = false, prefetched = false;
@@ -731,27 +873,32 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
         // blocks (final below it_j0, predicted from there on), the prediction and the state behind the round if it holds
         uint32_t P0 = 0, P1 = 0, it_j0 = kNone, it_state = 0, it_raw = 0, it_mode = 0, it_end = 0;
         bool have_turn = false;
-      for (;;) {   // (re-entered after an abort, and by an ordered round whose prediction failed: the answers have replaced the addresses, so the operands are made again)
+      for (bool reentered = false;; reentered = true) {   // (re-entered after an abort, and by an ordered round whose prediction failed: the answers have replaced the addresses, so the operands are made again)
+        uint32_t zblocks = 0, zq = 0;
+        bool zsusp = false;
+        auto prepare = [&](const uint32_t (&qq)[R]) {
         uint32_t zmin = 0xffffffffu;
 #pragma unroll
         for (uint32_t j = 0; j < R; ++j) {
-            operands(q[j], ra[j], mask[j], val[j], kKeepHash ? &hp[j] : nullptr);
+            operands(qq[j], ra[j], mask[j], val[j], kKeepHash ? &hp[j] : nullptr);
             zmin = val[j] < zmin ? val[j] : zmin;
             __builtin_amdgcn_sched_barrier(0);                                    // block by block: short live ranges, not maximal overlap
         }
         // Blocks with a quad that needs the zero-entry map (about one quad in 64 Ki): found here, ahead of the waits, together with the
         // first such block's quads, so that the commit — which holds up every later round — has next to nothing left to look up.
-        uint32_t zblocks = 0, zq = 0;
-        bool zsusp = false;
         if (__builtin_expect(ballot64(zmin == 0) != 0, 0)) {                      // a stored entry 0: the zero quad (harmless) or one outside slot 0
+            asm volatile("");                                                     // (nothing of this block is worth computing ahead of the test: sixteen compares of the common path otherwise)
 #pragma unroll
-            for (uint32_t j = 0; j < R; ++j) zblocks |= (ballot64(val[j] == 0 && q[j] != 0) != 0 ? 1u : 0u) << j;
+            for (uint32_t j = 0; j < R; ++j) zblocks |= (ballot64(val[j] == 0 && qq[j] != 0) != 0 ? 1u : 0u) << j;
             if (zblocks) {
                 const uint32_t j0 = (uint32_t)__builtin_ctz(zblocks);
-                zq = pick<R>(q, j0);
+                zq = pick<R>(qq, j0);
                 zsusp = pick<R>(val, j0) == 0 && zq != 0;
             }
         }
+        };
+        if (SPLIT && reentered) reload_quads(q, r);
+        prepare(q);
         const bool zero_round = zblocks != 0;
         uint32_t tokaddr = lane == 0 ? sy + kSyD : sy + kSySink + 4u * lane;
         uint32_t tokval = (r + 1u) << 1;                                          // (in its register before the wait, like the operands)
@@ -806,7 +953,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
                 clk.stamp(r, 2, lane);
                 // EARLY: the next round's quads are asked for HERE, a signature pass and a commit wait earlier than behind the commit (their
                 // latency under load is of the order of a whole emit); once per round, whatever becomes of it (an abort re-enters the loop)
-                if (EARLY && kKeepQuads && !prefetched && r + W < nrounds) { prefetch_quads<R, W>(src + (uint64_t)(r + W) * (R * kBlock) + 4u * lane); prefetched = true; }
+                if constexpr (EARLY && KEEP) if (!prefetched && r + W < nrounds) { prefetch_quads<R, W>(src + (uint64_t)(r + W) * (R * kBlock) + 4u * lane); prefetched = true; }
                 // The signatures (chameleon.rs:90-99: MAP flag = 1 iff the slot held this quad), block j's into lane j of slo / shi.  gfx950: an SGPR
                 // written by a VALU instruction — the compare — needs 2 wait states before a VALU instruction — the lane write — reads it, which the
                 // compiler sees to in its own code but not inside an asm statement: so block j's two lane writes go out behind block j + 1's compare
@@ -845,7 +992,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
                 }
                 uint32_t hits = 0;                                                                        // (only the rare zero-entry path below wants the count itself)
                 asm volatile("" : "+s"(inc), "+s"(sum));                        // computed HERE: left to itself the compiler sinks both — and the 16 signatures they need — below the token wait, into the commit
-                if (!kKeepQuads) load_round(q, r);                        // the quads again (from L2): not kept across the wait for the token
+                if (!kKeepQuads && !SPLIT) load_round(q, r);              // the quads again (from L2): not kept across the wait for the token (split: the emit wave has them)
                 clk.mark(3);
                 // ---- O chain: commit ----
                 bool aborted = false;
@@ -864,12 +1011,15 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
                 // and not just never anything.  `flipped`: the marks this round set itself (taken back if the round is rolled back).
                 uint32_t flipped = 0;
                 if (__builtin_expect(zero_round, 0)) {
+                    uint32_t qz_[R];
+                    if constexpr (SPLIT) reload_quads(qz_, r);
+                    const uint32_t (&qz)[R] = *(SPLIT ? &qz_ : &q);
                     clk.note(r, 1, lane);
                     hits = (R * (kSig + kBlock) - sum) >> 1;
                     bool first = true;
                     for (uint32_t zb = zblocks; zb; zb &= zb - 1u, first = false) {
                         const uint32_t j = (uint32_t)__builtin_ctz(zb);
-                        const uint32_t qv = first ? zq : pick<R>(q, j);
+                        const uint32_t qv = first ? zq : pick<R>(qz, j);
                         const bool susp = first ? zsusp : (pick<R>(val, j) == 0 && qv != 0);
                         const uint32_t zbit = zmap_claim_in_order(zmap, susp, (qv * kHashMul) >> 16, lane);
                         flipped |= (susp && !zbit ? 1u : 0u) << j;
@@ -886,9 +1036,12 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
                 const uint32_t t = inc & ((inc << 1) | ((P1 >> 16) & 1u));
                 if (__builtin_expect((P1 & 0xffu) != 0 || (t & ((1u << (R - 1)) - 1u)) != 0, 0)) {
                     if (ballot64(flipped != 0)) {
+                        uint32_t qz_[R];
+                        if constexpr (SPLIT) reload_quads(qz_, r);
+                        const uint32_t (&qz)[R] = *(SPLIT ? &qz_ : &q);
                         for (uint32_t zb = zblocks; zb; zb &= zb - 1u) {
                             const uint32_t j = (uint32_t)__builtin_ctz(zb);
-                            if ((flipped >> j) & 1u) zmap.clear((pick<R>(q, j) * kHashMul) >> 16);
+                            if ((flipped >> j) & 1u) zmap.clear((pick<R>(qz, j) * kHashMul) >> 16);
                         }
                     }
                     // (the chunk's abort count, for the ordered rounds' patience: this wave holds the commit token, the payload is its to amend)
@@ -917,7 +1070,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
                 __builtin_amdgcn_s_setprio(0);
                 fast_commit = true;
                 if (PAGED && refill) page_refill();
-                if (kKeepQuads && !prefetched && r + W < nrounds) prefetch_quads<R, W>(src + (uint64_t)(r + W) * (R * kBlock) + 4u * lane);   // next round's quads: in flight behind the commit, landed by the end of the emit
+                if constexpr (KEEP) if (!prefetched && r + W < nrounds) prefetch_quads<R, W>(src + (uint64_t)(r + W) * (R * kBlock) + 4u * lane);   // next round's quads: in flight behind the commit, landed by the end of the emit
                 clk.mark(4);
                 clk.count(0, lane);
                 poll_tries = 16;
@@ -950,7 +1103,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
                     }
                     if (aborted) continue;
                     have_turn = true;
-                    if (!kKeepQuads) load_round(q, r);                            // (as in the fast path: the quads are not kept across the waits)
+                    if (!kKeepQuads && !SPLIT) load_round(q, r);                  // (as in the fast path: the quads are not kept across the waits; split: every use below loads its own)
                     // (a fresh chunk's first round is the cold start — raw copies for certain, nothing to predict —, and the rare zero-entry quads
                     // are settled block by block: those rounds are walked in order, below)
                     if (!zero_round && !(r == 0 && !seg.init_images)) {
@@ -1034,7 +1187,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
             if (!batched) {
                 clk.count(3, lane);
                 slo = 0; shi = 0;
-                park(0, q);                                                       // (a rolled loop, as in rollback_round)
+                if constexpr (SPLIT) { uint32_t t[R]; reload_quads(t, r); park(0, t); } else park(0, q);   // (a rolled loop, as in rollback_round)
 #pragma nounroll
                 for (uint32_t j = 0; j < R; ++j) {
                     const uint32_t qv = parked(0, j);
@@ -1062,7 +1215,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
                 lds_poke(sy + kSyO, r + 1u);
                 lds_poke(sy + kSyD, ((r + 1u) << 1) | stay_slow);
             }
-            if (kKeepQuads && !prefetched && r + W < nrounds) prefetch_quads<R, W>(src + (uint64_t)(r + W) * (R * kBlock) + 4u * lane);   // (as behind a fast commit)
+            if constexpr (KEEP) if (!prefetched && r + W < nrounds) prefetch_quads<R, W>(src + (uint64_t)(r + W) * (R * kBlock) + 4u * lane);   // (as behind a fast commit)
             poll_tries = 2;
             if (PAGED && refill) page_refill();
             clk.mark(7);
@@ -1073,22 +1226,30 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
         clk.mark(5);
 
         // ---- emit: records of this round and their block-index bytes ----
-        if (__builtin_expect(copy_mask == 0, 1)) {
-            emit_round_coded(opos, idx ? idx + (uint64_t)r * R : nullptr, slo, shi);
+        if (SPLIT && copy_mask == 0) {
+            mbox_post(r, opos, slo, shi, 0u);                                     // the partner writes the records (it has the quads)
+        } else if (__builtin_expect(copy_mask == 0, 1)) {
+            emit_round_coded(q, opos, idx ? idx + (uint64_t)r * R : nullptr, slo, shi);
         } else {
             // (unrolled since round 5 — ordered rounds made incompressible data a common case: the rolled loop picked every block's quads out of
             // the registers by a chain of selects, ten thousand cycles a round)
             uint8_t* rec = dst + opos;
+            uint32_t qe_[R];
+            if constexpr (SPLIT) reload_quads(qe_, r);
+            const uint32_t (&qe)[R] = *(SPLIT ? &qe_ : &q);
             if (idx && lane < R) idx[(uint64_t)r * R + lane] = (uint8_t)(((copy_mask >> lane) & 1u) ? kIdxCopy : (uint32_t)(__builtin_popcount(slo) + __builtin_popcount(shi)));
 #pragma unroll
             for (uint32_t j = 0; j < R; ++j) {
                 const bool raw = (copy_mask >> j) & 1u;
                 const uint64_t sg = ((uint64_t)rlane_u(shi, (int)j) << 32) | rlane_u(slo, (int)j);
-                emit_block(rec, q[j], sg, raw);
+                emit_block(rec, qe[j], sg, raw);
                 rec += raw ? kBlock : kSig + kBlock - 2u * (uint32_t)__builtin_popcountll(sg);
             }
+            if (SPLIT) mbox_post(r, opos, slo, shi, 1u);                          // (the partner drops its copy of the round)
         }
-        if (kKeepQuads) {
+        if constexpr (SPLIT) {
+            // (the next round's quads come out of the ring at the top of the loop)
+        } else if constexpr (KEEP) {
             // (both ways out of the round have asked for the next one's quads)
             if (r + W < nrounds) {
                 // behind a fast commit at least R stores are younger than the R loads (emit_round_coded: one store per record, one or two for the
@@ -1100,6 +1261,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
         }
         clk.mark(6);
         clk.stamp(r, 3, lane);
+    }
     }
     clk.flush(wave, lane);
 
@@ -1147,7 +1309,7 @@ __global__ __launch_bounds__(W * 64) void chameleon_encode_rot(const uint8_t* __
         wg_barrier();
         uint4* image = reinterpret_cast<uint4*>(seg.final_images + chunk * kSegImageBytes);
         const uint4* p = reinterpret_cast<const uint4*>(smem);
-        for (uint32_t i = threadIdx.x; i < (kTableBytes + kZmapBytes) / 16; i += W * 64) image[i] = p[i];
+        for (uint32_t i = threadIdx.x; i < (kTableBytes + kZmapBytes) / 16; i += kThreads) image[i] = p[i];
     }
 }
 
@@ -2002,6 +2164,8 @@ uint32_t rot_tune() {
 }
 }  // namespace
 
+bool g_rotor_split = kRotorSplitDefault;
+constexpr int kSplitRound = 16;                // blocks per round of the split encoder: 12 fit the 128 registers sixteen waves have (16 spill: DESIGN.md 4.3)
 bool rotor_encode_eligible(const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks) {
     const bool aligned = ((uintptr_t)d_in % 4 == 0) && (n_chunks == 1 || chunk_bytes % 4 == 0);
     return aligned && (n_chunks == 1 ? total : chunk_bytes) < (1ull << 31);   // 32-bit stream positions
@@ -2015,6 +2179,15 @@ hipError_t launch_rotor_encode(const uint8_t* d_in, uint64_t total, uint64_t chu
     // The default asks for the next round's quads right behind its exchanges (EARLY: 2 % faster than behind the commit); bit 8: behind the commit
     const uint32_t sel = (rot_tune() >> 2) & 7u;
     const bool early = !((rot_tune() >> 8) & 1u);
+    if (g_rotor_split && sel == 0) {
+        // the split encoder (round 5): 8 chain + 8 emit waves, the quads handed over through an LDS ring (kernel variant bit 11 selects the other one)
+        auto ks = prof ? chameleon_encode_rot<kSplitRound, 8, true, false, false, false, true> : chameleon_encode_rot<kSplitRound, 8, false, false, false, false, true>;
+        hipError_t es = hipFuncSetAttribute((const void*)ks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEncLdsSplit);
+        if (es != hipSuccess) return es;
+        hipLaunchKernelGGL(ks, dim3(n_chunks), dim3(1024), kEncLdsSplit, stream, d_in, total, chunk_bytes, d_out, out_stride, d_sizes, d_index, d_err, SegArgs{}, prof);
+        rot_prof_report("encode (split)", "- | ring wait / D wait | exchange | signatures | O wait+commit / mail box wait | ring take / loads issued | emit / post | in-order rounds", prof, stream, 16);
+        return hipGetLastError();
+    }
     const uint32_t waves = sel == 1 ? 16 : sel == 2 ? 12 : 8;
     auto kernel = sel == 1 ? (prof ? chameleon_encode_rot<8, 16, true> : chameleon_encode_rot<8, 16, false>)
                 : sel == 2 ? (prof ? chameleon_encode_rot<16, 12, true> : chameleon_encode_rot<16, 12, false>)
@@ -2028,12 +2201,13 @@ hipError_t launch_rotor_encode(const uint8_t* d_in, uint64_t total, uint64_t chu
 }
 hipError_t launch_rotor_encode_paged(const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_pages, uint32_t page_limit,
                                      uint32_t* d_page_counter, uint32_t* d_dir, uint32_t dir_words, uint64_t* d_sizes, uint8_t* d_index, uint32_t* d_err, hipStream_t stream) {
-    auto kernel = chameleon_encode_rot<16, 8, false, true, true, true>;
-    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEncLds);
+    auto kernel = g_rotor_split ? chameleon_encode_rot<kSplitRound, 8, false, false, false, true, true> : chameleon_encode_rot<16, 8, false, true, true, true>;
+    const uint32_t lds = g_rotor_split ? kEncLdsSplit : kEncLds;
+    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     SegArgs pg;
     pg.page_counter = d_page_counter; pg.page_dir = d_dir; pg.page_dir_words = dir_words; pg.page_limit = page_limit;
-    hipLaunchKernelGGL(kernel, dim3(n_chunks), dim3(512), kEncLds, stream, d_in, total, chunk_bytes, d_pages, (uint64_t)0, d_sizes, d_index, d_err, pg, (uint64_t*)nullptr);
+    hipLaunchKernelGGL(kernel, dim3(n_chunks), dim3(g_rotor_split ? 1024 : 512), lds, stream, d_in, total, chunk_bytes, d_pages, (uint64_t)0, d_sizes, d_index, d_err, pg, (uint64_t*)nullptr);
     return hipGetLastError();
 }
 bool rotor_decode_eligible(const uint8_t* d_out, uint32_t n_chunks, uint64_t out_stride, uint64_t out_total, const uint8_t* d_index, const uint32_t* d_zmap) {
@@ -2093,10 +2267,11 @@ hipError_t launch_rotor_selftest(uint32_t* d_fail, hipStream_t stream) {
 
 hipError_t launch_rotor_encode_seg(const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_out, uint64_t out_stride,
                                    uint64_t* d_sizes, uint32_t* d_err, SegArgs seg, hipStream_t stream) {
-    auto kernel = chameleon_encode_rot<16, 8, false, true, true>;
-    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEncLds);
+    auto kernel = g_rotor_split ? chameleon_encode_rot<kSplitRound, 8, false, false, false, false, true> : chameleon_encode_rot<16, 8, false, true, true>;
+    const uint32_t lds = g_rotor_split ? kEncLdsSplit : kEncLds;
+    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kernel, dim3(n_chunks), dim3(512), kEncLds, stream, d_in, total, chunk_bytes, d_out, out_stride, d_sizes, (uint8_t*)nullptr, d_err, seg, (uint64_t*)nullptr);
+    hipLaunchKernelGGL(kernel, dim3(n_chunks), dim3(g_rotor_split ? 1024 : 512), lds, stream, d_in, total, chunk_bytes, d_out, out_stride, d_sizes, (uint8_t*)nullptr, d_err, seg, (uint64_t*)nullptr);
     return hipGetLastError();
 }
 hipError_t launch_rotor_lastwriters(const uint8_t* d_in, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_images, uint32_t* d_err, hipStream_t stream) {

@@ -17,7 +17,8 @@ KAT = json.load(open(os.path.join(HERE, "golden", "kat.json")))
 ALGO = "chameleon"
 
 
-VARIANTS = {"rotor": 0, "rotor-noindex": 2, "pipelined": 4, "pipelined-noindex": 6, "simple": 1, "rotor-hostpipe": 256}   # 256: the host-pointer container calls pipelined whatever the size, a slice per chunk
+VARIANTS = {"rotor": 0, "rotor-noindex": 2, "pipelined": 4, "pipelined-noindex": 6, "simple": 1, "rotor-hostpipe": 256,
+            "rotor-alt": 2048}   # 2048: the OTHER rotation encoder (kernels.hpp kRotorSplitDefault: the split one — 8 chain + 8 emit waves — or the 8-wave one)   # 256: the host-pointer container calls pipelined whatever the size, a slice per chunk
 
 
 @pytest.fixture(autouse=True, params=list(VARIANTS))

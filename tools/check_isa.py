@@ -88,7 +88,20 @@ def main():
     total = bad = 0
     for name, body in funcs.items():
         # every encoder instance with kept quads (last template argument): 8 waves stage in v(256-R)..v255, 12 waves in v(168-R)..v167
-        m = re.match(r"^_ZN7density20chameleon_encode_rotILi(\d+)ELi(\d+)ELb[01]ELb1ELb[01]ELb[01]EE", name)   # (<R, W, kProf, KEEP, EARLY, PAGED>)
+        ms = re.match(r"^_ZN7density20chameleon_encode_rotILi(\d+)ELi(\d+)ELb[01]ELb0ELb0ELb[01]ELb1EE", name)   # (<R, W, kProf, KEEP, EARLY, PAGED, SPLIT>: the split encoder)
+        if ms:
+            # sixteen waves share the CU: 128 registers each.  The common path of a chain wave must not touch scratch memory (a reload between the
+            # token and the first exchange is hundreds of cycles of the critical section): from the ring's reads to the round's exchanges nothing but
+            # what the rare paths (laid out in between) need — a handful of spills in all, none of them next to the exchanges
+            R = int(ms.group(1))
+            first = next((k for k, t in enumerate(body) if t.startswith("ds_mskor_rtn_b32")), None)
+            near = [t for t in body[max(0, (first or 0) - 12):(first or 0) + R + 4] if t.startswith("scratch_")]
+            spills = sum(t.startswith("scratch_") for t in body)
+            if first is None or near or spills > 64:
+                print(f"{name}: split encoder: scratch traffic at the exchanges {near} / {spills} scratch instructions in all")
+                bad += 1
+            continue
+        m = re.match(r"^_ZN7density20chameleon_encode_rotILi(\d+)ELi(\d+)ELb[01]ELb1ELb[01]ELb[01]ELb0EE", name)   # (<R, W, kProf, KEEP, EARLY, PAGED, SPLIT>)
         if not m:
             continue
         g, b = check_function(name, int(m.group(1)), body, 256 if int(m.group(2)) == 8 else 168)
