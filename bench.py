@@ -280,7 +280,7 @@ def other_config(container, algo, label, host, steps=3, warmup=1, cpu_sample=32 
     E = int(hdr.container_len)                                                         # the packed container: the algorithmic E
     _, payloads = container.chunk_payloads(cont[:E].cpu().numpy())
     # timed like the headline workload: the slotted container (no stitch pass; same chunk streams)
-    back.zero_()
+    back.zero_(); torch.cuda.synchronize()                 # (a null caller stream means the library's own stream: not ordered behind torch's memset)
     hdr = container.encode_device_slotted(algo, x.data_ptr(), n, cont.data_ptr(), cap, chunk, stream=s)
     Ec = int(hdr.container_len)
     assert container.decode_device(cont.data_ptr(), Ec, back.data_ptr(), n, header=hdr, stream=s) == n and torch.equal(back, x), f"{algo}: round trip mismatch (slotted)"
@@ -521,7 +521,7 @@ def main():
     if form != "packed":
         # the timed form: decodes to the input, and its chunk streams — read the way a CPU reader of the container reads them (slots / page
         # directory: container.chunk_payloads) — are byte for byte the packed container's, i.e. the oracle's
-        back.zero_()
+        back.zero_(); torch.cuda.synchronize()         # (a null caller stream means the library's own stream: not ordered behind torch's memset)
         hdr = enc_dev(algo, x.data_ptr(), n, cont.data_ptr(), cap, chunk, stream=s, workspace=(ws.data_ptr(), ws_size))
         Ec = int(hdr.container_len)
         if form == "paged" and not (hdr.flags & container.FLAG_PAGED):

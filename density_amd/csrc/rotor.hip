@@ -754,6 +754,7 @@ __global__ __launch_bounds__(SPLIT ? 2 * W * 64 : W * 64) void chameleon_encode_
     auto ring_take = [&](uint32_t (&d)[R], uint32_t r) {
         const uint32_t slot = r % kRingSlots;
         for (uint32_t spins = 0; !poll_word(kEncRingSync + 4u * slot, r + 1u, 4);) { join_abort(); __builtin_amdgcn_s_sleep(1); watchdog(spins, sy, err, lane); }
+        clk.mark(5);
         const uint32_t at = kEncRing + slot * kSlotBytes + 4u * lane;
         // (one statement, issue to wait: an answer of an asynchronous LDS read exists for the compiler only when the statement ends)
         if constexpr (R == 16) asm volatile("ds_read_b32 %0, %16 offset:0\n\t"
@@ -795,8 +796,13 @@ __global__ __launch_bounds__(SPLIT ? 2 * W * 64 : W * 64) void chameleon_encode_
     // emit wave: round r's quads into the ring, once the chain wave of round r - kRingSlots has drained the slot
     auto ring_put = [&](const uint32_t (&d)[R], uint32_t r) {
         const uint32_t slot = r % kRingSlots;
-        if (r >= kRingSlots)
-            for (uint32_t spins = 0; !poll_word(kEncRingSync + 16u + 4u * slot, r + 1u - kRingSlots, 2);) { join_abort(); __builtin_amdgcn_s_sleep(4); watchdog(spins, sy, err, lane); }
+        // (this wave is idle most of a round — it waits here for about five hand-offs of the chain —: long naps at the lowest priority, so that its
+        // polls take neither LDS cycles from the exchanges nor issue slots from the waves it waits for)
+        if (r >= kRingSlots) {
+            __builtin_amdgcn_s_setprio(0);
+            for (uint32_t spins = 0; !poll_word(kEncRingSync + 16u + 4u * slot, r + 1u - kRingSlots, 1);) { join_abort(); __builtin_amdgcn_s_sleep(12); watchdog(spins, sy, err, lane); }
+            __builtin_amdgcn_s_setprio(1);
+        }
         const uint32_t base = kEncRing + slot * kSlotBytes + 4u * lane;
 #pragma unroll
         for (uint32_t j = 0; j < R; ++j) DENSITY_LDS_POKE_AT(base, j * 256u, d[j]);
@@ -814,11 +820,13 @@ __global__ __launch_bounds__(SPLIT ? 2 * W * 64 : W * 64) void chameleon_encode_
     auto mbox_wait = [&](uint32_t e, uint32_t r, uint32_t& pos, uint32_t& lo, uint32_t& hi) -> bool {
         const uint32_t mb = kEncMbox + kMboxBytes * e;
         uint32_t seq;
+        __builtin_amdgcn_s_setprio(0);
         for (uint32_t spins = 0;;) {
             seq = rfl(lds_peek1(mb + 128u));
             if ((seq >> 1) == r + 1u) break;
-            join_abort(); __builtin_amdgcn_s_sleep(4); watchdog(spins, sy, err, lane);
+            join_abort(); __builtin_amdgcn_s_sleep(6); watchdog(spins, sy, err, lane);
         }
+        __builtin_amdgcn_s_setprio(1);
         pos = rfl(lds_peek1(mb + 132u));
         const u32x2 sg = lds_peek2(mb + 8u * (lane < R ? lane : 0u));
         lo = lane < R ? sg.x : 0u; hi = lane < R ? sg.y : 0u;
@@ -826,32 +834,48 @@ __global__ __launch_bounds__(SPLIT ? 2 * W * 64 : W * 64) void chameleon_encode_
         return (seq & 1u) != 0;
     };
     if (SPLIT && wave >= (uint32_t)W) {
-        // ---- emit wave e: loads the rounds e, e + 8, ... (plain loads: nothing else of this wave waits on the memory queue), hands their quads to the
-        // chain wave e through the ring — a round ahead of the one it is about to write out — and writes a round's records once the chain wave has
-        // committed it (mail box).  Two register sets: the round waiting for its commit and the next one.
-        __builtin_amdgcn_s_setprio(0);
+        // ---- emit wave e: loads the rounds e, e + 8, ..., hands their quads to the chain wave e through the ring — a round ahead of the one it is
+        // about to write out — and writes a round's records once the chain wave has committed it (mail box).  Three register sets: the round waiting
+        // for its commit, the next one (on its way into the ring) and the one after that, whose loads are issued BEFORE the wait for the commit and
+        // the emit, so that their latency lies under both.
+        // The memory queue and the compiler: its bookkeeping cannot see the record stores (issued inside asm statements) and is conservative across
+        // the loop's edge, so a wait it places for a LOAD also waits for stores it does not know of.  Inside the emit that was ruinous (measured:
+        // 4600 instead of 2600 cycles per round — from the ninth record on, every record waited for the acknowledgement of an older record's store),
+        // so the quads are "laundered" once they have landed: an empty statement that redefines them, after which the compiler attaches no pending
+        // load to them and the emit runs without a wait.  What is left is one over-long wait per round, in front of the ring transfer (the loads it
+        // waits for were issued before the last emit's stores: it sits that emit's stores out too), where this wave has slack.  (Loads issued by hand,
+        // out of the compiler's sight, were tried: it copies the "defined" registers at the loop's edge before they have landed — tools/check_isa.py
+        // finds such copies.)
+        // Priority 1 like a chain wave that hashes: below the chain's critical steps (2, 3), above the waves that only poll for this one's work (0).
+        __builtin_amdgcn_s_setprio(1);
         const uint32_t e = wave - W;
-        uint32_t qa[R], qb[R];
+        auto launder = [&](uint32_t (&d)[R]) {
 #pragma unroll
-        for (uint32_t j = 0; j < R; ++j) { qa[j] = 0; qb[j] = 0; }
+            for (uint32_t j = 0; j < R; ++j) asm volatile("" : "+v"(d[j]));
+        };
+        uint32_t qa[R], qb[R], qc[R];
+#pragma unroll
+        for (uint32_t j = 0; j < R; ++j) { qa[j] = 0; qb[j] = 0; qc[j] = 0; }
         load_round(qa, e);
         if (e < nrounds) ring_put(qa, e);
+        launder(qa);
         load_round(qb, e + W);
-        auto step = [&](uint32_t (&cur)[R], uint32_t (&nxt)[R], uint32_t r) {
+        auto step = [&](uint32_t (&cur)[R], uint32_t (&nxt)[R], uint32_t (&fut)[R], uint32_t r) {
             clk.start();
             if (r + W < nrounds) ring_put(nxt, r + W);
+            launder(nxt);
             clk.mark(1);
+            load_round(fut, r + 2u * W);
             uint32_t pos, lo, hi;
             const bool skip = mbox_wait(e, r, pos, lo, hi);
             clk.mark(4);
             if (!skip) emit_round_coded(cur, pos, idx ? idx + (uint64_t)r * R : nullptr, lo, hi);
             clk.mark(6);
-            load_round(cur, r + 2u * W);
-            clk.mark(5);
         };
-        for (uint32_t r = e; r < nrounds; r += 2u * W) {
-            step(qa, qb, r);
-            if (r + W < nrounds) step(qb, qa, r + W);
+        for (uint32_t r = e; r < nrounds; r += 3u * W) {
+            step(qa, qb, qc, r);
+            if (r + W < nrounds) step(qb, qc, qa, r + W);
+            if (r + 2u * W < nrounds) step(qc, qa, qb, r + 2u * W);
         }
     } else {
     if constexpr (KEEP) {
@@ -865,7 +889,7 @@ __global__ __launch_bounds__(SPLIT ? 2 * W * 64 : W * 64) void chameleon_encode_
     for (uint32_t r = wave; r < nrounds; r += W) {
         clk.start();
         __builtin_amdgcn_s_setprio(1);                                   // (see the priorities note at the exchange)
-        if (SPLIT) { cur_round = r; ring_take(q, r); clk.mark(5); }
+        if (SPLIT) { cur_round = r; ring_take(q, r); clk.mark(7); }
         uint32_t slo = 0, shi = 0;                                                // lane j: the signature of block j (codec.rs:24-26)
         uint32_t copy_mask = 0, opos = 0;
         bool fast_commit = false, prefetched = false;
@@ -1227,6 +1251,7 @@ __global__ __launch_bounds__(SPLIT ? 2 * W * 64 : W * 64) void chameleon_encode_
 
         // ---- emit: records of this round and their block-index bytes ----
         if (SPLIT && copy_mask == 0) {
+            __builtin_amdgcn_s_setprio(1);
             mbox_post(r, opos, slo, shi, 0u);                                     // the partner writes the records (it has the quads)
         } else if (__builtin_expect(copy_mask == 0, 1)) {
             emit_round_coded(q, opos, idx ? idx + (uint64_t)r * R : nullptr, slo, shi);
@@ -2185,7 +2210,7 @@ hipError_t launch_rotor_encode(const uint8_t* d_in, uint64_t total, uint64_t chu
         hipError_t es = hipFuncSetAttribute((const void*)ks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEncLdsSplit);
         if (es != hipSuccess) return es;
         hipLaunchKernelGGL(ks, dim3(n_chunks), dim3(1024), kEncLdsSplit, stream, d_in, total, chunk_bytes, d_out, out_stride, d_sizes, d_index, d_err, SegArgs{}, prof);
-        rot_prof_report("encode (split)", "- | ring wait / D wait | exchange | signatures | O wait+commit / mail box wait | ring take / loads issued | emit / post | in-order rounds", prof, stream, 16);
+        rot_prof_report("encode (split)", "chain waves 0-7: hash | D wait | exchange | signatures | O wait+commit | ring: wait for the quads | post | ring: the reads (+ in-order rounds);  emit waves 8-15: - | ring transfer incl. the wait for the slot | - | - | mail box wait | - | emit | -", prof, stream, 16);
         return hipGetLastError();
     }
     const uint32_t waves = sel == 1 ? 16 : sel == 2 ? 12 : 8;

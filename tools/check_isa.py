@@ -100,6 +100,26 @@ def main():
             if first is None or near or spills > 64:
                 print(f"{name}: split encoder: scratch traffic at the exchanges {near} / {spills} scratch instructions in all")
                 bad += 1
+            # the emit waves' hand-issued loads (SGPR base + 32-bit offset): their destination registers are not named by any instruction before a
+            # wait on the memory queue (the statement that claims them) — the compiler, which takes them for defined values, has moved or read none
+            hand = 0
+            for k, t in enumerate(body):
+                m2 = re.match(r"^global_load_dword v(\d+), v\d+, s\[\d+:\d+\]", t)
+                if not m2:
+                    continue
+                hand += 1
+                x = int(m2.group(1))
+                for u in body[k + 1:]:
+                    if u.startswith("s_waitcnt") and "vmcnt(" in u:
+                        break
+                    if x in regs_of(u) and not re.match(r"^global_load_dword v\d+, v\d+, s\[", u):
+                        print(f"{name}: v{x}, in flight since `{t}`, is named by `{u}` before any wait on the memory queue")
+                        bad += 1
+                        break
+            if not hand:
+                print(f"{name}: split encoder: no hand-issued loads found")
+                bad += 1
+            total += hand
             continue
         m = re.match(r"^_ZN7density20chameleon_encode_rotILi(\d+)ELi(\d+)ELb[01]ELb1ELb[01]ELb[01]ELb0EE", name)   # (<R, W, kProf, KEEP, EARLY, PAGED, SPLIT>)
         if not m:

@@ -25,7 +25,7 @@ for rep in range(2):
     for name, enc in forms.items():
         hdr = enc("chameleon", x.data_ptr(), n, cont.data_ptr(), cap, chunk, stream=s)
         te = timed(lambda: enc("chameleon", x.data_ptr(), n, cont.data_ptr(), cap, chunk, stream=s, want_header=False))
-        back.zero_()
+        back.zero_(); torch.cuda.synchronize()
         td = timed(lambda: container.decode_device(cont.data_ptr(), hdr.container_len, back.data_ptr(), n, header=hdr, stream=s, sync=False))
         e, d = sum(te.values()), sum(td.values())
         print(f"{name:>8}: encode {e:.4f} ms ({', '.join(f'{k} {v:.4f}' for k, v in te.items())})  decode {d:.4f} ms  round trip {n / (e + d) / 1e6:.1f} GB/s  "

@@ -1,7 +1,15 @@
 #!/bin/bash
 # The round's ONE GPU job script (rewritten per call; git history keeps the versions): gpurun -- 'bash tools/gpu_job.sh'
-# r5a: the split encoder (8 chain + 8 emit waves) against the 8-wave one — parity of the split one first, then the A/B
-T=gpurun_out/r5a; mkdir -p $T; export TMPDIR=/tmp
-timeout 420 python -m pytest tests/test_gpu_chameleon.py -m gpu -x -q -k "rotor-alt" 2>&1 | grep -v amdgpu.ids | tail -15 | tee $T/pytest_alt.txt
-DENSITY_TEST_VARIANT=2048 timeout 300 python -m pytest tests/test_gpu_paged.py tests/test_gpu_slotted.py tests/test_gpu_shipped_configs.py -m gpu -x -q 2>&1 | grep -v amdgpu.ids | tail -8 | tee $T/pytest_alt2.txt
-timeout 400 python tools/gpu_split_ab.py 10 2>&1 | grep -v amdgpu.ids | tee $T/split_ab.txt
+# r5g: the whole GPU suite on the tree's library, then the bench line (paged container as the headline)
+T=gpurun_out/r5g; mkdir -p $T; export TMPDIR=/tmp
+timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | grep -v amdgpu.ids | tail -12 | tee $T/suite.txt
+timeout 600 python bench.py > $T/bench.json 2> $T/bench.err; echo "bench rc=$?"; tail -3 $T/bench.err
+python - <<'PY'
+import json
+r = json.load(open("gpurun_out/r5g/bench.json"))
+print({k: r[k] for k in ("value", "ms_per_step", "compression_ratio", "encoded_bytes", "container_form", "value_packed", "value_slotted", "encode_ms", "decode_ms", "kernel_ms")})
+print(r["roofline"])
+print({k: r["cpu_baseline"][k] for k in ("value", "encode_MBps", "decode_MBps")}, r["cpu_baseline"]["all_cores"])
+for o in r.get("data_kinds", []) + r.get("other_configs", []):
+    print(o.get("config", "")[:60], o.get("value"), o.get("encode_ms"), o.get("decode_ms"), o.get("compression_ratio"), (o.get("cpu_baseline") or {}).get("all_cores"))
+PY
