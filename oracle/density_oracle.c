@@ -327,3 +327,43 @@ done:
 EXPORT_ALGO(chameleon, ALGO_CHAMELEON)
 EXPORT_ALGO(cheetah, ALGO_CHEETAH)
 EXPORT_ALGO(lion, ALGO_LION)
+
+/* ---- the chunks of a buffer on all host cores (bench.py's all-cores baseline: SURVEY.md 8d "N-thread run over the same chunks") ----
+ * Chunk i of `in` (chunk bytes, the last one shorter) is one independent reference stream — what the container holds —, written to / read from
+ * out + i * stride; one chunk per task (OpenMP, dynamic schedule); sizes[i] = the stream's length.  Returns the number of chunks that failed. */
+#include <malloc.h>
+static void keep_tables_on_the_heap(void) {
+    /* a stream's tables (256 KiB .. 1.75 MiB, calloc'ed per stream like the reference's Vec per call) would be mapped and unmapped per chunk: with a few
+     * hundred threads that is one address-space lock for all of them (measured: Cheetah 0.3 GB/s on 255 threads).  Kept in the threads' arenas instead. */
+    static int done = 0;
+    if (!done) { mallopt(M_MMAP_THRESHOLD, 1 << 30); mallopt(M_TRIM_THRESHOLD, 1 << 30); done = 1; }
+}
+ORACLE_API int oracle_encode_chunks_mt(int algo, const uint8_t* in, size_t n, size_t chunk, uint8_t* out, size_t stride, uint64_t* sizes, int threads) {
+    keep_tables_on_the_heap();
+    const long n_chunks = (long)((n + chunk - 1) / chunk);
+    int bad = 0;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads) reduction(+ : bad)
+    for (long i = 0; i < n_chunks; ++i) {
+        const size_t len = (size_t)(i + 1) * chunk <= n ? chunk : n - (size_t)i * chunk;
+        const uint8_t* p = in + (size_t)i * chunk; uint8_t* o = out + (size_t)i * stride;
+        const size_t e = algo == ALGO_CHAMELEON ? encode_stream(ALGO_CHAMELEON, p, len, o, stride, NULL)
+                       : algo == ALGO_CHEETAH ? encode_stream(ALGO_CHEETAH, p, len, o, stride, NULL) : encode_stream(ALGO_LION, p, len, o, stride, NULL);
+        sizes[i] = e;
+        if (e == 0 && len != 0) ++bad;
+    }
+    return bad;
+}
+ORACLE_API int oracle_decode_chunks_mt(int algo, const uint8_t* in, size_t stride, const uint64_t* sizes, uint8_t* out, size_t n, size_t chunk, int threads) {
+    keep_tables_on_the_heap();
+    const long n_chunks = (long)((n + chunk - 1) / chunk);
+    int bad = 0;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads) reduction(+ : bad)
+    for (long i = 0; i < n_chunks; ++i) {
+        const size_t len = (size_t)(i + 1) * chunk <= n ? chunk : n - (size_t)i * chunk;
+        const uint8_t* p = in + (size_t)i * stride; uint8_t* o = out + (size_t)i * chunk;
+        const size_t d = algo == ALGO_CHAMELEON ? decode_stream(ALGO_CHAMELEON, p, (size_t)sizes[i], o, len)
+                       : algo == ALGO_CHEETAH ? decode_stream(ALGO_CHEETAH, p, (size_t)sizes[i], o, len) : decode_stream(ALGO_LION, p, (size_t)sizes[i], o, len);
+        if (d != len) ++bad;
+    }
+    return bad;
+}

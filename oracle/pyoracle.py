@@ -43,8 +43,21 @@ def lib():
             fn = getattr(L, f"oracle_{a}_safe_encode_buffer_size")
             fn.restype = ctypes.c_size_t
             fn.argtypes = [ctypes.c_size_t]
+        L.oracle_encode_chunks_mt.restype = ctypes.c_int
+        L.oracle_encode_chunks_mt.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int]
+        L.oracle_decode_chunks_mt.restype = ctypes.c_int
+        L.oracle_decode_chunks_mt.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int]
         _lib = L
     return _lib
+
+
+def encode_chunks_mt(algo, src_addr, n, chunk, dst_addr, stride, sizes_addr, threads):
+    """All chunks of a buffer, one chunk per OpenMP task (bench.py's all-cores baseline).  Returns the number of failed chunks."""
+    return lib().oracle_encode_chunks_mt(ALGOS.index(algo), src_addr, n, chunk, dst_addr, stride, sizes_addr, threads)
+
+
+def decode_chunks_mt(algo, src_addr, stride, sizes_addr, dst_addr, n, chunk, threads):
+    return lib().oracle_decode_chunks_mt(ALGOS.index(algo), src_addr, stride, sizes_addr, dst_addr, n, chunk, threads)
 
 
 def _as_buf(data):

@@ -27,7 +27,7 @@ def test_one_rank_rccl_runs_the_process_group_branch():
     mg = d["multi_gpu"]
     assert d["n_gpus"] == 1 and mg["process_group"] == "nccl (RCCL)"
     assert mg["concat_to_rank0_ms"] is not None and mg["concat_decodes_to_input"] is True
-    assert mg["global_container_bytes"] == d["encoded_bytes"]
+    assert mg["global_container_bytes"] == d["encoded_bytes_packed"]          # (the layout exchange is of the packed form; `encoded_bytes` describes the timed, paged one)
 
 
 def test_exchange_layout_and_concat_on_device_tensors():
