@@ -324,6 +324,28 @@ __device__ __forceinline__ void exchange_some<16>(uint32_t (&ra)[16], const uint
                  : "v"(mask[0]), "v"(mask[1]), "v"(mask[2]), "v"(mask[3]), "v"(mask[4]), "v"(mask[5]), "v"(mask[6]), "v"(mask[7]), "v"(mask[8]), "v"(mask[9]), "v"(mask[10]), "v"(mask[11]), "v"(mask[12]), "v"(mask[13]), "v"(mask[14]), "v"(mask[15]), "v"(val[0]), "v"(val[1]), "v"(val[2]), "v"(val[3]), "v"(val[4]), "v"(val[5]), "v"(val[6]), "v"(val[7]), "v"(val[8]), "v"(val[9]), "v"(val[10]), "v"(val[11]), "v"(val[12]), "v"(val[13]), "v"(val[14]), "v"(val[15]), [idle] "s"(idle)
                  : "memory", "scc");
 }
+// the same for a round that RUNS AHEAD (below): the dictionary token — its run-ahead words {state predicted for the next round, 1}, then the token
+// word — is written behind the exchanges in the same statement, by lane 0 alone, before their answers are waited for
+template <int R>
+__device__ __forceinline__ void exchange_some_ahead(uint32_t (&ra)[R], const uint32_t (&mask)[R], const uint32_t (&val)[R], uint32_t idle, uint32_t dline, uint32_t state, uint32_t token) {
+    exchange_some<R>(ra, mask, val, idle);
+    if ((threadIdx.x & 63u) == 0) { lds_poke2(dline + 8u, state, 1u); lds_poke(dline, token); }
+}
+template <>
+__device__ __forceinline__ void exchange_some_ahead<16>(uint32_t (&ra)[16], const uint32_t (&mask)[16], const uint32_t (&val)[16], uint32_t idle, uint32_t dline, uint32_t state, uint32_t token) {
+    const u32x2 words = {state, 1u};
+    const uint32_t dline2 = dline + 8u;
+    asm volatile(DENSITY_ROT_XC16
+                 "s_mov_b64 exec, 1\n\t"
+                 "ds_write_b64 %[d2], %[w]\n\t"
+                 "ds_write_b32 %[d], %[t]\n\t"
+                 "s_mov_b64 exec, -1\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(ra[4]), "+v"(ra[5]), "+v"(ra[6]), "+v"(ra[7]), "+v"(ra[8]), "+v"(ra[9]), "+v"(ra[10]), "+v"(ra[11]), "+v"(ra[12]), "+v"(ra[13]), "+v"(ra[14]), "+v"(ra[15])
+                 : "v"(mask[0]), "v"(mask[1]), "v"(mask[2]), "v"(mask[3]), "v"(mask[4]), "v"(mask[5]), "v"(mask[6]), "v"(mask[7]), "v"(mask[8]), "v"(mask[9]), "v"(mask[10]), "v"(mask[11]), "v"(mask[12]), "v"(mask[13]), "v"(mask[14]), "v"(mask[15]), "v"(val[0]), "v"(val[1]), "v"(val[2]), "v"(val[3]), "v"(val[4]), "v"(val[5]), "v"(val[6]), "v"(val[7]), "v"(val[8]), "v"(val[9]), "v"(val[10]), "v"(val[11]), "v"(val[12]), "v"(val[13]), "v"(val[14]), "v"(val[15]), [idle] "s"(idle),
+                   [d2] "v"(dline2), [w] "v"(words), [d] "v"(dline), [t] "v"(token)
+                 : "memory", "scc");
+}
 // (keeps a set of operands from being scheduled past this point, i.e. into the critical section behind the token wait)
 template <int R>
 __device__ __forceinline__ void pin_operands(uint32_t (&ra)[R], uint32_t (&mask)[R], uint32_t (&val)[R]) {
@@ -404,6 +426,7 @@ __device__ __forceinline__ void fsm_predict(uint32_t st, uint32_t j0, uint32_t s
 // on text at 1 GiB and 6 % faster at 10 MB — the cold start of every 64 KiB chunk is ordered rounds now, not block-by-block walks —, waiting for
 // 6 always costs text 1.3 % / 10 % / 13 % at 1 GiB / 100 MB / 10 MB; data that flips every few KiB aborts a work-group per flip when it leaves early.)
 __device__ __forceinline__ uint32_t quiet_rounds(uint32_t P1) { const uint32_t q = 2u + 2u * ((P1 >> 24) & 3u); return q > 7u ? 7u : q; }
+constexpr uint32_t kStormRounds = 3;                                              // ordered rounds of one unbroken incompressible stretch before the dictionary token runs ahead of the commit
 constexpr uint32_t kSpinLimit = 1u << 22, kPoison = 0xfffffffeu, kErrWatchdog = 16u;
 __device__ __forceinline__ void wave_exit() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_endpgm" ::: "memory"); }
 __device__ __forceinline__ void watchdog(uint32_t& spins, uint32_t sync_base, uint32_t* err, uint32_t lane) {
@@ -447,7 +470,7 @@ struct PhaseClock<true> {
         if (out && r < kProfRounds && lane == 0) out[128 + 4 * kProfRounds + r] = v;
     }
     __device__ __forceinline__ void flush(uint32_t wave, uint32_t lane) { if (out && lane == 0) for (int k = 0; k < 8; ++k) out[8 * wave + k] = ph[k]; }
-    // event counters of work-group 0 (encoder: 0 fast rounds committed, 1 ordered rounds that held, 2 ordered rounds taken back, 3 rounds walked in order, 4 aborts raised)
+    // event counters of work-group 0 (encoder: 0 fast rounds committed, 1 ordered rounds that held, 2 ordered rounds taken back, 3 rounds walked in order, 4 aborts raised, 5 ordered rounds that ran ahead)
     __device__ __forceinline__ void count(int k, uint32_t lane) { if (out && lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(out + 128 + 5 * kProfRounds + k), 1ull); }
 };
 
@@ -459,6 +482,14 @@ __device__ __forceinline__ void backoff(uint32_t dist) {
     if (dist > 8) __builtin_amdgcn_s_sleep(24);
     else if (dist > 4) __builtin_amdgcn_s_sleep(8);
     else __builtin_amdgcn_s_sleep(3);
+}
+// the same between ORDERED rounds, whose hand-offs take a thousand cycles and more: only the next wave polls, the others nap for most of their distance
+// (seven waves polling two 16-byte lines each kept the LDS busy enough to triple the round trip of the holder's own look-ups)
+__device__ __forceinline__ void backoff_ordered(uint32_t dist) {
+    if (dist <= 1) return;
+    if (dist > 4) __builtin_amdgcn_s_sleep(40);
+    else if (dist > 2) __builtin_amdgcn_s_sleep(20);
+    else __builtin_amdgcn_s_sleep(8);
 }
 // up to `tries` back-to-back polls of one token word for one value
 // (Written out: the compiled loop kept its counter in a vector register and took ten instructions per poll — every one of them between
@@ -698,15 +729,17 @@ __global__ __launch_bounds__(SPLIT ? 2 * W * 64 : W * 64) void chameleon_encode_
     // Abort protocol (all 16 waves; `holding`: this wave has exchanged `hold_round` and not committed it).  After the first
     // barrier nobody is inside a critical section, D says how far the dictionary got (rounds < d exchanged), A which round
     // failed; rounds d-1 .. A are rolled back one per barrier step by their owners, then the chain restarts at A in slow mode.
+    uint32_t hold_skip = 0;                                                       // blocks of the round this wave holds that exchanged nothing (a run-ahead round's predicted raw copies)
     auto abort_sync = [&](bool holding, uint32_t hold_round) {
         wg_barrier();
         const u32x2 v = lds_peek2(sy + kSyD);
         const uint32_t d = rfl(v.x) >> 1, a = rfl(v.y);
         for (uint32_t x = d; x-- > a;) {
-            if (holding && hold_round == x) rollback_round();
+            if (holding && hold_round == x) rollback_round(hold_skip);
             wg_barrier();
         }
         if (wave == a % W && lane == 0) {
+            lds_poke(sy + kSyD + 12, 0u);                                         // (no run-ahead behind an abort: the restarted round waits for its payload)
             lds_poke(sy + kSyD, (a << 1) | 1u);
             lds_poke(sy + kSyD + 4, kNone);
             lds_poke(sy + kSyO + 4, kNone);
@@ -896,7 +929,8 @@ __global__ __launch_bounds__(SPLIT ? 2 * W * 64 : W * 64) void chameleon_encode_
         // an ORDERED round (below): its commit payload, and how far it is final — blocks below it_j0, the FSM state in front of it_j0, the raw-copy
         // blocks (final below it_j0, predicted from there on), the prediction and the state behind the round if it holds
         uint32_t P0 = 0, P1 = 0, it_j0 = kNone, it_state = 0, it_raw = 0, it_mode = 0, it_end = 0;
-        bool have_turn = false;
+        bool have_turn = false, ahead = false;
+        hold_skip = 0;
       for (bool reentered = false;; reentered = true) {   // (re-entered after an abort, and by an ordered round whose prediction failed: the answers have replaced the addresses, so the operands are made again)
         uint32_t zblocks = 0, zq = 0;
         bool zsusp = false;
@@ -934,31 +968,33 @@ __global__ __launch_bounds__(SPLIT ? 2 * W * 64 : W * 64) void chameleon_encode_
         __builtin_amdgcn_s_setprio(2);
         {
             // ---- D chain: wait for this round's turn ----
-            uint32_t slow = 1;
+            uint32_t slow = 1, dS = 0, dF = 0;                                    // dS, dF: the D line's run-ahead words (below: ordered rounds that run ahead)
             bool got_payload = false;
             if (!have_turn)
             for (uint32_t spins = 0;;) {
                 if (poll_tries != 16) {
                     // this wave's last round was an ordered one: most likely this one is too, and then it needs the commit payload as well —
-                    // the D line and the O line in one look instead of one after the other
+                    // the D line and the O line in one look instead of one after the other (behind a few tight polls for this round's slow token:
+                    // a round that runs ahead is handed over like a fast one, and the two-line look alone found it 775 cycles late)
+                    (void)poll_word(sy + kSyD, (r << 1) | 1u, 8);
                     u32x4 dl, ol;
                     lds_peek4x2(sy + kSyD, dl, ol);
                     const uint32_t D = rfl(dl.x), A = rfl(dl.y);
                     if (__builtin_expect(A != kNone, 0)) { if (A == kPoison) wave_exit(); abort_sync(false, 0); continue; }
                     if ((D >> 1) == r) {
-                        slow = D & 1u;
+                        slow = D & 1u; dS = rfl(dl.z); dF = rfl(dl.w);
                         if (slow && rfl(ol.x) == r) { P0 = rfl(ol.z); P1 = rfl(ol.w); got_payload = true; }
                         break;
                     }
-                    backoff(r - (D >> 1));
+                    if (D & 1u) backoff_ordered(r - (D >> 1)); else backoff(r - (D >> 1));
                     watchdog(spins, sy, err, lane);
                     continue;
                 }
                 if (poll_word(sy + kSyD, r << 1, 16)) { slow = 0; break; }         // the common hand-off: fast token for this round
-                const u32x2 v = lds_peek2(sy + kSyD);
+                const u32x4 v = lds_peek4(sy + kSyD);
                 const uint32_t D = rfl(v.x), A = rfl(v.y);
                 if (__builtin_expect(A != kNone, 0)) { if (A == kPoison) wave_exit(); abort_sync(false, 0); continue; }
-                if ((D >> 1) == r) { slow = D & 1u; break; }
+                if ((D >> 1) == r) { slow = D & 1u; dS = rfl(v.z); dF = rfl(v.w); break; }
                 backoff(r - (D >> 1));
                 watchdog(spins, sy, err, lane);
             }
@@ -1076,7 +1112,7 @@ __global__ __launch_bounds__(SPLIT ? 2 * W * 64 : W * 64) void chameleon_encode_
                 }
                 uint32_t g_out;
                 if (__builtin_expect((P1 & 0x1ffffu) == 0 && inc == 0, 1)) {
-                    g_out = (P1 & 0xffe1ffffu) | ((((P1 >> 17) + R) & 15u) << 17);    // calm, start == 1: only the block counter moves
+                    g_out = (P1 & 0xe3e1ffffu) | ((((P1 >> 17) + R) & 15u) << 17);    // calm, start == 1: only the block counter moves (and no incompressible stretch is running: its count, bits 26..28, goes)
                 } else {
                     Guard g = unpack_guard(P1);
 #pragma unroll
@@ -1116,7 +1152,15 @@ __global__ __launch_bounds__(SPLIT ? 2 * W * 64 : W * 64) void chameleon_encode_
             {
                 if (!have_turn) {
                     bool aborted = false;
-                    if (!got_payload)
+                    // RUN-AHEAD (round 5): inside a long incompressible stretch — random input, data that is compressed already — the state behind a
+                    // round is its prediction round after round (every coded block incompressible: the FSM is a function of its state alone), so the
+                    // dictionary token need not wait for the commit: the predecessor passed it on right behind its exchanges, with the state it
+                    // PREDICTS for this round (D line, words 2 and 3).  This round predicts from that, exchanges, passes the token on the same way,
+                    // and only then waits for its commit payload — which must show the state it assumed, and its own signatures the stretch going on;
+                    // if not, the abort protocol takes back what ran ahead, as for a fast round, and the chain restarts here without run-ahead.
+                    // An ordinary ordered round starts it after kStormRounds rounds of an unbroken stretch (payload bits 26..28).
+                    ahead = dF == 1u && !zero_round && (dS & 0x100ffu) != 0;
+                    if (!got_payload && !ahead)
                     for (uint32_t spins = 0;;) {
                         const u32x4 v = lds_peek4(sy + kSyO);
                         const uint32_t O = rfl(v.x), A = rfl(v.y);
@@ -1131,10 +1175,10 @@ __global__ __launch_bounds__(SPLIT ? 2 * W * 64 : W * 64) void chameleon_encode_
                     // (a fresh chunk's first round is the cold start — raw copies for certain, nothing to predict —, and the rare zero-entry quads
                     // are settled block by block: those rounds are walked in order, below)
                     if (!zero_round && !(r == 0 && !seg.init_images)) {
-                        it_j0 = 0; it_state = P1 & 0x1fffffu; it_raw = 0;
+                        it_j0 = 0; it_state = ahead ? dS & 0x1fffffu : P1 & 0x1fffffu; it_raw = 0;
                         it_end = (it_state & ~0x1e0000u) | ((((it_state >> 17) + R) & 15u) << 17);   // (calm, start == 1, no incompressible block: only the counter moves)
-                        it_mode = (P1 & 0x100ffu) != 0 ? 1u : 0u;                    // penalty running or the last coded block incompressible
-                        if ((P1 & 0x1ffffu) != 0) {                                // (calm, start == 1: no raw copy while no block is incompressible, only the counter moves: the check below)
+                        it_mode = (it_state & 0x100ffu) != 0 ? 1u : 0u;              // penalty running or the last coded block incompressible
+                        if ((it_state & 0x1ffffu) != 0) {                                // (calm, start == 1: no raw copy while no block is incompressible, only the counter moves: the check below)
                             // Inside an incompressible stretch the state in front of a round repeats with a period of a few rounds (the counter moves
                             // by R = 16 a round, penalty and start go round a short cycle), and the prediction is a function of that state alone: a
                             // memo of eight in the sync block, touched only by the holder of the commit token, saves the walk — a few hundred scalar
@@ -1162,6 +1206,11 @@ __global__ __launch_bounds__(SPLIT ? 2 * W * 64 : W * 64) void chameleon_encode_
                 // only the blocks from it_j0 on that are predicted coded exchange (final blocks and raw copies — codec.rs:35-37 — touch no state); no
                 // token behind them: it leaves with the commit
                 const uint32_t keep_lo = slo, keep_hi = shi;                       // (final blocks keep their signatures)
+                if (ahead) {                                                      // the token behind the exchanges (LDS order), with the state predicted for the next round
+                    exchange_some_ahead<R>(ra, mask, val, rfl(it_raw), sy + kSyD, it_end, ((r + 1u) << 1) | 1u);
+                    hold_skip = it_raw;
+                    clk.stamp(r, 2, lane);
+                } else
                 exchange_some<R>(ra, mask, val, rfl(it_raw | ((1u << it_j0) - 1u)));
 #pragma unroll
                 for (uint32_t j = 0; j < R; ++j) {                                // chameleon.rs:90-99 (an idle block's "signature" is never looked at)
@@ -1178,6 +1227,25 @@ __global__ __launch_bounds__(SPLIT ? 2 * W * 64 : W * 64) void chameleon_encode_
                     const uint32_t inc_all = (uint32_t)ballot64(lane < R && nh2 <= 4u) & ~it_raw;   // codec.rs:68, coded blocks
                     const uint32_t coded_new = all & ~it_raw & ~below;
                     bool done = ((inc_all ^ (it_mode ? all : 0u)) & coded_new) == 0;   // every block behaved as predicted: the prediction's end state stands
+                    if (ahead) {
+                        // the commit turn: only now is the state in front of this round known — it must be the one that was assumed
+                        bool aborted = false;
+                        for (uint32_t spins = 0;;) {
+                            const u32x4 v = lds_peek4(sy + kSyO);
+                            const uint32_t O = rfl(v.x), A = rfl(v.y);
+                            if (O == r) { P0 = rfl(v.z); P1 = rfl(v.w); break; }
+                            if (A != kNone) { if (A == kPoison) wave_exit(); abort_sync(true, r); aborted = true; break; }
+                            backoff_ordered(r - O);
+                            watchdog(spins, sy, err, lane);
+                        }
+                        if (!aborted && (!done || (P1 & 0x1fffffu) != it_state)) {
+                            if (lane == 0) { lds_poke(sy + kSyO + 12, ((P1 >> 24) & 3u) < 3u ? P1 + 0x01000000u : P1); lds_poke(sy + kSyD + 4, r); lds_poke(sy + kSyO + 4, r); }
+                            clk.count(4, lane);
+                            abort_sync(true, r);
+                            aborted = true;
+                        }
+                        if (aborted) { ahead = false; have_turn = false; it_j0 = kNone; hold_skip = 0; continue; }
+                    } else
                     if (!done) {
                         uint32_t sm, mm;
                         const uint32_t jm = fsm_verify<R>(it_state, it_j0, inc_all, it_raw, sm, mm);
@@ -1234,11 +1302,18 @@ __global__ __launch_bounds__(SPLIT ? 2 * W * 64 : W * 64) void chameleon_encode_
             // ahead — dozens of ordered rounds' worth
             const uint32_t streak = (g.penalty | copy_mask | unrest) != 0 ? 0u : (((P1 >> 21) & 7u) < 7u ? ((P1 >> 21) & 7u) + 1u : 7u);
             const uint32_t stay_slow = streak < quiet_rounds(P1) ? 1u : 0u;
+            // (rounds in a row that were one incompressible stretch, as predicted from their first block on: run-ahead starts behind kStormRounds of them)
+            const uint32_t storm = batched && it_mode && it_j0 == 0 ? (((P1 >> 26) & 7u) < 7u ? ((P1 >> 26) & 7u) + 1u : 7u) : 0u;
             if (lane == 0) {
-                lds_poke2(sy + kSyO + 8, opos + sum, pack_guard(g) | (streak << 21) | (P1 & 0x03000000u));
+                lds_poke2(sy + kSyO + 8, opos + sum, pack_guard(g) | (streak << 21) | (P1 & 0x03000000u) | (storm << 26));
                 lds_poke(sy + kSyO, r + 1u);
-                lds_poke(sy + kSyD, ((r + 1u) << 1) | stay_slow);
+                if (!ahead) {                                                     // (a round that ran ahead passed the dictionary token on behind its exchanges)
+                    lds_poke2(sy + kSyD + 8, pack_guard(g), storm >= kStormRounds && stay_slow ? 1u : 0u);
+                    lds_poke(sy + kSyD, ((r + 1u) << 1) | stay_slow);
+                }
             }
+            hold_skip = 0;
+            if (ahead) clk.count(5, lane);
             if constexpr (KEEP) if (!prefetched && r + W < nrounds) prefetch_quads<R, W>(src + (uint64_t)(r + W) * (R * kBlock) + 4u * lane);   // (as behind a fast commit)
             poll_tries = 2;
             if (PAGED && refill) page_refill();
@@ -2121,8 +2196,8 @@ void rot_prof_report(const char* what, const char* phases, uint64_t* buf, hipStr
     fprintf(stderr, "[density_hip prof] %s work-group 0, kcycles per wave by phase (%s)\n", what, phases);
     {
         const uint64_t* c = h + 128 + 5 * kProfRounds;
-        fprintf(stderr, "[density_hip prof]   events: fast rounds %llu, ordered rounds held %llu / taken back %llu, rounds walked in order %llu, aborts raised %llu\n",
-                (unsigned long long)c[0], (unsigned long long)c[1], (unsigned long long)c[2], (unsigned long long)c[3], (unsigned long long)c[4]);
+        fprintf(stderr, "[density_hip prof]   events: fast rounds %llu, ordered rounds held %llu (%llu of them ran ahead) / taken back %llu, rounds walked in order %llu, aborts raised %llu\n",
+                (unsigned long long)c[0], (unsigned long long)c[1], (unsigned long long)c[5], (unsigned long long)c[2], (unsigned long long)c[3], (unsigned long long)c[4]);
     }
     for (int w = 0; w < 16; ++w) {
         uint64_t tot = 0;

@@ -97,7 +97,7 @@ def main():
             first = next((k for k, t in enumerate(body) if t.startswith("ds_mskor_rtn_b32")), None)
             near = [t for t in body[max(0, (first or 0) - 12):(first or 0) + R + 4] if t.startswith("scratch_")]
             spills = sum(t.startswith("scratch_") for t in body)
-            if first is None or near or spills > 64:
+            if first is None or near or spills > 128:
                 print(f"{name}: split encoder: scratch traffic at the exchanges {near} / {spills} scratch instructions in all")
                 bad += 1
             # the emit waves' hand-issued loads (SGPR base + 32-bit offset): their destination registers are not named by any instruction before a
