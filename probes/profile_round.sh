@@ -32,10 +32,13 @@ for f in glob.glob(sys.argv[1] + "/**/*_counter_collection.csv", recursive=True)
 PY
 done
 timeout 120 ./probes/vmem_width > $R/$OUT/vmem_width.txt 2>/dev/null
-DENSITY_HIP_PROF=1 timeout 300 $B --settle-ms 0 --steps 1 --warmup 1 > $R/$OUT/phase_profile.json 2> $R/$OUT/phase_profile.txt
+# (the cycle accounting is compiled into the debug build only: tools/gpu_phase_prof.py loads it)
+: > $R/$OUT/phase_profile.txt
+for k in text random mixed; do DENSITY_HIP_PROF=1 timeout 300 python tools/gpu_phase_prof.py $k 2>&1 | grep -v amdgpu.ids >> $R/$OUT/phase_profile.txt; done
 timeout 600 python bench.py --steps 10 --warmup 3 --no-extra > $R/$OUT/bench.json 2>/dev/null
 # the packed container (with the stitch pass) and Cheetah at its automatic chunk, kernel by kernel
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/stats_packed -- $B --packed --steps 5 --warmup 1 > $R/$OUT/bench_stats_packed.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/stats_slotted -- $B --slotted --steps 5 --warmup 1 > $R/$OUT/bench_stats_slotted.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/stats_cheetah -- python bench.py --algo cheetah --data prose --size 100000000 --steps 5 --warmup 2 --no-cpu --no-sweep --no-extra > $R/$OUT/bench_stats_cheetah.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/stats_lion -- python bench.py --algo lion --data prose --size 100000000 --steps 5 --warmup 2 --no-cpu --no-sweep --no-extra > $R/$OUT/bench_stats_lion.log 2>&1
 find $R/$OUT -name "*_kernel_stats.csv" -o -name "*_counter_collection.csv"

@@ -30,7 +30,7 @@ out = {"unit": "bytes per launch",
        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 2 --warmup 1 --no-cpu",
        "calibration": {"raw_KB_for_1GiB": calib, "factor_read4": round(k_r4, 4), "factor_read16": round(k_r16, 4), "factor_write4": round(k_w4, 4), "factor_write2": round(k_w2, 4),
                        "note": "probes/fetch_calib.hip streams exactly 1 GiB per kernel at each access width; factor = true bytes / counter bytes"},
-       "workload": "bench.py default: chameleon rep-text 1 GiB, automatic chunk (4 MiB), container with block index", "kernels": {}}
+       "workload": "bench.py default: chameleon rep-text 1 GiB, automatic chunk (4 MiB), PAGED container with block index (round 5; rounds 3-4: slotted)", "kernels": {}}
 # the kernel generation these counters belong to: bench.py quotes them as `roofline.traffic` only for a library of the same kernels id
 try:
     out["kernels_id"] = json.load(open(f"{src}/bench.json")).get("kernels_id")
@@ -76,7 +76,7 @@ if os.path.exists(f"{src}/ta_sq.txt"):
     shutil.copy(f"{src}/ta_sq.txt", f"profiles/{tag}_ta_sq_counters.txt")
 if os.path.exists(f"{src}/vmem_width.txt"):
     shutil.copy(f"{src}/vmem_width.txt", f"profiles/{tag}_probe_vmem_width.log")
-for extra in ("packed", "cheetah", "lion"):
+for extra in ("packed", "slotted", "cheetah", "lion"):
     m = glob.glob(f"{src}/stats_{extra}/**/*_kernel_stats.csv", recursive=True)
     if m:
         shutil.copy(m[0], f"profiles/{tag}_{extra}_kernel_stats.csv")
