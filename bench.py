@@ -40,7 +40,10 @@ def cpu_all_cores(src, chunk, algo, gpu_payloads=None):
         dec = np.empty(n, dtype=np.uint8)
         ncpu = os.cpu_count() or 1
         nchunks = (n + chunk - 1) // chunk
-        threads = min(ncpu, nchunks)
+        # one thread per PHYSICAL core at most (os.cpu_count() counts SMT siblings): measured on the GPU box's host, 256 logical cores — Cheetah 0.39 MiB chunks
+        # 1 / 8 / 32 / 64 / 128 threads: 0.77 / 5.9 / 21.7 / 39.3 / 57.4 GB/s encode, and 0.5 GB/s on 255 (every logical core taken: the team's spinning waiters
+        # and the interpreter's own threads starve the workers)
+        threads = max(1, min(ncpu // 2, nchunks))
         ccap = (pyoracle.safe_encode_buffer_size(algo, chunk) + 63) // 64 * 64
         encs = np.empty((nchunks, ccap), dtype=np.uint8)
         sizes = np.zeros(nchunks, dtype=np.uint64)
@@ -52,9 +55,12 @@ def cpu_all_cores(src, chunk, algo, gpu_payloads=None):
             t0 = time.perf_counter(); enc(); t1 = time.perf_counter(); dcd(); t2 = time.perf_counter()
             te.append(t1 - t0); td.append(t2 - t1)
         assert np.array_equal(dec, src)
-        e, d = sorted(te)[2], sorted(td)[2]
+        # the FASTEST of the five, medians beside it: bursts of all cores get throttled on the GPU box's host now and then (the same call: 157 GB/s, then 11), so
+        # a median of five says more about the box's scheduler than about the codec
+        e, d = min(te), min(td)
         out = {"value": round(n / (e + d) / 1e6, 1), "unit": "MB/s", "cores": ncpu, "threads": threads, "encode_MBps": round(n / e / 1e6, 1), "decode_MBps": round(n / d / 1e6, 1),
-               "ratio_chunked": round(n / int(sizes.sum()), 4), "chunk": chunk, "n_chunks": nchunks, "timing": "median of 5",
+               "median": {"value": round(n / (sorted(te)[2] + sorted(td)[2]) / 1e6, 1), "encode_MBps": round(n / sorted(te)[2] / 1e6, 1), "decode_MBps": round(n / sorted(td)[2] / 1e6, 1)},
+               "ratio_chunked": round(n / int(sizes.sum()), 4), "chunk": chunk, "n_chunks": nchunks, "timing": "fastest of 5 (median beside it)",
                "sample": f"{n} B in {nchunks} chunks of {chunk} B, one chunk per task on {threads} OpenMP threads ({ncpu} host cores), C restatement (oracle/density_oracle.c)"}
         if gpu_payloads is not None:
             m = min(nchunks, len(gpu_payloads))
@@ -98,7 +104,8 @@ def cpu_baseline(host, chunk, sample_bytes, algo="chameleon", reps=25, gpu_paylo
            "encode_MBps": round(n / med_e / 1e6, 1), "decode_MBps": round(n / med_d / 1e6, 1),
            "fastest": {"value": round(n / (best_e + best_d) / 1e6, 1), "encode_MBps": round(n / best_e / 1e6, 1), "decode_MBps": round(n / best_d / 1e6, 1)},
            "ratio_whole_stream": round(n / esize, 4)}
-    out["all_cores"] = cpu_all_cores(src, chunk, algo, gpu_payloads)
+    # ... and all cores over the chunks of the WHOLE buffer (every chunk the GPU made is compared: full-coverage parity at bench size)
+    out["all_cores"] = cpu_all_cores(np.ascontiguousarray(host), chunk, algo, gpu_payloads)
     return out
 
 
@@ -725,8 +732,7 @@ def main():
         if n_gpus == 1 and not args.no_sweep:
             result["size_sweep"] = size_sweep(container, algo, x, [10_000_000, 100_000_000, n])
         if not args.no_cpu and n_gpus == 1:                                              # (rank 0 at N = 1 only: at N > 1 the other ranks would sit in the final barrier meanwhile)
-            nchk = (min(args.cpu_sample, n) + chunk - 1) // chunk
-            result["cpu_baseline"] = cpu_baseline(host, chunk, args.cpu_sample, algo, gpu_payloads=payloads[:nchk])
+            result["cpu_baseline"] = cpu_baseline(host, chunk, args.cpu_sample, algo, gpu_payloads=payloads)
             result["host_api"] = host_api_rates(algo, host, chunk, args.host_sample)
         if n_gpus == 1 and not args.no_extra and algo == "chameleon" and args.data == "rep-text":
             # SURVEY.md 8d's hostile inputs at their stated size through the same device container path (never `value`): all-zero (every quad hits:

@@ -75,15 +75,33 @@ typedef struct {
     uint32_t  last_hash;
 } state_t;
 
+/* (the all-cores runs at the end of this file keep a thread's tables from chunk to chunk — zeroed, not re-allocated: a few hundred threads mapping and
+ * unmapping 0.75-1.75 MiB per chunk spend their time in the address-space lock, not in the codec.  Single calls allocate and free, like the reference's
+ * Vec per call.) */
+static __thread int tls_keep_tables = 0;
+static __thread state_t tls_tables[3];
 static int state_alloc(state_t* st, int algo) {
     memset(st, 0, sizeof *st);
+    if (tls_keep_tables) {
+        state_t* k = &tls_tables[algo];
+        if (algo == ALGO_CHAMELEON) { if (!k->dict) k->dict = malloc(65536 * sizeof(uint32_t)); if (!k->dict) return 0; memset(k->dict, 0, 65536 * sizeof(uint32_t)); }
+        else {
+            if (!k->dict2) k->dict2 = malloc(65536 * sizeof(pair_t));
+            if (algo == ALGO_CHEETAH) { if (!k->pred) k->pred = malloc(65536 * sizeof(uint32_t)); } else if (!k->pred5) k->pred5 = malloc(65536 * sizeof(pred5_t));
+            if (!k->dict2 || !(algo == ALGO_CHEETAH ? (void*)k->pred : (void*)k->pred5)) return 0;
+            memset(k->dict2, 0, 65536 * sizeof(pair_t));
+            if (algo == ALGO_CHEETAH) memset(k->pred, 0, 65536 * sizeof(uint32_t)); else memset(k->pred5, 0, 65536 * sizeof(pred5_t));
+        }
+        *st = *k; st->last_hash = 0;
+        return 1;
+    }
     if (algo == ALGO_CHAMELEON) { st->dict = calloc(65536, sizeof(uint32_t)); return st->dict != NULL; }
     st->dict2 = calloc(65536, sizeof(pair_t));
     if (algo == ALGO_CHEETAH) st->pred = calloc(65536, sizeof(uint32_t));
     else st->pred5 = calloc(65536, sizeof(pred5_t));
     return st->dict2 && (st->pred || st->pred5);
 }
-static void state_free(state_t* st) { free(st->dict); free(st->dict2); free(st->pred); free(st->pred5); }
+static void state_free(state_t* st) { if (tls_keep_tables) return; free(st->dict); free(st->dict2); free(st->pred); free(st->pred5); }
 
 /* optional statistics for tests (not part of the reference) */
 typedef struct { uint64_t copy_blocks, coded_blocks, flags[8]; } oracle_stats_t;
@@ -331,39 +349,34 @@ EXPORT_ALGO(lion, ALGO_LION)
 /* ---- the chunks of a buffer on all host cores (bench.py's all-cores baseline: SURVEY.md 8d "N-thread run over the same chunks") ----
  * Chunk i of `in` (chunk bytes, the last one shorter) is one independent reference stream — what the container holds —, written to / read from
  * out + i * stride; one chunk per task (OpenMP, dynamic schedule); sizes[i] = the stream's length.  Returns the number of chunks that failed. */
-#include <malloc.h>
-static void keep_tables_on_the_heap(void) {
-    /* a stream's tables (256 KiB .. 1.75 MiB, calloc'ed per stream like the reference's Vec per call) would be mapped and unmapped per chunk: with a few
-     * hundred threads that is one address-space lock for all of them (measured: Cheetah 0.3 GB/s on 255 threads).  Kept in the threads' arenas instead. */
-    static int done = 0;
-    if (!done) { mallopt(M_MMAP_THRESHOLD, 1 << 30); mallopt(M_TRIM_THRESHOLD, 1 << 30); done = 1; }
-}
 ORACLE_API int oracle_encode_chunks_mt(int algo, const uint8_t* in, size_t n, size_t chunk, uint8_t* out, size_t stride, uint64_t* sizes, int threads) {
-    keep_tables_on_the_heap();
     const long n_chunks = (long)((n + chunk - 1) / chunk);
     int bad = 0;
 #pragma omp parallel for schedule(dynamic, 1) num_threads(threads) reduction(+ : bad)
     for (long i = 0; i < n_chunks; ++i) {
+        tls_keep_tables = 1;
         const size_t len = (size_t)(i + 1) * chunk <= n ? chunk : n - (size_t)i * chunk;
         const uint8_t* p = in + (size_t)i * chunk; uint8_t* o = out + (size_t)i * stride;
         const size_t e = algo == ALGO_CHAMELEON ? encode_stream(ALGO_CHAMELEON, p, len, o, stride, NULL)
                        : algo == ALGO_CHEETAH ? encode_stream(ALGO_CHEETAH, p, len, o, stride, NULL) : encode_stream(ALGO_LION, p, len, o, stride, NULL);
         sizes[i] = e;
         if (e == 0 && len != 0) ++bad;
+        tls_keep_tables = 0;
     }
     return bad;
 }
 ORACLE_API int oracle_decode_chunks_mt(int algo, const uint8_t* in, size_t stride, const uint64_t* sizes, uint8_t* out, size_t n, size_t chunk, int threads) {
-    keep_tables_on_the_heap();
     const long n_chunks = (long)((n + chunk - 1) / chunk);
     int bad = 0;
 #pragma omp parallel for schedule(dynamic, 1) num_threads(threads) reduction(+ : bad)
     for (long i = 0; i < n_chunks; ++i) {
+        tls_keep_tables = 1;
         const size_t len = (size_t)(i + 1) * chunk <= n ? chunk : n - (size_t)i * chunk;
         const uint8_t* p = in + (size_t)i * stride; uint8_t* o = out + (size_t)i * chunk;
         const size_t d = algo == ALGO_CHAMELEON ? decode_stream(ALGO_CHAMELEON, p, (size_t)sizes[i], o, len)
                        : algo == ALGO_CHEETAH ? decode_stream(ALGO_CHEETAH, p, (size_t)sizes[i], o, len) : decode_stream(ALGO_LION, p, (size_t)sizes[i], o, len);
         if (d != len) ++bad;
+        tls_keep_tables = 0;
     }
     return bad;
 }

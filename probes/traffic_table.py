@@ -10,9 +10,9 @@ E = bench["roofline"]["algorithmic_bytes_per_launch"] - N
 avg = {}
 for row in csv.DictReader(open(f"profiles/{tag}_kernel_stats.csv")):
     m = re.search(r"(chameleon_encode_rot|chameleon_decode_rot|compact_kernel)", row["Name"])
-    if m:
+    if m and int(row["Calls"]) > avg.get(m.group(1), (0, 0))[1]:             # (several instances of a template: the one the timed steps launched)
         avg[m.group(1)] = (float(row["AverageNs"]) / 1e3, int(row["Calls"]))
-rows = [("chameleon_encode_rot", "reads N, writes E into slots + block index", N + E),
+rows = [("chameleon_encode_rot", "reads N, writes E into pages + directory + block index" if tag >= "r05" else "reads N, writes E into slots + block index", N + E),
         ("chameleon_decode_rot", "reads E + index, writes N", N + E),
         ("compact_kernel", "reads E, writes E; only in density_hip_pack_device" if tag >= "r03" else "reads E, writes E", 2 * E)]
 print(f"N = {N:,} input bytes, E = {E:,} container bytes (ratio {N / E:.4f}); peak 8000 GB/s\n")
