@@ -379,6 +379,37 @@ def test_abort_and_recovery_paths(kernel_variant):
     assert container.decode(cont[:cn], back) == data.size and np.array_equal(back, data)
 
 
+def test_long_incompressible_stretches_and_their_ends(kernel_variant):
+    """Stretches of incompressible data LONG enough for the encoder's ordered rounds to run ahead of their commit (rotor.hip: three rounds of one
+    unbroken stretch, 12 KiB, start it), ended by data that compresses — where the round that ran ahead finds its assumption wrong, raises the abort and
+    the waves behind it take back exactly the blocks that exchanged — by zeros, by low-entropy noise, by the chunk's end; at chunk sizes from one round of
+    run-ahead to the headline's 4 MiB, as container (every chunk stream == the oracle's) and as one stream."""
+    rng = np.random.default_rng(23)
+    text = datagen.prose(1 << 20, seed=41)
+    pieces = []
+    for k, ln in enumerate([300_000, 70_000, 49_152, 4096, 1_000_000, 256, 131_072, 20_000, 700_000, 12_288 + 256, 65_536]):
+        kind = k % 4
+        if kind in (0, 2):
+            pieces.append(rng.integers(0, 256, size=ln + int(rng.integers(0, 300)), dtype=np.uint8))              # incompressible
+        elif kind == 1:
+            pieces.append(text[k * 4099:k * 4099 + ln])                                                            # compresses
+        else:
+            pieces.append(np.zeros(ln, dtype=np.uint8) if k % 8 == 3 else rng.integers(0, 4, size=ln, dtype=np.uint8))
+    data = np.concatenate(pieces)
+    want, st = pyoracle.encode_stats(ALGO, data)
+    assert st["copy_blocks"] > 3000
+    assert gpu_encode(data) == want
+    assert gpu_decode(want, data.size) == data.tobytes()
+    for chunk in (1 << 16, 1 << 18, 1 << 20, 4 << 20):
+        cont = np.zeros(container.container_bound(ALGO, data.size, chunk), dtype=np.uint8)
+        cn = container.encode(ALGO, data, cont, chunk)
+        _, payloads = container.chunk_payloads(cont[:cn])
+        for i, p in enumerate(payloads):
+            assert p == pyoracle.encode(ALGO, data[i * chunk:(i + 1) * chunk]), (chunk, i)
+        back = np.zeros(data.size, dtype=np.uint8)
+        assert container.decode(cont[:cn], back) == data.size and np.array_equal(back, data), chunk
+
+
 def test_full_size_properties_device_resident():
     """256 MiB device-resident container round trip (BASELINE config-2 shape at a quarter of the size): decode(encode(x))
     == x bit for bit, header arithmetic, and a sample of chunk streams equal to the oracle."""
