@@ -514,6 +514,31 @@ __device__ __forceinline__ bool poll_word(uint32_t addr, uint32_t want, uint32_t
     return seen == want;
 }
 
+// the same on a whole 16-byte line whose first word is the token: the line as it was when the token matched, or as last seen (four one-word reads in
+// one round trip: a tuple register cannot be named word by word in an asm statement)
+__device__ __forceinline__ bool poll_line(uint32_t addr, uint32_t want, uint32_t tries, u32x4& line) {
+    uint32_t seen, w0, w1, w2, w3;
+    asm volatile(
+        "1:\n\t"
+        "ds_read_b32 %[w0], %[a]\n\t"
+        "ds_read_b32 %[w1], %[a] offset:4\n\t"
+        "ds_read_b32 %[w2], %[a] offset:8\n\t"
+        "ds_read_b32 %[w3], %[a] offset:12\n\t"
+        "s_sub_u32 %[n], %[n], 1\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_readfirstlane_b32 %[s], %[w0]\n\t"
+        "s_cmp_eq_u32 %[s], %[w]\n\t"
+        "s_cbranch_scc1 2f\n\t"
+        "s_cmp_lg_u32 %[n], 0\n\t"
+        "s_cbranch_scc1 1b\n"
+        "2:"
+        : [w0] "=&v"(w0), [w1] "=&v"(w1), [w2] "=&v"(w2), [w3] "=&v"(w3), [s] "=&s"(seen), [n] "+s"(tries)
+        : [a] "v"(addr), [w] "s"(want)
+        : "scc", "memory");
+    line = u32x4{w0, w1, w2, w3};
+    return seen == want;
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -970,13 +995,22 @@ __global__ __launch_bounds__(SPLIT ? 2 * W * 64 : W * 64) void chameleon_encode_
             // ---- D chain: wait for this round's turn ----
             uint32_t slow = 1, dS = 0, dF = 0;                                    // dS, dF: the D line's run-ahead words (below: ordered rounds that run ahead)
             bool got_payload = false;
+            // (the memo of FSM predictions as it stands now, read AHEAD of the wait: inside a stretch its entries are stable, and the look-up behind the
+            // token is then a compare instead of an LDS round trip — 200 cycles of every run-ahead hop; a miss reads it again)
+            u32x4 memo_early = {kNone, 0u, 0u, 0u};
+            if (poll_tries != 16 && !have_turn) memo_early = lds_peek4(sy + kSyMemo + 16u * (lane & (kMemoEntries - 1u)));
             if (!have_turn)
             for (uint32_t spins = 0;;) {
                 if (poll_tries != 16) {
                     // this wave's last round was an ordered one: most likely this one is too, and then it needs the commit payload as well —
                     // the D line and the O line in one look instead of one after the other (behind a few tight polls for this round's slow token:
                     // a round that runs ahead is handed over like a fast one, and the two-line look alone found it 775 cycles late)
-                    (void)poll_word(sy + kSyD, (r << 1) | 1u, 8);
+                    // (first a few tight polls of the D line for this round's slow token — a round that runs ahead is handed over like a fast one, every
+                    // LDS round trip on the way is 200 cycles of the hop: the line's run-ahead words come with the token)
+                    {
+                        u32x4 dl1;
+                        if (poll_line(sy + kSyD, (r << 1) | 1u, 8, dl1) && rfl(dl1.y) == kNone) { slow = 1; dS = rfl(dl1.z); dF = rfl(dl1.w); break; }
+                    }
                     u32x4 dl, ol;
                     lds_peek4x2(sy + kSyD, dl, ol);
                     const uint32_t D = rfl(dl.x), A = rfl(dl.y);
@@ -1183,8 +1217,10 @@ __global__ __launch_bounds__(SPLIT ? 2 * W * 64 : W * 64) void chameleon_encode_
                             // by R = 16 a round, penalty and start go round a short cycle), and the prediction is a function of that state alone: a
                             // memo of eight in the sync block, touched only by the holder of the commit token, saves the walk — a few hundred scalar
                             // instructions in the one place where every later round waits.
-                            const u32x4 e = lds_peek4(sy + kSyMemo + 16u * (lane & (kMemoEntries - 1u)));   // lane l: entry l mod 8; the round's number picks the one to replace
-                            const uint64_t found = ballot64(e.x == it_state);
+                            u32x4 e = memo_early;                                    // lane l: entry l mod 8; the round's number picks the one to replace
+                            uint64_t found = ballot64(e.x == it_state);
+                            if (it_mode && found) clk.count(6, lane);
+                            if (!(it_mode && found)) { e = lds_peek4(sy + kSyMemo + 16u * (lane & (kMemoEntries - 1u))); found = ballot64(e.x == it_state); if (it_mode && found) clk.count(7, lane); }
                             if (it_mode && found) {
                                 const uint32_t l0 = (uint32_t)__builtin_ctzll(found);
                                 it_raw = rlane(e.y, l0); it_end = rlane(e.z, l0);
@@ -2198,6 +2234,7 @@ void rot_prof_report(const char* what, const char* phases, uint64_t* buf, hipStr
         const uint64_t* c = h + 128 + 5 * kProfRounds;
         fprintf(stderr, "[density_hip prof]   events: fast rounds %llu, ordered rounds held %llu (%llu of them ran ahead) / taken back %llu, rounds walked in order %llu, aborts raised %llu\n",
                 (unsigned long long)c[0], (unsigned long long)c[1], (unsigned long long)c[5], (unsigned long long)c[2], (unsigned long long)c[3], (unsigned long long)c[4]);
+        fprintf(stderr, "[density_hip prof]   memo of predictions: %llu found in the early copy, %llu on a second look\n", (unsigned long long)c[6], (unsigned long long)c[7]);
     }
     for (int w = 0; w < 16; ++w) {
         uint64_t tot = 0;

@@ -1,3 +1,3 @@
 #!/bin/bash
-# r5q: the new test of long incompressible stretches (all kernel variants)
-timeout 600 python -m pytest tests/test_gpu_chameleon.py -m gpu -x -q -k "long_incompressible" 2>&1 | grep -v amdgpu.ids | tail -4
+T=gpurun_out/r5r; mkdir -p $T; export TMPDIR=/tmp
+timeout 200 python tools/gpu_phase_prof.py random 2>&1 | grep "events: fast\|D chain\|memo of" | head -3 | tee $T/prof_random.txt
