@@ -241,10 +241,30 @@ def hostile_data(kind, n):
     return out
 
 
-def roofline_entry(name, alg_bytes, ms):
+def roofline_entry(name, alg_bytes, ms, traffic=None, traffic_source=None):
     ach = alg_bytes / (ms * 1e-3) / 1e9 if ms else 0.0
     return {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
-            "traffic": None, "algorithmic_bytes_per_launch": int(alg_bytes), "kernel_avg_ms": round(ms, 4)}
+            "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": int(alg_bytes), "kernel_avg_ms": round(ms, 4)}
+
+
+def direction_traffic(algo, n, chunk):
+    """Counter traffic per encode / decode CALL of configs 3 / 4 from the committed passes (probes/profile_directions.sh -> profiles/rNN_pmc_directions.json:
+    all kernels and fills of a direction summed) — quoted only for the workload they were taken on (100 MB of prose at the automatic chunk) and the library
+    whose kernels id they record."""
+    try:
+        import glob as _glob, re as _re
+        from density_amd import _lib
+        cand = sorted(_glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_directions.json")))
+        if not cand or n != 100_000_000 or chunk != int(_lib.lib().density_hip_auto_chunk_for(_lib.ALGO_IDS[algo], n)):
+            return {}
+        pm = json.load(open(cand[-1]))
+        m = _re.search(r"kernels ([0-9a-f]+)", _lib.lib().density_hip_version().decode())
+        if algo not in pm["configs"] or not m or pm.get("kernels_id") != m.group(1):
+            return {}
+        src = os.path.relpath(cand[-1], ROOT)
+        return {d: (int(pm["configs"][algo][d]["hbm_bytes_corrected"]), src) for d in ("encode", "decode")}
+    except Exception:
+        return {}
 
 
 def settle(step, ms):
@@ -332,8 +352,8 @@ def other_config(container, algo, label, host, steps=3, warmup=1, cpu_sample=32 
             "container_form": "slotted (the packed size stated)",
             "encode_ms": round(t_enc, 4), "decode_ms": round(t_dec, 4), "kernel_ms": {k: round(v, 4) for k, v in tot.items()},
             "residency": "HBM-bound" if 2 * n > (256 << 20) else "cache-resident (fits the 256 MiB Infinity Cache)",
-            "roofline": {"encode": roofline_entry(f"{algo} encode (all kernels of the direction)", n + E, t_enc),
-                         "decode": roofline_entry(f"{algo} decode (all kernels of the direction)", n + E, t_dec)},
+            "roofline": {"encode": roofline_entry(f"{algo} encode (all kernels of the direction)", n + E, t_enc, *direction_traffic(algo, n, chunk).get("encode", (None, None))),
+                         "decode": roofline_entry(f"{algo} decode (all kernels of the direction)", n + E, t_dec, *direction_traffic(algo, n, chunk).get("decode", (None, None)))},
             "cpu_baseline": {"value": round(m / (c2 - c0) / 1e6, 1), "unit": "MB/s", "cores": 1, "kind": "port",
                              "encode_MBps": round(m / (c1 - c0) / 1e6, 1), "decode_MBps": round(m / (c2 - c1) / 1e6, 1),
                              "ratio_whole_stream": round(m / es, 4),

@@ -1,5 +1,4 @@
 #!/bin/bash
-# r5s: repetition of the tests that drive the encoder off calm text (aborts, ordered rounds, run-ahead), and the encode fuzzer on fresh seeds
-T=gpurun_out/r5s; mkdir -p $T; export TMPDIR=/tmp
-for i in 1 2 3; do timeout 300 python -m pytest tests/test_gpu_chameleon.py tests/test_gpu_shipped_configs.py -m gpu -x -q -k "abort or incompressible or hostile or patch or random or mixed" 2>&1 | grep -v amdgpu.ids | tail -1; done | tee $T/repeat.txt
-for seed in 11 12 13 14; do timeout 200 python tools/gpu_fuzz_encode.py 60 $seed 2>&1 | grep -v amdgpu.ids | tail -1; done | tee $T/fuzz_seeds.txt
+# r5u: the bench line of the final tree (counter traffic of the headline kernels and of configs 3 / 4 quoted)
+T=gpurun_out/r5u; mkdir -p $T; export TMPDIR=/tmp
+timeout 900 python bench.py --steps 20 --warmup 5 > $T/bench_full.json 2> $T/bench_full.err; echo "bench rc=$?"; head -c 200 $T/bench_full.json; echo
