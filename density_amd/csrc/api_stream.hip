@@ -73,8 +73,9 @@ struct SegEncode {
 // The passes of the segmented encode from segment `first` on, whose predecessor (if any) is final — d_final / d_gfinal of first - 1 are exact — with the
 // last writers of every inner segment in d_lw.  Returns the number of slots in use through *used (a remainder encoded as one chunk sits in the slot of
 // its first segment); the sizes of slots first .. used - 1 are left in h_sizes.
-hipError_t seg_encode_passes(const SegEncode& L, const uint8_t* d_in, size_t first, hipStream_t s, std::vector<uint64_t>& h_sizes, size_t* used, bool trace) {
+hipError_t seg_encode_passes(const SegEncode& L, const uint8_t* d_in, size_t first, hipStream_t s, std::vector<uint64_t>& h_sizes, size_t* used, bool trace, uint32_t* h_err = nullptr) {
     const size_t S = L.S, img = kSegImageBytes;
+    bool sizes_are_current = false;
     std::vector<uint32_t> h_gfinal(S), h_raw(S);
     hipError_t e = hipSuccess;
     size_t advanced = S;                                                           // segments the previous pass made final
@@ -103,8 +104,13 @@ hipError_t seg_encode_passes(const SegEncode& L, const uint8_t* d_in, size_t fir
         if (e == hipSuccess) e = L.speculate(d_in, first + 1, rest, s);
         if (e == hipSuccess) e = hipMemcpyAsync(h_gfinal.data(), L.d_gfinal, S * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipMemcpyAsync(h_raw.data(), L.d_raw, S * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+        // (with the report: the sizes of every slot and the error word as they stand — if this pass turns out to be the last one they are final, and the
+        // call saves two host round trips: round 5)
+        if (e == hipSuccess) e = hipMemcpyAsync(h_sizes.data() + first_in, L.d_sizes + first_in, (S - first_in) * sizeof(uint64_t), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess && h_err) e = hipMemcpyAsync(h_err, L.d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (e != hipSuccess) break;
+        sizes_are_current = true;
         // segment first+1 started from the truth; k >= first+2 is final iff every segment first+1 .. k-1 coded all its blocks and k-1 ended calm
         size_t k = first + 2;
         while (k < S && h_raw[k - 1] == 0 && (h_gfinal[k - 1] & 0x7fffffffu) == 0) ++k;
@@ -112,11 +118,14 @@ hipError_t seg_encode_passes(const SegEncode& L, const uint8_t* d_in, size_t fir
         advanced = k - first;
         first = k;                                                                // (== S: done)
         ++g_stream_stats[1];
+        if (first < S) sizes_are_current = false;                                  // (another pass follows: it writes sizes again)
     }
     if (e != hipSuccess) return e;
     // passes that ran out at `first` < S: slots first .. are ONE stream in slot `first`
     *used = first < S ? first + 1 : S;
+    if (sizes_are_current) return hipSuccess;                                      // the last pass's report carried them (and the error word)
     e = hipMemcpyAsync(h_sizes.data() + first_in, L.d_sizes + first_in, (*used - first_in) * sizeof(uint64_t), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess && h_err) e = hipMemcpyAsync(h_err, L.d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     return e;
 }
@@ -136,9 +145,8 @@ int run_stream_encode_segmented(DeviceCtx* c, const uint8_t* d_in, size_t n, uin
     if (e == hipSuccess) e = hipEventRecord(c->stitch_done, c->stitch_stream);
     if (e == hipSuccess) e = hipStreamWaitEvent(s, c->stitch_done, 0);
     size_t used = S;
-    if (e == hipSuccess) e = seg_encode_passes(L, d_in, 0, s, h_sizes, &used, trace);
     uint32_t h_err = 0;
-    if (e == hipSuccess) e = hipMemcpy(&h_err, L.d_err, sizeof(h_err), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = seg_encode_passes(L, d_in, 0, s, h_sizes, &used, trace, &h_err);   // (the sizes and the error word: read with the last pass's report)
     if (e != hipSuccess) { set_error("segmented stream encode", e); return DENSITY_HIP_ERR_RUNTIME; }
     if (h_err) { set_error("stream encode: device-side watchdog"); return DENSITY_HIP_ERR_RUNTIME; }
     uint64_t total = 0;
@@ -261,12 +269,15 @@ int run_stream_decode_segmented(DeviceCtx* c, const uint8_t* d_in, size_t E, uin
     uint32_t from_block = 0;
     uint64_t from_pos = 0;
     bool parsed = false;
+    std::vector<uint64_t> h_off(max_chunks + 2), h_offsets, h_sizes;
     for (int episode = 0; e == hipSuccess && episode < 16; ++episode) {
+        // ONE host round trip per episode (round 5; there were three): the start words go up in front of the parse on the same stream — they live
+        // on this frame until the synchronisation below —, the verdict and the chunk offsets come down together behind it
         const uint32_t start[3] = {from_block, (uint32_t)from_pos, (uint32_t)(from_pos >> 32)};
         e = hipMemcpyAsync(d_info + 8, start, sizeof(start), hipMemcpyHostToDevice, s);
-        if (e == hipSuccess) e = hipStreamSynchronize(s);                         // (`start` lives on this frame)
         if (e == hipSuccess) e = launch_stream_parse(d_in, E, from_pos, base, d_index, max_chunks * kChunkBlocks, d_chunk_offset, kChunkBlocks, d_pos32, d_info, s);
         if (e == hipSuccess) e = hipMemcpyAsync(info, d_info, sizeof(info), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(h_off.data(), d_chunk_offset, (max_chunks + 2) * sizeof(uint64_t), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (e != hipSuccess) break;
         if (trace) fprintf(stderr, "[density_hip prof] segmented stream decode: parse from block %u: status %u, head to block %u, %u whole blocks, first incompressible pair at %d\n",
@@ -285,11 +296,9 @@ int run_stream_decode_segmented(DeviceCtx* c, const uint8_t* d_in, size_t E, uin
     // `whole` comes from the (untrusted) stream, the index was sized from the OUTPUT capacity: a stream that holds more blocks than the
     // output has room for is the sequential path's to refuse (a format error), before anything is sized or filled with it
     if (whole > max_chunks * kChunkBlocks || whole > index_bytes) { if (trace) fprintf(stderr, "[density_hip prof]   -> sequential path (stream longer than the output: %llu blocks)\n", (unsigned long long)whole); return DENSITY_HIP_OK; }
-    std::vector<uint64_t> h_off(max_chunks + 2), h_offsets, h_sizes;
-    e = hipMemcpyAsync(h_off.data(), d_chunk_offset, (max_chunks + 2) * sizeof(uint64_t), hipMemcpyDeviceToHost, s);
-    // beyond the whole blocks the index says "ragged" = stop (an episode that was started over may have written further)
-    if (e == hipSuccess) e = hipMemsetAsync(d_index + whole, 0x7f, index_bytes - whole, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    // beyond the whole blocks the index says "ragged" = stop (an episode that was started over may have written further); in stream order in front of
+    // the decode passes, no round trip
+    e = hipMemsetAsync(d_index + whole, 0x7f, index_bytes - whole, s);
     if (e != hipSuccess) { set_error("segmented stream decode (parse)", e); return DENSITY_HIP_ERR_RUNTIME; }
     const bool ragged = end_pos < E;
     const size_t n_chunks = (whole + (ragged ? 1 : 0) + kChunkBlocks - 1) / kChunkBlocks;
