@@ -2101,7 +2101,9 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
             else tail_delta = pg_delta[n_pages - 1u];
         }
         const uint32_t end_at = (uint32_t)end_key + tail_delta;
-        const uint64_t elen_at = elen64 + tail_delta;
+        // (32-bit arithmetic like every page offset: the last page may lie BELOW the stream bytes in front of it — a producer may number its pages in any
+        // order; this library's encoder never does, its counter only grows —, and the sum must wrap like the offsets it is compared with)
+        const uint64_t elen_at = (uint32_t)((uint32_t)elen64 + tail_delta);
         uint64_t ip = npr * R < nvalid ? (rfl(lds_peek1(kDecPos + npr * 4u)) & (PAGED ? ~1u : ~0u)) : end_at, op = (uint64_t)npr * R * kBlock;
         for (uint32_t i = npr * R; i < nvalid && !bad; ++i) {
             const uint32_t ent = smem[kDecIdx + i];

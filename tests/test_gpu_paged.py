@@ -90,3 +90,24 @@ def test_a_lying_page_directory_is_a_format_error():
         d = torch.from_numpy(bad).cuda()
         with pytest.raises(DecodeError):
             container.decode_device(d.data_ptr(), bad.size, back.data_ptr(), n)
+
+
+@pytest.mark.parametrize("kind,n,chunk,shuffle", [("mixed", (6 << 20) + 4321, 1 << 20, False), ("rep-text", 16 << 20, 4 << 20, True), ("random", (4 << 20) + 256, 2 << 20, True)])
+def test_gpu_decodes_a_cpu_built_paged_container(kind, n, chunk, shuffle):
+    """A paged container assembled on the CPU from the oracle's streams by the header's layout alone (tests/paged_cpu.py), its pages in chunk order or shuffled:
+    the GPU decoder takes it like one of its own."""
+    import torch
+    import paged_cpu
+    from density_amd import container
+    data = datagen.rep_text(n) if kind == "rep-text" else datagen.by_kind(kind, n, seed=7)
+    blob = paged_cpu.build(data, chunk)
+    if shuffle:
+        from test_paged_cpu_reader import _dir_heads
+        hdr, _ = container.chunk_payloads(blob)
+        total = sum(int.from_bytes(bytes(blob[d:d + 4]), "little") for d in _dir_heads(blob, hdr, chunk))   # pages in use
+        blob = paged_cpu.build(data, chunk, page_order=list(np.random.default_rng(3).permutation(total)))
+    d = torch.from_numpy(blob).cuda()
+    back = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    assert container.decode_device(d.data_ptr(), blob.size, back.data_ptr(), n) == n
+    assert np.array_equal(back.cpu().numpy(), data)
+

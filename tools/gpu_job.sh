@@ -1,16 +1,22 @@
 #!/bin/bash
-# round 5's closing run: GPU suite, smoke, the driver's bench line, the rocprofv3 passes behind profiles/r05_*, the bench harness, the A/B of the two rotation
-# encoders, the fuzzers.  Afterwards, here: python probes/profile_summary.py gpurun_out/prof5 r05 ; cp the rest into profiles/ (see profiles/README.md)
-T=gpurun_out/r5_final; mkdir -p $T; export TMPDIR=/tmp
-date +%s > $T/t0
-timeout 900 python -m pytest tests -m gpu -x -q > $T/pytest.log 2>&1; echo "pytest rc=$?"; tail -3 $T/pytest.log
-timeout 200 python __graft_entry__.py smoke > $T/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 $T/smoke.log
-echo "elapsed $(( $(date +%s) - $(cat $T/t0) )) s"
-bash probes/profile_round.sh gpurun_out/prof5 > $T/profile_round.log 2>&1; echo "profile rc=$?"; tail -3 $T/profile_round.log
-echo "elapsed $(( $(date +%s) - $(cat $T/t0) )) s"
-timeout 600 python bench.py --steps 20 --warmup 5 > $T/bench_full.json 2> $T/bench_full.err; echo "bench rc=$?"; head -c 300 $T/bench_full.json; echo
-timeout 400 python benches/density.py > $T/benches_density.txt 2>&1; echo "harness rc=$?"; tail -24 $T/benches_density.txt
-timeout 300 python tools/gpu_split_ab.py 10 > $T/split_ab.txt 2>&1; echo "split A/B rc=$?"; grep -v amdgpu.ids $T/split_ab.txt | tail -12
-timeout 200 python tools/gpu_forms.py 10 2>&1 | grep -v amdgpu.ids > $T/forms.txt; tail -6 $T/forms.txt
-for f in encode streams passes; do timeout 200 python tools/gpu_fuzz_$f.py > $T/fuzz_$f.log 2>&1; echo "fuzz $f rc=$?"; tail -2 $T/fuzz_$f.log; done
-echo "elapsed $(( $(date +%s) - $(cat $T/t0) )) s"
+# r5y: paged containers with their pages in any order (the tail's 32-bit arithmetic), then the whole paged / chameleon files
+timeout 600 python -m pytest tests/test_gpu_paged.py -m gpu -x -q 2>&1 | grep -v amdgpu.ids | tail -3
+python - <<'PY' 2>&1 | grep -v amdgpu.ids
+import sys; sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import numpy as np, torch, datagen, paged_cpu
+from density_amd import container
+from test_paged_cpu_reader import _dir_heads
+bad = 0
+for seed in range(12):
+    kind, n, chunk = [("random", 3 << 20, 1 << 20), ("mixed", (5 << 20) + 999, 1 << 20), ("rep", 8 << 20, 2 << 20)][seed % 3]
+    data = datagen.rep_text(n) if kind == "rep" else datagen.by_kind(kind, n, seed=seed)
+    blob = paged_cpu.build(data, chunk)
+    hdr, _ = container.chunk_payloads(blob)
+    total = sum(int.from_bytes(bytes(blob[d:d + 4]), "little") for d in _dir_heads(blob, hdr, chunk))
+    blob = paged_cpu.build(data, chunk, page_order=list(np.random.default_rng(100 + seed).permutation(total)))
+    d = torch.from_numpy(blob).cuda(); back = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    try: ok = container.decode_device(d.data_ptr(), blob.size, back.data_ptr(), n) == n and np.array_equal(back.cpu().numpy(), data)
+    except Exception as ex: ok = False
+    bad += not ok
+print("shuffled CPU-built paged containers: 12 tried,", bad, "failed")
+PY
