@@ -18,7 +18,7 @@ def test_python_script_parses(path, tmp_path):
     py_compile.compile(path, cfile=str(tmp_path / "x.pyc"), doraise=True)
 
 
-@pytest.mark.parametrize("path", [p for p in SH if "/round4/" not in p and os.path.basename(p) in ("gpu_round_end5.sh", "profile_round.sh")],
+@pytest.mark.parametrize("path", [p for p in SH if "/round4/" not in p and os.path.basename(p) in ("gpu_round_end5.sh", "profile_round.sh", "profile_directions.sh")],
                          ids=lambda p: os.path.relpath(p, ROOT))
 def test_recipe_scripts_name_existing_files(path):
     text = open(path).read()
