@@ -325,7 +325,8 @@ int run_pack_container(DeviceCtx* c, const uint8_t* d_in, size_t container_size,
     prof.mark("layout_encode");
     if (e == hipSuccess) {
         if (stride) e = launch_compact(d_in + pbase, stride, d_sizes64, d_sizes, h.n_chunks, d_out, d_err, s);
-        else e = hipMemcpyAsync(d_out + pbase, d_in + pbase, container_size - pbase, hipMemcpyDeviceToDevice, s);
+        else if (h.container_len > cap || h.container_len < pbase) { set_error("output capacity below the container's length"); return DENSITY_HIP_ERR_CAPACITY; }
+        else e = hipMemcpyAsync(d_out + pbase, d_in + pbase, h.container_len - pbase, hipMemcpyDeviceToDevice, s);   // (already packed: its own bytes, no more)
     }
     prof.mark("compact");
     if (e != hipSuccess) { set_error("kernel launch (pack)", e); return DENSITY_HIP_ERR_RUNTIME; }
@@ -453,6 +454,8 @@ int density_hip_pack_device(const void* d_container, size_t container_size, cons
         if (e != hipSuccess) { set_error("header read-back", e); return DENSITY_HIP_ERR_RUNTIME; }
     }
     if (check_header(h, container_size) != DENSITY_HIP_OK) { set_error("bad container header"); return DENSITY_HIP_ERR_FORMAT; }
+    // a PAGED container is wire-ready as it stands, and its streams are not where the packed / slotted arithmetic looks for them
+    if (h.flags & DENSITY_HIP_FLAG_PAGED) { set_error("density_hip_pack_device: a paged container is not packed (it is wire-ready; decode it or read its pages)"); return DENSITY_HIP_ERR_UNSUPPORTED; }
     const size_t need = plan_decode(h.algo, h.n_chunks).total;
     uint8_t* ws = (uint8_t*)d_workspace;
     if (ws) { if (workspace_size < need) { set_error("workspace too small"); return DENSITY_HIP_ERR_CAPACITY; } }
@@ -493,7 +496,7 @@ size_t density_hip_auto_chunk(size_t input_size) { return auto_chunk(input_size)
 size_t density_hip_auto_chunk_for(int algo, size_t input_size) { return valid_algo(algo) ? auto_chunk(input_size, algo) : 0; }
 
 void density_hip_set_profiling(int enabled) { g_profiling = enabled; }
-void density_hip_set_kernel_variant(int variant) { g_variant = variant;   /* bit 3 (8): encode in batches with the stitch of one batch beside the encoding of the next */ density::g_force_simple = (variant & 1) != 0; density::g_force_pipeline = (variant & 4) != 0; density::g_force_lane_codec = (variant & 16) != 0; density::g_force_wave_codec = (variant & 32) != 0; density::g_stage_audit = (variant & 64) != 0; density::g_force_serial_decode = (variant & 128) != 0; density::g_serial_parse = (variant & 1024) != 0; density::g_rotor_split = density::kRotorSplitDefault != ((variant & 2048) != 0); }
+void density_hip_set_kernel_variant(int variant) { g_variant = variant;   /* bit 3 (8): encode in batches with the stitch of one batch beside the encoding of the next */ density::g_force_simple = (variant & 1) != 0; density::g_force_pipeline = (variant & 4) != 0; density::g_force_lane_codec = (variant & 16) != 0; density::g_force_wave_codec = (variant & 32) != 0; density::g_stage_audit = (variant & 64) != 0; density::g_force_serial_decode = (variant & 128) != 0; density::g_serial_parse = (variant & 1024) != 0; density::g_chain_walk = (variant & 4096) != 0; density::g_rotor_split = density::kRotorSplitDefault != ((variant & 2048) != 0); }
 
 int density_hip_last_timings(float* milliseconds, const char** names, int capacity) {
     int dev = -1;

@@ -71,7 +71,7 @@ size_t decode_container_pipelined(DeviceCtx* c, const uint8_t* container, const 
     *handled = false;
     const uint32_t nc = h.n_chunks;
     const size_t chunk = h.chunk_size, total = h.total_len;
-    if (!pipe_wanted(h.algo, total, chunk, nc) || (h.flags & DENSITY_HIP_FLAG_SLOTTED)) return 0;
+    if (!pipe_wanted(h.algo, total, chunk, nc) || (h.flags & (DENSITY_HIP_FLAG_SLOTTED | DENSITY_HIP_FLAG_PAGED))) return 0;   // (slices follow the PACKED layout: a paged blob's streams lie in pages — the staged call reads them in place)
     PinnedInPlace pin_in(container, h.container_len), pin_out(output, total);
     if (!pin_in || !pin_out) return 0;
     const bool with_index = h.flags & DENSITY_HIP_FLAG_BLOCK_INDEX;

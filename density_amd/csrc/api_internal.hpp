@@ -83,9 +83,12 @@ inline uint32_t paged_pages_per_chunk(size_t chunk) { return pages_per_chunk(saf
 inline size_t paged_dir_bytes(size_t n_chunks, size_t chunk) { return 4 * (size_t)page_dir_words(paged_pages_per_chunk(chunk)) * n_chunks; }
 inline size_t paged_pages_base(size_t n_chunks, size_t total_len, size_t chunk) { return align_up(paged_dir_base(n_chunks, total_len) + paged_dir_bytes(n_chunks, chunk), kAlign); }
 // what the paged form is for: Chameleon, chunks of 1 MiB and more (a chunk's last page is half empty on average: 3 % of a MiB of text), 32-bit positions
+// — and of at most 4 MiB: only the index-fed rotation decoder reads pages in place (kPagedMaxChunk = its kRotMaxBlocks blocks, its directory copy holds
+// kPagedMaxPages pages), and the library writes no container it cannot read
 inline bool paged_eligible(int algo, size_t n, size_t chunk) {
     const size_t nc = chunk_count(n, chunk);
-    return algo == DENSITY_HIP_CHAMELEON && want_index(algo) && nc > 1 && chunk >= (1u << 20) && (uint64_t)nc * paged_pages_per_chunk(chunk) * kPageBytes < (1ull << 32);
+    return algo == DENSITY_HIP_CHAMELEON && want_index(algo) && nc > 1 && chunk >= (1u << 20) && chunk <= kPagedMaxChunk && paged_pages_per_chunk(chunk) <= kPagedMaxPages &&
+           (uint64_t)nc * paged_pages_per_chunk(chunk) * kPageBytes < (1ull << 32);
 }
 size_t container_bound_paged(int algo, size_t n, size_t chunk);
 inline size_t slot_stride(int algo, size_t chunk) { return align_up(safe_size(algo, chunk), kAlign); }
@@ -206,7 +209,8 @@ constexpr size_t kSerialTableBudget = 8ull << 30;   // ... but never more than 8
 inline size_t serial_slots(int algo, size_t n_chunks) {
     if (algo == DENSITY_HIP_CHAMELEON) return 0;
     const size_t by_memory = kSerialTableBudget / serial_table_bytes(algo);
-    const size_t cap = kSerialSlots < by_memory ? kSerialSlots : by_memory;
+    size_t cap = kSerialSlots < by_memory ? kSerialSlots : by_memory;
+    if (const char* e = debug_env("DENSITY_HIP_SERIAL_SLOTS")) { const size_t v = (size_t)atoll(e); if (v >= 1 && v < cap) cap = v; }   // (debug builds: streams in flight, tools/gpu_lion_slots.py)
     return n_chunks < cap ? n_chunks : cap;
 }
 inline size_t serial_tables(int algo, size_t n_chunks) { return algo == DENSITY_HIP_CHAMELEON ? 0 : align_up(serial_slots(algo, n_chunks) * serial_table_bytes(algo), kAlign); }

@@ -135,6 +135,14 @@ __global__ __launch_bounds__(kScanThreads) void layout_encode_paged_kernel(const
     if (threadIdx.x < ibase - table_end) container[table_end + threadIdx.x] = 0;
     if (threadIdx.x >= 32 && threadIdx.x - 32 < dir_base - iend) container[iend + threadIdx.x - 32] = 0;
     for (uint64_t i = dir_end + threadIdx.x; i < pages_base; i += kScanThreads) container[i] = 0;
+    // the directory entries behind a chunk's last page are part of the wire bytes too: zeros, not what the buffer held
+    uint32_t* dir = reinterpret_cast<uint32_t*>(container + dir_base);
+    const uint32_t words = n ? (uint32_t)((dir_end - dir_base) / 4 / n) : 0u;
+    for (uint64_t i = threadIdx.x; i < (uint64_t)n * words; i += kScanThreads) {
+        const uint32_t c = (uint32_t)(i / words), w = (uint32_t)(i % words);
+        const uint32_t used = dir[(uint64_t)c * words];                           // pages of chunk c (word 0 of its directory; never rewritten here)
+        if (w >= 4u * (used + 1u)) dir[i] = 0u;
+    }
 }
 
 __global__ __launch_bounds__(kScanThreads) void layout_decode_kernel(const uint8_t* __restrict__ container, uint64_t container_size,

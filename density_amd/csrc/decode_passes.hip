@@ -38,6 +38,7 @@ namespace density {
 extern __shared__ __attribute__((aligned(16))) uint8_t pass_lds[];
 bool g_force_serial_decode = false;   // density_hip_set_kernel_variant(128): Cheetah containers on the one-wave decoder instead
 bool g_serial_parse = false;          // density_hip_set_kernel_variant(1024): the records of a chunk found by the one-wave walk alone (no window kernels)
+bool g_chain_walk = false;            // density_hip_set_kernel_variant(4096): the contexts walked run by run (round 5's walk) instead of 64 quads at a time
 
 namespace {
 
@@ -50,11 +51,10 @@ constexpr uint32_t kErrFormat = 1u, kErrWatchdog = 16u;
 constexpr uint32_t kSpinLimit = 1u << 22, kPoison = 0xfffffffeu;
 
 __device__ __forceinline__ uint32_t hash16(uint32_t q) { return (q * kHashMul) >> 16; }
-// vec[lane] = val (both wave-uniform scalars; the lane select goes through M0: an SGPR value and an SGPR lane select together would
-// break gfx9's one-scalar-operand rule)
+// vec[lane] = val (both wave-uniform scalars): a compare and a select — v_writelane_b32 would want its lane select in M0 (an SGPR value and an SGPR
+// lane select together break gfx9's one-scalar-operand rule), and M0 is the compiler's, not an asm statement's, to write
 __device__ __forceinline__ uint32_t writelane(uint32_t vec, uint32_t val, uint32_t lane) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(vec) : "s"(val), "s"(lane) : "m0");
-    return vec;
+    return lane_id() == lane ? val : vec;
 }
 
 // per chunk, left by `parse`: blocks, decoded bytes, quads and raw tail bytes of a ragged last record, where those bytes sit in the stream
@@ -533,6 +533,21 @@ __global__ __launch_bounds__(kPassWaves * 64) void cheetah_pass(PassArgs a) {
 // walk: the contexts (cheetah.rs:97-102,161: last_hash) — the one chain of the decoder, on 16-bit hashes in LDS
 // ---------------------------------------------------------------------------------------------------------------
 constexpr uint32_t kWalkTable = 65536u * 2u, kTileBlocks = 16, kTileBytes = kTileBlocks * 256u, kWalkLds = kWalkTable + 2u * kTileBytes;
+// VEC (round 6): 64 quads at a time.  The chain is only as long as its DEPENDENT links: a predicted quad's context is the hash of the quad before it,
+// which is in the descriptor unless that quad was predicted too — in 100 MB of prose four of five predicted quads follow a quad that was not.  So per
+// block of 64 quads (a quad per lane):
+//   speculate  the contexts of the lanes behind predicted quads by plain READS of H as it stands, level by level (a lane's level = the predicted lanes
+//              right in front of it: one LDS round trip per level for all 64 lanes, where the run-by-run walk paid one per run and quad);
+//   execute    ALL 64 table operations in one ordered instruction (ds_mskor_rtn_b32 on the 16-bit halves: gfx950 serves the lanes of one LDS
+//              instruction in ascending order — §4.2 of DESIGN.md, verified at start-up —, a predicted lane reads, the others write H[context]);
+//   verify     a predicted lane must have read in the ordered pass what its successors' contexts were derived from.  If every one did, the contexts
+//              ARE the sequential ones (induction over the lanes: lane 0's context is the running one; if lanes 0..i hold the right contexts the
+//              ordered pass did to H exactly what cheetah.rs:72,81,90,97-102 do up to quad i, so what lane i read is right, and with it lane i+1's
+//              context).  If lane i0 is the first that read something else (a context written earlier in the SAME block: "the " twice within 256
+//              bytes with two followers), lanes 0..i0 stand, the lanes behind it take their writes back — old halves, highest lane first: the lane-
+//              reversed store of rotor.hip — and go again from what lane i0 really read.
+// Blocks with a run of eight and more predicted quads (periodic input, zeros) keep the run-by-run chain below: a level costs what a link does.
+template <bool VEC>
 __global__ __launch_bounds__(64) void cheetah_walk(PassArgs a) {
     const uint32_t lane = threadIdx.x;
     const uint64_t chunk = blockIdx.x;
@@ -582,6 +597,53 @@ __global__ __launch_bounds__(64) void cheetah_walk(PassArgs a) {
         const uint32_t hprev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h, 0x138, 0xf, 0xf, false);   // wave_shr:1
         uint32_t cv = hprev;                                                       // my context: the hash of the quad before me, unless patched below
         const uint64_t active = P | N;
+        uint64_t longrun = P & (P >> 1); longrun &= longrun >> 2; longrun &= longrun >> 4;   // bit i: lanes i .. i+7 are all predicted
+        if (VEC && __builtin_expect(active == ~0ull && longrun == 0, 1)) {
+            const uint64_t K0 = (N << 1) | 1ull;                                     // lanes whose context is in the descriptors (lane 0: the running context)
+            cv = lane == 0 ? c : hprev;
+            const bool lp = (P >> lane) & 1ull;
+            uint64_t fin = 0, known = K0;
+            uint32_t rfin = 0;                                                       // predicted lanes: what they read (their successor's context)
+            for (;;) {
+                // speculate
+                uint32_t rs = 0;
+                uint64_t rdone = fin;
+                for (;;) {
+                    const uint64_t R = P & known & ~rdone;
+                    if (!R) break;
+                    uint32_t r;
+                    asm volatile("ds_read_u16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(lds0 + 2u * cv) : "memory");
+                    const uint32_t up = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x138, 0xf, 0xf, false);   // wave_shr:1
+                    if ((R >> lane) & 1ull) rs = r;
+                    if (((R << 1) >> lane) & 1ull) cv = up;
+                    known |= R << 1; rdone |= R;
+                }
+                // execute: every lane that does not stand yet, in stream order
+                const bool pend = !((fin >> lane) & 1ull), wr = pend && !lp;
+                const uint32_t sh = (cv & 1u) * 16u;
+                uint32_t ret;
+                asm volatile("ds_mskor_rtn_b32 %0, %1, %2, %3\n\ts_waitcnt lgkmcnt(0)" : "=v"(ret) : "v"(lds0 + ((2u * cv) & ~3u)), "v"(wr ? 0xffffu << sh : 0u), "v"(wr ? hw << sh : 0u) : "memory");
+                const uint32_t r2 = (ret >> sh) & 0xffffu;
+                // verify
+                const uint64_t bad = ballot64(pend && lp && r2 != rs);
+                if (__builtin_expect(bad == 0, 1)) { if (pend) rfin = r2; break; }
+                const uint32_t i0 = (uint32_t)__builtin_ctzll(bad);
+                const uint64_t stands = (2ull << i0) - 1ull;                           // lanes 0 .. i0 (i0 == 63: all of them)
+                const uint64_t undo = N & ~stands;                                   // the writes behind i0 (every pending lane beyond i0 that is not predicted wrote)
+                if (undo) {
+                    const uint32_t ar = bperm(63u - lane, lds0 + 2u * cv), old = bperm(63u - lane, r2);
+                    if ((undo >> (63u - lane)) & 1ull) asm volatile("ds_write_b16 %0, %1" ::"v"(ar), "v"(old) : "memory");
+                }
+                if (pend && ((stands >> lane) & 1ull)) rfin = r2;
+                fin = stands;
+                if (fin == ~0ull) break;
+                const uint32_t truth = (uint32_t)__builtin_amdgcn_readlane((int)r2, (int)i0);
+                if (lane == i0 + 1u) cv = truth;
+                known = stands | (stands << 1) | K0;
+            }
+            const uint32_t last = lp ? rfin : h;
+            c = (uint32_t)__builtin_amdgcn_readlane((int)last, 63);
+        } else
         if (__builtin_expect(active == ~0ull && P != 0 && P != ~0ull, 1)) {
             // Every quad of the block takes part (no raw-copy block, not the chunk's end) and some, not all, are predicted: the chain in as
             // few instructions as it takes — a lone wave issues one instruction every 4-5 cycles, so the instruction count IS the walk's
@@ -595,9 +657,10 @@ __global__ __launch_bounds__(64) void cheetah_walk(PassArgs a) {
             const uint32_t h2 = lds0 + 2u * h;                                      // what the running context becomes behind a quad that is not predicted
             uint64_t prem = P;
             uint32_t c2 = lds0 + 2u * c;
-            uint32_t s_pos, s_p, s_r, v_t, v_u;
+            uint32_t s_pos, s_p, s_r, v_t, v_u, s_m0;
             uint64_t s_m;
             asm volatile(
+                "s_mov_b32 %[m0s], m0\n\t"                                            // (M0 is the compiler's: handed back as found)
                 "s_mov_b32 %[pos], 0\n"
                 "1:\n\t"                                                             // ---- next run of quads that are not predicted: [pos, p)
                 "s_ff1_i32_b64 %[p], %[prem]\n\t"
@@ -638,9 +701,10 @@ __global__ __launch_bounds__(64) void cheetah_walk(PassArgs a) {
                 "s_mov_b32 %[pos], %[p]\n\t"
                 "s_branch 1b\n"
                 "4:\n\t"
-                : [av] "+v"(av), [c2] "+s"(c2), [prem] "+s"(prem), [pos] "=&s"(s_pos), [p] "=&s"(s_p), [r] "=&s"(s_r), [m] "=&s"(s_m), [t] "=&v"(v_t), [u] "=&v"(v_u)
+                "s_mov_b32 m0, %[m0s]\n\t"
+                : [av] "+v"(av), [c2] "+s"(c2), [prem] "+s"(prem), [pos] "=&s"(s_pos), [p] "=&s"(s_p), [r] "=&s"(s_r), [m] "=&s"(s_m), [t] "=&v"(v_t), [u] "=&v"(v_u), [m0s] "=&s"(s_m0)
                 : [h] "v"(hw), [h2] "v"(h2), [lds0] "s"(lds0)
-                : "memory", "m0", "scc");
+                : "memory", "scc");
             c = (c2 - lds0) >> 1;
             cv = (av - lds0) >> 1;
         } else {
@@ -741,7 +805,8 @@ hipError_t launch_decode_passes(int algo, const uint8_t* d_in, const uint64_t* d
     hipError_t e = hipFuncSetAttribute((const void*)cheetah_pass<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pass_lds_bytes());
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)cheetah_pass<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pass_lds_bytes());
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)cheetah_pass<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pass_lds_bytes());
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)cheetah_walk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWalkLds);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)cheetah_walk<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWalkLds);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)cheetah_walk<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWalkLds);
     if (e != hipSuccess) return e;
     // the records of calm stretches are found by the window kernels (their tables live where the descriptors and contexts will: nothing else is in use yet)
     const uint64_t slot_bound = out_stride + out_stride / kRecBytes * kSigBytes + kSigBytes;
@@ -767,7 +832,8 @@ hipError_t launch_decode_passes(int algo, const uint8_t* d_in, const uint64_t* d
     hipLaunchKernelGGL(cheetah_prepare, dim3((uint32_t)((pairs + 3) / 4)), dim3(256), 0, stream, a, blocks_per_chunk);
     hipLaunchKernelGGL(cheetah_pass<0>, dim3(2 * n_chunks), dim3(kPassWaves * 64), pass_lds_bytes(), stream, a);
     hipLaunchKernelGGL(cheetah_pass<1>, dim3(4 * n_chunks), dim3(kPassWaves * 64), pass_lds_bytes(), stream, a);
-    hipLaunchKernelGGL(cheetah_walk, dim3(n_chunks), dim3(64), kWalkLds, stream, a);
+    if (g_chain_walk) hipLaunchKernelGGL(cheetah_walk<false>, dim3(n_chunks), dim3(64), kWalkLds, stream, a);
+    else hipLaunchKernelGGL(cheetah_walk<true>, dim3(n_chunks), dim3(64), kWalkLds, stream, a);
     hipLaunchKernelGGL(cheetah_pass<2>, dim3(2 * n_chunks), dim3(kPassWaves * 64), pass_lds_bytes(), stream, a);
     hipLaunchKernelGGL(cheetah_finish, dim3((n_chunks + 255) / 256), dim3(256), 0, stream, a, exact ? 1u : 0u, d_produced);
     return hipGetLastError();

@@ -43,6 +43,9 @@ constexpr uint32_t kPageShift = 16, kPageBytes = 1u << kPageShift;
 // its directory
 __host__ __device__ inline uint32_t pages_per_chunk(uint64_t worst_stream_bytes) { return (uint32_t)(worst_stream_bytes / (kPageBytes - 4352u)) + 2u; }
 __host__ __device__ inline uint32_t page_dir_words(uint32_t pages) { return 4u * (pages + 1u); }
+// what the paged DECODER takes (rotor.hip: kRotMaxBlocks blocks of index, kDecMaxPages directory entries in LDS): the encoder offers no more
+constexpr uint64_t kPagedMaxChunk = 4ull << 20;
+constexpr uint32_t kPagedMaxPages = 96;
 bool rotor_encode_eligible(const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks);
 // the rotation encoder writing a PAGED container's pages (d_pages: page 0) and directory; d_page_counter zeroed by the caller
 hipError_t launch_rotor_encode_paged(const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_pages, uint32_t page_limit,
@@ -125,6 +128,7 @@ hipError_t launch_stage_encode(int algo, const uint8_t* d_in, uint64_t total, ui
 // exchange passes over the whole chunk, the chain of contexts alone on one wave per chunk) ----
 extern bool g_force_serial_decode;   // density_hip_set_kernel_variant(128): the one-wave-per-stream decoder instead
 extern bool g_serial_parse;          // density_hip_set_kernel_variant(1024): Cheetah's decode passes find the records by the one-wave walk alone
+extern bool g_chain_walk;            // density_hip_set_kernel_variant(4096): Cheetah's contexts walked run by run (round 5) instead of 64 quads at a time
 bool decode_pass_eligible(int algo, const uint8_t* d_out, uint32_t n_chunks, uint64_t out_stride, uint64_t out_total);
 uint64_t decode_pass_scratch_bytes(uint64_t out_stride, uint32_t n_chunks);
 hipError_t launch_decode_passes(int algo, const uint8_t* d_in, const uint64_t* d_offsets, const uint64_t* d_sizes, uint32_t n_chunks, uint8_t* d_out,

@@ -70,7 +70,8 @@ constexpr uint32_t dec_zmap_at(uint32_t R) { return kDecPos + dec_pos_bytes(R); 
 constexpr uint32_t dec_sync_at(uint32_t R) { return dec_zmap_at(R) + (dec_zmap_in_lds(R) ? kZmapBytes : 0u); }
 constexpr uint32_t dec_lds_bytes(uint32_t R) { return dec_sync_at(R) + kSyBytes; }
 // PAGED decoder: behind the sync block, per page of the chunk its first block and what turns a stream position into an offset from page 0
-constexpr uint32_t kDecMaxPages = 96;
+constexpr uint32_t kDecMaxPages = kPagedMaxPages;
+static_assert(kPagedMaxChunk == (uint64_t)kRotMaxBlocks * 256u, "the paged form ends where the index-fed decoder does");
 constexpr uint32_t dec_pages_at(uint32_t R) { return dec_lds_bytes(R); }
 constexpr uint32_t dec_lds_bytes_paged(uint32_t R) { return dec_lds_bytes(R) + 8u * kDecMaxPages; }
 static_assert(dec_lds_bytes_paged(12) <= 160u * 1024u, "LDS budget of the paged decoder");
@@ -790,7 +791,10 @@ __global__ __launch_bounds__(SPLIT ? 2 * W * 64 : W * 64) void chameleon_encode_
             const u32x4 v = {spare << kPageShift, before + (pos - base), kNone, count + 1u};
             asm volatile("ds_write_b128 %0, %1" ::"v"(sy + kSyPage), "v"(v) : "memory");
         }
-        refill = true;
+        // a new spare only if the stream is LIKELY to outgrow this page: what is left of the chunk at the bytes per block the stream has had so far, and
+        // an eighth on top.  The last page of a chunk mostly needs none, and a spare nobody uses is 64 KiB of the container (one per chunk until round 6:
+        // 2.4 % of the headline blob).  If the guess is wrong the next change of pages takes its page from the counter itself (above: spare == kNone).
+        refill = (uint64_t)(nfull - first_block + 1u) * (before + (pos - base)) * 9u >= (uint64_t)first_block * (8u * kPageBytes);
         return spare << kPageShift;
     };
     auto page_refill = [&]() {
@@ -1747,6 +1751,9 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
                 for (uint32_t b = first / R * R; b < first; ++b) { const uint32_t ent = smem[kDecIdx + b]; at += (ent & kIdxCopy) ? kBlock : kSig + kBlock - 2u * (ent & 0x7fu); }
                 ok = at == before;
             }
+            // the pages hold the chunk's stream and nothing else: the last page ends where the size table says the stream ends — which also keeps
+            // every stream position below `elen` inside a page of the directory (no read through a directory that is shorter than its stream)
+            if (k + 1u == n_pages && (uint64_t)before + used != elen64) ok = false;
             if (!ok) bad_index = 1;
         }
         if (!dir_ok) bad_index = 1;

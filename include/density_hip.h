@@ -231,7 +231,8 @@ void density_hip_stage_stats(uint64_t* out2);
  * keep / hand back (density_hip_stage_stats; reads the verdicts back, so the encode call synchronises), 128 = Cheetah containers on the
  * one-wave-per-stream decoder instead of the decode passes (decode_passes.hip), 256 = the host-pointer container calls pipelined
  * whatever the size, a slice per chunk, 512 = never pipelined (below; the reference symbols on long streams too), 1024 = Cheetah's decode passes find
- * a chunk's records by the one-wave walk alone (no window kernels).
+ * a chunk's records by the one-wave walk alone (no window kernels), 2048 = the other rotation encoder (8 chain + 8 emit waves), 4096 = Cheetah's decode
+ * passes walk the contexts run by run (round 5's walk) instead of 64 quads at a time.
  * Payload bytes are identical in every variant. */
 void density_hip_set_kernel_variant(int variant);
 

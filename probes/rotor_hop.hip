@@ -68,6 +68,14 @@ __global__ __launch_bounds__(1024) void hop_kernel(uint64_t* out, uint32_t round
         const uint32_t tv = r + 1u;
         if (mode & 4u) {
             asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(ta), "v"(tv) : "memory");
+        } else if (mode & (64u | 128u | 256u)) {
+            // round 6: the exchanges under an EXEC mask of 32 / 16 / 8 lanes (every 2nd / 4th / 8th lane) — is an ordered exchange paid per lane or per instruction?
+            const uint64_t em = (mode & 64u) ? 0x5555555555555555ull : (mode & 128u) ? 0x1111111111111111ull : 0x0101010101010101ull;
+            asm volatile("s_mov_b64 exec, %34\n\t" XCHG8 "s_mov_b64 exec, -1\n\tds_write_b32 %32, %33\n\ts_waitcnt lgkmcnt(0)"
+                : "=&v"(ret[0]), "=&v"(ret[1]), "=&v"(ret[2]), "=&v"(ret[3]), "=&v"(ret[4]), "=&v"(ret[5]), "=&v"(ret[6]), "=&v"(ret[7])
+                : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "v"(addr[4]), "v"(addr[5]), "v"(addr[6]), "v"(addr[7]),
+                  "v"(mask[0]), "v"(mask[1]), "v"(mask[2]), "v"(mask[3]), "v"(mask[4]), "v"(mask[5]), "v"(mask[6]), "v"(mask[7]),
+                  "v"(val[0]), "v"(val[1]), "v"(val[2]), "v"(val[3]), "v"(val[4]), "v"(val[5]), "v"(val[6]), "v"(val[7]), "v"(ta), "v"(tv), "s"(em) : "memory");
         } else if (mode & 32u) {
             asm volatile(XCHG8 "s_waitcnt lgkmcnt(0)\n\tds_write_b32 %32, %33" OPS(ret, addr, mask, val, ta, tv));
         } else {
@@ -134,6 +142,11 @@ int main() {
         {2, 16, "16 waves, simple poll + setprio, random"}, {3, 16, "16 waves, pipelined poll + setprio, random"},
         {4, 16, "16 waves, token only, simple poll"}, {5, 16, "16 waves, token only, pipelined poll"}, {32, 16, "16 waves, token after answers, random"},
         {0, 4, "4 waves, simple poll, random"}, {0, 2, "2 waves, simple poll, random"},
+        // round 6 (price the ordered exchange by active lanes before building two dictionary tokens)
+        {64, 1, "lone wave, random, 32 of 64 lanes active"}, {128, 1, "lone wave, random, 16 of 64 lanes active"}, {256, 1, "lone wave, random, 8 of 64 lanes active"},
+        {64 | 8, 1, "lone wave, text-like, 32 lanes active"},
+        {64, 16, "16 waves, simple poll, random, 32 lanes active"}, {128, 16, "16 waves, simple poll, random, 16 lanes active"},
+        {64 | 8, 16, "16 waves, simple poll, text-like, 32 lanes"},
     };
     for (auto& c : cases) {
         hipMemset(d, 0, 64 * 8);

@@ -111,3 +111,144 @@ def test_gpu_decodes_a_cpu_built_paged_container(kind, n, chunk, shuffle):
     assert container.decode_device(d.data_ptr(), blob.size, back.data_ptr(), n) == n
     assert np.array_equal(back.cpu().numpy(), data)
 
+
+
+def _directory(blob, hdr):
+    """[(page, first block, bytes used), ...] per chunk, and the offset of the directory."""
+    from density_amd import _lib
+    off = (32 + 4 * hdr.n_chunks + 15) // 16 * 16
+    off = (off + (hdr.total_len + 255) // 256 + 15) // 16 * 16
+    ppc = int(_lib.lib().density_hip_paged_pages_per_chunk(hdr.chunk_size))
+    b = bytes(blob[:off + 16 * (ppc + 1) * hdr.n_chunks])                          # (the front matter only)
+    out = []
+    for i in range(hdr.n_chunks):
+        d = off + 16 * (ppc + 1) * i
+        k = int.from_bytes(b[d:d + 4], "little")
+        out.append([tuple(int.from_bytes(b[d + 16 * (j + 1) + 4 * f:d + 16 * (j + 1) + 4 * f + 4], "little") for f in range(3)) for j in range(k)])
+        tail = b[d + 16 * (k + 1):d + 16 * (ppc + 1)]
+        assert tail == bytes(len(tail)), f"chunk {i}: directory entries behind the last page are part of the wire bytes: zeros"
+    return off, ppc, out
+
+
+def test_config2_full_size_paged_container_is_the_oracles_streams():
+    """The HEADLINE form at the headline size (what bench.py times): 1 GiB of rep-text through density_hip_encode_device_paged — 256 work-groups racing
+    for one page counter, ~10,000 pages.  Every chunk, reassembled on the CPU the way a CPU reader does (directory -> used bytes of the pages), equals the
+    oracle's stream of that chunk (codec.rs:72-80 per chunk); the directory is sound (every page used once, first blocks on multiples of 16, the bytes
+    used add up to the size table); the pages decode in place; and a SECOND encode gives the same chunk streams although its page order is its own."""
+    import os
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    from density_amd import container
+    from oracle import pyoracle
+    n, chunk = 1 << 30, 4 << 20
+    host = datagen.rep_text(n)
+    x, cont, hdr = _encode_paged(host, chunk)
+    assert hdr.flags & container.FLAG_PAGED and (hdr.n_chunks, hdr.total_len, hdr.chunk_size) == (256, n, chunk)
+    back = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    assert container.decode_device(cont.data_ptr(), hdr.container_len, back.data_ptr(), n, header=hdr) == n
+    assert torch.equal(back, x)
+    blob = cont[:hdr.container_len].cpu().numpy()
+    h, streams = container.chunk_payloads(blob)
+
+    def check(i):
+        return streams[i] == pyoracle.encode("chameleon", host[i * chunk:(i + 1) * chunk])
+    with ThreadPoolExecutor(os.cpu_count() or 4) as ex:
+        ok = list(ex.map(check, range(hdr.n_chunks)))
+    assert all(ok), [i for i, v in enumerate(ok) if not v][:8]
+    off, ppc, pages = _directory(blob, hdr)
+    sizes = [int.from_bytes(bytes(blob[32 + 4 * i:36 + 4 * i]), "little") for i in range(hdr.n_chunks)]
+    seen = set()
+    for i, pp in enumerate(pages):
+        assert 1 <= len(pp) <= ppc and pp[0][1] == 0
+        assert sum(u for _, _, u in pp) == sizes[i] == len(streams[i])
+        for k, (page, first, used) in enumerate(pp):
+            assert first % 16 == 0 and used <= 65536 and page not in seen and (k == 0 or first > pp[k - 1][1])
+            seen.add(page)
+    pages_base = (off + 16 * (ppc + 1) * hdr.n_chunks + 255) // 256 * 256
+    n_pages = (hdr.container_len - pages_base) // 65536
+    assert (hdr.container_len - pages_base) % 65536 == 0 and max(seen) < n_pages
+    # pages the counter handed out and nobody wrote to (spares): fewer than one per two chunks since round 6
+    assert n_pages - len(seen) <= hdr.n_chunks // 2 + 8, (n_pages, len(seen))
+    order1 = [p for pp in pages for p, _, _ in pp]
+    del blob, streams
+    # again: the same streams, whatever the pages' order
+    x2, cont2, hdr2 = _encode_paged(host, chunk)
+    back.zero_()
+    assert container.decode_device(cont2.data_ptr(), hdr2.container_len, back.data_ptr(), n, header=hdr2) == n
+    assert torch.equal(back, x)
+    blob2 = cont2[:hdr2.container_len].cpu().numpy()
+    _, streams2 = container.chunk_payloads(blob2)
+    with ThreadPoolExecutor(os.cpu_count() or 4) as ex:
+        ok = list(ex.map(lambda i: streams2[i] == pyoracle.encode("chameleon", host[i * chunk:(i + 1) * chunk]), range(hdr2.n_chunks)))
+    assert all(ok)
+    _, _, pages2 = _directory(blob2, hdr2)
+    assert [[(f, u) for _, f, u in pp] for pp in pages2] == [[(f, u) for _, f, u in pp] for pp in pages]     # page boundaries are the stream's, not the run's
+    print("page order identical between the two runs:", order1 == [p for pp in pages2 for p, _, _ in pp])
+
+
+def test_a_directory_shorter_than_its_stream_is_a_format_error():
+    """the last page's `used` must end where the size table says the stream ends — a crafted container with ONE page, a full chunk's
+    index and an inflated size would otherwise map stream positions past the page (and past the container)."""
+    import torch
+    from density_amd import container, _lib
+    from density_amd.codec import DecodeError
+    n, chunk = 8 << 20, 2 << 20
+    host = datagen.rep_text(n)
+    x, cont, hdr = _encode_paged(host, chunk)
+    blob = cont[:hdr.container_len].cpu().numpy().copy()
+    off, ppc, pages = _directory(blob, hdr)
+    back = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    pages_base = (off + 16 * (ppc + 1) * hdr.n_chunks + 255) // 256 * 256
+    last_page = (hdr.container_len - pages_base) // 65536 - 1
+
+    def put(b, at, v): b[at:at + 4] = np.frombuffer(int(v).to_bytes(4, "little"), dtype=np.uint8)
+    cases = {}
+    # (a) the directory truncated to its first page, which is moved to the container's last page; the size table untouched
+    bad = blob.copy(); d = off + 16 * (ppc + 1) * 1
+    put(bad, d, 1); put(bad, d + 16, last_page); cases["one page, full size"] = bad
+    # (b) the size table inflated over a true directory
+    bad = blob.copy(); put(bad, 32 + 4 * 2, int(chunk * 1.03)); cases["inflated size"] = bad
+    # (c) the size table deflated
+    bad = blob.copy(); put(bad, 32 + 4 * 3, int.from_bytes(bytes(blob[32 + 12:32 + 16]), "little") - 264); cases["deflated size"] = bad
+    # (d) the last page's used bytes grown
+    bad = blob.copy(); e = off + 16 * (ppc + 1) * 0 + 16 * len(pages[0]); put(bad, e + 8, pages[0][-1][2] + 136); cases["last page grown"] = bad
+    for what, bad in cases.items():
+        d = torch.from_numpy(bad).cuda()
+        with pytest.raises(DecodeError):
+            container.decode_device(d.data_ptr(), bad.size, back.data_ptr(), n)
+    assert container.decode_device(cont.data_ptr(), hdr.container_len, back.data_ptr(), n) == n and torch.equal(back, x)   # (the library is fine afterwards)
+
+
+def test_host_pointer_decode_of_a_large_paged_blob():
+    """density_hip_decode() on host pointers takes a wire-ready paged blob of 32 MiB and more (it used to enter the pipelined path,
+    whose slices follow the PACKED layout)."""
+    from density_amd import container
+    n, chunk = 48 << 20, 4 << 20
+    host = datagen.rep_text(n)
+    x, cont, hdr = _encode_paged(host, chunk)
+    assert hdr.flags & container.FLAG_PAGED and hdr.n_chunks >= 4
+    blob = cont[:hdr.container_len].cpu().numpy()
+    back = np.zeros(n, dtype=np.uint8)
+    assert container.decode(blob, back) == n
+    assert np.array_equal(back, host)
+
+
+def test_pack_device_refuses_a_paged_container_and_large_chunks_come_out_slotted():
+    """ADVICE r5 (medium x2): density_hip_pack_device is for slotted containers — a paged one is wire-ready and not laid out the way the pack reads —;
+    and the paged encoder offers only what the paged decoder takes (chunks of at most 4 MiB): an 8 MiB chunk comes out slotted and decodes."""
+    import torch
+    from density_amd import container
+    from density_amd.codec import EncodeError
+    n, chunk = 16 << 20, 2 << 20
+    host = datagen.rep_text(n)
+    x, cont, hdr = _encode_paged(host, chunk)
+    out = torch.empty(container.container_bound("chameleon", n, chunk), dtype=torch.uint8, device="cuda")
+    with pytest.raises(EncodeError):
+        container.pack_device(cont.data_ptr(), hdr.container_len, out.data_ptr(), out.numel(), header=hdr)
+    n, chunk = 32 << 20, 8 << 20
+    host = datagen.rep_text(n)
+    x, cont, hdr = _encode_paged(host, chunk)
+    assert not (hdr.flags & container.FLAG_PAGED) and (hdr.flags & container.FLAG_SLOTTED)
+    back = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    assert container.decode_device(cont.data_ptr(), hdr.container_len, back.data_ptr(), n, header=hdr) == n
+    assert torch.equal(back, x)
