@@ -23,6 +23,9 @@ import time
 
 import numpy as np
 
+# the all-cores CPU rows: one OpenMP thread per core, where it was started (read by the OpenMP runtime when oracle/libdensity_oracle.so loads)
+os.environ.setdefault("OMP_PROC_BIND", "close")
+os.environ.setdefault("OMP_PLACES", "cores")
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -51,16 +54,18 @@ def cpu_all_cores(src, chunk, algo, gpu_payloads=None):
         dcd = lambda: pyoracle.decode_chunks_mt(algo, encs.ctypes.data, ccap, sizes.ctypes.data, dec.ctypes.data, n, chunk, threads)
         assert enc() == 0 and dcd() == 0                                                      # warm (pages of the buffers, the thread team)
         te, td = [], []
-        for _ in range(5):
+        for _ in range(7):
             t0 = time.perf_counter(); enc(); t1 = time.perf_counter(); dcd(); t2 = time.perf_counter()
             te.append(t1 - t0); td.append(t2 - t1)
         assert np.array_equal(dec, src)
-        # the FASTEST of the five, medians beside it: bursts of all cores get throttled on the GPU box's host now and then (the same call: 157 GB/s, then 11), so
-        # a median of five says more about the box's scheduler than about the codec
-        e, d = min(te), min(td)
-        out = {"value": round(n / (e + d) / 1e6, 1), "unit": "MB/s", "cores": ncpu, "threads": threads, "encode_MBps": round(n / e / 1e6, 1), "decode_MBps": round(n / d / 1e6, 1),
-               "median": {"value": round(n / (sorted(te)[2] + sorted(td)[2]) / 1e6, 1), "encode_MBps": round(n / sorted(te)[2] / 1e6, 1), "decode_MBps": round(n / sorted(td)[2] / 1e6, 1)},
-               "ratio_chunked": round(n / int(sizes.sum()), 4), "chunk": chunk, "n_chunks": nchunks, "timing": "fastest of 5 (median beside it)",
+        # The MEDIAN of seven, threads pinned (OMP_PROC_BIND=close, OMP_PLACES=cores: set at the top of this file, before the OpenMP runtime starts), with the
+        # fastest and the slowest beside it — round 5 printed the fastest of five, and on a host that throttles bursts of all its cores (the same call: 157 GB/s,
+        # then 11) a minimum says what the box can do once, not what it does.
+        rt = sorted(a + b for a, b in zip(te, td))
+        e, d = sorted(te)[3], sorted(td)[3]
+        out = {"value": round(n / rt[3] / 1e6, 1), "unit": "MB/s", "cores": ncpu, "threads": threads, "encode_MBps": round(n / e / 1e6, 1), "decode_MBps": round(n / d / 1e6, 1),
+               "fastest": round(n / rt[0] / 1e6, 1), "slowest": round(n / rt[-1] / 1e6, 1), "samples": 7,
+               "ratio_chunked": round(n / int(sizes.sum()), 4), "chunk": chunk, "n_chunks": nchunks, "timing": "median of 7 round trips (fastest / slowest beside it), threads pinned to cores",
                "sample": f"{n} B in {nchunks} chunks of {chunk} B, one chunk per task on {threads} OpenMP threads ({ncpu} host cores), C restatement (oracle/density_oracle.c)"}
         if gpu_payloads is not None:
             m = min(nchunks, len(gpu_payloads))
@@ -294,7 +299,7 @@ def other_config(container, algo, label, host, steps=3, warmup=1, cpu_sample=32 
     n = host.size
     chunk = chunk or int(_lib.lib().density_hip_auto_chunk_for(_lib.ALGO_IDS[algo], n))
     x = torch.from_numpy(host).cuda()
-    cap = container.container_bound_slotted(algo, n, chunk)
+    cap = max(container.container_bound_slotted(algo, n, chunk), container.container_bound_paged(algo, n, chunk) if algo == "chameleon" else 0)
     cont = torch.empty(cap, dtype=torch.uint8, device="cuda")
     back = torch.empty(n, dtype=torch.uint8, device="cuda")
     s = torch.cuda.current_stream().cuda_stream
@@ -302,33 +307,54 @@ def other_config(container, algo, label, host, steps=3, warmup=1, cpu_sample=32 
     assert container.decode_device(cont.data_ptr(), hdr.container_len, back.data_ptr(), n, header=hdr, stream=s) == n and torch.equal(back, x), f"{algo}: round trip mismatch"
     E = int(hdr.container_len)                                                         # the packed container: the algorithmic E
     _, payloads = container.chunk_payloads(cont[:E].cpu().numpy())
-    # timed like the headline workload: the slotted container (no stitch pass; same chunk streams)
+    # Timed: the PACKED container — encode, size scan, stitch, decode — i.e. the wire-ready form whose size `compression_ratio` states (round 6: until then these
+    # rows timed the slotted form and printed the packed ratio beside it).  The slotted form (no stitch, not wire-ready) is timed for a few steps beside it.
+    # Chameleon shapes the PAGED form serves (two chunks and more of 1 MiB .. 4 MiB) are timed on it instead — wire-ready as the encode kernel leaves it, no stitch.
     back.zero_(); torch.cuda.synchronize()                 # (a null caller stream means the library's own stream: not ordered behind torch's memset)
-    hdr = container.encode_device_slotted(algo, x.data_ptr(), n, cont.data_ptr(), cap, chunk, stream=s)
-    Ec = int(hdr.container_len)
-    assert container.decode_device(cont.data_ptr(), Ec, back.data_ptr(), n, header=hdr, stream=s) == n and torch.equal(back, x), f"{algo}: round trip mismatch (slotted)"
+    enc_fn, form, Et = container.encode_device, "packed", E
+    if algo == "chameleon":
+        hdr_p = container.encode_device_paged(algo, x.data_ptr(), n, cont.data_ptr(), cap, chunk, stream=s)
+        if hdr_p.flags & container.FLAG_PAGED:
+            enc_fn, form, hdr, Et = container.encode_device_paged, "paged", hdr_p, int(hdr_p.container_len)
+            _, pp = container.chunk_payloads(cont[:Et].cpu().numpy())
+            assert pp == payloads, "paged chunk streams differ from the packed form's"
 
     def step():
-        container.encode_device_slotted(algo, x.data_ptr(), n, cont.data_ptr(), cap, chunk, stream=s, want_header=False)
-        container.decode_device(cont.data_ptr(), Ec, back.data_ptr(), n, header=hdr, stream=s, sync=False)
+        enc_fn(algo, x.data_ptr(), n, cont.data_ptr(), cap, chunk, stream=s, want_header=False)
+        container.decode_device(cont.data_ptr(), Et, back.data_ptr(), n, header=hdr, stream=s, sync=False)
+
+    def timed(fn, k):
+        torch.cuda.synchronize()
+        container.set_profiling(True)
+        container.last_timings()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            fn()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        tm = container.last_timings()
+        container.set_profiling(False)
+        return dt, tm
 
     settle(step, settle_ms)
     for _ in range(warmup):
         step()
-    torch.cuda.synchronize()
-    container.set_profiling(True)
-    container.last_timings()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    timings = container.last_timings()
-    container.set_profiling(False)
+    dt, timings = timed(step, steps)
     assert torch.equal(back, x), f"{algo}: round trip mismatch after the timed steps"
     tot = {}
     for name, ms in timings:
         tot[name] = tot.get(name, 0.0) + ms / steps
+    # beside it: the slotted form of the same chunk streams
+    hdr_s = container.encode_device_slotted(algo, x.data_ptr(), n, cont.data_ptr(), cap, chunk, stream=s)
+    Ec = int(hdr_s.container_len)
+
+    def step_slotted():
+        container.encode_device_slotted(algo, x.data_ptr(), n, cont.data_ptr(), cap, chunk, stream=s, want_header=False)
+        container.decode_device(cont.data_ptr(), Ec, back.data_ptr(), n, header=hdr_s, stream=s, sync=False)
+    back.zero_(); torch.cuda.synchronize()
+    step_slotted()
+    dt_s, _ = timed(step_slotted, steps)
+    assert torch.equal(back, x), f"{algo}: round trip mismatch (slotted)"
     dec_names = ("layout_decode", f"{algo}_decode_chunks")
     t_dec = sum(v for k, v in tot.items() if k in dec_names)
     t_enc = sum(v for k, v in tot.items() if k not in dec_names)
@@ -348,8 +374,10 @@ def other_config(container, algo, label, host, steps=3, warmup=1, cpu_sample=32 
     cores = cpu_all_cores(np.ascontiguousarray(host), chunk, algo, gpu_payloads=payloads) if all_cores else None
     return {"config": label, "algorithm": algo, "bytes": int(n), "chunk_bytes": int(chunk), "n_chunks": int(hdr.n_chunks),
             "value": round(n * steps / dt / 1e6, 1), "unit": "MB/s", "steps": steps, "ms_per_step": round(dt / steps * 1e3, 4),
-            "compression_ratio": round(n / E, 4), "encoded_bytes": E,
-            "container_form": "slotted (the packed size stated)",
+            "compression_ratio": round(n / Et, 4), "encoded_bytes": Et, "encoded_bytes_packed": E,
+            "container_form": ("paged (wire-ready as the encode kernel leaves it; compression_ratio is of these bytes, the roofline's E is the packed size)" if form == "paged" else
+                               "packed (wire-ready: encode + size scan + stitch + decode are all inside the timed steps; compression_ratio is of these bytes)"),
+            "value_slotted": round(n * steps / dt_s / 1e6, 1),
             "encode_ms": round(t_enc, 4), "decode_ms": round(t_dec, 4), "kernel_ms": {k: round(v, 4) for k, v in tot.items()},
             "residency": "HBM-bound" if 2 * n > (256 << 20) else "cache-resident (fits the 256 MiB Infinity Cache)",
             "roofline": {"encode": roofline_entry(f"{algo} encode (all kernels of the direction)", n + E, t_enc, *direction_traffic(algo, n, chunk).get("encode", (None, None))),
@@ -766,6 +794,9 @@ def main():
                 kinds[-1]["data_kind"] = kind
                 del data
             result["data_kinds"] = kinds
+            # ... and where the driver's `parsed.roofline` shows them: per kind the slower direction's fraction of the same roofline
+            result["roofline"]["data_kinds"] = {k["data_kind"]: {"encode_frac": k["roofline"]["encode"]["frac"], "decode_frac": k["roofline"]["decode"]["frac"],
+                                                                 "round_trip_MBps": k["value"], "container_form": k["container_form"].split(" ")[0]} for k in kinds}
             # BASELINE's other configurations in the same run (never `value`): configs 3 / 4 on the enwik8 stand-in, and the headline buffer as
             # ONE reference stream (the reference's own call shape)
             extra = [strict_stream_leg(host, x)]

@@ -34,6 +34,17 @@ class GlobalLayout(ctypes.Structure):
                                                 "chunk_offset", "payload_offset", "input_offset", "payload_bytes_padded")]
 
 
+class MultiHeader(ctypes.Structure):
+    """density_hip_multi_header_t"""
+    _fields_ = [("magic", ctypes.c_uint32), ("version", ctypes.c_uint8), ("algo", ctypes.c_uint8), ("flags", ctypes.c_uint16),
+                ("n_ranks", ctypes.c_uint32), ("chunk_size", ctypes.c_uint32), ("total_len", ctypes.c_uint64), ("container_len", ctypes.c_uint64)]
+
+
+class MultiRow(ctypes.Structure):
+    """density_hip_multi_row_t"""
+    _fields_ = [(k, ctypes.c_uint64) for k in ("offset", "length", "input_bytes")]
+
+
 _lib = None
 
 # every symbol include/density_hip.h declares: name -> (restype, argtypes)
@@ -76,6 +87,9 @@ SYMBOLS.update({
     "density_hip_shard_range": (_I, [_SZ, _SZ, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(Shard)]),
     "density_hip_global_layout": (_I, [ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64),
                                        ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(GlobalLayout)]),
+    "density_hip_multi_layout": (_I, [ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), ctypes.c_uint32, _I, _SZ,
+                                      ctypes.POINTER(MultiHeader), ctypes.POINTER(MultiRow)]),
+    "density_hip_multi_row": (_I, [_VP, _SZ, _SZ, ctypes.c_uint32, ctypes.POINTER(MultiHeader), ctypes.POINTER(MultiRow)]),
     "density_hip_shutdown": (None, []),
 })
 

@@ -39,6 +39,7 @@ extern __shared__ __attribute__((aligned(16))) uint8_t pass_lds[];
 bool g_force_serial_decode = false;   // density_hip_set_kernel_variant(128): Cheetah containers on the one-wave decoder instead
 bool g_serial_parse = false;          // density_hip_set_kernel_variant(1024): the records of a chunk found by the one-wave walk alone (no window kernels)
 bool g_chain_walk = false;            // density_hip_set_kernel_variant(4096): the contexts walked run by run (round 5's walk) instead of 64 quads at a time
+int g_walk_blocks = 2;                // blocks of 64 quads the walk speculates together (1, 2, 4; tuning runs: density_hip_set_kernel_variant bits 13-14)
 
 namespace {
 
@@ -547,8 +548,38 @@ constexpr uint32_t kWalkTable = 65536u * 2u, kTileBlocks = 16, kTileBytes = kTil
 //              bytes with two followers), lanes 0..i0 stand, the lanes behind it take their writes back — old halves, highest lane first: the lane-
 //              reversed store of rotor.hip — and go again from what lane i0 really read.
 // Blocks with a run of eight and more predicted quads (periodic input, zeros) keep the run-by-run chain below: a level costs what a link does.
-template <bool VEC>
+// NB > 1: NB blocks (128 / 256 quads, NB registers per lane) go through speculate / execute / verify TOGETHER — the levels' reads of all of them are in
+// flight at once, the ordered pass is NB instructions back to back (a wave's LDS instructions execute in issue order: block 0's lanes, then block 1's ...),
+// so the LDS round trips, which are what a lone wave waits for, are shared by NB blocks; a wrong speculation costs one more pass over what lies behind it.
+// lane-mask select: mask[lane] ? a : b with the mask in a scalar register pair (one VALU instruction; the compiler's own form of "(m >> lane) & 1" is three)
+__device__ __forceinline__ uint32_t msel(uint64_t m, uint32_t ifset, uint32_t ifclear) {
+    uint32_t r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(ifclear), "v"(ifset), "s"(m));
+    return r;
+}
+// G LDS operations issued back to back and waited for inside ONE statement (an answer in flight lives in a register the compiler believes written:
+// nothing but the wait may stand between issue and use)
+template <uint32_t G>
+__device__ __forceinline__ void lds_read_u16_group(uint32_t (&r)[G], const uint32_t (&addr)[G]) {
+    static_assert(G == 1 || G == 2 || G == 4, "group of 1, 2 or 4 blocks");
+    if constexpr (G == 1) asm volatile("ds_read_u16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r[0]) : "v"(addr[0]) : "memory");
+    else if constexpr (G == 2) asm volatile("ds_read_u16 %0, %2\n\tds_read_u16 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r[0]), "=&v"(r[1]) : "v"(addr[0]), "v"(addr[1]) : "memory");
+    else asm volatile("ds_read_u16 %0, %4\n\tds_read_u16 %1, %5\n\tds_read_u16 %2, %6\n\tds_read_u16 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+                      : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]) : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]) : "memory");
+}
+template <uint32_t G>
+__device__ __forceinline__ void lds_mskor_group(uint32_t (&r)[G], const uint32_t (&addr)[G], const uint32_t (&mk)[G], const uint32_t (&vl)[G]) {
+    if constexpr (G == 1) asm volatile("ds_mskor_rtn_b32 %0, %1, %2, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r[0]) : "v"(addr[0]), "v"(mk[0]), "v"(vl[0]) : "memory");
+    else if constexpr (G == 2) asm volatile("ds_mskor_rtn_b32 %0, %2, %4, %6\n\tds_mskor_rtn_b32 %1, %3, %5, %7\n\ts_waitcnt lgkmcnt(0)"
+                                            : "=&v"(r[0]), "=&v"(r[1]) : "v"(addr[0]), "v"(addr[1]), "v"(mk[0]), "v"(mk[1]), "v"(vl[0]), "v"(vl[1]) : "memory");
+    else asm volatile("ds_mskor_rtn_b32 %0, %4, %8, %12\n\tds_mskor_rtn_b32 %1, %5, %9, %13\n\tds_mskor_rtn_b32 %2, %6, %10, %14\n\tds_mskor_rtn_b32 %3, %7, %11, %15\n\ts_waitcnt lgkmcnt(0)"
+                      : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3])
+                      : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "v"(mk[0]), "v"(mk[1]), "v"(mk[2]), "v"(mk[3]), "v"(vl[0]), "v"(vl[1]), "v"(vl[2]), "v"(vl[3]) : "memory");
+}
+template <int NB>
 __global__ __launch_bounds__(64) void cheetah_walk(PassArgs a) {
+    constexpr bool VEC = NB >= 1;
+    constexpr uint32_t G = NB > 1 ? NB : 1;
     const uint32_t lane = threadIdx.x;
     const uint64_t chunk = blockIdx.x;
     const ChunkInfo ci = a.info[chunk];
@@ -587,6 +618,121 @@ __global__ __launch_bounds__(64) void cheetah_walk(PassArgs a) {
     for (uint32_t blk = 0; blk < nblk; ++blk) {
         const uint32_t t = blk / kTileBlocks, j = blk % kTileBlocks;
         if (j == 0) fetch(t + 1u);
+        if (NB > 1 && j % G == 0 && blk + G <= nblk) {
+            // ---- a group of G blocks, if every one of them is whole and has no long run ----
+            uint32_t dv[G], hv[G], hwv[G], cvv[G], rsv[G], rfv[G], r2v[G], shv[G];
+            uint64_t Pm[G], Nm[G], K0m[G], known[G], fin[G], rdone[G];
+            bool ok = true;
+#pragma unroll
+            for (uint32_t b = 0; b < G; ++b) {
+                dv[b] = stage[(t & 1u) * (kTileBytes / 4) + (j + b) * 64u + lane];
+                hv[b] = dv[b] & 0xffffu;
+                hwv[b] = (dv[b] & kDescZero) ? 0u : hv[b];
+                const bool none = (dv[b] & kDescNone) != 0, pred = ((dv[b] >> 16) & 3u) == kFlagPred;
+                Pm[b] = ballot64(!none && pred); Nm[b] = ballot64(!none && !pred);
+                uint64_t lr = Pm[b] & (Pm[b] >> 1); lr &= lr >> 2; lr &= lr >> 4;
+                ok = ok && (Pm[b] | Nm[b]) == ~0ull && lr == 0;
+            }
+            if (__builtin_expect(ok, 1)) {
+                if (j + G == kTileBlocks || blk + G == nblk) land(t + 1u);
+#pragma unroll
+                for (uint32_t b = 0; b < G; ++b) {
+                    const uint32_t hp = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hv[b], 0x138, 0xf, 0xf, false);   // wave_shr:1
+                    const uint32_t first = b == 0 ? c : (uint32_t)__builtin_amdgcn_readlane((int)hv[b ? b - 1 : 0], 63);   // (meaningful only where the quad before was not predicted)
+                    cvv[b] = lane == 0 ? first : hp;
+                    K0m[b] = (Nm[b] << 1) | (b == 0 ? 1ull : (Nm[b ? b - 1 : 0] >> 63));
+                    known[b] = K0m[b]; fin[b] = 0; rsv[b] = 0; rfv[b] = 0;
+                }
+                for (;;) {
+                    // speculate: every level's reads of all G blocks in flight together
+#pragma unroll
+                    for (uint32_t b = 0; b < G; ++b) rdone[b] = fin[b];
+                    for (;;) {
+                        uint64_t R[G], any = 0;
+#pragma unroll
+                        for (uint32_t b = 0; b < G; ++b) { R[b] = Pm[b] & known[b] & ~rdone[b]; any |= R[b]; }
+                        if (!any) break;
+                        uint32_t r[G], ad[G];
+#pragma unroll
+                        for (uint32_t b = 0; b < G; ++b) ad[b] = lds0 + 2u * cvv[b];
+                        lds_read_u16_group<G>(r, ad);                                  // (every block reads, whether or not one of its lanes needs it: a stale context is a valid address)
+#pragma unroll
+                        for (uint32_t b = 0; b < G; ++b) {
+                            const uint64_t in = (R[b] << 1) | (b == 0 ? 0ull : (R[b ? b - 1 : 0] >> 63));   // the lanes that learn their context this round
+                            if (R[b]) rsv[b] = msel(R[b], r[b], rsv[b]);
+                            if (in) {
+                                uint32_t up = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r[b], 0x138, 0xf, 0xf, false);   // wave_shr:1
+                                if (b != 0 && (in & 1ull)) { const uint32_t carry = (uint32_t)__builtin_amdgcn_readlane((int)r[b ? b - 1 : 0], 63); up = lane == 0 ? carry : up; }
+                                cvv[b] = msel(in, up, cvv[b]);
+                            }
+                            known[b] |= in; rdone[b] |= R[b];
+                        }
+                    }
+                    // execute: the lanes that do not stand yet, block after block, each in lane order
+                    uint32_t ret[G], xa[G], xm[G], xv[G];
+#pragma unroll
+                    for (uint32_t b = 0; b < G; ++b) {
+                        shv[b] = (cvv[b] & 1u) * 16u;
+                        const uint64_t w = Nm[b] & ~fin[b];
+                        xa[b] = lds0 + ((2u * cvv[b]) & ~3u);
+                        xm[b] = msel(w, 0xffffu << shv[b], 0u); xv[b] = msel(w, hwv[b] << shv[b], 0u);
+                    }
+                    lds_mskor_group<G>(ret, xa, xm, xv);
+                    // verify
+                    uint64_t bad[G], anybad = 0;
+#pragma unroll
+                    for (uint32_t b = 0; b < G; ++b) {
+                        r2v[b] = (ret[b] >> shv[b]) & 0xffffu;
+                        bad[b] = ballot64(r2v[b] != rsv[b]) & Pm[b] & ~fin[b];
+                        anybad |= bad[b];
+                    }
+                    if (__builtin_expect(anybad == 0, 1)) {
+#pragma unroll
+                        for (uint32_t b = 0; b < G; ++b) rfv[b] = msel(~fin[b], r2v[b], rfv[b]);
+                        break;
+                    }
+                    uint32_t b0 = 0;
+#pragma unroll
+                    for (uint32_t b = G; b-- > 0;) if (bad[b]) b0 = b;
+                    uint64_t badb = bad[0];
+#pragma unroll
+                    for (uint32_t b = 1; b < G; ++b) badb = b0 == b ? bad[b] : badb;
+                    const uint32_t i0 = (uint32_t)__builtin_ctzll(badb);
+                    const uint64_t upto = (2ull << i0) - 1ull;                           // lanes 0 .. i0 of block b0 (i0 == 63: all of them)
+                    uint64_t stands[G];
+#pragma unroll
+                    for (uint32_t b = 0; b < G; ++b) stands[b] = b < b0 ? ~0ull : b == b0 ? upto : 0ull;
+                    // the writes behind the first wrong read are taken back: old halves, the latest write first (blocks from the last to b0, lanes reversed)
+#pragma unroll
+                    for (uint32_t b = G; b-- > 0;) {
+                        const uint64_t undo = Nm[b] & ~stands[b] & ~fin[b];
+                        if (undo) {
+                            const uint32_t ar = bperm(63u - lane, lds0 + 2u * cvv[b]), old = bperm(63u - lane, r2v[b]);
+                            if ((undo >> (63u - lane)) & 1ull) asm volatile("ds_write_b16 %0, %1" ::"v"(ar), "v"(old) : "memory");
+                        }
+                    }
+                    const uint32_t truth = (uint32_t)__builtin_amdgcn_readlane((int)(b0 == 0 ? r2v[0] : b0 == 1 ? r2v[G > 1 ? 1 : 0] : b0 == 2 ? r2v[G > 2 ? 2 : 0] : r2v[G > 3 ? 3 : 0]), (int)i0);
+                    bool all = true;
+#pragma unroll
+                    for (uint32_t b = 0; b < G; ++b) {
+                        rfv[b] = msel(stands[b] & ~fin[b], r2v[b], rfv[b]);
+                        fin[b] = stands[b];
+                        all = all && fin[b] == ~0ull;
+                        // the lane behind (b0, i0) now knows its context; everything else behind it is as unknown as before the first round
+                        const uint64_t next = b == b0 ? (i0 == 63u ? 0ull : (2ull << i0) & ~upto) : (b == b0 + 1u && i0 == 63u ? 1ull : 0ull);
+                        if (next) cvv[b] = msel(next, truth, cvv[b]);
+                        known[b] = stands[b] | next | K0m[b];
+                    }
+                    if (all) break;
+                }
+                const uint32_t last = msel(Pm[G - 1], rfv[G - 1], hv[G - 1]);
+                c = (uint32_t)__builtin_amdgcn_readlane((int)last, 63);
+#pragma unroll
+                for (uint32_t b = 0; b < G; ++b) { const uint32_t i = (blk + b) * 64u + lane; if (i < nsteps) ctx[i] = (uint16_t)cvv[b]; }
+                blk += G - 1u;
+                continue;
+            }
+        }
         const uint32_t d = stage[(t & 1u) * (kTileBytes / 4) + j * 64u + lane];
         if (j == kTileBlocks - 1u || blk + 1u == nblk) land(t + 1u);                 // (behind the read of the tile's last block: the other buffer)
         const uint32_t h = d & 0xffffu;
@@ -805,8 +951,9 @@ hipError_t launch_decode_passes(int algo, const uint8_t* d_in, const uint64_t* d
     hipError_t e = hipFuncSetAttribute((const void*)cheetah_pass<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pass_lds_bytes());
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)cheetah_pass<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pass_lds_bytes());
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)cheetah_pass<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pass_lds_bytes());
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)cheetah_walk<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWalkLds);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)cheetah_walk<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWalkLds);
+    const int walk_nb = g_chain_walk ? 0 : g_walk_blocks;
+    auto walk = walk_nb == 0 ? cheetah_walk<0> : walk_nb == 1 ? cheetah_walk<1> : walk_nb == 4 ? cheetah_walk<4> : cheetah_walk<2>;
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)walk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWalkLds);
     if (e != hipSuccess) return e;
     // the records of calm stretches are found by the window kernels (their tables live where the descriptors and contexts will: nothing else is in use yet)
     const uint64_t slot_bound = out_stride + out_stride / kRecBytes * kSigBytes + kSigBytes;
@@ -832,8 +979,7 @@ hipError_t launch_decode_passes(int algo, const uint8_t* d_in, const uint64_t* d
     hipLaunchKernelGGL(cheetah_prepare, dim3((uint32_t)((pairs + 3) / 4)), dim3(256), 0, stream, a, blocks_per_chunk);
     hipLaunchKernelGGL(cheetah_pass<0>, dim3(2 * n_chunks), dim3(kPassWaves * 64), pass_lds_bytes(), stream, a);
     hipLaunchKernelGGL(cheetah_pass<1>, dim3(4 * n_chunks), dim3(kPassWaves * 64), pass_lds_bytes(), stream, a);
-    if (g_chain_walk) hipLaunchKernelGGL(cheetah_walk<false>, dim3(n_chunks), dim3(64), kWalkLds, stream, a);
-    else hipLaunchKernelGGL(cheetah_walk<true>, dim3(n_chunks), dim3(64), kWalkLds, stream, a);
+    hipLaunchKernelGGL(walk, dim3(n_chunks), dim3(64), kWalkLds, stream, a);
     hipLaunchKernelGGL(cheetah_pass<2>, dim3(2 * n_chunks), dim3(kPassWaves * 64), pass_lds_bytes(), stream, a);
     hipLaunchKernelGGL(cheetah_finish, dim3((n_chunks + 255) / 256), dim3(256), 0, stream, a, exact ? 1u : 0u, d_produced);
     return hipGetLastError();

@@ -51,4 +51,43 @@ int density_hip_global_layout(const uint64_t* chunks, const uint64_t* payload_by
     return DENSITY_HIP_OK;
 }
 
+// ---- the multi-rank container "DHCM" (include/density_hip.h): every rank's blob as it stands behind a table of {offset, length, input bytes} ----
+int density_hip_multi_layout(const uint64_t* lengths, const uint64_t* input_bytes, uint32_t n_ranks, int algo, size_t chunk_size,
+                             density_hip_multi_header_t* header_out, density_hip_multi_row_t* rows_out) {
+    if (!lengths || !input_bytes || !header_out || !rows_out || n_ranks == 0 || algo < DENSITY_HIP_CHAMELEON || algo > DENSITY_HIP_LION) return DENSITY_HIP_ERR_ARGUMENT;
+    uint64_t at = (sizeof(density_hip_multi_header_t) + (uint64_t)n_ranks * sizeof(density_hip_multi_row_t) + 255u) / 256u * 256u, total = 0;
+    for (uint32_t r = 0; r < n_ranks; ++r) {
+        rows_out[r] = density_hip_multi_row_t{at, lengths[r], input_bytes[r]};
+        total += input_bytes[r];
+        at += lengths[r];
+        if (r + 1 < n_ranks) at = (at + 255u) / 256u * 256u;                         // (the last blob is not padded at its end)
+    }
+    *header_out = density_hip_multi_header_t{DENSITY_HIP_MULTI_MAGIC, 1, (uint8_t)algo, 0, n_ranks, (uint32_t)chunk_size, total, at};
+    return DENSITY_HIP_OK;
+}
+
+int density_hip_multi_row(const void* front, size_t front_size, size_t container_size, uint32_t rank, density_hip_multi_header_t* header_out, density_hip_multi_row_t* row_out) {
+    if (!front || !header_out || !row_out) return DENSITY_HIP_ERR_ARGUMENT;
+    if (front_size < sizeof(density_hip_multi_header_t)) return DENSITY_HIP_ERR_FORMAT;
+    density_hip_multi_header_t h;
+    __builtin_memcpy(&h, front, sizeof(h));
+    if (h.magic != DENSITY_HIP_MULTI_MAGIC || h.version != 1 || h.flags != 0 || h.algo > DENSITY_HIP_LION || h.n_ranks == 0 || h.n_ranks > (1u << 20)) return DENSITY_HIP_ERR_FORMAT;
+    const uint64_t rows_end = sizeof(h) + (uint64_t)h.n_ranks * sizeof(density_hip_multi_row_t);
+    if (front_size < rows_end || h.container_len > container_size || h.container_len < rows_end) return DENSITY_HIP_ERR_FORMAT;
+    if (rank >= h.n_ranks) return DENSITY_HIP_ERR_ARGUMENT;
+    uint64_t at = rows_end, total = 0;
+    for (uint32_t r = 0; r < h.n_ranks; ++r) {                                       // rows in order, inside the container, not overlapping; input bytes add up
+        density_hip_multi_row_t row;
+        __builtin_memcpy(&row, static_cast<const uint8_t*>(front) + sizeof(h) + (uint64_t)r * sizeof(row), sizeof(row));
+        if (row.offset < at || row.offset % 256u != 0 || row.offset > h.container_len || row.length > h.container_len - row.offset) return DENSITY_HIP_ERR_FORMAT;
+        if (row.input_bytes > h.total_len - total) return DENSITY_HIP_ERR_FORMAT;
+        at = row.offset + row.length;
+        total += row.input_bytes;
+        if (r == rank) *row_out = row;
+    }
+    if (total != h.total_len) return DENSITY_HIP_ERR_FORMAT;
+    *header_out = h;
+    return DENSITY_HIP_OK;
+}
+
 }  // extern "C"

@@ -123,3 +123,100 @@ def concat_to_rank0(local_container, chunk_size, group=None):
     head = struct.pack("<IBBHIIQQ", MAGIC, hdr["algo"], 1, hdr["flags"], chunk_size, glob["n_chunks"], glob["total_len"], glob["container_len"])
     out[:HEADER_BYTES] = torch.frombuffer(bytearray(head), dtype=torch.uint8).to(dev)
     return out
+
+
+# ---- config 5's wire form: the multi-rank container "DHCM" (include/density_hip.h) ----
+# Every rank's container travels AS IT STANDS — the paged blob the rank times, or a packed / slotted one: each is a self-describing DHC1 container of that
+# rank's shard — behind a 32-byte super-header and one {offset, length, input bytes} row per rank.  Still ONE collective: an all-gather of two u64 per rank.
+MULTI_MAGIC = 0x4D434844
+MULTI_HEADER = "<IBBHIIQQ"
+MULTI_ROW = "<QQQ"
+
+
+def _align256(v):
+    return (v + 255) // 256 * 256
+
+
+def multi_layout(lengths, input_bytes, algo=0, chunk_size=0):
+    """(header bytes, [(offset, length, input_bytes)], container_len) of the super-container over the ranks' blobs (the arithmetic of
+    density_hip_multi_layout: tests/test_placement_abi.py holds the two against each other)."""
+    world = len(lengths)
+    at = _align256(32 + 24 * world)
+    rows = []
+    for r in range(world):
+        rows.append((at, int(lengths[r]), int(input_bytes[r])))
+        at += int(lengths[r])
+        if r + 1 < world:
+            at = _align256(at)
+    head = struct.pack(MULTI_HEADER, MULTI_MAGIC, 1, algo, 0, world, chunk_size, sum(int(v) for v in input_bytes), at)
+    return head + b"".join(struct.pack(MULTI_ROW, *row) for row in rows), rows, at
+
+
+def exchange_multi_layout(container_len_local, input_bytes_local, device, algo=0, chunk_size=0, group=None):
+    """The collective of config 5: all-gather of (container length, input bytes) per rank -> the super-container's front matter, every rank's row, its length."""
+    world = dist.get_world_size(group)
+    mine = torch.tensor([container_len_local, input_bytes_local], dtype=torch.int64, device=device)
+    gathered = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(gathered, mine, group=group)
+    rows = torch.stack(gathered).cpu().tolist()
+    return multi_layout([r[0] for r in rows], [r[1] for r in rows], algo, chunk_size)
+
+
+def parse_multi(blob):
+    """(header dict, [(offset, length, input_bytes)]) of a super-container (1-D uint8 tensor, any device); raises ValueError on a malformed front."""
+    head = bytes(blob[:32].cpu().numpy())
+    if len(head) < 32:
+        raise ValueError("not a DHCM container")
+    magic, version, algo, flags, world, chunk_size, total_len, container_len = struct.unpack(MULTI_HEADER, head)
+    if magic != MULTI_MAGIC or version != 1 or flags != 0 or world == 0 or 32 + 24 * world > blob.numel() or container_len > blob.numel():
+        raise ValueError("not a DHCM container")
+    raw = bytes(blob[32:32 + 24 * world].cpu().numpy())
+    rows = [struct.unpack_from(MULTI_ROW, raw, 24 * r) for r in range(world)]
+    at, total = 32 + 24 * world, 0
+    for off, ln, nb in rows:
+        if off < at or off % 256 or off + ln > container_len:
+            raise ValueError("DHCM rows out of order or outside the container")
+        at, total = off + ln, total + nb
+    if total != total_len:
+        raise ValueError("DHCM input bytes do not add up")
+    return dict(algo=algo, n_ranks=world, chunk_size=chunk_size, total_len=total_len, container_len=container_len), rows
+
+
+def concat_multi_to_rank0(local_blob, input_bytes_local, algo=0, chunk_size=0, group=None):
+    """Optional gather of config 5's output onto one GPU: rank 0 receives every rank's blob straight into its place of the super-container (one batched P2P
+    group: the senders use their own xGMI links at once) and returns it; the others return None.  xGMI-bound, never part of `value`."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = local_blob.device
+    front, rows, total = exchange_multi_layout(local_blob.numel(), input_bytes_local, dev, algo, chunk_size, group)
+    if rank != 0:
+        if local_blob.numel():
+            for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, local_blob.contiguous(), 0, group=group)]):
+                w.wait()
+        return None
+    out = torch.zeros(total, dtype=torch.uint8, device=dev)
+    out[:len(front)] = torch.frombuffer(bytearray(front), dtype=torch.uint8).to(dev)
+    ops = []
+    for r, (off, ln, _) in enumerate(rows):
+        if ln == 0:
+            continue
+        if r == 0:
+            out[off:off + ln].copy_(local_blob)
+        else:
+            ops.append(dist.P2POp(dist.irecv, out[off:off + ln], r, group=group))
+    for w in (dist.batch_isend_irecv(ops) if ops else []):
+        w.wait()
+    return out
+
+
+def decode_multi_device(blob, out):
+    """Decodes a device-resident super-container rank by rank on THIS device (density_hip_decode_device per row, each blob in place); returns the bytes written."""
+    from . import container
+    hdr, rows = parse_multi(blob)
+    at = 0
+    for off, ln, nb in rows:
+        if nb:
+            got = container.decode_device(blob.data_ptr() + off, ln, out.data_ptr() + at, nb)
+            assert got == nb
+        at += nb
+    return at

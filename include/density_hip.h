@@ -232,7 +232,7 @@ void density_hip_stage_stats(uint64_t* out2);
  * one-wave-per-stream decoder instead of the decode passes (decode_passes.hip), 256 = the host-pointer container calls pipelined
  * whatever the size, a slice per chunk, 512 = never pipelined (below; the reference symbols on long streams too), 1024 = Cheetah's decode passes find
  * a chunk's records by the one-wave walk alone (no window kernels), 2048 = the other rotation encoder (8 chain + 8 emit waves), 4096 = Cheetah's decode
- * passes walk the contexts run by run (round 5's walk) instead of 64 quads at a time.
+ * passes walk the contexts run by run (round 5's walk) instead of 128 quads at a time, 8192 / 16384 = 64 / 256 quads at a time.
  * Payload bytes are identical in every variant. */
 void density_hip_set_kernel_variant(int variant);
 
@@ -265,6 +265,36 @@ typedef struct density_hip_global_layout {
 } density_hip_global_layout_t;
 int density_hip_global_layout(const uint64_t* chunks, const uint64_t* payload_bytes, const uint64_t* input_bytes, uint32_t world, uint32_t rank,
                               uint32_t flags, density_hip_global_layout_t* out);
+
+/*
+ * Config 5's wire form: the MULTI-RANK container "DHCM" (round 6).  Every rank's own container — packed, slotted or PAGED, whatever the rank made: each is a
+ * self-describing DHC1 blob of that rank's shard — travels as it stands; a 32-byte super-header and one 24-byte row per rank say where each blob lies:
+ *
+ *     [0,32)               density_hip_multi_header_t {magic "DHCM", version 1, algo, flags 0, n_ranks, chunk_size, total_len, container_len}
+ *     [32, 32 + 24 R)      per rank {offset, length, input_bytes}: the blob's place from the start of the super-container (256-byte aligned), its length,
+ *                          the input bytes it decodes to (rank r's output starts at the sum of the input_bytes before it)
+ *     (256-byte aligned)   blob 0, blob 1, ...
+ *
+ * The only collective is still one all-gather of two u64 per rank {container length, input bytes} (ncclAllGather over xGMI); density_hip_multi_layout() then
+ * gives every rank its row and the super-container's length — a rank can write its blob at its offset of a shared file, or send it there (parallel.py:
+ * concat_multi_to_rank0).  A reader decodes blob by blob (density_hip_decode / _decode_device per row).  There is nothing in the reference to match (its
+ * stream is one chain, codec/codec.rs:72-80).  Pure host arithmetic.
+ */
+#define DENSITY_HIP_MULTI_MAGIC 0x4D434844u /* "DHCM" little-endian */
+typedef struct density_hip_multi_header {
+    uint32_t magic;
+    uint8_t version, algo;
+    uint16_t flags;
+    uint32_t n_ranks, chunk_size;
+    uint64_t total_len, container_len;
+} density_hip_multi_header_t;
+typedef struct density_hip_multi_row { uint64_t offset, length, input_bytes; } density_hip_multi_row_t;
+/* rows[r] for every rank and the header (algo / chunk_size as given) from the gathered {length, input_bytes}; returns DENSITY_HIP_OK or _ERR_ARGUMENT */
+int density_hip_multi_layout(const uint64_t* lengths, const uint64_t* input_bytes, uint32_t n_ranks, int algo, size_t chunk_size,
+                             density_hip_multi_header_t* header_out, density_hip_multi_row_t* rows_out);
+/* Validates a super-container's front matter (magic, version, rows inside the container, in order, not overlapping, input bytes adding up) and copies
+ * row `rank` out; container_size = bytes available.  DENSITY_HIP_OK / _ERR_FORMAT / _ERR_ARGUMENT. */
+int density_hip_multi_row(const void* front, size_t front_size, size_t container_size, uint32_t rank, density_hip_multi_header_t* header_out, density_hip_multi_row_t* row_out);
 
 /* Releases what the library holds on every device it has used (staging buffers, workspaces, streams, events); the next call sets them up
  * again.  Not needed for correctness — a process may simply exit — and must not run beside other calls into the library. */

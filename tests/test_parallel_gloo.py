@@ -112,6 +112,50 @@ def test_two_rank_gather_and_concat_matches_single_process(with_index):
         assert ret["round_trip"]
 
 
+def _multi_worker(rank, world, initfile, total, chunk, ret):
+    """Config 5's wire form: every rank's PAGED container (built on the CPU by the header's layout, tests/paged_cpu.py) travels as it stands behind the DHCM
+    front matter; rank 0 gathers the blobs, a CPU reader decodes them rank by rank."""
+    import paged_cpu
+    from density_amd import container
+    dist.init_process_group("gloo", init_method=f"file://{initfile}", rank=rank, world_size=world)
+    try:
+        data = datagen.mixed(total, seed=5)
+        c0, c1, b0, b1 = parallel.shard_chunks(total, chunk, rank, world)
+        blob = paged_cpu.build(data[b0:b1], chunk) if b1 > b0 else np.zeros(0, dtype=np.uint8)
+        local = torch.frombuffer(bytearray(blob.tobytes()), dtype=torch.uint8) if blob.size else torch.zeros(0, dtype=torch.uint8)
+        front, rows, length = parallel.exchange_multi_layout(local.numel(), b1 - b0, torch.device("cpu"), 0, chunk)
+        assert rows[rank][1] == local.numel() and sum(r[2] for r in rows) == total and rows[rank][0] % 256 == 0
+        merged = parallel.concat_multi_to_rank0(local, b1 - b0, 0, chunk)
+        if rank == 0:
+            hdr, got_rows = parallel.parse_multi(merged)
+            assert got_rows == rows and hdr["total_len"] == total and hdr["container_len"] == merged.numel() == length and hdr["n_ranks"] == world
+            out = bytearray()
+            for off, ln, nb in got_rows:                                        # a CPU reader: blob by blob, chunk by chunk (INTEGRATION.md 4)
+                if not nb:
+                    continue
+                sub = merged[off:off + ln].numpy()
+                h, streams = container.chunk_payloads(sub)
+                assert h.flags & container.FLAG_PAGED
+                for i, st in enumerate(streams):
+                    out += pyoracle.decode(ALGO, st, min(h.chunk_size, h.total_len - i * h.chunk_size))
+            ret["multi_round_trip"] = bytes(out) == data.tobytes()
+            ret["own_blob_in_place"] = bytes(merged[rows[0][0]:rows[0][0] + rows[0][1]].numpy()) == blob.tobytes()
+        else:
+            assert merged is None
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_multi_container_of_paged_blobs():
+    total, chunk, world = 5 * 65536 + 4321, 65536, 2
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as d:
+        mgr = mp.Manager()
+        ret = mgr.dict()
+        mp.spawn(_multi_worker, args=(world, os.path.join(d, "init"), total, chunk, ret), nprocs=world, join=True)
+        assert ret["multi_round_trip"] and ret["own_blob_in_place"]
+
+
 def test_bench_launcher_starts_the_ranks_itself():
     """bench.py --gpus N without a torchrun environment re-executes under torch.distributed.run with N ranks and reports the world size the
     process group saw (dry mode: CPU tensors, gloo)."""

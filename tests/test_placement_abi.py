@@ -115,3 +115,45 @@ def test_global_layout_describes_a_real_stitched_container():
     import struct
     out[:32] = np.frombuffer(struct.pack("<IBBHIIQQ", parallel.MAGIC, parts[0][0]["algo"], 1, flags, chunk, g.n_chunks, g.total_len, g.container_len), dtype=np.uint8)
     assert bytes(out) == bytes(whole)
+
+
+# ---- the multi-rank container "DHCM" (config 5's wire form) ----
+def _c_multi(lengths, inputs, algo, chunk):
+    w = len(lengths)
+    A = ctypes.c_uint64 * w
+    hdr = _lib.MultiHeader()
+    rows = (_lib.MultiRow * w)()
+    rc = _lib.lib().density_hip_multi_layout(A(*lengths), A(*inputs), w, algo, chunk, ctypes.byref(hdr), rows)
+    return rc, hdr, [(r.offset, r.length, r.input_bytes) for r in rows]
+
+
+def test_multi_layout_matches_parallel_py_and_validates():
+    rnd = random.Random(11)
+    for _ in range(300):
+        w = rnd.randint(1, 16)
+        lengths = [rnd.choice([0, rnd.randint(1, 1 << 34)]) for _ in range(w)]
+        inputs = [rnd.randint(0, 1 << 34) for _ in range(w)]
+        algo, chunk = rnd.randint(0, 2), 256 * rnd.randint(1, 1 << 14)
+        rc, hdr, rows = _c_multi(lengths, inputs, algo, chunk)
+        front, prows, total = parallel.multi_layout(lengths, inputs, algo, chunk)
+        assert rc == _lib.OK and rows == prows and hdr.container_len == total and hdr.total_len == sum(inputs) and hdr.n_ranks == w
+        assert bytes(hdr) == front[:32]
+        assert all(o % 256 == 0 for o, _, _ in rows) and all(rows[i][0] + rows[i][1] <= rows[i + 1][0] for i in range(w - 1))
+        # the reader's check of the front matter gives every row back ...
+        got_h, got_r = _lib.MultiHeader(), _lib.MultiRow()
+        for r in range(w):
+            assert _lib.lib().density_hip_multi_row(front, len(front), total, r, ctypes.byref(got_h), ctypes.byref(got_r)) == _lib.OK
+            assert (got_r.offset, got_r.length, got_r.input_bytes) == rows[r] and got_h.container_len == total
+        assert _lib.lib().density_hip_multi_row(front, len(front), total, w, ctypes.byref(got_h), ctypes.byref(got_r)) == _lib.ERR_ARGUMENT
+        # ... and refuses a front that lies: a truncated container, a row moved inside its predecessor, input bytes that do not add up, a wrong magic
+        if total:
+            assert _lib.lib().density_hip_multi_row(front, len(front), total - 1, 0, ctypes.byref(got_h), ctypes.byref(got_r)) == _lib.ERR_FORMAT
+        bad = bytearray(front); bad[0] ^= 1
+        assert _lib.lib().density_hip_multi_row(bytes(bad), len(bad), total, 0, ctypes.byref(got_h), ctypes.byref(got_r)) == _lib.ERR_FORMAT
+        bad = bytearray(front); bad[32 + 16:32 + 24] = (inputs[0] + 1).to_bytes(8, "little")
+        assert _lib.lib().density_hip_multi_row(bytes(bad), len(bad), total, 0, ctypes.byref(got_h), ctypes.byref(got_r)) == _lib.ERR_FORMAT
+        if w > 1 and lengths[0] > 256:
+            bad = bytearray(front); bad[32 + 24:32 + 32] = (rows[0][0]).to_bytes(8, "little")      # rank 1's blob on top of rank 0's
+            assert _lib.lib().density_hip_multi_row(bytes(bad), len(bad), total, 1, ctypes.byref(got_h), ctypes.byref(got_r)) == _lib.ERR_FORMAT
+    assert _c_multi([1], [1], 3, 256)[0] == _lib.ERR_ARGUMENT
+    assert _lib.lib().density_hip_multi_layout(None, None, 1, 0, 256, None, None) == _lib.ERR_ARGUMENT
