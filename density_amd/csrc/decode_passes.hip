@@ -46,8 +46,8 @@ namespace {
 constexpr uint32_t kRecBytes = 128, kRecQuads = 32, kSigBytes = 8;        // cheetah.rs:188-196
 constexpr uint32_t kRaw = 0x80000000u;                                    // rec[]: the block is a raw copy (codec.rs:89-91)
 constexpr uint32_t kFlagPlain = 0, kFlagMapA = 1, kFlagPred = 3;                      // (2: MAP_B)   // cheetah.rs:17-23
-// descriptor of a quad: slot [0,16) | flag [16,18) | order bit it meets [18] | takes no part (raw block, beyond the end) [19]
-constexpr uint32_t kDescO = 1u << 18, kDescNone = 1u << 19, kDescZero = 1u << 20;   // kDescZero: a MAP quad that read 0 (see the walk)
+// descriptor of a quad: slot [0,16) | flag [16,18) | takes no part (raw block, beyond the end) [19] | a MAP quad that read a never-written 0 [20]
+constexpr uint32_t kDescNone = 1u << 19, kDescZero = 1u << 20;   // kDescZero: a MAP quad that read 0 (see the walk)
 constexpr uint32_t kErrFormat = 1u, kErrWatchdog = 16u;
 constexpr uint32_t kSpinLimit = 1u << 22, kPoison = 0xfffffffeu;
 
@@ -394,10 +394,11 @@ __global__ __launch_bounds__(256) void cheetah_prepare(PassArgs a, uint32_t bloc
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// ordered passes: one table (a half of its slots) per work-group, the quads of the chunk in stream order behind an LDS token
+// ordered passes: one table (a part of its slots) per work-group, the quads of the chunk in stream order behind LDS tokens
 // ---------------------------------------------------------------------------------------------------------------
-constexpr uint32_t kHalfSlots = 32768, kTable = kHalfSlots * 4, kAhead = 16, kPassWaves = 8;
-constexpr uint32_t pass_lds_bytes() { return kTable + kPassWaves * 64 * 4 + 16; }
+constexpr uint32_t kHalfSlots = 32768, kQuarterSlots = 16384, kTable = kHalfSlots * 4, kAhead = 16, kPassWaves = 8;
+constexpr uint32_t kOrderBytes = kQuarterSlots / 8;                         // the order bits of a quarter of the slots
+constexpr uint32_t pass_lds_bytes() { return kTable + kPassWaves * 64 * 4 + 16 + kOrderBytes; }
 
 #define DENSITY_PASS_X16(OP, ra, m, v, tokaddr, tokval)                                                                            \
     asm volatile(                                                                                                                 \
@@ -431,94 +432,121 @@ constexpr uint32_t pass_lds_bytes() { return kTable + kPassWaves * 64 * 4 + 16; 
           "v"(tokaddr), "v"(tokval)                                                                                               \
         : "memory")
 
-// PASS 0 `order`: slot = the quad's dictionary slot; PLAIN and MAP_B toggle the slot's order bit, MAP_A reads it (cheetah.rs:71-72,87-89)
-// PASS 1 `cells`: cell = blockIdx & 1 (X = 0, Y = 1): PLAIN writes its quad to the cell b sits in, MAP_A / MAP_B read the cell a / b sits in
-// PASS 2 `values`: slot = the quad's context; predicted quads read, the others write their quad (cheetah.rs:72,81,90,98)
-// Work-groups: (chunk, [cell,] half of the slots); 8 waves take the trips of 16 blocks of 64 quads in rotation (exchange_stages.hip).
+// PASS 1 `dictionary` (round 6: `order` and `cells` in one kernel): a work-group owns a QUARTER of the slots, both cells X, Y of each (16 Ki x 2 dwords) and
+//        their order bits (16 Ki bits).  Per trip two ordered groups of LDS operations, each behind a token of its own:
+//        A  an ordered XOR on the slot's order bit — PLAIN and MAP_B toggle it, MAP_A reads it (cheetah.rs:71-72,87-89); what comes back is the o the quad meets;
+//        B  an ordered exchange on the cell the quad touches — a sits in cell o, b in cell 1 - o: PLAIN writes its quad to b's cell, MAP_A / MAP_B read a's / b's.
+//        (Up to round 5 two kernels: `order` — two work-groups per chunk on dword-wide order bits, o written back into the descriptors — and `cells` — four
+//        per chunk, (cell, half of the slots) — every one of them streaming the chunk's descriptors: 0.17 + 0.42 ms per 100 MB.)
+// PASS 2 `values`: slot = the quad's context (a half of them per work-group); predicted quads read, the others write their quad (cheetah.rs:72,81,90,98)
+// The 8 waves take the trips of 16 blocks of 64 quads in rotation (exchange_stages.hip); a wave asks for its NEXT trip's descriptors, quads and contexts
+// before it waits for its turn (round 6: until then a trip began with its loads, and a wave's iteration was two memory round trips long — 2,600 cycles per
+// trip and work-group where the exchanges and the hand-off take 700).
 template <int PASS>
 __global__ __launch_bounds__(kPassWaves * 64) void cheetah_pass(PassArgs a) {
+    static_assert(PASS == 1 || PASS == 2, "dictionary or values");
     constexpr uint32_t W = kPassWaves;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = rfl(threadIdx.x >> 6);
-    const uint32_t parts = PASS == 1 ? 4u : 2u;
+    constexpr uint32_t parts = PASS == 1 ? 4u : 2u;
     const uint64_t chunk = blockIdx.x / parts;
-    const uint32_t half = blockIdx.x & 1u, cell = (blockIdx.x >> 1) & 1u;
+    const uint32_t mypart = blockIdx.x % parts;
     const ChunkInfo ci = a.info[chunk];
     if (ci.bad) return;
     const uint32_t nsteps = ci.blocks * kRecQuads;                                 // (quads of a ragged last record beyond its end carry kDescNone)
     const uint32_t trips = (nsteps + kAhead * 64u - 1u) / (kAhead * 64u);
     const uint64_t s0 = chunk * (a.out_stride / 4);
     uint32_t* w = reinterpret_cast<uint32_t*>(pass_lds);
-    for (uint32_t k = threadIdx.x; k < kHalfSlots + W * 64u + 4u; k += W * 64u) w[k] = 0u;   // the reference's zeroed tables; sinks; the token
+    for (uint32_t k = threadIdx.x; k < pass_lds_bytes() / 4u; k += W * 64u) w[k] = 0u;   // the reference's zeroed tables; sinks; the tokens; the order bits
     __syncthreads();
     uint32_t* __restrict__ desc = a.desc + s0;
     const uint16_t* __restrict__ ctx = a.ctx + s0;
     uint32_t* __restrict__ val = reinterpret_cast<uint32_t*>(a.out + chunk * a.out_stride);
     const uint32_t lds0 = lds_addr(pass_lds);
     const uint32_t sink = lds0 + kTable + threadIdx.x * 4u;
-    const uint32_t token = lds0 + kTable + W * 256u;
-    const uint32_t limit = (uint32_t)((chunk_cap(a, chunk) + 3) / 4);              // dwords of this chunk's output that exist
-    for (uint32_t t = wave; t < trips; t += W) {
-        uint32_t ra[kAhead], m[kAhead], v[kAhead];
-        uint32_t dd[kAhead];
-        bool rd[kAhead];
+    const uint32_t token_a = lds0 + kTable + W * 256u, token_b = token_a + 4u;
+    const uint32_t obits = token_a + 16u;
+    const uint64_t cap = chunk_cap(a, chunk);
+    const uint32_t limit = (uint32_t)((cap + 3) / 4), whole = (uint32_t)(cap / 4);   // dwords of this chunk's output that exist / that exist whole
+    uint32_t nd[kAhead], nv[kAhead], nk[kAhead];
+    auto fetch = [&](uint32_t t) {
 #pragma unroll
         for (uint32_t j = 0; j < kAhead; ++j) {
             const uint32_t i = (t * kAhead + j) * 64u + lane;
-            const uint32_t d = i < nsteps ? desc[i] : kDescNone;
-            dd[j] = d;
-            const uint32_t f = (d >> 16) & 3u;
-            const bool none = (d & kDescNone) != 0;
-            uint32_t key = d & 0xffffu;
-            bool part, write;
-            uint32_t value = 0;
-            if (PASS == 0) {
-                part = !none && f != kFlagPred;
-                write = f != kFlagMapA;                                            // toggles
-                value = write ? 1u : 0u;
-            } else if (PASS == 1) {
-                const uint32_t o = (d >> 18) & 1u;
-                // a sits in cell o, b in cell 1 - o (X = 0, Y = 1): PLAIN writes b's cell, MAP_A reads a's, MAP_B reads b's
-                const uint32_t mycell = f == kFlagMapA ? o : 1u - o;
-                part = !none && f != kFlagPred && mycell == cell;
-                write = f == kFlagPlain;
-                if (part && write) value = val[i];
-            } else {
-                key = i < nsteps ? ctx[i] : 0u;
-                part = !none;
-                write = f != kFlagPred;
-                if (part && write) value = val[i];
-            }
-            part = part && (key >> 15) == half;
-            ra[j] = part ? lds0 + (key & (kHalfSlots - 1u)) * 4u : sink;
-            m[j] = (part && write) ? 0xffffffffu : 0u;
-            v[j] = (part && write) ? value : 0u;
-            rd[j] = part && !write;
+            nd[j] = i < nsteps ? desc[i] : kDescNone;
+            nv[j] = i < whole ? val[i] : 0u;                                       // (a writer's quad, left there by `prepare` / `cells`; anything for the others)
+            nk[j] = (PASS == 2 && i < nsteps) ? ctx[i] : 0u;
         }
-        bool poisoned = false;
-        for (uint32_t spins = 0;; ++spins) {                                       // my turn: every earlier trip's exchanges are queued
+    };
+    // my turn on a token: every earlier trip's operations of that group are queued
+    auto await = [&](uint32_t token, uint32_t t) -> bool {
+        for (uint32_t spins = 0;; ++spins) {
             uint32_t seen;
             asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(seen) : "v"(token) : "memory");
             seen = rfl(seen);
-            if (seen == t) break;
+            if (seen == t) return true;
             if (seen == kPoison || spins > kSpinLimit) {
-                if (seen != kPoison && lane == 0) { atomicOr(a.err, kErrWatchdog); w[kHalfSlots + W * 64u] = kPoison; }
-                poisoned = true;
-                break;
+                if (seen != kPoison && lane == 0) { atomicOr(a.err, kErrWatchdog); w[(token_a - lds0) / 4u] = kPoison; w[(token_b - lds0) / 4u] = kPoison; }
+                return false;
             }
         }
-        if (poisoned) break;
-        const uint32_t tokaddr = lane == 0 ? token : sink, tokval = t + 1u;
-        if (PASS == 0) { DENSITY_PASS_XOR16(ra, v, tokaddr, tokval); }
-        else { DENSITY_PASS_X16("ds_mskor_rtn_b32", ra, m, v, tokaddr, tokval); }
+    };
+    if (wave < trips) fetch(wave);
+    for (uint32_t t = wave; t < trips; t += W) {
+        uint32_t ra[kAhead], m[kAhead], v[kAhead];
+        uint32_t dd[kAhead], sh[kAhead];
+        uint32_t minebits = 0, rdbits = 0;                                         // per lane, bit j: block j's quad is this work-group's / reads (in a vector register: 32 lane masks spill the scalar file)
+#pragma unroll
+        for (uint32_t j = 0; j < kAhead; ++j) {
+            const uint32_t d = nd[j];
+            dd[j] = d;
+            const uint32_t f = (d >> 16) & 3u;
+            const bool none = (d & kDescNone) != 0;
+            if (PASS == 1) {
+                const uint32_t key = d & 0xffffu, sq = key & (kQuarterSlots - 1u);
+                const bool mine = !none && f != kFlagPred && (key >> 14) == mypart;
+                minebits |= (mine ? 1u : 0u) << j;
+                sh[j] = sq & 31u;
+                ra[j] = mine ? obits + (sq >> 5) * 4u : sink;
+                m[j] = (mine && f != kFlagMapA) ? 1u << sh[j] : 0u;                // toggles
+                v[j] = nv[j];
+            } else {
+                const uint32_t key = nk[j];
+                const bool write = f != kFlagPred;
+                const bool mine = !none && (key >> 15) == mypart;
+                ra[j] = mine ? lds0 + (key & (kHalfSlots - 1u)) * 4u : sink;
+                m[j] = (mine && write) ? 0xffffffffu : 0u;
+                v[j] = (mine && write) ? nv[j] : 0u;
+                rdbits |= ((mine && !write) ? 1u : 0u) << j;
+            }
+        }
+        if (t + W < trips) fetch(t + W);                                           // in flight across the waits below
+        if (!await(token_a, t)) break;
+        if (PASS == 1) {
+            const uint32_t tokaddr = lane == 0 ? token_a : sink, tokval = t + 1u;
+            DENSITY_PASS_XOR16(ra, m, tokaddr, tokval);
+#pragma unroll
+            for (uint32_t j = 0; j < kAhead; ++j) {
+                const uint32_t f = (dd[j] >> 16) & 3u, o = (ra[j] >> sh[j]) & 1u;
+                // a sits in cell o, b in cell 1 - o (X = 0, Y = 1): PLAIN writes b's cell, MAP_A reads a's, MAP_B reads b's
+                const uint32_t mycell = f == kFlagMapA ? o : 1u - o;
+                const bool write = f == kFlagPlain, mine = (minebits >> j) & 1u;
+                ra[j] = mine ? lds0 + (((dd[j] & (kQuarterSlots - 1u)) * 2u + mycell) * 4u) : sink;
+                m[j] = (mine && write) ? 0xffffffffu : 0u;
+                v[j] = (mine && write) ? v[j] : 0u;
+                rdbits |= ((mine && !write) ? 1u : 0u) << j;
+            }
+            if (!await(token_b, t)) break;
+            const uint32_t tokaddr_b = lane == 0 ? token_b : sink;
+            DENSITY_PASS_X16("ds_mskor_rtn_b32", ra, m, v, tokaddr_b, tokval);
+        } else {
+            const uint32_t tokaddr = lane == 0 ? token_a : sink, tokval = t + 1u;
+            DENSITY_PASS_X16("ds_mskor_rtn_b32", ra, m, v, tokaddr, tokval);
+        }
 #pragma unroll
         for (uint32_t j = 0; j < kAhead; ++j) {
             const uint32_t i = (t * kAhead + j) * 64u + lane;
-            if (PASS == 0) {
-                // every taking-part quad of this half learns the order bit it met
-                const bool mine = i < nsteps && !(dd[j] & kDescNone) && ((dd[j] >> 16) & 3u) != kFlagPred && ((dd[j] & 0xffffu) >> 15) == half;
-                if (mine && (ra[j] & 1u)) desc[i] = dd[j] | kDescO;
-            } else if (rd[j] && i < limit) {
+            if (((rdbits >> j) & 1u) && i < limit) {
                 val[i] = ra[j];                                                    // cheetah.rs:80,87 / :96: the quad
                 // A MAP quad's NEXT context is its item (cheetah.rs:78-83,85-92: the hash returned is the one read from the stream), but what a
                 // later predicted quad in ITS context hashes to is the hash of the VALUE (:97-102).  The two agree whenever the cell holds a quad
@@ -948,8 +976,7 @@ hipError_t launch_decode_passes(int algo, const uint8_t* d_in, const uint64_t* d
     a.info = reinterpret_cast<ChunkInfo*>(p);
     a.err = d_err;
     const uint32_t blocks_per_chunk = (uint32_t)(out_stride / kRecBytes);
-    hipError_t e = hipFuncSetAttribute((const void*)cheetah_pass<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pass_lds_bytes());
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)cheetah_pass<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pass_lds_bytes());
+    hipError_t e = hipFuncSetAttribute((const void*)cheetah_pass<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pass_lds_bytes());
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)cheetah_pass<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pass_lds_bytes());
     const int walk_nb = g_chain_walk ? 0 : g_walk_blocks;
     auto walk = walk_nb == 0 ? cheetah_walk<0> : walk_nb == 1 ? cheetah_walk<1> : walk_nb == 4 ? cheetah_walk<4> : cheetah_walk<2>;
@@ -977,7 +1004,6 @@ hipError_t launch_decode_passes(int algo, const uint8_t* d_in, const uint64_t* d
     }
     const uint64_t pairs = (uint64_t)n_chunks * (blocks_per_chunk / 2);
     hipLaunchKernelGGL(cheetah_prepare, dim3((uint32_t)((pairs + 3) / 4)), dim3(256), 0, stream, a, blocks_per_chunk);
-    hipLaunchKernelGGL(cheetah_pass<0>, dim3(2 * n_chunks), dim3(kPassWaves * 64), pass_lds_bytes(), stream, a);
     hipLaunchKernelGGL(cheetah_pass<1>, dim3(4 * n_chunks), dim3(kPassWaves * 64), pass_lds_bytes(), stream, a);
     hipLaunchKernelGGL(walk, dim3(n_chunks), dim3(64), kWalkLds, stream, a);
     hipLaunchKernelGGL(cheetah_pass<2>, dim3(2 * n_chunks), dim3(kPassWaves * 64), pass_lds_bytes(), stream, a);
