@@ -32,6 +32,7 @@
 #include "kernels.hpp"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace density {
 
@@ -398,7 +399,9 @@ __global__ __launch_bounds__(256) void cheetah_prepare(PassArgs a, uint32_t bloc
 // ---------------------------------------------------------------------------------------------------------------
 constexpr uint32_t kHalfSlots = 32768, kQuarterSlots = 16384, kTable = kHalfSlots * 4, kAhead = 16, kPassWaves = 8;
 constexpr uint32_t kOrderBytes = kQuarterSlots / 8;                         // the order bits of a quarter of the slots
-constexpr uint32_t pass_lds_bytes() { return kTable + kPassWaves * 64 * 4 + 16 + kOrderBytes; }
+constexpr uint32_t kDenseCap = 384;                                         // quads of a trip (of 1024) that the dictionary pass packs into whole blocks: six blocks' worth
+constexpr uint32_t kPassBase = kTable + kPassWaves * 64 * 4 + 16 + kOrderBytes;
+constexpr uint32_t pass_lds_bytes(int pass) { return kPassBase + (pass == 1 ? kPassWaves * kDenseCap * 8u : 0u); }
 
 #define DENSITY_PASS_X16(OP, ra, m, v, tokaddr, tokval)                                                                            \
     asm volatile(                                                                                                                 \
@@ -432,6 +435,34 @@ constexpr uint32_t pass_lds_bytes() { return kTable + kPassWaves * 64 * 4 + 16 +
           "v"(tokaddr), "v"(tokval)                                                                                               \
         : "memory")
 
+// K ordered operations and the token behind them in ONE statement (the dense form of the dictionary pass: K = 3 or 6 whole blocks per trip)
+template <uint32_t K>
+__device__ __forceinline__ void lds_xor_token(uint32_t (&ra)[K], const uint32_t (&x)[K], uint32_t tokaddr, uint32_t tokval) {
+    static_assert(K == 3 || K == 6, "three or six blocks");
+    if constexpr (K == 3)
+        asm volatile("ds_xor_rtn_b32 %0, %0, %3\n\tds_xor_rtn_b32 %1, %1, %4\n\tds_xor_rtn_b32 %2, %2, %5\n\tds_write_b32 %6, %7\n\ts_waitcnt lgkmcnt(0)"
+                     : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]) : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(tokaddr), "v"(tokval) : "memory");
+    else
+        asm volatile("ds_xor_rtn_b32 %0, %0, %6\n\tds_xor_rtn_b32 %1, %1, %7\n\tds_xor_rtn_b32 %2, %2, %8\n\tds_xor_rtn_b32 %3, %3, %9\n\tds_xor_rtn_b32 %4, %4, %10\n\tds_xor_rtn_b32 %5, %5, %11\n\t"
+                     "ds_write_b32 %12, %13\n\ts_waitcnt lgkmcnt(0)"
+                     : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(ra[4]), "+v"(ra[5])
+                     : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(tokaddr), "v"(tokval) : "memory");
+}
+template <uint32_t K>
+__device__ __forceinline__ void lds_mskor_token(uint32_t (&ra)[K], const uint32_t (&mk)[K], const uint32_t (&vl)[K], uint32_t tokaddr, uint32_t tokval) {
+    static_assert(K == 3 || K == 6, "three or six blocks");
+    if constexpr (K == 3)
+        asm volatile("ds_mskor_rtn_b32 %0, %0, %3, %6\n\tds_mskor_rtn_b32 %1, %1, %4, %7\n\tds_mskor_rtn_b32 %2, %2, %5, %8\n\tds_write_b32 %9, %10\n\ts_waitcnt lgkmcnt(0)"
+                     : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2])
+                     : "v"(mk[0]), "v"(mk[1]), "v"(mk[2]), "v"(vl[0]), "v"(vl[1]), "v"(vl[2]), "v"(tokaddr), "v"(tokval) : "memory");
+    else
+        asm volatile("ds_mskor_rtn_b32 %0, %0, %6, %12\n\tds_mskor_rtn_b32 %1, %1, %7, %13\n\tds_mskor_rtn_b32 %2, %2, %8, %14\n\tds_mskor_rtn_b32 %3, %3, %9, %15\n\t"
+                     "ds_mskor_rtn_b32 %4, %4, %10, %16\n\tds_mskor_rtn_b32 %5, %5, %11, %17\n\tds_write_b32 %18, %19\n\ts_waitcnt lgkmcnt(0)"
+                     : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(ra[4]), "+v"(ra[5])
+                     : "v"(mk[0]), "v"(mk[1]), "v"(mk[2]), "v"(mk[3]), "v"(mk[4]), "v"(mk[5]), "v"(vl[0]), "v"(vl[1]), "v"(vl[2]), "v"(vl[3]), "v"(vl[4]), "v"(vl[5]),
+                       "v"(tokaddr), "v"(tokval) : "memory");
+}
+
 // PASS 1 `dictionary` (round 6: `order` and `cells` in one kernel): a work-group owns a QUARTER of the slots, both cells X, Y of each (16 Ki x 2 dwords) and
 //        their order bits (16 Ki bits).  Per trip two ordered groups of LDS operations, each behind a token of its own:
 //        A  an ordered XOR on the slot's order bit — PLAIN and MAP_B toggle it, MAP_A reads it (cheetah.rs:71-72,87-89); what comes back is the o the quad meets;
@@ -457,7 +488,7 @@ __global__ __launch_bounds__(kPassWaves * 64) void cheetah_pass(PassArgs a) {
     const uint32_t trips = (nsteps + kAhead * 64u - 1u) / (kAhead * 64u);
     const uint64_t s0 = chunk * (a.out_stride / 4);
     uint32_t* w = reinterpret_cast<uint32_t*>(pass_lds);
-    for (uint32_t k = threadIdx.x; k < pass_lds_bytes() / 4u; k += W * 64u) w[k] = 0u;   // the reference's zeroed tables; sinks; the tokens; the order bits
+    for (uint32_t k = threadIdx.x; k < kPassBase / 4u; k += W * 64u) w[k] = 0u;   // the reference's zeroed tables; sinks; the tokens; the order bits
     __syncthreads();
     uint32_t* __restrict__ desc = a.desc + s0;
     const uint16_t* __restrict__ ctx = a.ctx + s0;
@@ -492,13 +523,64 @@ __global__ __launch_bounds__(kPassWaves * 64) void cheetah_pass(PassArgs a) {
         }
     };
     if (wave < trips) fetch(wave);
-    for (uint32_t t = wave; t < trips; t += W) {
+    // The dictionary pass in DENSE form (round 6): a quarter of the slots means one lane in six takes part in a block's operations, and an ordered LDS
+    // instruction costs its 23+ cycles whatever its exec mask.  So a wave packs the taking-part quads of its trip, in stream order, into whole blocks first —
+    // {slot | flag | place in the trip, quad} through a staging area of its own in LDS (ballot, count of the lanes below, one 8-byte write per block; a wave's LDS
+    // operations execute in order: no barrier) — and both ordered groups run on 3 (up to 192 quads) or 6 (up to 384) blocks instead of 16; a trip with more
+    // (one slot over and over) keeps the sixteen-block form below.  Results go back to the quads' places by the place each entry carries.
+    auto dense_trip = [&](auto kc, uint32_t t, uint32_t cnt, uint32_t stg) -> bool {
+        constexpr uint32_t K = decltype(kc)::value, kOff = 1u << 31;
+        uint32_t lo[K], ra[K], x[K], m[K], v[K];
+#pragma unroll
+        for (uint32_t b = 0; b < K; ++b) {
+            uint64_t e;
+            asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(e) : "v"(stg + (b * 64u + lane) * 8u) : "memory");
+            const bool on = b * 64u + lane < cnt;
+            lo[b] = on ? (uint32_t)e : kOff;                                  // (an entry's low word: slot [0,16) | flag [16,18) | place in the trip [18,28))
+            v[b] = (uint32_t)(e >> 32);
+            const uint32_t sq = lo[b] & (kQuarterSlots - 1u), f = (lo[b] >> 16) & 3u;
+            ra[b] = on ? obits + (sq >> 5) * 4u : sink;
+            x[b] = (on && f != kFlagMapA) ? 1u << (sq & 31u) : 0u;                 // toggles
+        }
+#pragma unroll
+        for (uint32_t b = 0; b < K; ++b) asm volatile("" : "+v"(ra[b]), "+v"(x[b]));   // (made ahead of the wait, not behind it)
+        if (!await(token_a, t)) return false;
+        const uint32_t tokval = t + 1u;
+        lds_xor_token<K>(ra, x, lane == 0 ? token_a : sink, tokval);
+#pragma unroll
+        for (uint32_t b = 0; b < K; ++b) {
+            const bool on = !(lo[b] & kOff);
+            const uint32_t sq = lo[b] & (kQuarterSlots - 1u), f = (lo[b] >> 16) & 3u, o = (ra[b] >> (sq & 31u)) & 1u;
+            const uint32_t mycell = f == kFlagMapA ? o : 1u - o;
+            const bool write = f == kFlagPlain;
+            ra[b] = on ? lds0 + ((sq * 2u + mycell) * 4u) : sink;
+            m[b] = (on && write) ? 0xffffffffu : 0u;
+            v[b] = (on && write) ? v[b] : 0u;
+        }
+#pragma unroll
+        for (uint32_t b = 0; b < K; ++b) asm volatile("" : "+v"(ra[b]), "+v"(m[b]), "+v"(v[b]));
+        if (!await(token_b, t)) return false;
+        lds_mskor_token<K>(ra, m, v, lane == 0 ? token_b : sink, tokval);
+#pragma unroll
+        for (uint32_t b = 0; b < K; ++b) {
+            const bool rd = !(lo[b] & kOff) && ((lo[b] >> 16) & 3u) != kFlagPlain;
+            const uint32_t i = t * (kAhead * 64u) + ((lo[b] >> 18) & 1023u);
+            if (rd && i < limit) {
+                val[i] = ra[b];
+                if (ra[b] == 0u) desc[i] = (lo[b] & 0x3ffffu) | kDescZero;           // (see below)
+            }
+        }
+        return true;
+    };
+    const uint32_t stage0 = lds0 + kPassBase + wave * (kDenseCap * 8u);
+    // the sixteen-block form of a trip, from descriptors / quads / contexts in registers (the values pass; the dictionary pass's trips that do not pack)
+    auto wide_trip = [&](uint32_t t, const uint32_t (&xd)[kAhead], const uint32_t (&xv)[kAhead], const uint32_t (&xk)[kAhead], bool fetch_next) -> bool {
         uint32_t ra[kAhead], m[kAhead], v[kAhead];
         uint32_t dd[kAhead], sh[kAhead];
         uint32_t minebits = 0, rdbits = 0;                                         // per lane, bit j: block j's quad is this work-group's / reads (in a vector register: 32 lane masks spill the scalar file)
 #pragma unroll
         for (uint32_t j = 0; j < kAhead; ++j) {
-            const uint32_t d = nd[j];
+            const uint32_t d = xd[j];
             dd[j] = d;
             const uint32_t f = (d >> 16) & 3u;
             const bool none = (d & kDescNone) != 0;
@@ -509,19 +591,23 @@ __global__ __launch_bounds__(kPassWaves * 64) void cheetah_pass(PassArgs a) {
                 sh[j] = sq & 31u;
                 ra[j] = mine ? obits + (sq >> 5) * 4u : sink;
                 m[j] = (mine && f != kFlagMapA) ? 1u << sh[j] : 0u;                // toggles
-                v[j] = nv[j];
+                v[j] = xv[j];
             } else {
-                const uint32_t key = nk[j];
+                const uint32_t key = xk[j];
                 const bool write = f != kFlagPred;
                 const bool mine = !none && (key >> 15) == mypart;
                 ra[j] = mine ? lds0 + (key & (kHalfSlots - 1u)) * 4u : sink;
                 m[j] = (mine && write) ? 0xffffffffu : 0u;
-                v[j] = (mine && write) ? nv[j] : 0u;
+                v[j] = (mine && write) ? xv[j] : 0u;
                 rdbits |= ((mine && !write) ? 1u : 0u) << j;
             }
         }
-        if (t + W < trips) fetch(t + W);                                           // in flight across the waits below
-        if (!await(token_a, t)) break;
+        if (fetch_next && t + W < trips) fetch(t + W);                             // in flight across the waits below
+        // (the operands are made HERE, ahead of the wait: left to itself the compiler sinks their 230 instructions behind the poll loop — into the critical
+        // section, where every later trip of the work-group waits for them)
+#pragma unroll
+        for (uint32_t j = 0; j < kAhead; ++j) asm volatile("" : "+v"(ra[j]), "+v"(m[j]), "+v"(v[j]));
+        if (!await(token_a, t)) return false;
         if (PASS == 1) {
             const uint32_t tokaddr = lane == 0 ? token_a : sink, tokval = t + 1u;
             DENSITY_PASS_XOR16(ra, m, tokaddr, tokval);
@@ -536,7 +622,9 @@ __global__ __launch_bounds__(kPassWaves * 64) void cheetah_pass(PassArgs a) {
                 v[j] = (mine && write) ? v[j] : 0u;
                 rdbits |= ((mine && !write) ? 1u : 0u) << j;
             }
-            if (!await(token_b, t)) break;
+#pragma unroll
+            for (uint32_t j = 0; j < kAhead; ++j) asm volatile("" : "+v"(ra[j]), "+v"(m[j]), "+v"(v[j]));
+            if (!await(token_b, t)) return false;
             const uint32_t tokaddr_b = lane == 0 ? token_b : sink;
             DENSITY_PASS_X16("ds_mskor_rtn_b32", ra, m, v, tokaddr_b, tokval);
         } else {
@@ -555,6 +643,49 @@ __global__ __launch_bounds__(kPassWaves * 64) void cheetah_pass(PassArgs a) {
                 if (PASS == 1 && ra[j] == 0u) desc[i] = dd[j] | kDescZero;
             }
         }
+        return true;
+    };
+    if (PASS == 2) {
+        for (uint32_t t = wave; t < trips; t += W)
+            if (!wide_trip(t, nd, nv, nk, true)) break;
+        return;
+    }
+    // the dictionary pass: trip t packed in the staging area, trip t + W's descriptors and quads in flight in registers
+    auto pack = [&]() -> uint32_t {
+        uint32_t cnt = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < kAhead; ++j) {
+            const uint32_t d = nd[j], f = (d >> 16) & 3u;
+            const bool mine = !(d & kDescNone) && f != kFlagPred && ((d & 0xffffu) >> 14) == mypart;
+            const uint64_t bm = ballot64(mine);
+            const uint32_t pos = cnt + mbcnt64(bm);
+            if (mine && pos < kDenseCap) {
+                const uint64_t e = (uint64_t)((d & 0x3ffffu) | ((j * 64u + lane) << 18)) | ((uint64_t)nv[j] << 32);
+                asm volatile("ds_write_b64 %0, %1" ::"v"(stage0 + pos * 8u), "v"(e) : "memory");
+            }
+            cnt += (uint32_t)__builtin_popcountll(bm);
+        }
+        return cnt;
+    };
+    uint32_t cnt = 0;
+    if (wave < trips) { cnt = pack(); if (wave + W < trips) fetch(wave + W); }
+    for (uint32_t t = wave; t < trips; t += W) {
+        bool ok;
+        if (cnt <= 192u) ok = dense_trip(std::integral_constant<uint32_t, 3>{}, t, cnt, stage0);
+        else if (cnt <= kDenseCap) ok = dense_trip(std::integral_constant<uint32_t, 6>{}, t, cnt, stage0);
+        else {                                                                     // (rare: the trip's own descriptors and quads again, nothing in flight for it)
+            uint32_t fd[kAhead], fv[kAhead], fk[kAhead];
+#pragma unroll
+            for (uint32_t j = 0; j < kAhead; ++j) {
+                const uint32_t i = (t * kAhead + j) * 64u + lane;
+                fd[j] = i < nsteps ? desc[i] : kDescNone;
+                fv[j] = i < whole ? val[i] : 0u;
+                fk[j] = 0u;
+            }
+            ok = wide_trip(t, fd, fv, fk, false);
+        }
+        if (!ok) break;
+        if (t + W < trips) { cnt = pack(); if (t + 2u * W < trips) fetch(t + 2u * W); }
     }
 }
 
@@ -976,8 +1107,8 @@ hipError_t launch_decode_passes(int algo, const uint8_t* d_in, const uint64_t* d
     a.info = reinterpret_cast<ChunkInfo*>(p);
     a.err = d_err;
     const uint32_t blocks_per_chunk = (uint32_t)(out_stride / kRecBytes);
-    hipError_t e = hipFuncSetAttribute((const void*)cheetah_pass<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pass_lds_bytes());
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)cheetah_pass<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pass_lds_bytes());
+    hipError_t e = hipFuncSetAttribute((const void*)cheetah_pass<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pass_lds_bytes(1));
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)cheetah_pass<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pass_lds_bytes(2));
     const int walk_nb = g_chain_walk ? 0 : g_walk_blocks;
     auto walk = walk_nb == 0 ? cheetah_walk<0> : walk_nb == 1 ? cheetah_walk<1> : walk_nb == 4 ? cheetah_walk<4> : cheetah_walk<2>;
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)walk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWalkLds);
@@ -1004,9 +1135,9 @@ hipError_t launch_decode_passes(int algo, const uint8_t* d_in, const uint64_t* d
     }
     const uint64_t pairs = (uint64_t)n_chunks * (blocks_per_chunk / 2);
     hipLaunchKernelGGL(cheetah_prepare, dim3((uint32_t)((pairs + 3) / 4)), dim3(256), 0, stream, a, blocks_per_chunk);
-    hipLaunchKernelGGL(cheetah_pass<1>, dim3(4 * n_chunks), dim3(kPassWaves * 64), pass_lds_bytes(), stream, a);
+    hipLaunchKernelGGL(cheetah_pass<1>, dim3(4 * n_chunks), dim3(kPassWaves * 64), pass_lds_bytes(1), stream, a);
     hipLaunchKernelGGL(walk, dim3(n_chunks), dim3(64), kWalkLds, stream, a);
-    hipLaunchKernelGGL(cheetah_pass<2>, dim3(2 * n_chunks), dim3(kPassWaves * 64), pass_lds_bytes(), stream, a);
+    hipLaunchKernelGGL(cheetah_pass<2>, dim3(2 * n_chunks), dim3(kPassWaves * 64), pass_lds_bytes(2), stream, a);
     hipLaunchKernelGGL(cheetah_finish, dim3((n_chunks + 255) / 256), dim3(256), 0, stream, a, exact ? 1u : 0u, d_produced);
     return hipGetLastError();
 }

@@ -185,6 +185,10 @@ __global__ __launch_bounds__(W * 64) void exchange_stage(const uint8_t* __restri
                 part[j] = !before[j] && (key[j] >> 15) == half;
                 ra[j] = part[j] ? lds0 + (key[j] & (kHalfSlots - 1u)) * 4u : sink;
             }
+            // (the operands are made HERE: left to itself the compiler sinks the hashing of a first stage — 150 instructions — behind the poll loop, into the
+            // critical section every later trip of the work-group waits for)
+#pragma unroll
+            for (uint32_t j = 0; j < kAhead; ++j) asm volatile("" : "+v"(ra[j]), "+v"(val[j]));
             if (W > 1) {                                                           // my turn: every earlier trip's exchanges are queued
                 bool poisoned = false;
                 for (uint32_t spins = 0;; ++spins) {

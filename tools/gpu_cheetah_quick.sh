@@ -1,7 +1,7 @@
 #!/bin/bash
 # config 3 (Cheetah, 100 MB of prose at the automatic chunk): round trip + kernel times, and the decode-pass parity tests
 T=gpurun_out/${1:-quick}; mkdir -p $T; export TMPDIR=/tmp
-timeout 600 python -m pytest tests/test_gpu_decode_passes.py -x -q 2>&1 | tail -2
+timeout 600 python -m pytest tests/test_gpu_decode_passes.py tests/test_gpu_cheetah_lion.py tests/test_gpu_shipped_configs.py tests/test_gpu_patchwork.py -x -q 2>&1 | tail -2
 timeout 300 python bench.py --algo cheetah --data prose --size 100000000 --steps 8 --warmup 2 --no-cpu --no-sweep --no-extra > $T/bench_cheetah.json 2> $T/bench_cheetah.err
 python - <<PY
 import json
