@@ -50,7 +50,7 @@ def decode_both(raw, n):
     return [res[0], res[2]]
 
 
-KINDS = ["prose", "mixed", "random", "zeros", "rep", "binaryish", "samehash", "patchy", "pairs"]
+KINDS = ["prose", "mixed", "random", "zeros", "rep", "binaryish", "samehash", "patchy", "pairs", "vocab30", "vocab60"]
 
 
 def make(kind, n, seed):
@@ -75,6 +75,18 @@ def make(kind, n, seed):
             parts.append(np.array(seq, dtype=np.uint32))
             total += len(seq)
         return np.concatenate(parts).astype("<u4").view(np.uint8)[:n].copy()
+    if kind.startswith("vocab"):
+        # Draws from a vocabulary of 4096 quads: nearly every quad is a dictionary quad (MAP_A / MAP_B / PLAIN — all of them take part in the dictionary
+        # pass), and a share of the vocabulary hashes into ONE quarter of the slots.  30 %: every quarter's trips hold 230-310 of their 1024 quads — the
+        # dense form's six-block case; 60 %: the heavy quarter holds ~610 — the sixteen-block fall-back —, the others ~135: the three-block case.
+        share = int(kind[5:]) / 100.0
+        rng = np.random.default_rng(seed)
+        cand = rng.integers(1, 2**32, size=200_000, dtype=np.uint64)
+        hq = ((cand * 0x9D6EF916) & 0xffffffff) >> 30                                     # the quarter of the slot: the hash's top two bits
+        heavy, rest = cand[hq == 0], cand[hq != 0]
+        k = int(4096 * share)
+        vocab = np.concatenate([heavy[:k], rest[:4096 - k]]).astype(np.uint32)
+        return vocab[rng.integers(0, 4096, size=n // 4 + 1)].astype("<u4").view(np.uint8)[:n].copy()
     return datagen.by_kind(kind, n, seed=seed)
 
 
