@@ -330,6 +330,17 @@ __device__ __forceinline__ void same_key_masks2(uint32_t k0, bool on0, uint32_t 
     eq0 = eq;                                                                     // (lanes 0..31)
     eq1 = bperm(lane | 32u, eq);                                                  // lanes 0..31 fetch their second mask from above
 }
+// the lanes whose 16-bit key equals this lane's, over all 64 lanes (bit-plane ballots: exact)
+__device__ __forceinline__ uint64_t same_key_mask64(uint32_t key, bool on) {
+    uint64_t eq = ~0ull;
+#pragma unroll
+    for (uint32_t b = 0; b < 16; ++b) {
+        const bool bit = (key >> b) & 1u;
+        const uint64_t plane = ballot64(bit && on);
+        eq &= bit ? plane : ~plane;
+    }
+    return eq & ballot64(on);
+}
 // 2-bit flags of lanes 0..31 -> the 64-bit signature (io/write_signature.rs:14-17: quad k at bits 2k, 2k+1)
 __device__ __forceinline__ uint64_t spread32(uint32_t x) {
     uint64_t v = x;
@@ -383,7 +394,6 @@ __global__ __launch_bounds__(64) void cheetah_encode_wave(const uint8_t* __restr
     Tables<DENSITY_HIP_CHEETAH> t;
     t.dict = reinterpret_cast<Pair*>(tables + slot * kTableBytes);
     t.pred = reinterpret_cast<uint32_t*>(tables + slot * kTableBytes + 65536ull * sizeof(Pair));
-    const bool act = lane < 32;
     for (uint64_t chunk = slot; chunk < n_chunks; chunk += n_slots) {
         const uint8_t* src = in + chunk * chunk_bytes;
         const uint64_t len = (total - chunk * chunk_bytes) < chunk_bytes ? (total - chunk * chunk_bytes) : chunk_bytes;
@@ -404,25 +414,34 @@ __global__ __launch_bounds__(64) void cheetah_encode_wave(const uint8_t* __restr
             pos = ts[0]; opos = ts[1]; last_hash = ts[2];
             guard.prev = ts[3]; guard.start = ts[4]; guard.counter = ts[5];
         }
-        uint32_t qnext = (act && pos + G::kBlock <= len) ? ld32u(src + pos + 4u * lane) : 0u;
+        // lanes 0..31 hold the quads of the block at `p`, lanes 32..63 those of the block behind it (where that one is whole)
+        auto load_at = [&](uint64_t p) -> uint32_t { return p + (uint64_t)G::kBlock * (1u + (lane >> 5)) <= len ? ld32u(src + p + 4u * lane) : 0u; };
+        uint32_t qnext = load_at(pos);
         // head mode: hand over to the exchange passes at the first 4 KiB boundary behind head_bytes where the blow-up protection has been quiet
         // for head_calm bytes; a chunk that is too short for that, or has not calmed down within four times head_bytes (or by its middle), is simply finished here
         bool may_hand_over = head_state && len >= 4ull * head_bytes, handed_over = false;
         uint64_t last_copy_end = 0;
-        for (; pos + G::kBlock <= len; pos += G::kBlock) {                    // whole blocks
+        while (pos + G::kBlock <= len) {                                      // whole blocks
             if (may_hand_over && pos >= head_bytes && (pos & 4095u) == 0) {
                 if (pos >= last_copy_end + head_calm && guard.penalty == 0) { handed_over = true; break; }
                 if (pos >= 4ull * head_bytes || pos >= len / 2) may_hand_over = false;   // raw copies this far in are not the cold start's: no hand-over
             }
-            const uint8_t* blk = src + pos;
             if (guard.block_is_copy()) {                                      // codec.rs:35-37
                 last_copy_end = pos + G::kBlock;
-                if (act) st32u(dst + opos + 4u * lane, qnext);
-                qnext = (act && pos + 2 * G::kBlock <= len) ? ld32u(blk + G::kBlock + 4u * lane) : 0u;
+                if (lane < 32) st32u(dst + opos + 4u * lane, qnext);
+                qnext = load_at(pos + G::kBlock);
                 opos += G::kBlock;
+                pos += G::kBlock;
                 guard.decay();
                 continue;
             }
+            // Round 6: TWO records per step where the second one is certain to be coded — a step costs its two memory round trips (gather, stores) whether
+            // 32 or 64 lanes take part, and the heads of the exchange passes' chunks are a chain of such steps on one wave per CU.  The block behind this one
+            // is coded whatever this one's size if the last record was not incompressible (then this one cannot start a penalty: protection_state.rs:38-47);
+            // it stays out where the loop's hand-over test belongs in front of it (a 4 KiB boundary).
+            const bool two = guard.prev == 0 && pos + 2ull * G::kBlock <= len && ((pos + G::kBlock) & 4095u) != 0;
+            const uint32_t nact = two ? 64u : 32u;
+            const bool act = lane < nact;
             // ---- 1. quads, slots, gather ----
             const uint32_t q = qnext;
             const uint32_t h = hash16(q);
@@ -432,26 +451,25 @@ __global__ __launch_bounds__(64) void cheetah_encode_wave(const uint8_t* __restr
             tbl_drain();                                                      // the previous step's table stores are in L2 (and its record stores, alas)
             st.pv = act ? tbl_load32(t.pred + ps) : 0u;
             const Pair e0 = act ? tbl_load_pair(t.dict + h) : Pair{0u, 0u};
-            qnext = (act && pos + 2 * G::kBlock <= len) ? ld32u(blk + G::kBlock + 4u * lane) : 0u;   // the next block's quads: in flight across this step
+            qnext = load_at(pos + (uint64_t)G::kBlock * (two ? 2u : 1u));     // the next step's quads: in flight across this step
             st.da = e0.a; st.db = e0.b; st.pdirty = 0; st.ddirty = 0;
             // ---- 2. who follows whom ----
-            const uint32_t below = (1u << (lane & 31u)) - 1u;
-            uint32_t peq, deq;
-            same_key_masks2(ps, act, h, act, lane, peq, deq);
-            const uint32_t pbefore = peq & below, dbefore = deq & below;
-            const uint32_t pprev = pbefore ? 31u - (uint32_t)__builtin_clz(pbefore) : 64u;   // 64: nobody
-            const uint32_t dprev = dbefore ? 31u - (uint32_t)__builtin_clz(dbefore) : 64u;
-            const bool plast = act && (peq >> (lane & 31u) >> 1) == 0, dlast = act && (deq >> (lane & 31u) >> 1) == 0;
+            const uint64_t below = (1ull << lane) - 1ull;
+            const uint64_t peq = same_key_mask64(ps, act), deq = same_key_mask64(h, act);
+            const uint64_t pbefore = peq & below, dbefore = deq & below;
+            const uint32_t pprev = pbefore ? 63u - (uint32_t)__builtin_clzll(pbefore) : 64u;   // 64: nobody
+            const uint32_t dprev = dbefore ? 63u - (uint32_t)__builtin_clzll(dbefore) : 64u;
+            const bool plast = act && ((peq >> lane) >> 1) == 0, dlast = act && ((deq >> lane) >> 1) == 0;
             // ---- 3. resolve in dependency order (cheetah.rs:123-149 per lane) ----
             uint32_t flag = 0;
             bool done = !act;
-            for (uint32_t round = 0; round < 32; ++round) {                   // (a chain has at most 32 links)
-                const uint32_t done_mask = (uint32_t)ballot64(done && act);
-                const bool pok = pprev == 64u || ((done_mask >> pprev) & 1u), dok = dprev == 64u || ((done_mask >> dprev) & 1u);
+            for (uint32_t round = 0; round < 64; ++round) {                   // (a chain has at most 64 links)
+                const uint64_t done_mask = ballot64(done && act);
+                const bool pok = pprev == 64u || ((done_mask >> (pprev & 63u)) & 1ull), dok = dprev == 64u || ((done_mask >> (dprev & 63u)) & 1ull);
                 const bool ready = !done && pok && dok;
                 // the state my predecessors left (read from their registers; garbage where there is no predecessor)
-                const uint32_t fpv = bperm(pprev & 31u, st.pv), fpd = bperm(pprev & 31u, st.pdirty);
-                const uint32_t fda = bperm(dprev & 31u, st.da), fdb = bperm(dprev & 31u, st.db), fdd = bperm(dprev & 31u, st.ddirty);
+                const uint32_t fpv = bperm(pprev & 63u, st.pv), fpd = bperm(pprev & 63u, st.pdirty);
+                const uint32_t fda = bperm(dprev & 63u, st.da), fdb = bperm(dprev & 63u, st.db), fdd = bperm(dprev & 63u, st.ddirty);
                 if (ready) {
                     if (pprev != 64u) { st.pv = fpv; st.pdirty = fpd; }
                     if (dprev != 64u) { st.da = fda; st.db = fdb; st.ddirty = fdd; }
@@ -465,20 +483,35 @@ __global__ __launch_bounds__(64) void cheetah_encode_wave(const uint8_t* __restr
                 }
                 if (ballot64(!done) == 0) break;
             }
-            // ---- 4. the record: signature, items (io/write_buffer.rs), tables ----
+            // ---- 4. the records: signatures, items (io/write_buffer.rs), tables ----
             const uint32_t ilen = !act ? 0u : (flag == 0 ? 4u : (flag == 3 ? 0u : 2u));
-            uint32_t items;
-            const uint32_t off = scan32(ilen, lane, items);
-            uint8_t* rec = dst + opos;
-            const uint64_t sig = spread32((uint32_t)ballot64(act && (flag & 1u))) | (spread32((uint32_t)ballot64(act && (flag & 2u))) << 1);
-            if (lane < 2) st32u(rec + 4u * lane, lane ? (uint32_t)(sig >> 32) : (uint32_t)sig);   // codec.rs:24-26
+            uint32_t incl = ilen;                                             // prefix sums within each half of the wave: rows of 16, then row 0's / row 2's total into rows 1 / 3
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xf, 0xf, true);   // row_shr:1
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xf, 0xf, true);   // row_shr:2
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xf, 0xf, true);   // row_shr:4
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xf, 0xf, true);   // row_shr:8
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x142, 0xa, 0xf, true);   // row_bcast:15 into rows 1 and 3
+            const uint32_t items_a = (uint32_t)__builtin_amdgcn_readlane((int)incl, 31), items_b = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            const uint32_t off = incl - ilen;
+            const uint32_t rlen_a = G::kSig + items_a, rlen_b = G::kSig + items_b;
+            uint8_t* rec = dst + opos + (lane >= 32 ? rlen_a : 0u);           // my record
+            const uint64_t lo = ballot64(act && (flag & 1u)), hi = ballot64(act && (flag & 2u));
+            const uint64_t sig_a = spread32((uint32_t)lo) | (spread32((uint32_t)hi) << 1), sig_b = spread32((uint32_t)(lo >> 32)) | (spread32((uint32_t)(hi >> 32)) << 1);
+            if (lane < 2) st32u(dst + opos + 4u * lane, lane ? (uint32_t)(sig_a >> 32) : (uint32_t)sig_a);   // codec.rs:24-26
+            if (two && (lane & ~1u) == 32u) st32u(dst + opos + rlen_a + 4u * (lane & 1u), (lane & 1u) ? (uint32_t)(sig_b >> 32) : (uint32_t)sig_b);
             if (ilen == 4) st32u(rec + G::kSig + off, q); else if (ilen == 2) st16u(rec + G::kSig + off, h);
             if (plast && st.pdirty) tbl_store32(t.pred + ps, st.pv);
             if (dlast && st.ddirty) tbl_store_pair(t.dict + h, Pair{st.da, st.db});
-            last_hash = rfl(bperm(31u, h));
-            const uint32_t rlen = G::kSig + items;
-            guard.update(rlen >= G::kBlock);                                  // codec.rs:68
-            opos += rlen;
+            last_hash = rfl(bperm(nact - 1u, h));
+            guard.update(rlen_a >= G::kBlock);                                // codec.rs:68
+            opos += rlen_a;
+            pos += G::kBlock;
+            if (two) {
+                (void)guard.block_is_copy();                                  // (it is not — see `two` — but the call counts the block: protection_state.rs:19-27)
+                guard.update(rlen_b >= G::kBlock);
+                opos += rlen_b;
+                pos += G::kBlock;
+            }
         }
         tbl_drain();
         if (head_state) {
@@ -740,16 +773,6 @@ __device__ __forceinline__ uint64_t spread16by3(uint32_t x16) {
     return x;
 }
 
-__device__ __forceinline__ uint64_t same_key_mask64(uint32_t key, bool on) {
-    uint64_t eq = ~0ull;
-#pragma unroll
-    for (uint32_t b = 0; b < 16; ++b) {
-        const bool bit = (key >> b) & 1u;
-        const uint64_t plane = ballot64(bit && on);
-        eq &= bit ? plane : ~plane;
-    }
-    return eq & ballot64(on);
-}
 __global__ __launch_bounds__(64) void lion_encode_wave(const uint8_t* __restrict__ in, uint64_t total, uint64_t chunk_bytes,
                                                        uint32_t n_chunks, uint8_t* __restrict__ out, uint64_t out_stride,
                                                        uint64_t* __restrict__ sizes, uint8_t* __restrict__ tables, uint32_t n_slots,
