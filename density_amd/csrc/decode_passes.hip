@@ -40,7 +40,7 @@ extern __shared__ __attribute__((aligned(16))) uint8_t pass_lds[];
 bool g_force_serial_decode = false;   // density_hip_set_kernel_variant(128): Cheetah containers on the one-wave decoder instead
 bool g_serial_parse = false;          // density_hip_set_kernel_variant(1024): the records of a chunk found by the one-wave walk alone (no window kernels)
 bool g_chain_walk = false;            // density_hip_set_kernel_variant(4096): the contexts walked run by run (round 5's walk) instead of 64 quads at a time
-int g_walk_blocks = 2;                // blocks of 64 quads the walk speculates together (1, 2, 4; tuning runs: density_hip_set_kernel_variant bits 13-14)
+int g_walk_blocks = 2;                // 2: the walk by a team of four waves (default); 1 / 4: by ONE wave, 64 / 128 quads at a time (density_hip_set_kernel_variant bits 13-14: cross-checks)
 
 namespace {
 
@@ -735,6 +735,66 @@ __device__ __forceinline__ void lds_mskor_group(uint32_t (&r)[G], const uint32_t
                       : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3])
                       : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "v"(mk[0]), "v"(mk[1]), "v"(mk[2]), "v"(mk[3]), "v"(vl[0]), "v"(vl[1]), "v"(vl[2]), "v"(vl[3]) : "memory");
 }
+// One block of 64 quads that all take part, some of them predicted: the chain run by run, in as few instructions as it takes (the comments are at its
+// use in cheetah_walk).  c: the running context in, out; returns every lane's context.
+__device__ __forceinline__ uint32_t walk_chain_block(uint32_t lds0, uint32_t& c, uint32_t hprev, uint32_t h, uint32_t hw, uint64_t Pin) {
+    const uint64_t P = ((uint64_t)rfl((uint32_t)(Pin >> 32)) << 32) | rfl((uint32_t)Pin);   // (wave-uniform by construction: said so to the register allocator)
+    uint32_t av = lds0 + 2u * hprev;
+    const uint32_t h2 = lds0 + 2u * h;                                      // what the running context becomes behind a quad that is not predicted
+    uint64_t prem = P;
+    uint32_t c2 = rfl(lds0 + 2u * c);
+    uint32_t s_pos, s_p, s_r, v_t, v_u, s_m0;
+    uint64_t s_m;
+    asm volatile(
+        "s_mov_b32 %[m0s], m0\n\t"                                            // (M0 is the compiler's: handed back as found)
+        "s_mov_b32 %[pos], 0\n"
+        "1:\n\t"                                                             // ---- next run of quads that are not predicted: [pos, p)
+        "s_ff1_i32_b64 %[p], %[prem]\n\t"
+        "s_min_u32 %[p], %[p], 64\n\t"                                       // (no predicted quad left: -1 -> 64)
+        "s_sub_u32 %[r], %[p], %[pos]\n\t"
+        "s_cmp_eq_u32 %[r], 0\n\t"
+        "s_cbranch_scc1 2f\n\t"
+        "s_bfm_b64 %[m], %[r], %[pos]\n\t"                                   // r bits from pos on (r < 64: some quad is predicted)
+        "s_mov_b32 m0, %[pos]\n\t"
+        "s_add_u32 %[r], %[p], -1\n\t"
+        "v_writelane_b32 %[av], %[c2], m0\n\t"
+        "s_mov_b64 exec, %[m]\n\t"
+        "ds_write_b16 %[av], %[h]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "v_readlane_b32 %[c2], %[h2], %[r]\n"
+        "2:\n\t"
+        "s_cmp_ge_u32 %[p], 64\n\t"
+        "s_cbranch_scc1 4f\n\t"
+        "v_mov_b32 %[t], %[c2]\n"
+        // ---- a predicted quad at lane p: c <- H[c] (cheetah.rs:97-102).  Round 4: the chain is the read, one add and the branch — ~85 cycles
+        // instead of ~105.  The address of H[c] (`t`, the same in every lane) goes into lane p's `av` by a select under a one-lane mask, the
+        // bookkeeping and the test "is the next quad predicted too" are issued while the read is in flight (its answer lands in `u`, so `t`
+        // stays readable), and the scalar copy of the context is taken once per run instead of once per quad.
+        "3:\n\t"
+        "ds_read_u16 %[u], %[t]\n\t"
+        "s_bfm_b64 %[m], 1, %[p]\n\t"
+        "s_bitset0_b64 %[prem], %[p]\n\t"
+        "s_add_u32 %[p], %[p], 1\n\t"
+        "v_cndmask_b32_e64 %[av], %[av], %[t], %[m]\n\t"
+        "s_bitcmp1_b64 %[prem], %[p]\n\t"                                    // (p == 64 tests bit 0, which is clear by now: lane 0 was either not predicted or has been taken)
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_lshl_add_u32 %[t], %[u], 1, %[lds0]\n\t"
+        "s_cbranch_scc1 3b\n\t"
+        "s_nop 0\n\t"
+        "v_readfirstlane_b32 %[c2], %[t]\n\t"
+        "s_cmp_ge_u32 %[p], 64\n\t"
+        "s_cbranch_scc1 4f\n\t"
+        "s_mov_b32 %[pos], %[p]\n\t"
+        "s_branch 1b\n"
+        "4:\n\t"
+        "s_mov_b32 m0, %[m0s]\n\t"
+        : [av] "+v"(av), [c2] "+s"(c2), [prem] "+s"(prem), [pos] "=&s"(s_pos), [p] "=&s"(s_p), [r] "=&s"(s_r), [m] "=&s"(s_m), [t] "=&v"(v_t), [u] "=&v"(v_u), [m0s] "=&s"(s_m0)
+        : [h] "v"(hw), [h2] "v"(h2), [lds0] "s"(lds0)
+        : "memory", "scc");
+    c = (c2 - lds0) >> 1;
+    return (av - lds0) >> 1;
+}
+
 template <int NB>
 __global__ __launch_bounds__(64) void cheetah_walk(PassArgs a) {
     constexpr bool VEC = NB >= 1;
@@ -1056,6 +1116,274 @@ __global__ __launch_bounds__(64) void cheetah_walk(PassArgs a) {
     (void)val;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// walk, by a TEAM of waves (round 6; the default).  One wave spends its time ISSUING: ~380 instructions per 128 quads at one instruction per five cycles —
+// classification, the speculative reads level by level, the bookkeeping — and only ~500 cycles of those 2,500 in what must happen in stream order (the ordered
+// pass over H and its verification).  So kTeam waves of one work-group share the chunk's H: wave w takes the groups g = w (mod kTeam) of 128 quads, does
+// everything that needs no order AHEAD of its turn — its descriptors come straight from memory into registers two turns ahead, the speculative reads see H
+// as it stands, groups of other waves not yet applied: speculation may be as stale as it likes, the verification below does not care how a context was
+// guessed — and then, holding the token (an LDS word: the group whose turn it is; the running context travels beside it):
+//   patch      lane 0's context, if the quad before the group was predicted (its hash is the predecessor's to tell);
+//   execute    the ordered pass (as above), verify, take back and go again from the first wrong read until every lane stands;
+//   hand on    the running context and the token; the contexts are stored behind that.
+// Groups the 128-at-a-time form does not take (a raw-copy block, the chunk's end, a run of eight predicted quads) are walked block by block under the token
+// by the run-by-run code.  A wave's LDS operations execute in issue order and the token is written behind them: whoever sees it sees H after them (§4.2).
+// ---------------------------------------------------------------------------------------------------------------
+#ifndef DENSITY_WALK_TEAM
+#define DENSITY_WALK_TEAM 4
+#endif
+#ifndef DENSITY_WALK_JIT
+#define DENSITY_WALK_JIT 1
+#endif
+constexpr uint32_t kTeam = DENSITY_WALK_TEAM, kTeamLds = kWalkTable + 64;
+template <uint32_t G>
+__global__ __launch_bounds__(kTeam * 64) void cheetah_walk_team(PassArgs a) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = rfl(threadIdx.x >> 6);
+    const uint64_t chunk = blockIdx.x;
+    const ChunkInfo ci = a.info[chunk];
+    if (ci.bad) return;
+    const uint32_t nsteps = ci.blocks * kRecQuads;
+    const uint32_t nblk = (nsteps + 63u) / 64u;
+    const uint32_t ngroups = (nblk + G - 1u) / G;
+    const uint64_t s0 = chunk * (a.out_stride / 4);
+    const uint32_t* __restrict__ desc = a.desc + s0;
+    uint16_t* __restrict__ ctx = a.ctx + s0;
+    {   // H starts as the hash of the reference's zeroed prediction table: hash(0) = 0; token 0, running context 0 (cheetah.rs:52)
+        uint4* p = reinterpret_cast<uint4*>(pass_lds);
+        for (uint32_t i = threadIdx.x; i < kTeamLds / 16; i += kTeam * 64) p[i] = make_uint4(0, 0, 0, 0);
+        __syncthreads();
+    }
+    const uint32_t lds0 = lds_addr(pass_lds);
+    const uint32_t token = lds0 + kWalkTable;                                       // {the group whose turn it is, the running context in front of it}: one 8-byte word
+    uint32_t nd[G], nprev = 0;
+    auto fetch = [&](uint32_t g) {
+#pragma unroll
+        for (uint32_t b = 0; b < G; ++b) {
+            const uint32_t i = (g * G + b) * 64u + lane;
+            nd[b] = i < nsteps ? desc[i] : kDescNone;
+        }
+        nprev = g ? desc[g * G * 64u - 1u] : 0u;                                      // the quad in front of the group
+    };
+    if (wave < ngroups) fetch(wave);
+    for (uint32_t g = wave; g < ngroups; g += kTeam) {
+        const uint32_t blk = g * G;
+        uint32_t dv[G], hv[G], hwv[G], cvv[G], rsv[G], rfv[G], r2v[G], shv[G];
+        uint64_t Pm[G], Nm[G], K0m[G], known[G], fin[G], rdone[G];
+        const uint32_t dprev = rfl(nprev);
+        bool ok = blk + G <= nblk;
+#pragma unroll
+        for (uint32_t b = 0; b < G; ++b) {
+            dv[b] = nd[b];
+            hv[b] = dv[b] & 0xffffu;
+            hwv[b] = (dv[b] & kDescZero) ? 0u : hv[b];
+            const bool none = (dv[b] & kDescNone) != 0, pred = ((dv[b] >> 16) & 3u) == kFlagPred;
+            Pm[b] = ballot64(!none && pred); Nm[b] = ballot64(!none && !pred);
+            uint64_t lr = Pm[b] & (Pm[b] >> 1); lr &= lr >> 2; lr &= lr >> 4;
+            ok = ok && (Pm[b] | Nm[b]) == ~0ull && lr == 0;
+        }
+        if (g + kTeam < ngroups) fetch(g + kTeam);                                    // in flight across this turn
+        // the context in front of the group, where the descriptors tell it: the hash of a quad that took part and was not predicted
+        const bool c_known = g == 0 || (!(dprev & kDescNone) && ((dprev >> 16) & 3u) != kFlagPred);
+        const uint32_t c_spec = g == 0 ? 0u : (dprev & 0xffffu);
+        // speculate: every level's reads of all G blocks in flight together (lanes whose context is known and who have not read yet)
+        auto speculate = [&]() __attribute__((always_inline)) {
+            for (;;) {
+                uint64_t R[G], any = 0;
+#pragma unroll
+                for (uint32_t b = 0; b < G; ++b) { R[b] = Pm[b] & known[b] & ~rdone[b]; any |= R[b]; }
+                if (!any) break;
+                uint32_t r[G], ad[G];
+#pragma unroll
+                for (uint32_t b = 0; b < G; ++b) ad[b] = lds0 + 2u * cvv[b];
+                lds_read_u16_group<G>(r, ad);                                          // (every block reads, whether or not one of its lanes needs it: a stale context is a valid address)
+#pragma unroll
+                for (uint32_t b = 0; b < G; ++b) {
+                    const uint64_t in = (R[b] << 1) | (b == 0 ? 0ull : (R[b ? b - 1 : 0] >> 63));   // the lanes that learn their context this round
+                    if (R[b]) rsv[b] = msel(R[b], r[b], rsv[b]);
+                    if (in) {
+                        uint32_t up = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r[b], 0x138, 0xf, 0xf, false);   // wave_shr:1
+                        if (b != 0 && (in & 1ull)) { const uint32_t carry = (uint32_t)__builtin_amdgcn_readlane((int)r[b ? b - 1 : 0], 63); up = lane == 0 ? carry : up; }
+                        cvv[b] = msel(in, up, cvv[b]);
+                    }
+                    known[b] |= in; rdone[b] |= R[b];
+                }
+            }
+        };
+        // the ordered pass's operands: made AHEAD of the turn too (only a patched lane 0 or a wrong read makes them again)
+        uint32_t xa[G], xm[G], xv[G];
+        auto prepare_exec = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (uint32_t b = 0; b < G; ++b) {
+                shv[b] = (cvv[b] & 1u) * 16u;
+                const uint64_t w = Nm[b] & ~fin[b];
+                xa[b] = lds0 + ((2u * cvv[b]) & ~3u);
+                xm[b] = msel(w, 0xffffu << shv[b], 0u); xv[b] = msel(w, hwv[b] << shv[b], 0u);
+            }
+        };
+        if (ok) {
+#pragma unroll
+            for (uint32_t b = 0; b < G; ++b) {
+                const uint32_t hp = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hv[b], 0x138, 0xf, 0xf, false);   // wave_shr:1
+                const uint32_t first = b == 0 ? c_spec : (uint32_t)__builtin_amdgcn_readlane((int)hv[b ? b - 1 : 0], 63);   // (meaningful only where the quad before was not predicted)
+                cvv[b] = lane == 0 ? first : hp;
+                K0m[b] = (Nm[b] << 1) | (b == 0 ? (c_known ? 1ull : 0ull) : (Nm[b ? b - 1 : 0] >> 63));
+                known[b] = K0m[b]; fin[b] = 0; rsv[b] = 0; rfv[b] = 0; rdone[b] = 0;
+            }
+            if (DENSITY_WALK_JIT && g >= DENSITY_WALK_JIT) {                              // (experiment: not before the turn is DENSITY_WALK_JIT groups away)
+                for (uint32_t spins = 0; spins < kSpinLimit; ++spins) {
+                    uint32_t seen;
+                    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(seen) : "v"(token) : "memory");
+                    seen = rfl(seen);
+                    if (seen + DENSITY_WALK_JIT >= g) break;
+                }
+            }
+            speculate();                                                              // AHEAD of my turn: H as it stands
+            prepare_exec();
+        }
+        // ---- my turn ----
+        uint32_t c;
+        {
+            bool poisoned = false;
+            for (uint32_t spins = 0;; ++spins) {
+                uint64_t tc;
+                asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(tc) : "v"(token) : "memory");
+                const uint32_t seen = rfl((uint32_t)tc);
+                if (seen == g) { c = rfl((uint32_t)(tc >> 32)); break; }
+                if (seen == kPoison || spins > kSpinLimit) {
+                    if (seen != kPoison && lane == 0) { atomicOr(a.err, kErrWatchdog); *reinterpret_cast<volatile uint32_t*>(pass_lds + kWalkTable) = kPoison; }
+                    poisoned = true;
+                    break;
+                }
+            }
+            if (poisoned) break;
+        }
+        if (ok) {
+            if (!c_known) {                                                          // the predecessor's last quad was predicted (or took no part): its hash is what the predecessor says
+                cvv[0] = lane == 0 ? c : cvv[0];
+                K0m[0] |= 1ull; known[0] |= 1ull;
+                speculate();                                                          // (what lane 0's context sets free)
+                prepare_exec();
+            }
+            for (;;) {
+                // execute: the lanes that do not stand yet, block after block, each in lane order
+                uint32_t ret[G];
+                lds_mskor_group<G>(ret, xa, xm, xv);
+                // verify
+                uint64_t bad[G], anybad = 0;
+#pragma unroll
+                for (uint32_t b = 0; b < G; ++b) {
+                    r2v[b] = (ret[b] >> shv[b]) & 0xffffu;
+                    // a predicted lane that has not read at all yet (its context never became known: cannot happen once lane 0's is) counts as wrong
+                    bad[b] = (ballot64(r2v[b] != rsv[b]) | ~rdone[b]) & Pm[b] & ~fin[b];
+                    anybad |= bad[b];
+                }
+                if (__builtin_expect(anybad == 0, 1)) {
+#pragma unroll
+                    for (uint32_t b = 0; b < G; ++b) rfv[b] = msel(~fin[b], r2v[b], rfv[b]);
+                    break;
+                }
+                uint32_t b0 = 0;
+#pragma unroll
+                for (uint32_t b = G; b-- > 0;) if (bad[b]) b0 = b;
+                uint64_t badb = bad[0];
+#pragma unroll
+                for (uint32_t b = 1; b < G; ++b) badb = b0 == b ? bad[b] : badb;
+                const uint32_t i0 = (uint32_t)__builtin_ctzll(badb);
+                const uint64_t upto = (2ull << i0) - 1ull;                           // lanes 0 .. i0 of block b0 (i0 == 63: all of them)
+                uint64_t stands[G];
+#pragma unroll
+                for (uint32_t b = 0; b < G; ++b) stands[b] = b < b0 ? ~0ull : b == b0 ? upto : 0ull;
+                // the writes behind the first wrong read are taken back: old halves, the latest write first (blocks from the last to b0, lanes reversed)
+#pragma unroll
+                for (uint32_t b = G; b-- > 0;) {
+                    const uint64_t undo = Nm[b] & ~stands[b] & ~fin[b];
+                    if (undo) {
+                        const uint32_t ar = bperm(63u - lane, lds0 + 2u * cvv[b]), old = bperm(63u - lane, r2v[b]);
+                        if ((undo >> (63u - lane)) & 1ull) asm volatile("ds_write_b16 %0, %1" ::"v"(ar), "v"(old) : "memory");
+                    }
+                }
+                const uint32_t truth = (uint32_t)__builtin_amdgcn_readlane((int)(b0 == 0 ? r2v[0] : b0 == 1 ? r2v[G > 1 ? 1 : 0] : b0 == 2 ? r2v[G > 2 ? 2 : 0] : r2v[G > 3 ? 3 : 0]), (int)i0);
+                bool all = true;
+#pragma unroll
+                for (uint32_t b = 0; b < G; ++b) {
+                    rfv[b] = msel(stands[b] & ~fin[b], r2v[b], rfv[b]);
+                    fin[b] = stands[b];
+                    all = all && fin[b] == ~0ull;
+                    // the lane behind (b0, i0) now knows its context; everything else behind it is as unknown as before the first round
+                    const uint64_t next = b == b0 ? (i0 == 63u ? 0ull : (2ull << i0) & ~upto) : (b == b0 + 1u && i0 == 63u ? 1ull : 0ull);
+                    if (next) cvv[b] = msel(next, truth, cvv[b]);
+                    known[b] = stands[b] | next | K0m[b];
+                }
+                if (all) break;
+#pragma unroll
+                for (uint32_t b = 0; b < G; ++b) rdone[b] = fin[b];
+                speculate();                                                          // everything behind the first wrong read again, from H as it is now
+                prepare_exec();
+            }
+            const uint32_t last = msel(Pm[G - 1], rfv[G - 1], hv[G - 1]);
+            c = (uint32_t)__builtin_amdgcn_readlane((int)last, 63);
+        } else {
+            // block by block, run by run (cheetah.rs:97-102; raw-copy blocks and quads beyond the end take no part: the context passes through)
+            auto one_block = [&](auto bc) __attribute__((always_inline)) {                                           // (written out per block: left as a loop over b the compiler keeps it rolled and the masks in vector registers)
+                constexpr uint32_t b = decltype(bc)::value;
+                if (blk + b >= nblk) { cvv[b] = 0; return; }
+                const uint32_t h = hv[b], hw = hwv[b];
+                const uint64_t P = Pm[b], N = Nm[b], active = P | N;
+                const uint32_t hprev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h, 0x138, 0xf, 0xf, false);   // wave_shr:1
+                if (active == ~0ull && P != 0 && P != ~0ull) {                        // every quad takes part, some are predicted: the hand-written chain (see cheetah_walk)
+                    cvv[b] = walk_chain_block(lds0, c, hprev, h, hw, P);
+                    return;
+                }
+                uint32_t cv = 0, pos = 0;
+                while (pos < 64u) {
+                    const uint64_t rest = active >> pos;
+                    if (!rest) break;
+                    pos += (uint32_t)__builtin_ctzll(rest);
+                    if ((N >> pos) & 1ull) {
+                        const uint64_t inv = ~(N >> pos);
+                        const uint32_t r = inv ? (uint32_t)__builtin_ctzll(inv) : 64u - pos;
+                        const bool in = lane >= pos && lane < pos + r;
+                        const uint32_t mine = lane == pos ? c : hprev;
+                        if (in) {
+                            cv = mine;
+                            asm volatile("ds_write_b16 %0, %1" ::"v"(lds0 + 2u * mine), "v"(hw) : "memory");
+                        }
+                        c = (uint32_t)__builtin_amdgcn_readlane((int)h, (int)(pos + r - 1u));
+                        pos += r;
+                    } else {
+                        const uint64_t inv = ~(P >> pos);
+                        const uint32_t r = inv ? (uint32_t)__builtin_ctzll(inv) : 64u - pos;
+                        for (uint32_t t = 0; t < r; ++t) {
+                            if (lane == pos + t) cv = c;
+                            uint32_t nx;
+                            asm volatile("ds_read_u16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(nx) : "v"(lds0 + 2u * c) : "memory");
+                            nx = rfl(nx);
+                            if (nx == c) {                                             // a fixed point: the table does not change inside a run
+                                if (lane > pos + t && lane < pos + r) cv = c;
+                                break;
+                            }
+                            c = nx;
+                        }
+                        pos += r;
+                    }
+                }
+                cvv[b] = cv;
+            };
+            one_block(std::integral_constant<uint32_t, 0>{});
+            if constexpr (G > 1) one_block(std::integral_constant<uint32_t, 1>{});
+            if constexpr (G > 2) { one_block(std::integral_constant<uint32_t, 2>{}); one_block(std::integral_constant<uint32_t, 3>{}); }
+        }
+        // hand on: the token and the running context in one 8-byte write, behind everything this turn did to H (a wave's LDS operations execute as issued)
+        {
+            const uint64_t tc = (uint64_t)(g + 1u) | ((uint64_t)c << 32);
+            asm volatile("ds_write_b64 %0, %1" ::"v"(token), "v"(tc) : "memory");
+        }
+#pragma unroll
+        for (uint32_t b = 0; b < G; ++b) { const uint32_t i = (blk + b) * 64u + lane; if (i < nsteps) ctx[i] = (uint16_t)cvv[b]; }
+    }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1109,9 +1437,11 @@ hipError_t launch_decode_passes(int algo, const uint8_t* d_in, const uint64_t* d
     const uint32_t blocks_per_chunk = (uint32_t)(out_stride / kRecBytes);
     hipError_t e = hipFuncSetAttribute((const void*)cheetah_pass<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pass_lds_bytes(1));
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)cheetah_pass<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pass_lds_bytes(2));
-    const int walk_nb = g_chain_walk ? 0 : g_walk_blocks;
-    auto walk = walk_nb == 0 ? cheetah_walk<0> : walk_nb == 1 ? cheetah_walk<1> : walk_nb == 4 ? cheetah_walk<4> : cheetah_walk<2>;
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)walk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWalkLds);
+    // the walk: a team of four waves, 128 quads a turn (default); g_walk_blocks 1 / 4: ONE wave, 64 / 128 quads at a time; g_chain_walk: one wave, run by run
+    const bool team = !g_chain_walk && g_walk_blocks == 2;
+    auto walk = g_chain_walk ? cheetah_walk<0> : g_walk_blocks == 1 ? cheetah_walk<1> : cheetah_walk<2>;
+    if (e == hipSuccess) e = team ? hipFuncSetAttribute((const void*)cheetah_walk_team<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTeamLds)
+                                  : hipFuncSetAttribute((const void*)walk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWalkLds);
     if (e != hipSuccess) return e;
     // the records of calm stretches are found by the window kernels (their tables live where the descriptors and contexts will: nothing else is in use yet)
     const uint64_t slot_bound = out_stride + out_stride / kRecBytes * kSigBytes + kSigBytes;
@@ -1136,7 +1466,8 @@ hipError_t launch_decode_passes(int algo, const uint8_t* d_in, const uint64_t* d
     const uint64_t pairs = (uint64_t)n_chunks * (blocks_per_chunk / 2);
     hipLaunchKernelGGL(cheetah_prepare, dim3((uint32_t)((pairs + 3) / 4)), dim3(256), 0, stream, a, blocks_per_chunk);
     hipLaunchKernelGGL(cheetah_pass<1>, dim3(4 * n_chunks), dim3(kPassWaves * 64), pass_lds_bytes(1), stream, a);
-    hipLaunchKernelGGL(walk, dim3(n_chunks), dim3(64), kWalkLds, stream, a);
+    if (team) hipLaunchKernelGGL(cheetah_walk_team<2>, dim3(n_chunks), dim3(kTeam * 64), kTeamLds, stream, a);
+    else hipLaunchKernelGGL(walk, dim3(n_chunks), dim3(64), kWalkLds, stream, a);
     hipLaunchKernelGGL(cheetah_pass<2>, dim3(2 * n_chunks), dim3(kPassWaves * 64), pass_lds_bytes(2), stream, a);
     hipLaunchKernelGGL(cheetah_finish, dim3((n_chunks + 255) / 256), dim3(256), 0, stream, a, exact ? 1u : 0u, d_produced);
     return hipGetLastError();
