@@ -1132,6 +1132,9 @@ __global__ __launch_bounds__(64) void cheetah_walk(PassArgs a) {
 #ifndef DENSITY_WALK_TEAM
 #define DENSITY_WALK_TEAM 4
 #endif
+#ifndef DENSITY_WALK_G
+#define DENSITY_WALK_G 2
+#endif
 #ifndef DENSITY_WALK_JIT
 #define DENSITY_WALK_JIT 1
 #endif
@@ -1305,6 +1308,7 @@ __global__ __launch_bounds__(kTeam * 64) void cheetah_walk_team(PassArgs a) {
                 }
                 const uint32_t truth = (uint32_t)__builtin_amdgcn_readlane((int)(b0 == 0 ? r2v[0] : b0 == 1 ? r2v[G > 1 ? 1 : 0] : b0 == 2 ? r2v[G > 2 ? 2 : 0] : r2v[G > 3 ? 3 : 0]), (int)i0);
                 bool all = true;
+                uint64_t nextm[G];
 #pragma unroll
                 for (uint32_t b = 0; b < G; ++b) {
                     rfv[b] = msel(stands[b] & ~fin[b], r2v[b], rfv[b]);
@@ -1313,12 +1317,28 @@ __global__ __launch_bounds__(kTeam * 64) void cheetah_walk_team(PassArgs a) {
                     // the lane behind (b0, i0) now knows its context; everything else behind it is as unknown as before the first round
                     const uint64_t next = b == b0 ? (i0 == 63u ? 0ull : (2ull << i0) & ~upto) : (b == b0 + 1u && i0 == 63u ? 1ull : 0ull);
                     if (next) cvv[b] = msel(next, truth, cvv[b]);
-                    known[b] = stands[b] | next | K0m[b];
+                    nextm[b] = next;
                 }
                 if (all) break;
+                // What has to be guessed again is the CHAIN behind the wrong read — the lane that now knows its context, the run of predicted lanes it starts
+                // and the lane behind that run —, not the block: every other lane's context and speculative read are as good a guess as they were, and the
+                // next verification holds all of them to the ordered pass again.  (A chain that runs on into the next block: everything behind the wrong read, as before.)
+                const uint32_t cb = i0 == 63u ? b0 + 1u : b0, start = i0 == 63u ? 0u : i0 + 1u;
+                uint64_t pcb = Pm[0];
 #pragma unroll
-                for (uint32_t b = 0; b < G; ++b) rdone[b] = fin[b];
-                speculate();                                                          // everything behind the first wrong read again, from H as it is now
+                for (uint32_t b = 1; b < G; ++b) pcb = cb == b ? Pm[b] : pcb;
+                const uint64_t inv = ~(pcb >> start);
+                const uint32_t end = start + (inv ? (uint32_t)__builtin_ctzll(inv) : 64u);   // the lane behind the run (the chain's last)
+                if (end <= 63u) {
+                    const uint64_t A = ((2ull << end) - 1ull) & ~((1ull << start) - 1ull);
+#pragma unroll
+                    for (uint32_t b = 0; b < G; ++b)
+                        if (b == cb) { known[b] = (known[b] & ~A) | nextm[b]; rdone[b] &= ~A; }
+                } else {
+#pragma unroll
+                    for (uint32_t b = 0; b < G; ++b) { known[b] = fin[b] | nextm[b] | K0m[b]; rdone[b] = fin[b]; }
+                }
+                speculate();
                 prepare_exec();
             }
             const uint32_t last = msel(Pm[G - 1], rfv[G - 1], hv[G - 1]);
@@ -1440,7 +1460,7 @@ hipError_t launch_decode_passes(int algo, const uint8_t* d_in, const uint64_t* d
     // the walk: a team of four waves, 128 quads a turn (default); g_walk_blocks 1 / 4: ONE wave, 64 / 128 quads at a time; g_chain_walk: one wave, run by run
     const bool team = !g_chain_walk && g_walk_blocks == 2;
     auto walk = g_chain_walk ? cheetah_walk<0> : g_walk_blocks == 1 ? cheetah_walk<1> : cheetah_walk<2>;
-    if (e == hipSuccess) e = team ? hipFuncSetAttribute((const void*)cheetah_walk_team<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTeamLds)
+    if (e == hipSuccess) e = team ? hipFuncSetAttribute((const void*)cheetah_walk_team<DENSITY_WALK_G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTeamLds)
                                   : hipFuncSetAttribute((const void*)walk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWalkLds);
     if (e != hipSuccess) return e;
     // the records of calm stretches are found by the window kernels (their tables live where the descriptors and contexts will: nothing else is in use yet)
@@ -1466,7 +1486,7 @@ hipError_t launch_decode_passes(int algo, const uint8_t* d_in, const uint64_t* d
     const uint64_t pairs = (uint64_t)n_chunks * (blocks_per_chunk / 2);
     hipLaunchKernelGGL(cheetah_prepare, dim3((uint32_t)((pairs + 3) / 4)), dim3(256), 0, stream, a, blocks_per_chunk);
     hipLaunchKernelGGL(cheetah_pass<1>, dim3(4 * n_chunks), dim3(kPassWaves * 64), pass_lds_bytes(1), stream, a);
-    if (team) hipLaunchKernelGGL(cheetah_walk_team<2>, dim3(n_chunks), dim3(kTeam * 64), kTeamLds, stream, a);
+    if (team) hipLaunchKernelGGL(cheetah_walk_team<DENSITY_WALK_G>, dim3(n_chunks), dim3(kTeam * 64), kTeamLds, stream, a);
     else hipLaunchKernelGGL(walk, dim3(n_chunks), dim3(64), kWalkLds, stream, a);
     hipLaunchKernelGGL(cheetah_pass<2>, dim3(2 * n_chunks), dim3(kPassWaves * 64), pass_lds_bytes(2), stream, a);
     hipLaunchKernelGGL(cheetah_finish, dim3((n_chunks + 255) / 256), dim3(256), 0, stream, a, exact ? 1u : 0u, d_produced);
