@@ -47,7 +47,9 @@ constexpr uint32_t kHalfSlots = 32768;                   // slots per work-group
 constexpr uint32_t kTable = kHalfSlots * 4;              // 128 KiB of dwords
 constexpr uint32_t kAhead = 16;                          // blocks of 64 quads per trip: one statement of 16 exchanges, and what a wave has in flight from memory
 constexpr uint32_t kTrip = kAhead * 256;                 // bytes per trip: the passes cover whole trips
-constexpr uint32_t kStageWaves = 8;                      // waves of a stage work-group, taking the trips in rotation
+// waves of a stage work-group, taking the trips in rotation: 8; Cheetah's three stages 12 (round 6, same-box A/B: 0.735 -> 0.709 ms per 100 MB; Lion's
+// level stages spill registers at three waves per SIMD)
+constexpr uint32_t kStageWaves = 8, kStageWavesCheetah = 12;
 constexpr uint32_t kSpinLimit = 1u << 22, kPoison = 0xfffffffeu, kErrWatchdog = 16u;   // (as rotor.hip)
 // LDS: the half table | a sink word per lane (the quads of the other half / of earlier stages; the token store of lanes 1..63) | the token
 constexpr uint32_t stage_lds_bytes(uint32_t waves) { return kTable + waves * 64 * 4 + 16; }
@@ -414,9 +416,10 @@ hipError_t run_stages(const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes,
     // the head of every chunk in order (a wave per chunk, its tables left in d_tables), then the passes from those tables
     hipError_t e = launch_wave_encode_heads(ALGO, d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, head_state, G::kHeadBytes, G::kHeadCalm, stream);
     if (e != hipSuccess) return e;
-    constexpr uint32_t W = kStageWaves;
-    auto first = ALGO == DENSITY_HIP_CHEETAH ? exchange_stage<true, true, false, false, W> : exchange_stage<true, true, true, false, W>;
-    auto level = exchange_stage<true, false, true, true, W>, last_level = exchange_stage<true, false, false, true, W>;
+    constexpr uint32_t W = ALGO == DENSITY_HIP_CHEETAH ? kStageWavesCheetah : kStageWaves;
+    auto first = exchange_stage<true, true, ALGO != DENSITY_HIP_CHEETAH, false, W>;
+    // (Cheetah has one predictor level: the level kernels are Lion's — and are not even instantiated at Cheetah's wave count)
+    auto level = exchange_stage<true, false, true, true, kStageWaves>, last_level = exchange_stage<true, false, false, true, kStageWaves>;
     auto stage_a = exchange_stage<false, true, true, true, W>, stage_b = exchange_stage<false, false, false, true, W>;
     constexpr uint32_t kStageLds = stage_lds_bytes(W);
     for (const void* k : {(const void*)first, (const void*)level, (const void*)last_level, (const void*)stage_a, (const void*)stage_b}) {
