@@ -11,16 +11,17 @@
 //   dictionary chunk_map[h] = {a, b} is touched by the non-predicted quads only, at slots the STREAM names (the hash of a PLAIN quad, the
 //              item of a MAP quad): nothing in it depends on a predicted quad.  PLAIN: (a, b) <- (q, a); MAP_A reads a; MAP_B reads b and
 //              swaps (cheetah.rs:76-93).  With two cells X, Y per slot and an order bit o (a = o ? Y : X, b = o ? X : Y) this is:
-//              PLAIN writes the cell b sits in and toggles o; MAP_B toggles o; MAP_A changes nothing.  So `order` — an ordered XOR per
-//              slot over the chunk — gives every quad the o it meets, and then X and Y are plain last-writer cells: `cells`, an ordered
-//              exchange pass per cell (mask 0 = read), exactly what the encoder's stages do (exchange_stages.hip).  Every MAP quad is
-//              then known, without a single dependent look-up.
+//              PLAIN writes the cell b sits in and toggles o; MAP_B toggles o; MAP_A changes nothing.  So an ordered XOR per slot gives
+//              every quad the o it meets, and then X and Y are plain last-writer cells: an ordered exchange per cell (mask 0 = read),
+//              exactly what the encoder's stages do (exchange_stages.hip).  `dictionary` (round 6: one kernel, a quarter of the slots per
+//              work-group, the taking-part quads of a trip packed into whole blocks first) does both; every MAP quad is then known,
+//              without a single dependent look-up.
 //   contexts   prediction_map[last_hash] is read by predicted quads and written by the others (:72,81,90,98).  Its SLOT is the hash of the
 //              quad before — for a quad behind a predicted one the hash of a value that has to be looked up first: a chain of dependent
 //              reads through the data being produced.  This is the only sequential part, and it needs hashes, not quads: H[c] = hash of
-//              what follows context c is a table of 64 Ki x 16 bits = 128 KiB of LDS.  `walk`: one wave per chunk runs c' = H[c] for
-//              predicted quads (an LDS round trip each: the chain) and H[c] = h for runs of the others (one ordered 16-bit store per run),
-//              and leaves every quad's context.
+//              what follows context c is a table of 64 Ki x 16 bits = 128 KiB of LDS.  `walk`: per chunk a team of four waves takes 128
+//              quads a turn — speculative reads of H ahead of the turn, ONE ordered pass over H and its verification under a token
+//              (round 6; rounds 3-5: one wave, a dependent LDS round trip per predicted quad) — and leaves every quad's context.
 //   values     With the contexts known the prediction table is one more ordered exchange pass: predicted quads read T[c], the others write
 //              their quad (`values`); the answers are the predicted quads.
 //
@@ -1129,6 +1130,9 @@ __global__ __launch_bounds__(64) void cheetah_walk(PassArgs a) {
 // Groups the 128-at-a-time form does not take (a raw-copy block, the chunk's end, a run of eight predicted quads) are walked block by block under the token
 // by the run-by-run code.  A wave's LDS operations execute in issue order and the token is written behind them: whoever sees it sees H after them (§4.2).
 // ---------------------------------------------------------------------------------------------------------------
+// (geometry, as compile-time switches for same-box A/B builds — tools/build_variant.sh, tools/gpu_walk_ab.py: waves of a team, blocks of 64 quads a turn, how
+// many turns ahead of its own a wave starts its speculative reads.  Measured on config 3, decode ms: 2 x 4 waves, one turn ahead 1.207; 1 x 4 1.205; 2 x 3 1.208;
+// 2 x 2 1.29; 4 x 4 1.39; 2 x 6 1.23; 2 x 4 reading as early as it can — three turns ahead — 1.33)
 #ifndef DENSITY_WALK_TEAM
 #define DENSITY_WALK_TEAM 4
 #endif
@@ -1233,7 +1237,7 @@ __global__ __launch_bounds__(kTeam * 64) void cheetah_walk_team(PassArgs a) {
                 K0m[b] = (Nm[b] << 1) | (b == 0 ? (c_known ? 1ull : 0ull) : (Nm[b ? b - 1 : 0] >> 63));
                 known[b] = K0m[b]; fin[b] = 0; rsv[b] = 0; rfv[b] = 0; rdone[b] = 0;
             }
-            if (DENSITY_WALK_JIT && g >= DENSITY_WALK_JIT) {                              // (experiment: not before the turn is DENSITY_WALK_JIT groups away)
+            if (DENSITY_WALK_JIT && g >= DENSITY_WALK_JIT) {                              // not before my turn is DENSITY_WALK_JIT turns away: what is read earlier is stale more often than not
                 for (uint32_t spins = 0; spins < kSpinLimit; ++spins) {
                     uint32_t seen;
                     asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(seen) : "v"(token) : "memory");

@@ -128,8 +128,8 @@ hipError_t launch_stage_encode(int algo, const uint8_t* d_in, uint64_t total, ui
 // exchange passes over the whole chunk, the chain of contexts alone on one wave per chunk) ----
 extern bool g_force_serial_decode;   // density_hip_set_kernel_variant(128): the one-wave-per-stream decoder instead
 extern bool g_serial_parse;          // density_hip_set_kernel_variant(1024): Cheetah's decode passes find the records by the one-wave walk alone
-extern int g_walk_blocks;            // density_hip_set_kernel_variant(8192 / 16384): the walk speculates 1 / 4 blocks of 64 quads together instead of 2
-extern bool g_chain_walk;            // density_hip_set_kernel_variant(4096): Cheetah's contexts walked run by run (round 5) instead of 64 quads at a time
+extern int g_walk_blocks;            // density_hip_set_kernel_variant(8192 / 16384): the contexts walked by ONE wave, 64 / 128 quads at a time, instead of by a team of four
+extern bool g_chain_walk;            // density_hip_set_kernel_variant(4096): Cheetah's contexts walked run by run on one wave (round 5)
 bool decode_pass_eligible(int algo, const uint8_t* d_out, uint32_t n_chunks, uint64_t out_stride, uint64_t out_total);
 uint64_t decode_pass_scratch_bytes(uint64_t out_stride, uint32_t n_chunks);
 hipError_t launch_decode_passes(int algo, const uint8_t* d_in, const uint64_t* d_offsets, const uint64_t* d_sizes, uint32_t n_chunks, uint8_t* d_out,
