@@ -669,6 +669,15 @@ def main():
         glob = parallel.global_layout(lay, chunk, hdr_l["flags"])
     else:
         gather_ms, glob = 0.0, {"container_len": E, "n_chunks": int(hdr.n_chunks), "total_len": n}
+    # config 5's wire form (round 6): the ranks' TIMED blobs as they stand behind a super-header and a row per rank ("DHCM", include/density_hip.h) — one more
+    # all-gather of two u64 per rank; nothing is re-encoded or moved here
+    algo_id = {"chameleon": 0, "cheetah": 1, "lion": 2}[algo]
+    if use_pg:
+        torch.cuda.synchronize(); tm0 = time.perf_counter()
+        _, mrows, mlen = parallel.exchange_multi_layout(Ec, n, x.device, algo_id, chunk)
+        torch.cuda.synchronize(); multi_gather_ms = (time.perf_counter() - tm0) * 1e3
+    else:
+        (_, mrows, mlen), multi_gather_ms = parallel.multi_layout([Ec], [n], algo_id, chunk), 0.0
     concat_ms, concat_checked = None, None
     if use_pg and args.concat:
         torch.cuda.synchronize(); dist.barrier(); tc0 = time.perf_counter()
@@ -775,7 +784,9 @@ def main():
                                         "value_slotted": (side["slotted"]["value"] if "slotted" in side else None)}},
             "multi_gpu": {"process_group": ("nccl (RCCL)" if use_pg else None), "size_gather_ms": round(gather_ms, 3),
                           "concat_to_rank0_ms": (round(concat_ms, 3) if concat_ms is not None else None), "concat_decodes_to_input": concat_checked,
-                          "global_container_bytes": int(glob["container_len"])},
+                          "global_container_bytes": int(glob["container_len"]),
+                          "multi_container": {"format": "DHCM: the ranks' timed blobs as they stand behind a 32-byte header and a 24-byte row per rank", "bytes": int(mlen),
+                                              "ranks": len(mrows), "gather_ms": round(multi_gather_ms, 3)}},
         }
         if n_gpus == 1 and not args.no_sweep:
             result["size_sweep"] = size_sweep(container, algo, x, [10_000_000, 100_000_000, n])
