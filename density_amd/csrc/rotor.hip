@@ -2116,6 +2116,17 @@ __global__ __launch_bounds__(W * 64) void chameleon_decode_rot(const uint8_t* __
             const uint32_t ent = smem[kDecIdx + i];
             const uint64_t rec_end = ip + ((ent & kIdxCopy) ? kBlock : kSig + kBlock - 2u * (ent & 0x7fu));
             g.penalty = (ent & kIdxCopy) ? 1u : 0u; g.start = 1; g.prev = 0; g.counter = 1;
+            // The record's signature must say what the index says (as the rotating rounds check it): lengths alone do not — a corrupted signature with MORE
+            // MAP flags makes the record 8 or more bytes shorter than the index has it, and the bytes left over pass for a signature with no items behind it
+            // (codec.rs:102-123 on an exhausted buffer), where the reference reads the next record from the wrong place (tools/gpu_fuzz_tail.py, round 6).
+            if (!(ent & kIdxCopy)) {
+                if (rec_end > elen_at || ip + kSig > rec_end) bad = true;
+                else {
+                    const uint64_t sig = (uint64_t)rfl(ld32u(src + ip)) | ((uint64_t)rfl(ld32u(src + ip + 4)) << 32);
+                    if ((uint32_t)__builtin_popcountll(sig) != (ent & 0x7fu)) bad = true;
+                }
+                if (bad) break;
+            }
             bad = !decode_in_order(src, rec_end, dst, cap, g, ip, op, 0u, zmap, lane, seg.lastwriters_only != 0) || ip != rec_end;
         }
         g.penalty = (uint32_t)(end_key >> 32) & 1u; g.start = 1; g.prev = 0; g.counter = 1;    // the stopping block's raw-copy flag is all that is left of the FSM

@@ -320,6 +320,46 @@ def test_corrupt_streams_under_a_true_index(kernel_variant):
         assert accepted >= 20, (kind, accepted)
 
 
+def test_a_signature_with_more_map_flags_in_the_last_partial_round(kernel_variant):
+    """Round 6 (found by tools/gpu_fuzz_tail.py): in the decoder's in-order epilogue — the records of a chunk's last, partial round — record lengths came
+    from the index alone; a corrupted signature with MORE MAP flags makes its record 8 or more bytes shorter, and the bytes left over passed for a signature
+    with no items behind it, so the container was accepted where the reference reads its next record from the wrong place.  The signature's MAP count is now
+    held against the index there too.  Whatever is accepted must decode like the oracle decodes the corrupted chunk stream."""
+    if kernel_variant not in ("rotor", "pipelined"):
+        pytest.skip("the index-fed decoders")
+    for kind in ("prose", "mixed"):
+        for tail in (263, 999, 1500):
+            n, chunk = 3 * 262144 + tail, 262144
+            data = datagen.by_kind(kind, n, seed=21)
+            cont = np.zeros(container.container_bound(ALGO, n, chunk), dtype=np.uint8)
+            cn = container.encode(ALGO, data, cont, chunk)
+            good = cont[:cn].copy()
+            hdr, payloads = container.chunk_payloads(good)
+            off = (32 + 4 * hdr.n_chunks + 15) // 16 * 16
+            off = (off + (hdr.total_len + 255) // 256 + 15) // 16 * 16
+            offs = []
+            for p in payloads:
+                offs.append(off)
+                off = (off + len(p) + 15) // 16 * 16
+            last = len(payloads) - 1
+            out = np.zeros(n, dtype=np.uint8)
+            sig = int.from_bytes(good[offs[last]:offs[last] + 8].tobytes(), "little")
+            clear = [b for b in range(64) if not (sig >> b) & 1]
+            assert len(clear) >= 8, (kind, tail)
+            for extra in (4, 5, 8):                                                     # 4 more MAP flags: the record is 8 bytes shorter — exactly a signature's worth left over
+                bad = good.copy()
+                sig2 = sig
+                for b in clear[:extra]:
+                    sig2 |= 1 << b
+                bad[offs[last]:offs[last] + 8] = np.frombuffer(sig2.to_bytes(8, "little"), dtype=np.uint8)
+                want = pyoracle.decode(ALGO, bytes(bad[offs[last]:offs[last] + len(payloads[last])]), tail)
+                try:
+                    m = container.decode(bad, out)
+                except DecodeError:
+                    continue                                                            # (the reference panics or returns other bytes: refusing is right)
+                assert out[:m].tobytes() == data[:3 * chunk].tobytes() + want, (kind, tail, extra)
+
+
 def test_pipelined_host_calls_make_the_same_container(kernel_variant):
     """density_hip_encode / _decode through host pointers: inputs of 8 MiB and more go up, through the kernels and down in slices on separate
     streams (api.hip: *_container_pipelined).  The container must be byte for byte what the staged path (kernel variant 512) writes — header,
