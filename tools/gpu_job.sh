@@ -13,5 +13,5 @@ echo "elapsed $(( $(date +%s) - $(cat $T/t0) )) s"
 timeout 900 python bench.py --steps 20 --warmup 5 > $T/bench_full.json 2> $T/bench_full.err; echo "bench rc=$?"; head -c 300 $T/bench_full.json; echo
 timeout 400 python benches/density.py > $T/benches_density.txt 2>&1; echo "harness rc=$?"; tail -24 $T/benches_density.txt
 timeout 200 python tools/gpu_forms.py 10 2>&1 | grep -v amdgpu.ids > $T/forms.txt; tail -6 $T/forms.txt
-for f in encode streams passes; do timeout 200 python tools/gpu_fuzz_$f.py > $T/fuzz_$f.log 2>&1; echo "fuzz $f rc=$?"; tail -2 $T/fuzz_$f.log; done
+for f in encode streams passes tail paged; do timeout 200 python tools/gpu_fuzz_$f.py > $T/fuzz_$f.log 2>&1; echo "fuzz $f rc=$?"; tail -2 $T/fuzz_$f.log; done
 echo "elapsed $(( $(date +%s) - $(cat $T/t0) )) s"
