@@ -79,7 +79,7 @@ if os.path.exists(f"{src}/vmem_width.txt"):
 for extra in ("packed", "slotted", "cheetah", "lion"):
     m = glob.glob(f"{src}/stats_{extra}/**/*_kernel_stats.csv", recursive=True)
     if m:
-        shutil.copy(m[0], f"profiles/{tag}_{extra}_kernel_stats.csv")
+        shutil.copy(max(m, key=os.path.getmtime), f"profiles/{tag}_{extra}_kernel_stats.csv")   # (the newest: gpurun merges a call into what earlier calls left)
 shutil.copy(f"{src}/bench.json", f"profiles/{tag}_bench.json")
 for row in csv.DictReader(open(stats)):
     if "density::" in row["Name"]:
