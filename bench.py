@@ -55,6 +55,7 @@ def cpu_all_cores(src, chunk, algo, gpu_payloads=None):
         assert enc() == 0 and dcd() == 0                                                      # warm (pages of the buffers, the thread team)
         te, td = [], []
         for _ in range(7):
+            time.sleep(0.3)                                                                   # (a pause between the bursts: the GPU box's host throttles all-core bursts that follow one another — round 6 saw a median of 1.1 GB/s beside a fastest of 29)
             t0 = time.perf_counter(); enc(); t1 = time.perf_counter(); dcd(); t2 = time.perf_counter()
             te.append(t1 - t0); td.append(t2 - t1)
         assert np.array_equal(dec, src)
@@ -65,7 +66,7 @@ def cpu_all_cores(src, chunk, algo, gpu_payloads=None):
         e, d = sorted(te)[3], sorted(td)[3]
         out = {"value": round(n / rt[3] / 1e6, 1), "unit": "MB/s", "cores": ncpu, "threads": threads, "encode_MBps": round(n / e / 1e6, 1), "decode_MBps": round(n / d / 1e6, 1),
                "fastest": round(n / rt[0] / 1e6, 1), "slowest": round(n / rt[-1] / 1e6, 1), "samples": 7,
-               "ratio_chunked": round(n / int(sizes.sum()), 4), "chunk": chunk, "n_chunks": nchunks, "timing": "median of 7 round trips (fastest / slowest beside it), threads pinned to cores",
+               "ratio_chunked": round(n / int(sizes.sum()), 4), "chunk": chunk, "n_chunks": nchunks, "timing": "median of 7 round trips 0.3 s apart (fastest / slowest beside it), threads pinned to cores",
                "sample": f"{n} B in {nchunks} chunks of {chunk} B, one chunk per task on {threads} OpenMP threads ({ncpu} host cores), C restatement (oracle/density_oracle.c)"}
         if gpu_payloads is not None:
             m = min(nchunks, len(gpu_payloads))
