@@ -496,7 +496,7 @@ size_t density_hip_auto_chunk(size_t input_size) { return auto_chunk(input_size)
 size_t density_hip_auto_chunk_for(int algo, size_t input_size) { return valid_algo(algo) ? auto_chunk(input_size, algo) : 0; }
 
 void density_hip_set_profiling(int enabled) { g_profiling = enabled; }
-void density_hip_set_kernel_variant(int variant) { g_variant = variant;   /* bit 3 (8): encode in batches with the stitch of one batch beside the encoding of the next */ density::g_force_simple = (variant & 1) != 0; density::g_force_pipeline = (variant & 4) != 0; density::g_force_lane_codec = (variant & 16) != 0; density::g_force_wave_codec = (variant & 32) != 0; density::g_stage_audit = (variant & 64) != 0; density::g_force_serial_decode = (variant & 128) != 0; density::g_serial_parse = (variant & 1024) != 0; density::g_chain_walk = (variant & 4096) != 0; density::g_walk_blocks = (variant & 8192) ? 1 : (variant & 16384) ? 4 : 2; density::g_rotor_split = density::kRotorSplitDefault != ((variant & 2048) != 0); }
+void density_hip_set_kernel_variant(int variant) { g_variant = variant;   /* bit 3 (8): encode in batches with the stitch of one batch beside the encoding of the next */ density::g_force_simple = (variant & 1) != 0; density::g_force_pipeline = (variant & 4) != 0; density::g_force_lane_codec = (variant & 16) != 0; density::g_force_wave_codec = (variant & 32) != 0; density::g_stage_audit = (variant & 64) != 0; density::g_force_serial_decode = (variant & 128) != 0; density::g_serial_parse = (variant & 1024) != 0; density::g_chain_walk = (variant & 4096) != 0; density::g_lion_one_wave = (variant & 32768) != 0; density::g_walk_blocks = (variant & 8192) ? 1 : (variant & 16384) ? 4 : 2; density::g_rotor_split = density::kRotorSplitDefault != ((variant & 2048) != 0); }
 
 int density_hip_last_timings(float* milliseconds, const char** names, int capacity) {
     int dev = -1;

@@ -97,6 +97,7 @@ extern bool g_exchange_unsafe, g_rotor_unsafe;   // start-up self-test verdicts 
 
 // ---- serial_codec.hip (Cheetah: one wave per chunk stream; Lion, and Cheetah as a cross-check: one lane per stream; tables in global memory) ----
 extern bool g_force_lane_codec;   // density_hip_set_kernel_variant(16)
+extern bool g_lion_one_wave;      // density_hip_set_kernel_variant(32768): Lion's decode on one wave per stream instead of two
 uint64_t serial_table_bytes(int algo);
 hipError_t launch_serial_encode(int algo, const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_out,
                                 uint64_t out_stride, uint64_t* d_sizes, uint8_t* d_tables, uint32_t n_slots, hipStream_t stream);

@@ -15,6 +15,7 @@
 namespace density {
 
 bool g_force_lane_codec = false;   // density_hip_set_kernel_variant(16): Cheetah on the one-lane-per-stream kernels (cross-check)
+bool g_lion_one_wave = false;      // density_hip_set_kernel_variant(32768): Lion's decode on ONE wave per stream (round 4's) instead of two
 
 namespace {
 
@@ -1246,6 +1247,301 @@ __global__ __launch_bounds__(64) void lion_decode_wave(const uint8_t* __restrict
     }
 }
 
+__global__ __launch_bounds__(128) void lion_decode_pair(const uint8_t* __restrict__ in, const uint64_t* __restrict__ offsets,
+                                                        const uint64_t* __restrict__ sizes, uint32_t n_chunks,
+                                                        uint8_t* __restrict__ out, uint64_t out_stride, uint64_t out_total,
+                                                        uint32_t exact, uint64_t* __restrict__ produced, uint32_t* __restrict__ err,
+                                                        uint8_t* __restrict__ tables, uint32_t n_slots) {
+    using G = Geo<DENSITY_HIP_LION>;
+    const uint32_t slot = blockIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = rfl(threadIdx.x >> 6);
+    if (slot >= n_slots) return;
+    // what travels between the two waves (LDS): [0] the step whose PARSE may start, behind it [2..9] its {ipos, opos, guard}; [1] the step whose TABLE
+    // phase may start, behind it [10] the running hash; kExit in [0]: the stream's in-order end has been taken over, the other wave leaves
+    __shared__ uint32_t sy[16];
+    constexpr uint32_t kExit = 0xffffffffu;
+    const uint32_t sya = lds_addr(sy);
+    auto peek = [&](uint32_t word) -> uint32_t {
+        uint32_t v;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(sya + 4u * word) : "memory");
+        return rfl(v);
+    };
+    auto poke = [&](uint32_t word, uint32_t v) { asm volatile("ds_write_b32 %0, %1" ::"v"(sya + 4u * word), "v"(v) : "memory"); };
+    // waits until word `w` holds `want` (or kExit in word 0); false: leave (the other wave finished the stream, or the watchdog fired)
+    auto await = [&](uint32_t w, uint32_t want) -> bool {
+        for (uint32_t spins = 0;; ++spins) {
+            const uint32_t v = peek(w);
+            if (v == want) return true;
+            if (peek(0) == kExit) return false;
+            if (spins > (1u << 24)) { if (lane == 0) atomicOr(err, 16u); poke(0, kExit); return false; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    };
+    constexpr uint64_t kTableBytes = 65536ull * (sizeof(Pair) + 4ull * G::kPredWords);
+    constexpr uint32_t kMaxRecord = 8 + G::kBlock;                            // 6 + 16 x 4, and the signature is fetched as 8 bytes
+    Tables<DENSITY_HIP_LION> t;
+    t.dict = reinterpret_cast<Pair*>(tables + slot * kTableBytes);
+    t.pred = reinterpret_cast<uint32_t*>(tables + slot * kTableBytes + 65536ull * sizeof(Pair));
+    const uint32_t myrec = lane >> 4, k16 = lane & 15u;
+    const uint64_t below = (1ull << lane) - 1ull;
+    for (uint64_t chunk = slot; chunk < n_chunks; chunk += n_slots) {
+        const uint8_t* src = in + offsets[chunk];
+        const uint64_t elen = sizes[chunk];
+        uint8_t* dst = out + chunk * out_stride;
+        const uint64_t room_all = out_total - chunk * out_stride;
+        const uint64_t cap = room_all < out_stride ? room_all : out_stride;
+        if (chunk != slot) {
+            uint4* p = reinterpret_cast<uint4*>(tables + slot * kTableBytes);
+            const uint4 z = make_uint4(0, 0, 0, 0);
+            for (uint64_t i = threadIdx.x; i < kTableBytes / 16; i += 128) p[i] = z;
+            __threadfence();
+        }
+        __syncthreads();                                                          // (both waves are through with the chunk before; the tables are clear)
+        if (threadIdx.x < 16) sy[threadIdx.x] = threadIdx.x == 7 ? 1u : 0u;        // step 0 may parse and touch the tables; {ipos, opos} = 0, guard = {0, 1, 0, 0}, hash 0
+        __syncthreads();
+        uint32_t last_hash = 0;
+        Guard guard;
+        uint64_t ipos = 0, opos = 0;
+        bool bad = false, done = false, mine_to_finish = false;
+        uint32_t ahead = 0;                                                       // (a touch-ahead load's value: never looked at)
+        auto publish_parse = [&](uint32_t step, uint64_t ip, uint64_t op, const Guard& gg) {
+            poke(2, (uint32_t)ip); poke(3, (uint32_t)(ip >> 32)); poke(4, (uint32_t)op); poke(5, (uint32_t)(op >> 32));
+            poke(6, gg.penalty); poke(7, gg.start); poke(8, gg.prev); poke(9, gg.counter);
+            poke(0, step);                                                        // (behind its payload: a wave's LDS operations execute as issued)
+        };
+        for (uint32_t s = wave;; s += 2u) {
+            // ---- my PARSE turn: the state in front of step s ----
+            if (!await(0, s)) break;
+            ipos = (uint64_t)peek(2) | ((uint64_t)peek(3) << 32); opos = (uint64_t)peek(4) | ((uint64_t)peek(5) << 32);
+            guard.penalty = peek(6); guard.start = peek(7); guard.prev = peek(8); guard.counter = peek(9);
+            if (!(elen - ipos >= kMaxRecord && cap - opos >= G::kBlock)) {        // the hot loop ends here: the rest is mine, once the tables are mine
+                if (await(1, s)) { last_hash = peek(10); mine_to_finish = true; }
+                poke(0, kExit);
+                break;
+            }
+            if (guard.block_is_copy()) {                                      // codec.rs:89-91
+                Guard gn = guard;
+                gn.decay();
+                publish_parse(s + 1u, ipos + G::kBlock, opos + G::kBlock, gn);
+                if (lane < 16) st32u(dst + opos + 4u * lane, ld32u(src + ipos + 4u * lane));
+                if (!await(1, s)) break;                                      // (a raw block touches no table: the turn is passed on as it came)
+                poke(1, s + 1u);
+                continue;
+            }
+            // the step's records: the first, and up to three more while each is whole, has room and the FSM lets it be coded (codec.rs:88-99)
+            uint64_t sg0 = lion_sig_at(src + ipos), sg1 = 0, sg2 = 0, sg3 = 0;
+            uint32_t at1 = 0, at2 = 0, at3 = 0;                                    // where records 1..3 start, from ipos
+            uint32_t nrec = 1;
+            Guard g = guard;
+            uint32_t len = G::kSig + lion_item_bytes(sg0);                        // stream bytes of the step so far
+            g.update(len >= G::kBlock);                                           // codec.rs:98
+            {
+                Guard gc = g;
+                if (elen - ipos - len >= kMaxRecord && cap - opos >= 2u * G::kBlock && !gc.block_is_copy()) {
+                    g = gc; at1 = len; sg1 = lion_sig_at(src + ipos + len);
+                    const uint32_t rl = G::kSig + lion_item_bytes(sg1);
+                    g.update(rl >= G::kBlock); len += rl; nrec = 2;
+                }
+            }
+            if (nrec == 2) {
+                Guard gc = g;
+                if (elen - ipos - len >= kMaxRecord && cap - opos >= 3u * G::kBlock && !gc.block_is_copy()) {
+                    g = gc; at2 = len; sg2 = lion_sig_at(src + ipos + len);
+                    const uint32_t rl = G::kSig + lion_item_bytes(sg2);
+                    g.update(rl >= G::kBlock); len += rl; nrec = 3;
+                }
+            }
+            if (nrec == 3) {
+                Guard gc = g;
+                if (elen - ipos - len >= kMaxRecord && cap - opos >= 4u * G::kBlock && !gc.block_is_copy()) {
+                    g = gc; at3 = len; sg3 = lion_sig_at(src + ipos + len);
+                    const uint32_t rl = G::kSig + lion_item_bytes(sg3);
+                    g.update(rl >= G::kBlock); len += rl; nrec = 4;
+                }
+            }
+            publish_parse(s + 1u, ipos + len, opos + (uint64_t)nrec * G::kBlock, g);   // the other wave may parse the next step from here on
+            const uint32_t nact = 16u * nrec;
+            const bool act = lane < nact;
+            const uint64_t sig = myrec == 0 ? sg0 : myrec == 1 ? sg1 : myrec == 2 ? sg2 : sg3;
+            const uint32_t at = myrec == 0 ? 0u : myrec == 1 ? at1 : myrec == 2 ? at2 : at3;
+            const uint32_t flag = act ? (uint32_t)(sig >> (3u * k16)) & 7u : 1u;
+            const uint32_t ilen = !act ? 0u : (flag == 0 ? 4u : (flag >= 6 ? 2u : 0u));
+            uint32_t incl = ilen;                                                 // where my item lies behind my record's signature: a sum over the lanes of my row of 16
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xf, 0xf, true);   // row_shr:1
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xf, 0xf, true);   // row_shr:2
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xf, 0xf, true);   // row_shr:4
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xf, 0xf, true);   // row_shr:8
+            const uint8_t* ibase = src + ipos + at + G::kSig + (incl - ilen);
+            uint32_t q = 0, h = 0;
+            if (ilen == 4) { q = ld32u(ibase); h = hash16(q); } else if (ilen == 2) h = ld16u(ibase);
+            const bool dtouch = act && (flag == 0 || flag >= 6);              // touches the dictionary (lion.rs:85-186)
+            const bool predicted = act && flag >= 1 && flag <= 5;
+            // ---- AHEAD of my table turn: the lines this step will read, asked for while the other wave holds the tables — its dictionary pairs, and the
+            // prediction rows and entries of the lanes whose context is in the stream (the quad in front was not predicted); what comes back is not looked at
+            // (the other wave may still be writing those rows): the reads below find the lines in this CU's cache instead of in memory ----
+            {
+                const uint32_t hpa = bperm(lane ? lane - 1u : 0u, h);
+                const uint32_t ppa = bperm(lane ? lane - 1u : 0u, predicted ? 1u : 0u);
+                const bool ctx_known = act && lane != 0 && ppa == 0;
+                const Pair w0 = dtouch ? tbl_load_pair(t.dict + h) : Pair{0u, 0u};
+                const Row5 rw = ctx_known ? row_load(t.pred + 5u * hpa) : Row5{{0u, 0u, 0u, 0u, 0u}};
+                {
+                    const uint64_t far = ipos + 512u + 128u * (lane & 3u);
+                    const uint8_t* pa = src + (far + 4 <= elen ? far : ipos);
+                    ahead = lane < 4 ? ld32u(pa) : 0u;                         // (the stream, half a KiB on: as in the one-wave kernel)
+                }
+                asm volatile("s_waitcnt vmcnt(0)" : : "v"(w0.a), "v"(w0.b), "v"(rw.n[0]), "v"(rw.n[1]), "v"(rw.n[2]), "v"(rw.n[3]), "v"(rw.n[4]), "v"(ahead) : "memory");
+            }
+            const uint64_t deq = same_key_mask64(h, dtouch);                      // (who follows whom in the dictionary is in the stream: matched ahead of the turn)
+            // ---- my TABLE turn ----
+            if (!await(1, s)) break;
+            last_hash = peek(10);
+            const Pair e0 = dtouch ? tbl_load_pair(t.dict + h) : Pair{0u, 0u};
+            // ---- runs of predicted quads: one dependent read per round; speculation: nobody earlier in this step rewrote that row ----
+            bool known = !predicted;
+            for (uint32_t round = 0; round < 64; ++round) {
+                const uint32_t hp = bperm(lane ? lane - 1u : 0u, h);
+                const uint32_t kpv = bperm(lane ? lane - 1u : 0u, known ? 1u : 0u);
+                const bool kp = lane == 0 || kpv != 0;
+                if (!known && kp) {
+                    q = tbl_load32(t.pred + 5u * (lane == 0 ? last_hash : hp) + (flag - 1u));
+                    h = hash16(q);
+                    known = true;
+                }
+                if (ballot64(!known) == 0) break;
+            }
+            const uint32_t hprev = bperm(lane ? lane - 1u : 0u, h);
+            const uint32_t ps = lane == 0 ? last_hash : hprev;
+            Row5 row = act ? row_load(t.pred + 5u * ps) : Row5{{0u, 0u, 0u, 0u, 0u}};
+            const Row5 row_mem = row;                                             // as memory holds it (the repair below starts over from it)
+            // ---- dictionary, in dependency order among the lanes that touch it ----
+            const uint64_t peq = same_key_mask64(ps, act);
+            const uint64_t dbefore = deq & below;
+            const uint32_t dprev = dbefore ? 63u - (uint32_t)__builtin_clzll(dbefore) : 64u;
+            const bool dlast = dtouch && ((deq >> lane) >> 1) == 0;
+            uint32_t da = e0.a, db = e0.b, ddirty = 0;
+            bool ddone = !dtouch;
+            for (uint32_t round = 0; round < 64; ++round) {
+                const uint64_t done_mask = ballot64(ddone && dtouch);
+                const bool ready = !ddone && (dprev == 64u || ((done_mask >> (dprev & 63u)) & 1ull));
+                const uint32_t fda = bperm(dprev & 63u, da), fdb = bperm(dprev & 63u, db), fdd = bperm(dprev & 63u, ddirty);
+                if (ready) {
+                    if (dprev != 64u) { da = fda; db = fdb; ddirty = fdd; }
+                    if (flag == 0) { db = da; da = q; ddirty = 1; }
+                    else if (flag == 6) q = da;
+                    else { q = db; db = da; da = q; ddirty = 1; }
+                    ddone = true;
+                }
+                if (ballot64(!ddone) == 0) break;
+            }
+            // ---- predictor rows, in dependency order (every quad rewrites its row unless it hit the front entry) ----
+            const uint64_t pbefore = peq & below;
+            const uint32_t pprev = pbefore ? 63u - (uint32_t)__builtin_clzll(pbefore) : 64u;
+            const bool plast = act && ((peq >> lane) >> 1) == 0;
+            uint32_t pdirty = 0;
+            bool pdone = !act, wrong = false;
+            for (uint32_t round = 0; round < 64; ++round) {
+                const uint64_t done_mask = ballot64(pdone && act);
+                const bool ready = !pdone && (pprev == 64u || ((done_mask >> (pprev & 63u)) & 1ull));
+                const Row5 frow = row_from_lane(pprev & 63u, row);
+                const uint32_t fpd = bperm(pprev & 63u, pdirty);
+                if (ready) {
+                    if (pprev != 64u) { row = frow; pdirty = fpd; }
+                    if (predicted) {
+                        uint32_t cur = row.n[0];
+#pragma unroll
+                        for (uint32_t k = 1; k < 5; ++k) cur = flag == k + 1u ? row.n[k] : cur;
+                        wrong = cur != q;                                     // the row as it really stands does not hold what the speculation read
+                        if (flag > 1) { row_promote(row, flag - 1u, q); pdirty = 1; }
+                    } else {
+                        row_promote(row, 4, q); pdirty = 1;                   // lion.rs:50-57
+                    }
+                    pdone = true;
+                }
+                if (ballot64(!pdone) == 0) break;
+            }
+            uint32_t psf = ps;                                                    // the predictor slot my row is stored to
+            bool plastf = plast;
+            if (ballot64(wrong) != 0) {
+                // A speculation failed: a predicted quad read an entry that an earlier quad of this step has since moved.  Its real value — the entry of the
+                // row as forwarded — has another hash, so the quad behind it sits in another context than assumed, and so on.  Up to round 3 the whole record
+                // was decoded again by the scalar code on lane 0 (two dependent memory reads per quad: a fifth of the kernel's time on prose).  Now: ONE
+                // exact walk over the step's quads in stream order, in registers — every value wave-uniform — with rows forwarded between quads of one
+                // context, taken from the speculative gather where it was made at the right context, and read from memory only where the context turned
+                // out to be another one (lion.rs:85-186).
+                uint32_t ctx = last_hash;
+                uint32_t cxv = 0xffffffffu, dirtyv = 0;                           // per lane, once walked: my true context; my row differs from memory
+                Row5 rf = row_mem;
+#pragma nounroll
+                for (uint32_t i = 0; i < nact; ++i) {
+                    const uint64_t m = ballot64(lane < i && cxv == ctx);
+                    Row5 r;
+                    uint32_t dirty = 0;
+                    if (m) {                                                      // the latest earlier quad of this context hands its row on
+                        const uint32_t j = 63u - (uint32_t)__builtin_clzll(m);
+#pragma unroll
+                        for (int k = 0; k < 5; ++k) r.n[k] = rlane32(rf.n[k], j);
+                        dirty = rlane32(dirtyv, j);
+                    } else if (rlane32(ps, i) == ctx) {                           // nobody before it in this step: memory's row, gathered at the right place
+#pragma unroll
+                        for (int k = 0; k < 5; ++k) r.n[k] = rlane32(row_mem.n[k], i);
+                    } else {
+                        r = row_load(t.pred + 5u * ctx);
+                    }
+                    const uint32_t f = rlane32(flag, i);
+                    uint32_t qi, hi;
+                    if (f >= 1u && f <= 5u) {
+                        qi = r.n[0];
+#pragma unroll
+                        for (uint32_t k = 1; k < 5; ++k) qi = f == k + 1u ? r.n[k] : qi;
+                        hi = hash16(qi);
+                        if (f > 1u) { row_promote(r, f - 1u, qi); dirty = 1; }
+                    } else {
+                        qi = rlane32(q, i); hi = rlane32(h, i);                   // what the dictionary gave: no context in it
+                        row_promote(r, 4, qi); dirty = 1;
+                    }
+                    if (lane == i) { q = qi; h = hi; rf = r; cxv = ctx; dirtyv = dirty; }
+                    ctx = hi;
+                }
+                row = rf; pdirty = dirtyv; psf = cxv;
+                const uint64_t peq2 = same_key_mask64(cxv, act);
+                plastf = act && ((peq2 >> lane) >> 1) == 0;
+            }
+            if (plastf && pdirty) row_store(t.pred + 5u * psf, row);
+            if (dlast && ddirty) tbl_store_pair(t.dict + h, Pair{da, db});
+            last_hash = rlane32(h, nact - 1u);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // this step's table stores are through: the other wave's turn
+            poke(10, last_hash);
+            poke(1, s + 1u);
+            if (act) st32u(dst + opos + 4u * lane, q);                         // (the quads themselves: nobody waits for them)
+        }
+        asm volatile("s_waitcnt vmcnt(0)" : : "v"(ahead) : "memory");
+        __threadfence();
+        if (mine_to_finish && lane == 0) {                                    // the rest: scalar code, codec.rs:102-123
+            t.last_hash = last_hash;
+            while (ipos < elen && !bad && !done) {
+                const uint64_t rem = elen - ipos;
+                if (guard.block_is_copy()) {
+                    const uint32_t take = rem > G::kBlock ? G::kBlock : (uint32_t)rem;
+                    if (opos + take > cap) { bad = true; break; }
+                    for (uint32_t i = 0; i < take; ++i) dst[opos + i] = src[ipos + i];
+                    ipos += take; opos += take;
+                    if (rem <= G::kBlock) break;
+                    guard.decay();
+                    continue;
+                }
+                bad = lion_record_scalar(t, src, elen, ipos, dst, cap, opos, done, guard);
+            }
+            if (exact && !bad && opos != cap) bad = true;
+            produced[chunk] = opos;
+            if (bad) atomicOr(err, 1u);
+        }
+        __threadfence();
+    }
+}
+
+
 }  // namespace
 
 uint64_t serial_table_bytes(int algo) { return 65536ull * (sizeof(Pair) + 4ull * (algo == DENSITY_HIP_LION ? 5 : 1)); }
@@ -1305,6 +1601,8 @@ hipError_t launch_serial_decode(int algo, const uint8_t* d_in, const uint64_t* d
         hipLaunchKernelGGL(cheetah_decode_wave, dim3(n_slots), dim3(64), 0, stream, d_in, d_offsets, d_sizes, n_chunks, d_out, out_stride, out_total, exact ? 1u : 0u, d_produced, d_err, d_tables, n_slots);
     else if (algo == DENSITY_HIP_CHEETAH)
         hipLaunchKernelGGL(serial_decode_chunks<DENSITY_HIP_CHEETAH>, dim3(blocks), dim3(64), 0, stream, d_in, d_offsets, d_sizes, n_chunks, d_out, out_stride, out_total, exact ? 1u : 0u, d_produced, d_err, d_tables, n_slots);
+    else if (!g_force_lane_codec && !g_lion_one_wave)
+        hipLaunchKernelGGL(lion_decode_pair, dim3(n_slots), dim3(128), 0, stream, d_in, d_offsets, d_sizes, n_chunks, d_out, out_stride, out_total, exact ? 1u : 0u, d_produced, d_err, d_tables, n_slots);
     else if (!g_force_lane_codec)
         hipLaunchKernelGGL(lion_decode_wave, dim3(n_slots), dim3(64), 0, stream, d_in, d_offsets, d_sizes, n_chunks, d_out, out_stride, out_total, exact ? 1u : 0u, d_produced, d_err, d_tables, n_slots);
     else
