@@ -20,6 +20,7 @@ bool g_lion_one_wave = false;      // density_hip_set_kernel_variant(32768): Lio
 namespace {
 
 struct Pair { uint32_t a, b; };
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 template <int ALGO> struct Geo;
 template <> struct Geo<DENSITY_HIP_CHEETAH> {                 // cheetah.rs:17-23,188-196
@@ -1257,9 +1258,9 @@ __global__ __launch_bounds__(128) void lion_decode_pair(const uint8_t* __restric
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = rfl(threadIdx.x >> 6);
     if (slot >= n_slots) return;
-    // what travels between the two waves (LDS): [0] the step whose PARSE may start, behind it [2..9] its {ipos, opos, guard}; [1] the step whose TABLE
-    // phase may start, behind it [10] the running hash; kExit in [0]: the stream's in-order end has been taken over, the other wave leaves
-    __shared__ uint32_t sy[16];
+    // what travels between the two waves (LDS): [0] the step whose PARSE may start, behind it [4..11] its {ipos, opos, guard} (two 16-byte words); [1] the step
+    // whose TABLE phase may start, behind it [2] the running hash; kExit in [0]: the stream's in-order end has been taken over, the other wave leaves
+    __shared__ __attribute__((aligned(16))) uint32_t sy[16];   // [0] parse turn [1] table turn [2] running hash | [4,5] ipos [6,7] opos | [8..11] guard
     constexpr uint32_t kExit = 0xffffffffu;
     const uint32_t sya = lds_addr(sy);
     auto peek = [&](uint32_t word) -> uint32_t {
@@ -1298,7 +1299,7 @@ __global__ __launch_bounds__(128) void lion_decode_pair(const uint8_t* __restric
             __threadfence();
         }
         __syncthreads();                                                          // (both waves are through with the chunk before; the tables are clear)
-        if (threadIdx.x < 16) sy[threadIdx.x] = threadIdx.x == 7 ? 1u : 0u;        // step 0 may parse and touch the tables; {ipos, opos} = 0, guard = {0, 1, 0, 0}, hash 0
+        if (threadIdx.x < 16) sy[threadIdx.x] = threadIdx.x == 9 ? 1u : 0u;        // step 0 may parse and touch the tables; {ipos, opos} = 0, guard = {0, 1, 0, 0}, hash 0
         __syncthreads();
         uint32_t last_hash = 0;
         Guard guard;
@@ -1306,17 +1307,20 @@ __global__ __launch_bounds__(128) void lion_decode_pair(const uint8_t* __restric
         bool bad = false, done = false, mine_to_finish = false;
         uint32_t ahead = 0;                                                       // (a touch-ahead load's value: never looked at)
         auto publish_parse = [&](uint32_t step, uint64_t ip, uint64_t op, const Guard& gg) {
-            poke(2, (uint32_t)ip); poke(3, (uint32_t)(ip >> 32)); poke(4, (uint32_t)op); poke(5, (uint32_t)(op >> 32));
-            poke(6, gg.penalty); poke(7, gg.start); poke(8, gg.prev); poke(9, gg.counter);
-            poke(0, step);                                                        // (behind its payload: a wave's LDS operations execute as issued)
+            const u32x4 pa = {(uint32_t)ip, (uint32_t)(ip >> 32), (uint32_t)op, (uint32_t)(op >> 32)}, gu = {gg.penalty, gg.start, gg.prev, gg.counter};
+            asm volatile("ds_write_b128 %0, %1 offset:16\n\tds_write_b128 %0, %2 offset:32\n\tds_write_b32 %0, %3" ::"v"(sya), "v"(pa), "v"(gu), "v"(step) : "memory");   // (the turn behind its payload: a wave's LDS operations execute as issued)
         };
         for (uint32_t s = wave;; s += 2u) {
             // ---- my PARSE turn: the state in front of step s ----
             if (!await(0, s)) break;
-            ipos = (uint64_t)peek(2) | ((uint64_t)peek(3) << 32); opos = (uint64_t)peek(4) | ((uint64_t)peek(5) << 32);
-            guard.penalty = peek(6); guard.start = peek(7); guard.prev = peek(8); guard.counter = peek(9);
+            {
+                u32x4 pa, gu;
+                asm volatile("ds_read_b128 %0, %2 offset:16\n\tds_read_b128 %1, %2 offset:32\n\ts_waitcnt lgkmcnt(0)" : "=v"(pa), "=v"(gu) : "v"(sya) : "memory");
+                ipos = (uint64_t)rfl(pa.x) | ((uint64_t)rfl(pa.y) << 32); opos = (uint64_t)rfl(pa.z) | ((uint64_t)rfl(pa.w) << 32);
+                guard.penalty = rfl(gu.x); guard.start = rfl(gu.y); guard.prev = rfl(gu.z); guard.counter = rfl(gu.w);
+            }
             if (!(elen - ipos >= kMaxRecord && cap - opos >= G::kBlock)) {        // the hot loop ends here: the rest is mine, once the tables are mine
-                if (await(1, s)) { last_hash = peek(10); mine_to_finish = true; }
+                if (await(1, s)) { last_hash = peek(2); mine_to_finish = true; }
                 poke(0, kExit);
                 break;
             }
@@ -1396,7 +1400,7 @@ __global__ __launch_bounds__(128) void lion_decode_pair(const uint8_t* __restric
             const uint64_t deq = same_key_mask64(h, dtouch);                      // (who follows whom in the dictionary is in the stream: matched ahead of the turn)
             // ---- my TABLE turn ----
             if (!await(1, s)) break;
-            last_hash = peek(10);
+            last_hash = peek(2);
             const Pair e0 = dtouch ? tbl_load_pair(t.dict + h) : Pair{0u, 0u};
             // ---- runs of predicted quads: one dependent read per round; speculation: nobody earlier in this step rewrote that row ----
             bool known = !predicted;
@@ -1512,7 +1516,7 @@ __global__ __launch_bounds__(128) void lion_decode_pair(const uint8_t* __restric
             if (dlast && ddirty) tbl_store_pair(t.dict + h, Pair{da, db});
             last_hash = rlane32(h, nact - 1u);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // this step's table stores are through: the other wave's turn
-            poke(10, last_hash);
+            poke(2, last_hash);
             poke(1, s + 1u);
             if (act) st32u(dst + opos + 4u * lane, q);                         // (the quads themselves: nobody waits for them)
         }

@@ -40,7 +40,7 @@ extern "C" {
  *    lion_decode and short streams on one wave or one work-group.  The data-parallel path proper is the container API
  *    of section 2.
  *    SLOWER THAN THE CRATE on one CPU core (10 MB of prose, buffers on the device, profiles/r06_benches_density.txt): cheetah_decode
- *    ~0.32 GB/s against 1.4 (its chain of contexts is one team of four waves on one CU), lion_decode ~0.03 GB/s against 0.84 (one wave,
+ *    ~0.32 GB/s against 1.4 (its chain of contexts is one team of four waves on one CU), lion_decode ~0.04 GB/s against 0.84 (two waves,
  *    tables in memory); cheetah_encode 2.7 against 1.0 and lion_encode 1.0 against 0.65 only just win.  One stream is one dependency
  *    chain: a caller with more than one stream's worth of data wants the container calls, which are what this library is for.
  * ---------------------------------------------------------------------------------------------------------- */
@@ -236,7 +236,8 @@ void density_hip_stage_stats(uint64_t* out2);
  * one-wave-per-stream decoder instead of the decode passes (decode_passes.hip), 256 = the host-pointer container calls pipelined
  * whatever the size, a slice per chunk, 512 = never pipelined (below; the reference symbols on long streams too), 1024 = Cheetah's decode passes find
  * a chunk's records by the one-wave walk alone (no window kernels), 2048 = the other rotation encoder (8 chain + 8 emit waves), 4096 = Cheetah's decode
- * passes walk the contexts run by run on one wave (round 5's walk) instead of by a team of four waves, 8192 / 16384 = on ONE wave, 64 / 128 quads at a time.
+ * passes walk the contexts run by run on one wave (round 5's walk) instead of by a team of four waves, 8192 / 16384 = on ONE wave, 64 / 128 quads at a time,
+ * 32768 = Lion's container decode on one wave per stream (round 4's) instead of two.
  * Payload bytes are identical in every variant. */
 void density_hip_set_kernel_variant(int variant);
 
