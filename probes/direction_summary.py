@@ -8,9 +8,9 @@ src, tag = sys.argv[1], sys.argv[2]
 cal = json.load(open(f"profiles/{tag}_pmc_summary.json"))
 kf, kw = cal["calibration"]["factor_read4"], cal["calibration"]["factor_write4"]
 ENC = re.compile(r"encode_wave|exchange_stage|stage_emit_records|stage_record_layout|layout_encode|compact_kernel|encode_lane|scan_offsets|compact_bytes")
-DEC = re.compile(r"decode_wave|cheetah_parse|cheetah_prepare|cheetah_pass|cheetah_walk|cheetah_finish|layout_decode|decode_lane")
+DEC = re.compile(r"decode_wave|decode_pair|cheetah_parse|cheetah_prepare|cheetah_pass|cheetah_walk|cheetah_finish|layout_decode|decode_lane")
 ENC_CALL = re.compile(r"layout_encode_kernel|layout_encode_batch_kernel")
-DEC_CALL = re.compile(r"cheetah_finish|lion_decode_wave|cheetah_decode_wave")
+DEC_CALL = re.compile(r"cheetah_finish|lion_decode_wave|lion_decode_pair|cheetah_decode_wave")
 out = {"unit": "bytes per call (all kernels and fills of the direction)", "kernels_id": cal.get("kernels_id"),
        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --algo A --data prose --size 100000000 --settle-ms 0 --steps 2 --warmup 1 --no-cpu --no-sweep --no-extra",
        "factor_fetch": kf, "factor_write": kw, "configs": {}}
