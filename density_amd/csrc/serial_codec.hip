@@ -1474,11 +1474,16 @@ __global__ __launch_bounds__(128) void lion_decode_pair(const uint8_t* __restric
                 // exact walk over the step's quads in stream order, in registers — every value wave-uniform — with rows forwarded between quads of one
                 // context, taken from the speculative gather where it was made at the right context, and read from memory only where the context turned
                 // out to be another one (lion.rs:85-186).
-                uint32_t ctx = last_hash;
-                uint32_t cxv = 0xffffffffu, dirtyv = 0;                           // per lane, once walked: my true context; my row differs from memory
+                // (Round 6: the walk starts at the FIRST wrong lane — the lanes in front of it read what they should have, so their quads, contexts and
+                // resolved rows stand as they are and take part only as "the latest earlier quad of this context"; walked from lane 0 the repair was a
+                // fifth of the decoder's time.)
+                const uint32_t i0 = (uint32_t)__builtin_ctzll(ballot64(wrong));
+                uint32_t ctx = i0 == 0 ? last_hash : rlane32(h, i0 - 1u);
+                uint32_t cxv = lane < i0 ? ps : 0xffffffffu, dirtyv = lane < i0 ? pdirty : 0u;   // per lane, once walked (or standing): my true context; my row differs from memory
                 Row5 rf = row_mem;
+                if (lane < i0) rf = row;
 #pragma nounroll
-                for (uint32_t i = 0; i < nact; ++i) {
+                for (uint32_t i = i0; i < nact; ++i) {
                     const uint64_t m = ballot64(lane < i && cxv == ctx);
                     Row5 r;
                     uint32_t dirty = 0;

@@ -35,4 +35,4 @@ for rep in range(2):
         torch.cuda.synchronize()
         t = sum(ms for nm, ms in container.last_timings() if nm == "" + algo + "_decode_chunks") / 8
         container.set_profiling(False)
-        print(f"{name:>12}: decode {t:.4f} ms  equal: {bool(torch.equal(back, x))}", flush=True)
+        print(f"{name:>12}: decode {t:.4f} ms  equal: {bool(torch.equal(back, x))}  differing bytes: {int((back != x).sum())}", flush=True)
