@@ -1248,6 +1248,14 @@ __global__ __launch_bounds__(64) void lion_decode_wave(const uint8_t* __restrict
     }
 }
 
+#ifdef LION_PHASES
+__device__ unsigned long long g_lp[32];
+#define LP_T(x) const unsigned long long x = __builtin_readcyclecounter()
+#define LP_ADD(i, v) do { if (slot == 7 && lane == 0) atomicAdd(&g_lp[i], (unsigned long long)(v)); } while (0)
+#else
+#define LP_T(x)
+#define LP_ADD(i, v)
+#endif
 __global__ __launch_bounds__(128) void lion_decode_pair(const uint8_t* __restrict__ in, const uint64_t* __restrict__ offsets,
                                                         const uint64_t* __restrict__ sizes, uint32_t n_chunks,
                                                         uint8_t* __restrict__ out, uint64_t out_stride, uint64_t out_total,
@@ -1311,8 +1319,9 @@ __global__ __launch_bounds__(128) void lion_decode_pair(const uint8_t* __restric
             asm volatile("ds_write_b128 %0, %1 offset:16\n\tds_write_b128 %0, %2 offset:32\n\tds_write_b32 %0, %3" ::"v"(sya), "v"(pa), "v"(gu), "v"(step) : "memory");   // (the turn behind its payload: a wave's LDS operations execute as issued)
         };
         for (uint32_t s = wave;; s += 2u) {
-            // ---- my PARSE turn: the state in front of step s ----
+            LP_T(c0);
             if (!await(0, s)) break;
+            LP_T(c1);
             {
                 u32x4 pa, gu;
                 asm volatile("ds_read_b128 %0, %2 offset:16\n\tds_read_b128 %1, %2 offset:32\n\ts_waitcnt lgkmcnt(0)" : "=v"(pa), "=v"(gu) : "v"(sya) : "memory");
@@ -1381,25 +1390,19 @@ __global__ __launch_bounds__(128) void lion_decode_pair(const uint8_t* __restric
             if (ilen == 4) { q = ld32u(ibase); h = hash16(q); } else if (ilen == 2) h = ld16u(ibase);
             const bool dtouch = act && (flag == 0 || flag >= 6);              // touches the dictionary (lion.rs:85-186)
             const bool predicted = act && flag >= 1 && flag <= 5;
-            // ---- AHEAD of my table turn: the lines this step will read, asked for while the other wave holds the tables — its dictionary pairs, and the
-            // prediction rows and entries of the lanes whose context is in the stream (the quad in front was not predicted); what comes back is not looked at
-            // (the other wave may still be writing those rows): the reads below find the lines in this CU's cache instead of in memory ----
+            // ---- AHEAD of my table turn: what needs no table.  (A first version also READ the step's dictionary pairs and the rows of the lanes whose context
+            // is in the stream here, to warm their lines for the turn: measured against a build without those reads, 3.147 against 3.172 ms — nothing; what the
+            // second wave buys is the parse and the items off the turn.)  The stream is touched half a KiB on, as in the one-wave kernel. ----
             {
-                const uint32_t hpa = bperm(lane ? lane - 1u : 0u, h);
-                const uint32_t ppa = bperm(lane ? lane - 1u : 0u, predicted ? 1u : 0u);
-                const bool ctx_known = act && lane != 0 && ppa == 0;
-                const Pair w0 = dtouch ? tbl_load_pair(t.dict + h) : Pair{0u, 0u};
-                const Row5 rw = ctx_known ? row_load(t.pred + 5u * hpa) : Row5{{0u, 0u, 0u, 0u, 0u}};
-                {
-                    const uint64_t far = ipos + 512u + 128u * (lane & 3u);
-                    const uint8_t* pa = src + (far + 4 <= elen ? far : ipos);
-                    ahead = lane < 4 ? ld32u(pa) : 0u;                         // (the stream, half a KiB on: as in the one-wave kernel)
-                }
-                asm volatile("s_waitcnt vmcnt(0)" : : "v"(w0.a), "v"(w0.b), "v"(rw.n[0]), "v"(rw.n[1]), "v"(rw.n[2]), "v"(rw.n[3]), "v"(rw.n[4]), "v"(ahead) : "memory");
+                const uint64_t far = ipos + 512u + 128u * (lane & 3u);
+                const uint8_t* pa = src + (far + 4 <= elen ? far : ipos);
+                ahead = lane < 4 ? ld32u(pa) : 0u;
+                asm volatile("" : : "v"(ahead));
             }
             const uint64_t deq = same_key_mask64(h, dtouch);                      // (who follows whom in the dictionary is in the stream: matched ahead of the turn)
-            // ---- my TABLE turn ----
+            LP_T(c2);
             if (!await(1, s)) break;
+            LP_T(c3);
             last_hash = peek(2);
             const Pair e0 = dtouch ? tbl_load_pair(t.dict + h) : Pair{0u, 0u};
             // ---- runs of predicted quads: one dependent read per round; speculation: nobody earlier in this step rewrote that row ----
@@ -1413,13 +1416,16 @@ __global__ __launch_bounds__(128) void lion_decode_pair(const uint8_t* __restric
                     h = hash16(q);
                     known = true;
                 }
+                LP_ADD(10, 1);
                 if (ballot64(!known) == 0) break;
             }
+            LP_T(c4);
             const uint32_t hprev = bperm(lane ? lane - 1u : 0u, h);
             const uint32_t ps = lane == 0 ? last_hash : hprev;
             Row5 row = act ? row_load(t.pred + 5u * ps) : Row5{{0u, 0u, 0u, 0u, 0u}};
             const Row5 row_mem = row;                                             // as memory holds it (the repair below starts over from it)
-            // ---- dictionary, in dependency order among the lanes that touch it ----
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            LP_T(c5);
             const uint64_t peq = same_key_mask64(ps, act);
             const uint64_t dbefore = deq & below;
             const uint32_t dprev = dbefore ? 63u - (uint32_t)__builtin_clzll(dbefore) : 64u;
@@ -1439,7 +1445,7 @@ __global__ __launch_bounds__(128) void lion_decode_pair(const uint8_t* __restric
                 }
                 if (ballot64(!ddone) == 0) break;
             }
-            // ---- predictor rows, in dependency order (every quad rewrites its row unless it hit the front entry) ----
+            LP_T(c6);
             const uint64_t pbefore = peq & below;
             const uint32_t pprev = pbefore ? 63u - (uint32_t)__builtin_clzll(pbefore) : 64u;
             const bool plast = act && ((peq >> lane) >> 1) == 0;
@@ -1463,8 +1469,10 @@ __global__ __launch_bounds__(128) void lion_decode_pair(const uint8_t* __restric
                     }
                     pdone = true;
                 }
+                LP_ADD(11, 1);
                 if (ballot64(!pdone) == 0) break;
             }
+            LP_T(c7);
             uint32_t psf = ps;                                                    // the predictor slot my row is stored to
             bool plastf = plast;
             if (ballot64(wrong) != 0) {
@@ -1478,6 +1486,7 @@ __global__ __launch_bounds__(128) void lion_decode_pair(const uint8_t* __restric
                 // resolved rows stand as they are and take part only as "the latest earlier quad of this context"; walked from lane 0 the repair was a
                 // fifth of the decoder's time.)
                 const uint32_t i0 = (uint32_t)__builtin_ctzll(ballot64(wrong));
+                LP_ADD(12, 1); LP_ADD(13, nact - i0);
                 uint32_t ctx = i0 == 0 ? last_hash : rlane32(h, i0 - 1u);
                 uint32_t cxv = lane < i0 ? ps : 0xffffffffu, dirtyv = lane < i0 ? pdirty : 0u;   // per lane, once walked (or standing): my true context; my row differs from memory
                 Row5 rf = row_mem;
@@ -1517,10 +1526,13 @@ __global__ __launch_bounds__(128) void lion_decode_pair(const uint8_t* __restric
                 const uint64_t peq2 = same_key_mask64(cxv, act);
                 plastf = act && ((peq2 >> lane) >> 1) == 0;
             }
+            LP_T(c8);
             if (plastf && pdirty) row_store(t.pred + 5u * psf, row);
             if (dlast && ddirty) tbl_store_pair(t.dict + h, Pair{da, db});
             last_hash = rlane32(h, nact - 1u);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // this step's table stores are through: the other wave's turn
+            LP_T(c9);
+            LP_ADD(0, c1 - c0); LP_ADD(1, c2 - c1); LP_ADD(2, c3 - c2); LP_ADD(3, c4 - c3); LP_ADD(4, c5 - c4); LP_ADD(5, c6 - c5); LP_ADD(6, c7 - c6); LP_ADD(7, c8 - c7); LP_ADD(8, c9 - c8); LP_ADD(9, 1);
             poke(2, last_hash);
             poke(1, s + 1u);
             if (act) st32u(dst + opos + 4u * lane, q);                         // (the quads themselves: nobody waits for them)
@@ -1620,3 +1632,11 @@ hipError_t launch_serial_decode(int algo, const uint8_t* d_in, const uint64_t* d
 }
 
 }  // namespace density
+
+#ifdef LION_PHASES
+extern "C" void density_debug_lion_phases(unsigned long long* out, int reset) {
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(density::g_lp), sizeof(unsigned long long) * 32);
+    if (reset) { unsigned long long z[32] = {}; hipMemcpyToSymbol(HIP_SYMBOL(density::g_lp), z, sizeof z); }
+}
+#endif
