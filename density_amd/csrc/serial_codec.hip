@@ -1486,13 +1486,29 @@ __global__ __launch_bounds__(128) void lion_decode_pair(const uint8_t* __restric
                 // resolved rows stand as they are and take part only as "the latest earlier quad of this context"; walked from lane 0 the repair was a
                 // fifth of the decoder's time.)
                 const uint32_t i0 = (uint32_t)__builtin_ctzll(ballot64(wrong));
-                LP_ADD(12, 1); LP_ADD(13, nact - i0);
+                LP_ADD(12, 1);
                 uint32_t ctx = i0 == 0 ? last_hash : rlane32(h, i0 - 1u);
                 uint32_t cxv = lane < i0 ? ps : 0xffffffffu, dirtyv = lane < i0 ? pdirty : 0u;   // per lane, once walked (or standing): my true context; my row differs from memory
                 Row5 rf = row_mem;
                 if (lane < i0) rf = row;
+                // (Later in round 6: the walk SKIPS the stretches that stand.  Where the walk arrives at a quad in the context the vector pass assumed for it, the
+                // quads from there on are as the vector pass left them up to the next one that read wrong or whose context — assumed — is one that a walked quad
+                // has been in, assumed or truly: their rows were forwarded among themselves and from quads that stand.)
+                bool tainted = false;
+                uint32_t i = i0;
 #pragma nounroll
-                for (uint32_t i = i0; i < nact; ++i) {
+                while (i < nact) {
+                    if (ctx == rlane32(ps, i)) {
+                        const uint64_t stop = ballot64(act && lane >= i && (tainted || wrong));
+                        const uint32_t j = stop ? (uint32_t)__builtin_ctzll(stop) : nact;
+                        if (j > i) {
+                            if (lane >= i && lane < j) { cxv = ps; rf = row; dirtyv = pdirty; }
+                            ctx = rlane32(h, j - 1u);
+                            i = j;
+                            continue;
+                        }
+                    }
+                    LP_ADD(13, 1);
                     const uint64_t m = ballot64(lane < i && cxv == ctx);
                     Row5 r;
                     uint32_t dirty = 0;
@@ -1520,7 +1536,9 @@ __global__ __launch_bounds__(128) void lion_decode_pair(const uint8_t* __restric
                         row_promote(r, 4, qi); dirty = 1;
                     }
                     if (lane == i) { q = qi; h = hi; rf = r; cxv = ctx; dirtyv = dirty; }
+                    tainted = tainted || ps == rlane32(ps, i) || ps == ctx;       // quad i was walked: what the vector pass made of its two contexts — the assumed and the true one — does not stand
                     ctx = hi;
+                    ++i;
                 }
                 row = rf; pdirty = dirtyv; psf = cxv;
                 const uint64_t peq2 = same_key_mask64(cxv, act);
