@@ -1267,8 +1267,9 @@ __global__ __launch_bounds__(128) void lion_decode_pair(const uint8_t* __restric
     const uint32_t wave = rfl(threadIdx.x >> 6);
     if (slot >= n_slots) return;
     // what travels between the two waves (LDS): [0] the step whose PARSE may start, behind it [4..11] its {ipos, opos, guard} (two 16-byte words); [1] the step
-    // whose TABLE phase may start, behind it [2] the running hash; kExit in [0]: the stream's in-order end has been taken over, the other wave leaves
-    __shared__ __attribute__((aligned(16))) uint32_t sy[16];   // [0] parse turn [1] table turn [2] running hash | [4,5] ipos [6,7] opos | [8..11] guard
+    // whose TABLE phase may start and [3] the running hash beside it (one 8-byte word: read and written as one); kExit in [0]: the stream's in-order end has been
+    // taken over, the other wave leaves
+    __shared__ __attribute__((aligned(16))) uint32_t sy[16];   // [0] parse turn | [2] table turn [3] running hash | [4,5] ipos [6,7] opos | [8..11] guard
     constexpr uint32_t kExit = 0xffffffffu;
     const uint32_t sya = lds_addr(sy);
     auto peek = [&](uint32_t word) -> uint32_t {
@@ -1277,15 +1278,32 @@ __global__ __launch_bounds__(128) void lion_decode_pair(const uint8_t* __restric
         return rfl(v);
     };
     auto poke = [&](uint32_t word, uint32_t v) { asm volatile("ds_write_b32 %0, %1" ::"v"(sya + 4u * word), "v"(v) : "memory"); };
-    // waits until word `w` holds `want` (or kExit in word 0); false: leave (the other wave finished the stream, or the watchdog fired)
-    auto await = [&](uint32_t w, uint32_t want) -> bool {
+    // waits until the parse turn (word 0) holds `want`; false: leave (kExit in word 0: the other wave finished the stream, or the watchdog fired).  Two LDS reads and a nap
+    // per look (one read per look and no nap measured slower: the waiting wave's looks take issue slots from the working one; naps of 2 / 4 / 8 and a raised priority
+    // for the wave on turn: within the 2 % that two builds of ONE source differ by on one box — where their tables lie)
+    auto await = [&](uint32_t want) -> bool {
         for (uint32_t spins = 0;; ++spins) {
-            const uint32_t v = peek(w);
+            const uint32_t v = peek(0);
             if (v == want) return true;
             if (peek(0) == kExit) return false;
             if (spins > (1u << 24)) { if (lane == 0) atomicOr(err, 16u); poke(0, kExit); return false; }
             __builtin_amdgcn_s_sleep(1);
         }
+    };
+    // the table turn of step `want`: true once it is mine, the running hash read with it
+    auto await_tables = [&](uint32_t want, uint32_t& hash) -> bool {
+        for (uint32_t spins = 0;; ++spins) {
+            uint64_t v;
+            asm volatile("ds_read_b64 %0, %1 offset:8\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(sya) : "memory");
+            if (rfl((uint32_t)v) == want) { hash = rfl((uint32_t)(v >> 32)); return true; }
+            if (peek(0) == kExit) return false;
+            if (spins > (1u << 24)) { if (lane == 0) atomicOr(err, 16u); poke(0, kExit); return false; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    };
+    auto pass_tables = [&](uint32_t step, uint32_t hash) {
+        const uint64_t v = (uint64_t)step | ((uint64_t)hash << 32);
+        asm volatile("ds_write_b64 %0, %1 offset:8" ::"v"(sya), "v"(v) : "memory");
     };
     constexpr uint64_t kTableBytes = 65536ull * (sizeof(Pair) + 4ull * G::kPredWords);
     constexpr uint32_t kMaxRecord = 8 + G::kBlock;                            // 6 + 16 x 4, and the signature is fetched as 8 bytes
@@ -1320,7 +1338,7 @@ __global__ __launch_bounds__(128) void lion_decode_pair(const uint8_t* __restric
         };
         for (uint32_t s = wave;; s += 2u) {
             LP_T(c0);
-            if (!await(0, s)) break;
+            if (!await(s)) break;
             LP_T(c1);
             {
                 u32x4 pa, gu;
@@ -1329,7 +1347,7 @@ __global__ __launch_bounds__(128) void lion_decode_pair(const uint8_t* __restric
                 guard.penalty = rfl(gu.x); guard.start = rfl(gu.y); guard.prev = rfl(gu.z); guard.counter = rfl(gu.w);
             }
             if (!(elen - ipos >= kMaxRecord && cap - opos >= G::kBlock)) {        // the hot loop ends here: the rest is mine, once the tables are mine
-                if (await(1, s)) { last_hash = peek(2); mine_to_finish = true; }
+                if (await_tables(s, last_hash)) mine_to_finish = true;
                 poke(0, kExit);
                 break;
             }
@@ -1338,8 +1356,8 @@ __global__ __launch_bounds__(128) void lion_decode_pair(const uint8_t* __restric
                 gn.decay();
                 publish_parse(s + 1u, ipos + G::kBlock, opos + G::kBlock, gn);
                 if (lane < 16) st32u(dst + opos + 4u * lane, ld32u(src + ipos + 4u * lane));
-                if (!await(1, s)) break;                                      // (a raw block touches no table: the turn is passed on as it came)
-                poke(1, s + 1u);
+                if (!await_tables(s, last_hash)) break;                        // (a raw block touches no table: the turn is passed on as it came)
+                pass_tables(s + 1u, last_hash);
                 continue;
             }
             // the step's records: the first, and up to three more while each is whole, has room and the FSM lets it be coded (codec.rs:88-99)
@@ -1401,16 +1419,15 @@ __global__ __launch_bounds__(128) void lion_decode_pair(const uint8_t* __restric
             }
             const uint64_t deq = same_key_mask64(h, dtouch);                      // (who follows whom in the dictionary is in the stream: matched ahead of the turn)
             LP_T(c2);
-            if (!await(1, s)) break;
+            if (!await_tables(s, last_hash)) break;
             LP_T(c3);
-            last_hash = peek(2);
             const Pair e0 = dtouch ? tbl_load_pair(t.dict + h) : Pair{0u, 0u};
             // ---- runs of predicted quads: one dependent read per round; speculation: nobody earlier in this step rewrote that row ----
             bool known = !predicted;
             for (uint32_t round = 0; round < 64; ++round) {
-                const uint32_t hp = bperm(lane ? lane - 1u : 0u, h);
-                const uint32_t kpv = bperm(lane ? lane - 1u : 0u, known ? 1u : 0u);
-                const bool kp = lane == 0 || kpv != 0;
+                const uint32_t hp = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h, 0x138, 0xf, 0xf, false);                   // wave_shr:1 (no LDS round trip in the link)
+                const uint32_t kpv = (uint32_t)__builtin_amdgcn_update_dpp(1, (int)(known ? 1u : 0u), 0x138, 0xf, 0xf, false);
+                const bool kp = kpv != 0;                                         // (lane 0 keeps the old operand: 1)
                 if (!known && kp) {
                     q = tbl_load32(t.pred + 5u * (lane == 0 ? last_hash : hp) + (flag - 1u));
                     h = hash16(q);
@@ -1420,7 +1437,7 @@ __global__ __launch_bounds__(128) void lion_decode_pair(const uint8_t* __restric
                 if (ballot64(!known) == 0) break;
             }
             LP_T(c4);
-            const uint32_t hprev = bperm(lane ? lane - 1u : 0u, h);
+            const uint32_t hprev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h, 0x138, 0xf, 0xf, false);   // wave_shr:1
             const uint32_t ps = lane == 0 ? last_hash : hprev;
             Row5 row = act ? row_load(t.pred + 5u * ps) : Row5{{0u, 0u, 0u, 0u, 0u}};
             const Row5 row_mem = row;                                             // as memory holds it (the repair below starts over from it)
@@ -1432,7 +1449,13 @@ __global__ __launch_bounds__(128) void lion_decode_pair(const uint8_t* __restric
             const bool dlast = dtouch && ((deq >> lane) >> 1) == 0;
             uint32_t da = e0.a, db = e0.b, ddirty = 0;
             bool ddone = !dtouch;
-            for (uint32_t round = 0; round < 64; ++round) {
+            if (dtouch && dprev == 64u) {                                         // the first of its slot in this step: memory's pair, nothing to be handed on
+                if (flag == 0) { db = da; da = q; ddirty = 1; }
+                else if (flag == 6) q = da;
+                else { q = db; db = da; da = q; ddirty = 1; }
+                ddone = true;
+            }
+            for (uint32_t round = 0; round < 64 && ballot64(!ddone) != 0; ++round) {
                 const uint64_t done_mask = ballot64(ddone && dtouch);
                 const bool ready = !ddone && (dprev == 64u || ((done_mask >> (dprev & 63u)) & 1ull));
                 const uint32_t fda = bperm(dprev & 63u, da), fdb = bperm(dprev & 63u, db), fdd = bperm(dprev & 63u, ddirty);
@@ -1451,7 +1474,15 @@ __global__ __launch_bounds__(128) void lion_decode_pair(const uint8_t* __restric
             const bool plast = act && ((peq >> lane) >> 1) == 0;
             uint32_t pdirty = 0;
             bool pdone = !act, wrong = false;
-            for (uint32_t round = 0; round < 64; ++round) {
+            if (act && pprev == 64u) {                                            // the first of its context in this step: memory's row
+                if (predicted) {
+                    if (flag > 1) { row_promote(row, flag - 1u, q); pdirty = 1; }   // (it read that row itself: never wrong)
+                } else {
+                    row_promote(row, 4, q); pdirty = 1;
+                }
+                pdone = true;
+            }
+            for (uint32_t round = 0; round < 64 && ballot64(!pdone) != 0; ++round) {
                 const uint64_t done_mask = ballot64(pdone && act);
                 const bool ready = !pdone && (pprev == 64u || ((done_mask >> (pprev & 63u)) & 1ull));
                 const Row5 frow = row_from_lane(pprev & 63u, row);
@@ -1551,8 +1582,7 @@ __global__ __launch_bounds__(128) void lion_decode_pair(const uint8_t* __restric
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // this step's table stores are through: the other wave's turn
             LP_T(c9);
             LP_ADD(0, c1 - c0); LP_ADD(1, c2 - c1); LP_ADD(2, c3 - c2); LP_ADD(3, c4 - c3); LP_ADD(4, c5 - c4); LP_ADD(5, c6 - c5); LP_ADD(6, c7 - c6); LP_ADD(7, c8 - c7); LP_ADD(8, c9 - c8); LP_ADD(9, 1);
-            poke(2, last_hash);
-            poke(1, s + 1u);
+            pass_tables(s + 1u, last_hash);
             if (act) st32u(dst + opos + 4u * lane, q);                         // (the quads themselves: nobody waits for them)
         }
         asm volatile("s_waitcnt vmcnt(0)" : : "v"(ahead) : "memory");
