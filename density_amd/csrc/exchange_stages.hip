@@ -20,8 +20,8 @@
 // What the passes cannot know is the blow-up protection (codec.rs:35-37): a raw-copy block takes its quads out of every table, and
 // whether a block is copied depends on the sizes of the records before it.  Raw copies cluster where the dictionary is cold — the
 // first KiBs of every chunk — so:
-//   * the HEAD of every chunk is encoded in order by the one-wave kernel of serial_codec.hip — at least 16 KiB (Cheetah) / 48 KiB (Lion),
-//     and on to the first 4 KiB boundary where no block has been copied for 16 / 32 KiB (a chunk too short for that, or still restless
+//   * the HEAD of every chunk is encoded in order by the one-wave kernel of serial_codec.hip — at least 8 KiB (Cheetah; rounds 3-5: 16) / 48 KiB (Lion),
+//     and on to the first 4 KiB boundary where no block has been copied for 8 / 32 KiB (a chunk too short for that, or still restless
 //     four heads in, is simply finished there; the numbers: no late raw copy in 100 MB of prose and 64 MB of repetitive text) — which leaves its tables in global memory; the stages load their half of their table
 //     from there instead of starting from zeros;
 //   * behind the head the passes run as if no block were copied; the size scan sees whether two incompressible records ever meet
@@ -54,10 +54,18 @@ constexpr uint32_t kSpinLimit = 1u << 22, kPoison = 0xfffffffeu, kErrWatchdog = 
 // LDS: the half table | a sink word per lane (the quads of the other half / of earlier stages; the token store of lanes 1..63) | the token
 constexpr uint32_t stage_lds_bytes(uint32_t waves) { return kTable + waves * 64 * 4 + 16; }
 
+// Cheetah's head: two trips (8 KiB), handed over once no block has been copied for two trips.  Rounds 3-5: four and four; round 6 (tools/gpu_head_audit.py, 64 MiB per
+// kind, chunks of 256 KiB - 1 MiB): no chunk of prose, repetitive text, vocabulary draws, binary-like records, pair runs or zeros comes back from the passes with
+// either; the heads are a wave per chunk on an otherwise idle device, so half the head is 0.707 -> 0.653 ms per 100 MB of prose (zeros, pair runs: -30 %); a
+// text / random patchwork, which lives in the in-order kernel either way, +3 %; ONE trip never calms down inside its four heads and sends every chunk back (3.5 ms)
+#ifndef DENSITY_CHEETAH_HEAD_TRIPS
+#define DENSITY_CHEETAH_HEAD_TRIPS 2
+#define DENSITY_CHEETAH_CALM_TRIPS 2
+#endif
 // per algorithm: stages, record geometry (cheetah.rs:17-23,188-196; lion.rs:17-27,317-325), the in-order head, the table slot of serial_codec.hip
 template <int ALGO> struct StageGeo;
 template <> struct StageGeo<DENSITY_HIP_CHEETAH> {
-    static constexpr uint32_t kStages = 3, kRecQuads = 32, kSig = 8, kRec = 128, kHeadBytes = 4 * kTrip, kHeadCalm = 4 * kTrip;
+    static constexpr uint32_t kStages = 3, kRecQuads = 32, kSig = 8, kRec = 128, kHeadBytes = DENSITY_CHEETAH_HEAD_TRIPS * kTrip, kHeadCalm = DENSITY_CHEETAH_CALM_TRIPS * kTrip;
     static constexpr uint64_t kChunkTables = 65536ull * (8 + 4);
 };
 template <> struct StageGeo<DENSITY_HIP_LION> {
@@ -474,9 +482,10 @@ bool stage_encode_eligible(int algo, const uint8_t* d_in, uint64_t total, uint64
     // (two rounds of work-groups per stage) 5.7 against 3.0 — Lion's passes up to one work-group per CU.
     static const uint32_t most_override = debug_env("DENSITY_HIP_STAGE_MOST") ? (uint32_t)atoi(debug_env("DENSITY_HIP_STAGE_MOST")) : 0u;   // (tuning runs)
     const uint32_t most = most_override ? most_override : algo == DENSITY_HIP_CHEETAH ? 4096u : 256u;
+    const uint64_t least = 4 * head > 16 * kTrip ? 4 * head : 16 * kTrip;          // (four heads and more; 64 KiB at least, as with rounds 3-5's heads of 16 KiB)
     // (chunk bases must be whole 256-byte blocks; ONE chunk — a reference stream — may have any length: its ragged end is the in-order kernel's)
     return !g_force_lane_codec && !g_force_wave_codec && !g_rotor_unsafe && n_chunks != 0 && n_chunks <= most && (uintptr_t)d_in % 4 == 0 &&
-           (n_chunks == 1 || chunk_bytes % kTrip == 0) && chunk_bytes >= 4 * head && chunk_bytes < (1ull << 31) && total >= 4 * head &&
+           (n_chunks == 1 || chunk_bytes % kTrip == 0) && chunk_bytes >= least && chunk_bytes < (1ull << 31) && total >= least &&
            (uint64_t)n_chunks * slot <= (8ull << 30);                             // (a table slot per chunk: api.hip::kSerialTableBudget)
 }
 // vals (a dword per quad) | done masks (stages x 2 halves x a qword per 64-quad block) | record offsets | per-chunk verdicts, head and tail states
