@@ -22,6 +22,8 @@ namespace {
 struct Pair { uint32_t a, b; };
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
+// (Lion's prediction rows at a stride of 32 bytes instead of 20 — a row then never crosses a 32-byte sector — measured slower: decode 3.01 against 2.83 ms, encode 2.15
+// against 2.06: the tables grow by 43 %, and so do their clearing and their footprint in the caches)
 template <int ALGO> struct Geo;
 template <> struct Geo<DENSITY_HIP_CHEETAH> {                 // cheetah.rs:17-23,188-196
     static constexpr uint32_t kFlagBits = 2, kSig = 8, kBlock = 128, kPredWords = 1;
@@ -749,6 +751,15 @@ __device__ __forceinline__ Row5 row_load(const uint32_t* p) {
     for (int i = 0; i < 5; ++i) r.n[i] = tbl_load32(p + i);
     return r;
 }
+// The same as TWO memory instructions (16 + 4 bytes; a row is 4-byte aligned): for a wave that is the only one to touch its tables.  The loads are the caller's to
+// wait for (s_waitcnt vmcnt(0)): the compiler does not count an asm statement's
+__device__ __forceinline__ void row_load_wide(const uint32_t* p, bool on, u32x4& lo, uint32_t& hi) {   // (the lanes that are not `on` keep what they hold)
+    if (on) asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dword %1, %2, off offset:16" : "+v"(lo), "+v"(hi) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void row_store_wide(uint32_t* p, const Row5& r) {
+    const u32x4 lo = {r.n[0], r.n[1], r.n[2], r.n[3]};
+    asm volatile("global_store_dwordx4 %0, %1, off\n\tglobal_store_dword %0, %2, off offset:16" ::"v"(p), "v"(lo), "v"(r.n[4]) : "memory");
+}
 __device__ __forceinline__ void row_store(uint32_t* p, const Row5& r) {
 #pragma unroll
     for (int i = 0; i < 5; ++i) tbl_store32(p + i, r.n[i]);
@@ -845,11 +856,18 @@ __global__ __launch_bounds__(64) void lion_encode_wave(const uint8_t* __restrict
             const uint32_t hprev = bperm(lane ? lane - 1u : 0u, h);
             const uint32_t ps = lane == 0 ? last_hash : hprev;               // lion.rs:213,268
             tbl_drain();
-            Row5 row = act ? row_load(t.pred + 5u * ps) : Row5{{0u, 0u, 0u, 0u, 0u}};
-            const Pair e0 = act ? tbl_load_pair(t.dict + h) : Pair{0u, 0u};
+            // (the row as 16 + 4 bytes, two memory instructions instead of five: at three streams a CU the kernel is bound by the number of requests the memory system
+            // takes.  The pair is asked for BEHIND the row and loads return in order: once the compiler has waited for the pair — it must, before the statement that
+            // names it — the row is in as well)
+            u32x4 row_lo = {0u, 0u, 0u, 0u};
+            uint32_t row_hi = 0u;
+            row_load_wide(t.pred + 5u * ps, act, row_lo, row_hi);
+            Pair e0 = act ? tbl_load_pair(t.dict + h) : Pair{0u, 0u};
             const uint32_t qwin_next = window(pos + 4u * nact);                // (on the assumption that the step takes all its blocks)
-            uint32_t da = e0.a, db = e0.b, pdirty = 0, ddirty = 0;
             const uint64_t peq = same_key_mask64(ps, act), deq = same_key_mask64(h, act);
+            asm volatile("" : "+v"(row_lo), "+v"(row_hi), "+v"(e0.a), "+v"(e0.b));
+            Row5 row = Row5{{row_lo.x, row_lo.y, row_lo.z, row_lo.w, row_hi}};
+            uint32_t da = e0.a, db = e0.b, pdirty = 0, ddirty = 0;
             const uint64_t pbefore = peq & below, dbefore = deq & below;
             const uint32_t pprev = pbefore ? 63u - (uint32_t)__builtin_clzll(pbefore) : 64u;
             const uint32_t dprev = dbefore ? 63u - (uint32_t)__builtin_clzll(dbefore) : 64u;
@@ -909,7 +927,7 @@ __global__ __launch_bounds__(64) void lion_encode_wave(const uint8_t* __restrict
             const uint32_t myat = myrec == 0 ? 0u : myrec == 1 ? at1 : myrec == 2 ? at2 : at3;
             uint8_t* ip = rec + myat + G::kSig + (incl - ilen);
             if (mine) { if (ilen == 4) st32u(ip, q); else if (ilen == 2) st16u(ip, h); }
-            if (plast && pdirty) row_store(t.pred + 5u * ps, row);
+            if (plast && pdirty) row_store_wide(t.pred + 5u * ps, row);
             if (dlast && ddirty) tbl_store_pair(t.dict + h, Pair{da, db});
             last_hash = rlane32(h, 16u * nlive - 1u);
             guard = g;
@@ -1266,10 +1284,16 @@ __global__ __launch_bounds__(128) void lion_decode_pair(const uint8_t* __restric
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = rfl(threadIdx.x >> 6);
     if (slot >= n_slots) return;
-    // what travels between the two waves (LDS): [0] the step whose PARSE may start, behind it [4..11] its {ipos, opos, guard} (two 16-byte words); [1] the step
-    // whose TABLE phase may start and [3] the running hash beside it (one 8-byte word: read and written as one); kExit in [0]: the stream's in-order end has been
-    // taken over, the other wave leaves
-    __shared__ __attribute__((aligned(16))) uint32_t sy[16];   // [0] parse turn | [2] table turn [3] running hash | [4,5] ipos [6,7] opos | [8..11] guard
+    // Two waves, two ROLES (later in round 6; before: the waves took the steps in alternation, each parsing its step and then holding the tables — a turn then ended
+    // with the acknowledgement of its table stores, 1.45 k cycles of a step's 11.6 k, and a hand-on, because the OTHER wave read the tables next).  Wave 0 PARSES:
+    // signatures, the FSM, flags, items, hashes, the dictionary's key match — nothing of which needs a table — and the raw-copy blocks, step after step, and leaves
+    // every step in a ring in LDS.  Wave 1 holds the TABLES, all the time: its loads follow its own stores in program order, so nothing is drained and nothing handed on.
+    //   ring slot: 16 bytes per lane {flag | act << 3 | h << 16, q, the dictionary's key match (64 bits)} and a header {kind, quads, output position; at the end: stream
+    //   position and FSM}; sy[0] = steps published, sy[1] = steps taken (kExit in either: the watchdog fired)
+    constexpr uint32_t kRing = 4, kCoded = 0, kRawBlock = 1, kEnd = 2;
+    __shared__ __attribute__((aligned(16))) uint32_t sy[4];
+    __shared__ __attribute__((aligned(16))) uint32_t hdr[kRing][12];            // kind, quads, opos (2) | ipos (2), - , - | guard (4)
+    __shared__ __attribute__((aligned(16))) u32x4 ring[kRing][64];
     constexpr uint32_t kExit = 0xffffffffu;
     const uint32_t sya = lds_addr(sy);
     auto peek = [&](uint32_t word) -> uint32_t {
@@ -1278,32 +1302,16 @@ __global__ __launch_bounds__(128) void lion_decode_pair(const uint8_t* __restric
         return rfl(v);
     };
     auto poke = [&](uint32_t word, uint32_t v) { asm volatile("ds_write_b32 %0, %1" ::"v"(sya + 4u * word), "v"(v) : "memory"); };
-    // waits until the parse turn (word 0) holds `want`; false: leave (kExit in word 0: the other wave finished the stream, or the watchdog fired).  Two LDS reads and a nap
-    // per look (one read per look and no nap measured slower: the waiting wave's looks take issue slots from the working one; naps of 2 / 4 / 8 and a raised priority
-    // for the wave on turn: within the 2 % that two builds of ONE source differ by on one box — where their tables lie)
-    auto await = [&](uint32_t want) -> bool {
+    // waits while word `w` is below `least` (a step count); false: leave (the watchdog fired, here or in the other wave).  A nap between looks: a waiting wave that
+    // looks all the time takes issue slots from the working one
+    auto await_count = [&](uint32_t w, uint32_t least) -> bool {
         for (uint32_t spins = 0;; ++spins) {
-            const uint32_t v = peek(0);
-            if (v == want) return true;
-            if (peek(0) == kExit) return false;
-            if (spins > (1u << 24)) { if (lane == 0) atomicOr(err, 16u); poke(0, kExit); return false; }
+            const uint32_t v = peek(w);
+            if (v == kExit) return false;
+            if (v >= least) return true;
+            if (spins > (1u << 24)) { if (lane == 0) atomicOr(err, 16u); poke(0, kExit); poke(1, kExit); return false; }
             __builtin_amdgcn_s_sleep(1);
         }
-    };
-    // the table turn of step `want`: true once it is mine, the running hash read with it
-    auto await_tables = [&](uint32_t want, uint32_t& hash) -> bool {
-        for (uint32_t spins = 0;; ++spins) {
-            uint64_t v;
-            asm volatile("ds_read_b64 %0, %1 offset:8\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(sya) : "memory");
-            if (rfl((uint32_t)v) == want) { hash = rfl((uint32_t)(v >> 32)); return true; }
-            if (peek(0) == kExit) return false;
-            if (spins > (1u << 24)) { if (lane == 0) atomicOr(err, 16u); poke(0, kExit); return false; }
-            __builtin_amdgcn_s_sleep(1);
-        }
-    };
-    auto pass_tables = [&](uint32_t step, uint32_t hash) {
-        const uint64_t v = (uint64_t)step | ((uint64_t)hash << 32);
-        asm volatile("ds_write_b64 %0, %1 offset:8" ::"v"(sya), "v"(v) : "memory");
     };
     constexpr uint64_t kTableBytes = 65536ull * (sizeof(Pair) + 4ull * G::kPredWords);
     constexpr uint32_t kMaxRecord = 8 + G::kBlock;                            // 6 + 16 x 4, and the signature is fetched as 8 bytes
@@ -1325,291 +1333,336 @@ __global__ __launch_bounds__(128) void lion_decode_pair(const uint8_t* __restric
             __threadfence();
         }
         __syncthreads();                                                          // (both waves are through with the chunk before; the tables are clear)
-        if (threadIdx.x < 16) sy[threadIdx.x] = threadIdx.x == 9 ? 1u : 0u;        // step 0 may parse and touch the tables; {ipos, opos} = 0, guard = {0, 1, 0, 0}, hash 0
+        if (threadIdx.x < 4) sy[threadIdx.x] = 0u;
         __syncthreads();
-        uint32_t last_hash = 0;
-        Guard guard;
-        uint64_t ipos = 0, opos = 0;
-        bool bad = false, done = false, mine_to_finish = false;
-        uint32_t ahead = 0;                                                       // (a touch-ahead load's value: never looked at)
-        auto publish_parse = [&](uint32_t step, uint64_t ip, uint64_t op, const Guard& gg) {
-            const u32x4 pa = {(uint32_t)ip, (uint32_t)(ip >> 32), (uint32_t)op, (uint32_t)(op >> 32)}, gu = {gg.penalty, gg.start, gg.prev, gg.counter};
-            asm volatile("ds_write_b128 %0, %1 offset:16\n\tds_write_b128 %0, %2 offset:32\n\tds_write_b32 %0, %3" ::"v"(sya), "v"(pa), "v"(gu), "v"(step) : "memory");   // (the turn behind its payload: a wave's LDS operations execute as issued)
-        };
-        for (uint32_t s = wave;; s += 2u) {
-            LP_T(c0);
-            if (!await(s)) break;
-            LP_T(c1);
-            {
-                u32x4 pa, gu;
-                asm volatile("ds_read_b128 %0, %2 offset:16\n\tds_read_b128 %1, %2 offset:32\n\ts_waitcnt lgkmcnt(0)" : "=v"(pa), "=v"(gu) : "v"(sya) : "memory");
-                ipos = (uint64_t)rfl(pa.x) | ((uint64_t)rfl(pa.y) << 32); opos = (uint64_t)rfl(pa.z) | ((uint64_t)rfl(pa.w) << 32);
-                guard.penalty = rfl(gu.x); guard.start = rfl(gu.y); guard.prev = rfl(gu.z); guard.counter = rfl(gu.w);
-            }
-            if (!(elen - ipos >= kMaxRecord && cap - opos >= G::kBlock)) {        // the hot loop ends here: the rest is mine, once the tables are mine
-                if (await_tables(s, last_hash)) mine_to_finish = true;
-                poke(0, kExit);
-                break;
-            }
-            if (guard.block_is_copy()) {                                      // codec.rs:89-91
-                Guard gn = guard;
-                gn.decay();
-                publish_parse(s + 1u, ipos + G::kBlock, opos + G::kBlock, gn);
-                if (lane < 16) st32u(dst + opos + 4u * lane, ld32u(src + ipos + 4u * lane));
-                if (!await_tables(s, last_hash)) break;                        // (a raw block touches no table: the turn is passed on as it came)
-                pass_tables(s + 1u, last_hash);
-                continue;
-            }
-            // the step's records: the first, and up to three more while each is whole, has room and the FSM lets it be coded (codec.rs:88-99)
-            uint64_t sg0 = lion_sig_at(src + ipos), sg1 = 0, sg2 = 0, sg3 = 0;
-            uint32_t at1 = 0, at2 = 0, at3 = 0;                                    // where records 1..3 start, from ipos
-            uint32_t nrec = 1;
-            Guard g = guard;
-            uint32_t len = G::kSig + lion_item_bytes(sg0);                        // stream bytes of the step so far
-            g.update(len >= G::kBlock);                                           // codec.rs:98
-            {
-                Guard gc = g;
-                if (elen - ipos - len >= kMaxRecord && cap - opos >= 2u * G::kBlock && !gc.block_is_copy()) {
-                    g = gc; at1 = len; sg1 = lion_sig_at(src + ipos + len);
-                    const uint32_t rl = G::kSig + lion_item_bytes(sg1);
-                    g.update(rl >= G::kBlock); len += rl; nrec = 2;
+        if (wave == 0) {
+            // ================= the PARSER =================
+            Guard guard;
+            uint64_t ipos = 0, opos = 0;
+            uint32_t ahead = 0;                                                   // (a touch-ahead load's value: never looked at)
+            for (uint32_t s = 0;; ++s) {
+                const uint32_t at_slot = s % kRing;
+                const uint32_t ha = lds_addr(&hdr[at_slot][0]);
+                if (!(elen - ipos >= kMaxRecord && cap - opos >= G::kBlock)) {    // the hot loop ends here: the rest is the table wave's (scalar code, codec.rs:102-123)
+                    if (!await_count(1, s + 1u >= kRing ? s + 1u - kRing : 0u)) break;
+                    const u32x4 h0 = {kEnd, 0u, (uint32_t)opos, (uint32_t)(opos >> 32)}, h1 = {(uint32_t)ipos, (uint32_t)(ipos >> 32), 0u, 0u},
+                                h2 = {guard.penalty, guard.start, guard.prev, guard.counter};
+                    asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:16\n\tds_write_b128 %0, %3 offset:32" ::"v"(ha), "v"(h0), "v"(h1), "v"(h2) : "memory");
+                    poke(0, s + 1u);
+                    break;
                 }
-            }
-            if (nrec == 2) {
-                Guard gc = g;
-                if (elen - ipos - len >= kMaxRecord && cap - opos >= 3u * G::kBlock && !gc.block_is_copy()) {
-                    g = gc; at2 = len; sg2 = lion_sig_at(src + ipos + len);
-                    const uint32_t rl = G::kSig + lion_item_bytes(sg2);
-                    g.update(rl >= G::kBlock); len += rl; nrec = 3;
+                if (guard.block_is_copy()) {                                      // codec.rs:89-91: a raw block touches no table — copied here, the table wave skips it
+                    if (lane < 16) st32u(dst + opos + 4u * lane, ld32u(src + ipos + 4u * lane));
+                    if (!await_count(1, s + 1u >= kRing ? s + 1u - kRing : 0u)) break;
+                    const u32x4 h0 = {kRawBlock, 0u, 0u, 0u};
+                    asm volatile("ds_write_b128 %0, %1" ::"v"(ha), "v"(h0) : "memory");
+                    poke(0, s + 1u);
+                    guard.decay();
+                    ipos += G::kBlock; opos += G::kBlock;
+                    continue;
                 }
-            }
-            if (nrec == 3) {
-                Guard gc = g;
-                if (elen - ipos - len >= kMaxRecord && cap - opos >= 4u * G::kBlock && !gc.block_is_copy()) {
-                    g = gc; at3 = len; sg3 = lion_sig_at(src + ipos + len);
-                    const uint32_t rl = G::kSig + lion_item_bytes(sg3);
-                    g.update(rl >= G::kBlock); len += rl; nrec = 4;
+                LP_T(c1);
+                // the step's records: the first, and up to three more while each is whole, has room and the FSM lets it be coded (codec.rs:88-99)
+                uint64_t sg0 = lion_sig_at(src + ipos), sg1 = 0, sg2 = 0, sg3 = 0;
+                uint32_t at1 = 0, at2 = 0, at3 = 0;                                    // where records 1..3 start, from ipos
+                uint32_t nrec = 1;
+                Guard g = guard;
+                uint32_t len = G::kSig + lion_item_bytes(sg0);                        // stream bytes of the step so far
+                g.update(len >= G::kBlock);                                           // codec.rs:98
+                {
+                    Guard gc = g;
+                    if (elen - ipos - len >= kMaxRecord && cap - opos >= 2u * G::kBlock && !gc.block_is_copy()) {
+                        g = gc; at1 = len; sg1 = lion_sig_at(src + ipos + len);
+                        const uint32_t rl = G::kSig + lion_item_bytes(sg1);
+                        g.update(rl >= G::kBlock); len += rl; nrec = 2;
+                    }
                 }
-            }
-            publish_parse(s + 1u, ipos + len, opos + (uint64_t)nrec * G::kBlock, g);   // the other wave may parse the next step from here on
-            const uint32_t nact = 16u * nrec;
-            const bool act = lane < nact;
-            const uint64_t sig = myrec == 0 ? sg0 : myrec == 1 ? sg1 : myrec == 2 ? sg2 : sg3;
-            const uint32_t at = myrec == 0 ? 0u : myrec == 1 ? at1 : myrec == 2 ? at2 : at3;
-            const uint32_t flag = act ? (uint32_t)(sig >> (3u * k16)) & 7u : 1u;
-            const uint32_t ilen = !act ? 0u : (flag == 0 ? 4u : (flag >= 6 ? 2u : 0u));
-            uint32_t incl = ilen;                                                 // where my item lies behind my record's signature: a sum over the lanes of my row of 16
-            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xf, 0xf, true);   // row_shr:1
-            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xf, 0xf, true);   // row_shr:2
-            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xf, 0xf, true);   // row_shr:4
-            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xf, 0xf, true);   // row_shr:8
-            const uint8_t* ibase = src + ipos + at + G::kSig + (incl - ilen);
-            uint32_t q = 0, h = 0;
-            if (ilen == 4) { q = ld32u(ibase); h = hash16(q); } else if (ilen == 2) h = ld16u(ibase);
-            const bool dtouch = act && (flag == 0 || flag >= 6);              // touches the dictionary (lion.rs:85-186)
-            const bool predicted = act && flag >= 1 && flag <= 5;
-            // ---- AHEAD of my table turn: what needs no table.  (A first version also READ the step's dictionary pairs and the rows of the lanes whose context
-            // is in the stream here, to warm their lines for the turn: measured against a build without those reads, 3.147 against 3.172 ms — nothing; what the
-            // second wave buys is the parse and the items off the turn.)  The stream is touched half a KiB on, as in the one-wave kernel. ----
-            {
-                const uint64_t far = ipos + 512u + 128u * (lane & 3u);
-                const uint8_t* pa = src + (far + 4 <= elen ? far : ipos);
-                ahead = lane < 4 ? ld32u(pa) : 0u;
-                asm volatile("" : : "v"(ahead));
-            }
-            const uint64_t deq = same_key_mask64(h, dtouch);                      // (who follows whom in the dictionary is in the stream: matched ahead of the turn)
-            LP_T(c2);
-            if (!await_tables(s, last_hash)) break;
-            LP_T(c3);
-            const Pair e0 = dtouch ? tbl_load_pair(t.dict + h) : Pair{0u, 0u};
-            // ---- runs of predicted quads: one dependent read per round; speculation: nobody earlier in this step rewrote that row ----
-            bool known = !predicted;
-            for (uint32_t round = 0; round < 64; ++round) {
-                const uint32_t hp = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h, 0x138, 0xf, 0xf, false);                   // wave_shr:1 (no LDS round trip in the link)
-                const uint32_t kpv = (uint32_t)__builtin_amdgcn_update_dpp(1, (int)(known ? 1u : 0u), 0x138, 0xf, 0xf, false);
-                const bool kp = kpv != 0;                                         // (lane 0 keeps the old operand: 1)
-                if (!known && kp) {
-                    q = tbl_load32(t.pred + 5u * (lane == 0 ? last_hash : hp) + (flag - 1u));
-                    h = hash16(q);
-                    known = true;
+                if (nrec == 2) {
+                    Guard gc = g;
+                    if (elen - ipos - len >= kMaxRecord && cap - opos >= 3u * G::kBlock && !gc.block_is_copy()) {
+                        g = gc; at2 = len; sg2 = lion_sig_at(src + ipos + len);
+                        const uint32_t rl = G::kSig + lion_item_bytes(sg2);
+                        g.update(rl >= G::kBlock); len += rl; nrec = 3;
+                    }
                 }
-                LP_ADD(10, 1);
-                if (ballot64(!known) == 0) break;
+                if (nrec == 3) {
+                    Guard gc = g;
+                    if (elen - ipos - len >= kMaxRecord && cap - opos >= 4u * G::kBlock && !gc.block_is_copy()) {
+                        g = gc; at3 = len; sg3 = lion_sig_at(src + ipos + len);
+                        const uint32_t rl = G::kSig + lion_item_bytes(sg3);
+                        g.update(rl >= G::kBlock); len += rl; nrec = 4;
+                    }
+                }
+                const uint32_t nact = 16u * nrec;
+                const bool act = lane < nact;
+                const uint64_t sig = myrec == 0 ? sg0 : myrec == 1 ? sg1 : myrec == 2 ? sg2 : sg3;
+                const uint32_t at = myrec == 0 ? 0u : myrec == 1 ? at1 : myrec == 2 ? at2 : at3;
+                const uint32_t flag = act ? (uint32_t)(sig >> (3u * k16)) & 7u : 1u;
+                const uint32_t ilen = !act ? 0u : (flag == 0 ? 4u : (flag >= 6 ? 2u : 0u));
+                uint32_t incl = ilen;                                                 // where my item lies behind my record's signature: a sum over the lanes of my row of 16
+                incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xf, 0xf, true);   // row_shr:1
+                incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xf, 0xf, true);   // row_shr:2
+                incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xf, 0xf, true);   // row_shr:4
+                incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xf, 0xf, true);   // row_shr:8
+                const uint8_t* ibase = src + ipos + at + G::kSig + (incl - ilen);
+                uint32_t q = 0, h = 0;
+                if (ilen == 4) { q = ld32u(ibase); h = hash16(q); } else if (ilen == 2) h = ld16u(ibase);
+                const bool dtouch = act && (flag == 0 || flag >= 6);              // touches the dictionary (lion.rs:85-186)
+                const bool predicted = act && flag >= 1 && flag <= 5;
+                // ---- AHEAD of my table turn: what needs no table.  (A first version also READ the step's dictionary pairs and the rows of the lanes whose context
+                // is in the stream here, to warm their lines for the turn: measured against a build without those reads, 3.147 against 3.172 ms — nothing; what the
+                // second wave buys is the parse and the items off the turn.)  The stream is touched half a KiB on, as in the one-wave kernel. ----
+                {
+                    const uint64_t far = ipos + 512u + 128u * (lane & 3u);
+                    const uint8_t* pa = src + (far + 4 <= elen ? far : ipos);
+                    ahead = lane < 4 ? ld32u(pa) : 0u;
+                    asm volatile("" : : "v"(ahead));
+                }
+                const uint64_t deq = same_key_mask64(h, dtouch);                      // (who follows whom in the dictionary is in the stream: matched ahead of the turn)
+                LP_T(c2);
+                // the step into the ring (the count behind its payload: a wave's LDS operations execute as issued)
+                if (!await_count(1, s + 1u >= kRing ? s + 1u - kRing : 0u)) break;
+                LP_T(c2b);
+                {
+                    const u32x4 h0 = {kCoded, nact, (uint32_t)opos, (uint32_t)(opos >> 32)};
+                    const u32x4 mine = {flag | (act ? 8u : 0u) | (h << 16), q, (uint32_t)deq, (uint32_t)(deq >> 32)};
+                    asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %2, %3" ::"v"(ha), "v"(h0), "v"(lds_addr(&ring[at_slot][lane])), "v"(mine) : "memory");
+                    poke(0, s + 1u);
+                }
+                LP_ADD(0, c2b - c2); LP_ADD(1, c2 - c1);
+                guard = g;
+                ipos += len; opos += (uint64_t)nrec * G::kBlock;
             }
-            LP_T(c4);
-            const uint32_t hprev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h, 0x138, 0xf, 0xf, false);   // wave_shr:1
-            const uint32_t ps = lane == 0 ? last_hash : hprev;
-            Row5 row = act ? row_load(t.pred + 5u * ps) : Row5{{0u, 0u, 0u, 0u, 0u}};
-            const Row5 row_mem = row;                                             // as memory holds it (the repair below starts over from it)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            LP_T(c5);
-            const uint64_t peq = same_key_mask64(ps, act);
-            const uint64_t dbefore = deq & below;
-            const uint32_t dprev = dbefore ? 63u - (uint32_t)__builtin_clzll(dbefore) : 64u;
-            const bool dlast = dtouch && ((deq >> lane) >> 1) == 0;
-            uint32_t da = e0.a, db = e0.b, ddirty = 0;
-            bool ddone = !dtouch;
-            if (dtouch && dprev == 64u) {                                         // the first of its slot in this step: memory's pair, nothing to be handed on
-                if (flag == 0) { db = da; da = q; ddirty = 1; }
-                else if (flag == 6) q = da;
-                else { q = db; db = da; da = q; ddirty = 1; }
-                ddone = true;
-            }
-            for (uint32_t round = 0; round < 64 && ballot64(!ddone) != 0; ++round) {
-                const uint64_t done_mask = ballot64(ddone && dtouch);
-                const bool ready = !ddone && (dprev == 64u || ((done_mask >> (dprev & 63u)) & 1ull));
-                const uint32_t fda = bperm(dprev & 63u, da), fdb = bperm(dprev & 63u, db), fdd = bperm(dprev & 63u, ddirty);
-                if (ready) {
-                    if (dprev != 64u) { da = fda; db = fdb; ddirty = fdd; }
+            asm volatile("s_waitcnt vmcnt(0)" : : "v"(ahead) : "memory");
+        } else {
+            // ================= the TABLES =================
+            uint32_t last_hash = 0;
+            Guard guard;
+            uint64_t ipos = 0, opos = 0;
+            bool bad = false, done = false, mine_to_finish = false;
+            for (uint32_t s = 0;; ++s) {
+                LP_T(c2);
+                if (!await_count(0, s + 1u)) break;
+                LP_T(c3);
+                const uint32_t at_slot = s % kRing;
+                u32x4 h0, mine;
+                asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=v"(h0), "=v"(mine) : "v"(lds_addr(&hdr[at_slot][0])), "v"(lds_addr(&ring[at_slot][lane])) : "memory");
+                const uint32_t kind = rfl(h0.x);
+                if (kind == kEnd) {
+                    u32x4 h1, h2;
+                    asm volatile("ds_read_b128 %0, %2 offset:16\n\tds_read_b128 %1, %2 offset:32\n\ts_waitcnt lgkmcnt(0)" : "=v"(h1), "=v"(h2) : "v"(lds_addr(&hdr[at_slot][0])) : "memory");
+                    opos = (uint64_t)rfl(h0.z) | ((uint64_t)rfl(h0.w) << 32); ipos = (uint64_t)rfl(h1.x) | ((uint64_t)rfl(h1.y) << 32);
+                    guard.penalty = rfl(h2.x); guard.start = rfl(h2.y); guard.prev = rfl(h2.z); guard.counter = rfl(h2.w);
+                    mine_to_finish = true;
+                    break;
+                }
+                poke(1, s + 1u);                                                  // (the slot is in registers: the parser may have it back)
+                if (kind == kRawBlock) continue;
+                const uint32_t nact = rfl(h0.y);
+                opos = (uint64_t)rfl(h0.z) | ((uint64_t)rfl(h0.w) << 32);
+                const uint32_t flag = mine.x & 7u;
+                const bool act = (mine.x & 8u) != 0;
+                uint32_t q = mine.y, h = mine.x >> 16;
+                const uint64_t deq = (uint64_t)mine.z | ((uint64_t)mine.w << 32);
+                const bool dtouch = act && (flag == 0 || flag >= 6);              // touches the dictionary (lion.rs:85-186)
+                const bool predicted = act && flag >= 1 && flag <= 5;
+                const Pair e0 = dtouch ? tbl_load_pair(t.dict + h) : Pair{0u, 0u};
+                // ---- runs of predicted quads: one dependent read per round; speculation: nobody earlier in this step rewrote that row ----
+                // (a link reads its ONE entry; whole rows here — 16 + 4 bytes for every predicted lane, the row load behind the chain then for the others only — measured
+                // slower, 2.78 against 2.68 ms: a link's round trip grows with what it asks for)
+                bool known = !predicted;
+                for (uint32_t round = 0; round < 64; ++round) {
+                    const uint32_t hp = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h, 0x138, 0xf, 0xf, false);                   // wave_shr:1 (no LDS round trip in the link)
+                    const uint32_t kpv = (uint32_t)__builtin_amdgcn_update_dpp(1, (int)(known ? 1u : 0u), 0x138, 0xf, 0xf, false);
+                    const bool kp = kpv != 0;                                         // (lane 0 keeps the old operand: 1)
+                    if (!known && kp) {
+                        q = tbl_load32(t.pred + 5u * (lane == 0 ? last_hash : hp) + (flag - 1u));
+                        h = hash16(q);
+                        known = true;
+                    }
+                    LP_ADD(10, 1);
+                    if (ballot64(!known) == 0) break;
+                }
+                LP_T(c4);
+                const uint32_t hprev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h, 0x138, 0xf, 0xf, false);   // wave_shr:1
+                const uint32_t ps = lane == 0 ? last_hash : hprev;
+                // the rows: 16 + 4 bytes, two memory instructions (up to here five dwords in five: at three streams a CU the decoder is bound by the number of requests the
+                // memory system takes, not by their size — 2.94 -> 2.68 ms), waited for behind the dictionary rounds, which run under the load
+                u32x4 row_lo = {0u, 0u, 0u, 0u};
+                uint32_t row_hi = 0u;
+                row_load_wide(t.pred + 5u * ps, act, row_lo, row_hi);
+#ifdef LION_PHASES
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the account's stamp wants the rows in; the shipped kernel lets the dictionary rounds run under their load)
+#endif
+                LP_T(c5);
+                const uint64_t peq = same_key_mask64(ps, act);
+                const uint64_t dbefore = deq & below;
+                const uint32_t dprev = dbefore ? 63u - (uint32_t)__builtin_clzll(dbefore) : 64u;
+                const bool dlast = dtouch && ((deq >> lane) >> 1) == 0;
+                uint32_t da = e0.a, db = e0.b, ddirty = 0;
+                bool ddone = !dtouch;
+                if (dtouch && dprev == 64u) {                                         // the first of its slot in this step: memory's pair, nothing to be handed on
                     if (flag == 0) { db = da; da = q; ddirty = 1; }
                     else if (flag == 6) q = da;
                     else { q = db; db = da; da = q; ddirty = 1; }
                     ddone = true;
                 }
-                if (ballot64(!ddone) == 0) break;
-            }
-            LP_T(c6);
-            const uint64_t pbefore = peq & below;
-            const uint32_t pprev = pbefore ? 63u - (uint32_t)__builtin_clzll(pbefore) : 64u;
-            const bool plast = act && ((peq >> lane) >> 1) == 0;
-            uint32_t pdirty = 0;
-            bool pdone = !act, wrong = false;
-            if (act && pprev == 64u) {                                            // the first of its context in this step: memory's row
-                if (predicted) {
-                    if (flag > 1) { row_promote(row, flag - 1u, q); pdirty = 1; }   // (it read that row itself: never wrong)
-                } else {
-                    row_promote(row, 4, q); pdirty = 1;
+                for (uint32_t round = 0; round < 64 && ballot64(!ddone) != 0; ++round) {
+                    const uint64_t done_mask = ballot64(ddone && dtouch);
+                    const bool ready = !ddone && (dprev == 64u || ((done_mask >> (dprev & 63u)) & 1ull));
+                    const uint32_t fda = bperm(dprev & 63u, da), fdb = bperm(dprev & 63u, db), fdd = bperm(dprev & 63u, ddirty);
+                    if (ready) {
+                        if (dprev != 64u) { da = fda; db = fdb; ddirty = fdd; }
+                        if (flag == 0) { db = da; da = q; ddirty = 1; }
+                        else if (flag == 6) q = da;
+                        else { q = db; db = da; da = q; ddirty = 1; }
+                        ddone = true;
+                    }
+                    if (ballot64(!ddone) == 0) break;
                 }
-                pdone = true;
-            }
-            for (uint32_t round = 0; round < 64 && ballot64(!pdone) != 0; ++round) {
-                const uint64_t done_mask = ballot64(pdone && act);
-                const bool ready = !pdone && (pprev == 64u || ((done_mask >> (pprev & 63u)) & 1ull));
-                const Row5 frow = row_from_lane(pprev & 63u, row);
-                const uint32_t fpd = bperm(pprev & 63u, pdirty);
-                if (ready) {
-                    if (pprev != 64u) { row = frow; pdirty = fpd; }
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(row_lo), "+v"(row_hi) : : "memory");
+                Row5 row = Row5{{row_lo.x, row_lo.y, row_lo.z, row_lo.w, row_hi}};
+                const Row5 row_mem = row;                                             // as memory holds it (the repair below starts over from it)
+                LP_T(c6);
+                const uint64_t pbefore = peq & below;
+                const uint32_t pprev = pbefore ? 63u - (uint32_t)__builtin_clzll(pbefore) : 64u;
+                const bool plast = act && ((peq >> lane) >> 1) == 0;
+                uint32_t pdirty = 0;
+                bool pdone = !act, wrong = false;
+                if (act && pprev == 64u) {                                            // the first of its context in this step: memory's row
                     if (predicted) {
-                        uint32_t cur = row.n[0];
-#pragma unroll
-                        for (uint32_t k = 1; k < 5; ++k) cur = flag == k + 1u ? row.n[k] : cur;
-                        wrong = cur != q;                                     // the row as it really stands does not hold what the speculation read
-                        if (flag > 1) { row_promote(row, flag - 1u, q); pdirty = 1; }
+                        if (flag > 1) { row_promote(row, flag - 1u, q); pdirty = 1; }   // (it read that row itself: never wrong)
                     } else {
-                        row_promote(row, 4, q); pdirty = 1;                   // lion.rs:50-57
+                        row_promote(row, 4, q); pdirty = 1;
                     }
                     pdone = true;
                 }
-                LP_ADD(11, 1);
-                if (ballot64(!pdone) == 0) break;
-            }
-            LP_T(c7);
-            uint32_t psf = ps;                                                    // the predictor slot my row is stored to
-            bool plastf = plast;
-            if (ballot64(wrong) != 0) {
-                // A speculation failed: a predicted quad read an entry that an earlier quad of this step has since moved.  Its real value — the entry of the
-                // row as forwarded — has another hash, so the quad behind it sits in another context than assumed, and so on.  Up to round 3 the whole record
-                // was decoded again by the scalar code on lane 0 (two dependent memory reads per quad: a fifth of the kernel's time on prose).  Now: ONE
-                // exact walk over the step's quads in stream order, in registers — every value wave-uniform — with rows forwarded between quads of one
-                // context, taken from the speculative gather where it was made at the right context, and read from memory only where the context turned
-                // out to be another one (lion.rs:85-186).
-                // (Round 6: the walk starts at the FIRST wrong lane — the lanes in front of it read what they should have, so their quads, contexts and
-                // resolved rows stand as they are and take part only as "the latest earlier quad of this context"; walked from lane 0 the repair was a
-                // fifth of the decoder's time.)
-                const uint32_t i0 = (uint32_t)__builtin_ctzll(ballot64(wrong));
-                LP_ADD(12, 1);
-                uint32_t ctx = i0 == 0 ? last_hash : rlane32(h, i0 - 1u);
-                uint32_t cxv = lane < i0 ? ps : 0xffffffffu, dirtyv = lane < i0 ? pdirty : 0u;   // per lane, once walked (or standing): my true context; my row differs from memory
-                Row5 rf = row_mem;
-                if (lane < i0) rf = row;
-                // (Later in round 6: the walk SKIPS the stretches that stand.  Where the walk arrives at a quad in the context the vector pass assumed for it, the
-                // quads from there on are as the vector pass left them up to the next one that read wrong or whose context — assumed — is one that a walked quad
-                // has been in, assumed or truly: their rows were forwarded among themselves and from quads that stand.)
-                bool tainted = false;
-                uint32_t i = i0;
-#pragma nounroll
-                while (i < nact) {
-                    if (ctx == rlane32(ps, i)) {
-                        const uint64_t stop = ballot64(act && lane >= i && (tainted || wrong));
-                        const uint32_t j = stop ? (uint32_t)__builtin_ctzll(stop) : nact;
-                        if (j > i) {
-                            if (lane >= i && lane < j) { cxv = ps; rf = row; dirtyv = pdirty; }
-                            ctx = rlane32(h, j - 1u);
-                            i = j;
-                            continue;
+                for (uint32_t round = 0; round < 64 && ballot64(!pdone) != 0; ++round) {
+                    const uint64_t done_mask = ballot64(pdone && act);
+                    const bool ready = !pdone && (pprev == 64u || ((done_mask >> (pprev & 63u)) & 1ull));
+                    const Row5 frow = row_from_lane(pprev & 63u, row);
+                    const uint32_t fpd = bperm(pprev & 63u, pdirty);
+                    if (ready) {
+                        if (pprev != 64u) { row = frow; pdirty = fpd; }
+                        if (predicted) {
+                            uint32_t cur = row.n[0];
+#pragma unroll
+                            for (uint32_t k = 1; k < 5; ++k) cur = flag == k + 1u ? row.n[k] : cur;
+                            wrong = cur != q;                                     // the row as it really stands does not hold what the speculation read
+                            if (flag > 1) { row_promote(row, flag - 1u, q); pdirty = 1; }
+                        } else {
+                            row_promote(row, 4, q); pdirty = 1;                   // lion.rs:50-57
                         }
+                        pdone = true;
                     }
-                    LP_ADD(13, 1);
-                    const uint64_t m = ballot64(lane < i && cxv == ctx);
-                    Row5 r;
-                    uint32_t dirty = 0;
-                    if (m) {                                                      // the latest earlier quad of this context hands its row on
-                        const uint32_t j = 63u - (uint32_t)__builtin_clzll(m);
-#pragma unroll
-                        for (int k = 0; k < 5; ++k) r.n[k] = rlane32(rf.n[k], j);
-                        dirty = rlane32(dirtyv, j);
-                    } else if (rlane32(ps, i) == ctx) {                           // nobody before it in this step: memory's row, gathered at the right place
-#pragma unroll
-                        for (int k = 0; k < 5; ++k) r.n[k] = rlane32(row_mem.n[k], i);
-                    } else {
-                        r = row_load(t.pred + 5u * ctx);
-                    }
-                    const uint32_t f = rlane32(flag, i);
-                    uint32_t qi, hi;
-                    if (f >= 1u && f <= 5u) {
-                        qi = r.n[0];
-#pragma unroll
-                        for (uint32_t k = 1; k < 5; ++k) qi = f == k + 1u ? r.n[k] : qi;
-                        hi = hash16(qi);
-                        if (f > 1u) { row_promote(r, f - 1u, qi); dirty = 1; }
-                    } else {
-                        qi = rlane32(q, i); hi = rlane32(h, i);                   // what the dictionary gave: no context in it
-                        row_promote(r, 4, qi); dirty = 1;
-                    }
-                    if (lane == i) { q = qi; h = hi; rf = r; cxv = ctx; dirtyv = dirty; }
-                    tainted = tainted || ps == rlane32(ps, i) || ps == ctx;       // quad i was walked: what the vector pass made of its two contexts — the assumed and the true one — does not stand
-                    ctx = hi;
-                    ++i;
+                    LP_ADD(11, 1);
+                    if (ballot64(!pdone) == 0) break;
                 }
-                row = rf; pdirty = dirtyv; psf = cxv;
-                const uint64_t peq2 = same_key_mask64(cxv, act);
-                plastf = act && ((peq2 >> lane) >> 1) == 0;
-            }
-            LP_T(c8);
-            if (plastf && pdirty) row_store(t.pred + 5u * psf, row);
-            if (dlast && ddirty) tbl_store_pair(t.dict + h, Pair{da, db});
-            last_hash = rlane32(h, nact - 1u);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // this step's table stores are through: the other wave's turn
-            LP_T(c9);
-            LP_ADD(0, c1 - c0); LP_ADD(1, c2 - c1); LP_ADD(2, c3 - c2); LP_ADD(3, c4 - c3); LP_ADD(4, c5 - c4); LP_ADD(5, c6 - c5); LP_ADD(6, c7 - c6); LP_ADD(7, c8 - c7); LP_ADD(8, c9 - c8); LP_ADD(9, 1);
-            pass_tables(s + 1u, last_hash);
-            if (act) st32u(dst + opos + 4u * lane, q);                         // (the quads themselves: nobody waits for them)
-        }
-        asm volatile("s_waitcnt vmcnt(0)" : : "v"(ahead) : "memory");
-        __threadfence();
-        if (mine_to_finish && lane == 0) {                                    // the rest: scalar code, codec.rs:102-123
-            t.last_hash = last_hash;
-            while (ipos < elen && !bad && !done) {
-                const uint64_t rem = elen - ipos;
-                if (guard.block_is_copy()) {
-                    const uint32_t take = rem > G::kBlock ? G::kBlock : (uint32_t)rem;
-                    if (opos + take > cap) { bad = true; break; }
-                    for (uint32_t i = 0; i < take; ++i) dst[opos + i] = src[ipos + i];
-                    ipos += take; opos += take;
-                    if (rem <= G::kBlock) break;
-                    guard.decay();
-                    continue;
+                LP_T(c7);
+                uint32_t psf = ps;                                                    // the predictor slot my row is stored to
+                bool plastf = plast;
+                if (ballot64(wrong) != 0) {
+                    // A speculation failed: a predicted quad read an entry that an earlier quad of this step has since moved.  Its real value — the entry of the
+                    // row as forwarded — has another hash, so the quad behind it sits in another context than assumed, and so on.  Up to round 3 the whole record
+                    // was decoded again by the scalar code on lane 0 (two dependent memory reads per quad: a fifth of the kernel's time on prose).  Now: ONE
+                    // exact walk over the step's quads in stream order, in registers — every value wave-uniform — with rows forwarded between quads of one
+                    // context, taken from the speculative gather where it was made at the right context, and read from memory only where the context turned
+                    // out to be another one (lion.rs:85-186).
+                    // (Round 6: the walk starts at the FIRST wrong lane — the lanes in front of it read what they should have, so their quads, contexts and
+                    // resolved rows stand as they are and take part only as "the latest earlier quad of this context"; walked from lane 0 the repair was a
+                    // fifth of the decoder's time.)
+                    const uint32_t i0 = (uint32_t)__builtin_ctzll(ballot64(wrong));
+                    LP_ADD(12, 1);
+                    uint32_t ctx = i0 == 0 ? last_hash : rlane32(h, i0 - 1u);
+                    uint32_t cxv = lane < i0 ? ps : 0xffffffffu, dirtyv = lane < i0 ? pdirty : 0u;   // per lane, once walked (or standing): my true context; my row differs from memory
+                    Row5 rf = row_mem;
+                    if (lane < i0) rf = row;
+                    // (Later in round 6: the walk SKIPS the stretches that stand.  Where the walk arrives at a quad in the context the vector pass assumed for it, the
+                    // quads from there on are as the vector pass left them up to the next one that read wrong or whose context — assumed — is one that a walked quad
+                    // has been in, assumed or truly: their rows were forwarded among themselves and from quads that stand.)
+                    bool tainted = false;
+                    uint32_t i = i0;
+#pragma nounroll
+                    while (i < nact) {
+                        if (ctx == rlane32(ps, i)) {
+                            const uint64_t stop = ballot64(act && lane >= i && (tainted || wrong));
+                            const uint32_t j = stop ? (uint32_t)__builtin_ctzll(stop) : nact;
+                            if (j > i) {
+                                if (lane >= i && lane < j) { cxv = ps; rf = row; dirtyv = pdirty; }
+                                ctx = rlane32(h, j - 1u);
+                                i = j;
+                                continue;
+                            }
+                        }
+                        LP_ADD(13, 1);
+                        const uint64_t m = ballot64(lane < i && cxv == ctx);
+                        Row5 r;
+                        uint32_t dirty = 0;
+                        if (m) {                                                      // the latest earlier quad of this context hands its row on
+                            const uint32_t j = 63u - (uint32_t)__builtin_clzll(m);
+#pragma unroll
+                            for (int k = 0; k < 5; ++k) r.n[k] = rlane32(rf.n[k], j);
+                            dirty = rlane32(dirtyv, j);
+                        } else if (rlane32(ps, i) == ctx) {                           // nobody before it in this step: memory's row, gathered at the right place
+#pragma unroll
+                            for (int k = 0; k < 5; ++k) r.n[k] = rlane32(row_mem.n[k], i);
+                        } else {
+                            { u32x4 lo = {0u, 0u, 0u, 0u}; uint32_t hi = 0u; row_load_wide(t.pred + 5u * ctx, true, lo, hi); asm volatile("s_waitcnt vmcnt(0)" : "+v"(lo), "+v"(hi) : : "memory"); r = Row5{{lo.x, lo.y, lo.z, lo.w, hi}}; }
+                        }
+                        const uint32_t f = rlane32(flag, i);
+                        uint32_t qi, hi;
+                        if (f >= 1u && f <= 5u) {
+                            qi = r.n[0];
+#pragma unroll
+                            for (uint32_t k = 1; k < 5; ++k) qi = f == k + 1u ? r.n[k] : qi;
+                            hi = hash16(qi);
+                            if (f > 1u) { row_promote(r, f - 1u, qi); dirty = 1; }
+                        } else {
+                            qi = rlane32(q, i); hi = rlane32(h, i);                   // what the dictionary gave: no context in it
+                            row_promote(r, 4, qi); dirty = 1;
+                        }
+                        if (lane == i) { q = qi; h = hi; rf = r; cxv = ctx; dirtyv = dirty; }
+                        tainted = tainted || ps == rlane32(ps, i) || ps == ctx;       // quad i was walked: what the vector pass made of its two contexts — the assumed and the true one — does not stand
+                        ctx = hi;
+                        ++i;
+                    }
+                    row = rf; pdirty = dirtyv; psf = cxv;
+                    const uint64_t peq2 = same_key_mask64(cxv, act);
+                    plastf = act && ((peq2 >> lane) >> 1) == 0;
                 }
-                bad = lion_record_scalar(t, src, elen, ipos, dst, cap, opos, done, guard);
+                LP_T(c8);
+                if (plastf && pdirty) row_store_wide(t.pred + 5u * psf, row);
+                if (dlast && ddirty) tbl_store_pair(t.dict + h, Pair{da, db});
+                last_hash = rlane32(h, nact - 1u);
+                LP_T(c9);
+                LP_ADD(2, c3 - c2); LP_ADD(3, c4 - c3); LP_ADD(4, c5 - c4); LP_ADD(5, c6 - c5); LP_ADD(6, c7 - c6); LP_ADD(7, c8 - c7); LP_ADD(8, c9 - c8); LP_ADD(9, 1);
+                if (act) st32u(dst + opos + 4u * lane, q);
             }
-            if (exact && !bad && opos != cap) bad = true;
-            produced[chunk] = opos;
-            if (bad) atomicOr(err, 1u);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __threadfence();
+            if (mine_to_finish && lane == 0) {                                    // the rest: scalar code, codec.rs:102-123
+                t.last_hash = last_hash;
+                while (ipos < elen && !bad && !done) {
+                    const uint64_t rem = elen - ipos;
+                    if (guard.block_is_copy()) {
+                        const uint32_t take = rem > G::kBlock ? G::kBlock : (uint32_t)rem;
+                        if (opos + take > cap) { bad = true; break; }
+                        for (uint32_t i = 0; i < take; ++i) dst[opos + i] = src[ipos + i];
+                        ipos += take; opos += take;
+                        if (rem <= G::kBlock) break;
+                        guard.decay();
+                        continue;
+                    }
+                    bad = lion_record_scalar(t, src, elen, ipos, dst, cap, opos, done, guard);
+                }
+                if (exact && !bad && opos != cap) bad = true;
+                produced[chunk] = opos;
+                if (bad) atomicOr(err, 1u);
+            }
         }
         __threadfence();
     }
 }
-
 
 }  // namespace
 

@@ -6,11 +6,11 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch, datagen
 from density_amd import container, _lib
 algo = sys.argv[1]; sys.argv = sys.argv[:1] + sys.argv[2:]
-n = 100_000_000
+n = int(os.environ.get('AB_BYTES', 100_000_000))
 host = datagen.prose(n, seed=0xD1B54A32D192ED03)
 x = torch.from_numpy(host).cuda()
 tree = _lib.LIB_PATH
-chunk = int(_lib.lib().density_hip_auto_chunk_for(_lib.ALGO_IDS[algo], n))
+chunk = int(os.environ.get('AB_CHUNK', 0)) or int(_lib.lib().density_hip_auto_chunk_for(_lib.ALGO_IDS[algo], n))
 cap = container.container_bound_slotted(algo, n, chunk)
 cont = torch.empty(cap, dtype=torch.uint8, device="cuda"); back = torch.empty(n, dtype=torch.uint8, device="cuda")
 s = torch.cuda.current_stream().cuda_stream

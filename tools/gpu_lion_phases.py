@@ -1,5 +1,5 @@
 """Cycle account of the Lion pair decoder's steps (an experiment build with -DLION_PHASES: tools/build_variant.sh LP "-DLION_PHASES"): stream 7 of config 4's
-container, both waves summed.   python tools/gpu_lion_phases.py [name]"""
+container, the parser wave and the table wave.   python tools/gpu_lion_phases.py [name]"""
 import os, sys, ctypes
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -27,9 +27,10 @@ for _ in range(R): container.decode_device(cont.data_ptr(), hdr.container_len, b
 L.density_debug_lion_phases(buf, 1)
 v = list(buf); steps = v[9] or 1
 print("equal:", bool(torch.equal(back, x)), " chunk", chunk, " steps per decode", steps / R)
-names = ["wait for the parse turn", "parse + items + key match (to the table wait)", "wait for the table turn", "chain of predicted runs", "row load (drained)",
-         "dictionary rounds", "rows' rounds", "repair", "stores + drain"]
-tot = sum(v[:9])
-for i, nm in enumerate(names): print(f"{nm:>48}: {v[i] / steps:9.0f} cycles a step  {100 * v[i] / tot:5.1f} %")
-print(f"{'sum (one wave, from step to its step after next)':>48}: {tot / steps:9.0f}")
+names = ["PARSER: waiting for a free ring slot", "PARSER: parse + items + key match", "TABLES: waiting for a step", "chain of predicted runs", "row load (drained)",
+         "key match + dictionary rounds", "rows' rounds", "repair", "stores"]
+print("parser wave, cycles a step:")
+for i in (0, 1): print(f"{names[i]:>48}: {v[i] / steps:9.0f}")
+print(f"table wave, cycles a step (sum {sum(v[2:9]) / steps:.0f}):")
+for i in range(2, 9): print(f"{names[i]:>48}: {v[i] / steps:9.0f}")
 print(f"chain rounds a step {v[10] / steps:.2f}; rows' rounds a step {v[11] / steps:.2f}; steps repaired {v[12] / steps:.3f}; quads walked per repair {v[13] / max(v[12], 1):.1f}")
