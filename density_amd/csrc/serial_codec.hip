@@ -1327,6 +1327,7 @@ __global__ __launch_bounds__(128) void lion_decode_pair(const uint8_t* __restric
         const uint64_t room_all = out_total - chunk * out_stride;
         const uint64_t cap = room_all < out_stride ? room_all : out_stride;
         if (chunk != slot) {
+            __syncthreads();                                                      // (the table wave is through with the chunk before: the parser gets here long before it)
             uint4* p = reinterpret_cast<uint4*>(tables + slot * kTableBytes);
             const uint4 z = make_uint4(0, 0, 0, 0);
             for (uint64_t i = threadIdx.x; i < kTableBytes / 16; i += 128) p[i] = z;
