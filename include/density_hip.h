@@ -40,7 +40,7 @@ extern "C" {
  *    lion_decode and short streams on one wave or one work-group.  The data-parallel path proper is the container API
  *    of section 2.
  *    SLOWER THAN THE CRATE on one CPU core (10 MB of prose, buffers on the device, profiles/r06_benches_density.txt): cheetah_decode
- *    ~0.32 GB/s against 1.4 (its chain of contexts is one team of four waves on one CU), lion_decode ~0.08 GB/s against 0.84 (two waves,
+ *    ~0.32 GB/s against 1.4 (its chain of contexts is one team of four waves on one CU), lion_decode ~0.09 GB/s against 0.84 (two waves,
  *    tables in memory); cheetah_encode 3.2 against 1.0 and lion_encode 1.0 against 0.65 only just win.  One stream is one dependency
  *    chain: a caller with more than one stream's worth of data wants the container calls, which are what this library is for.
  * ---------------------------------------------------------------------------------------------------------- */
