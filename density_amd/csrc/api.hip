@@ -74,7 +74,8 @@ EncodePlan plan_encode(int algo, size_t n, size_t chunk) {
     // the exchange passes of Cheetah / Lion (exchange_stages.hip): a dword per quad, the per-block masks, the record offsets
     // — only where the passes will run: every condition of stage_encode_eligible but the input pointer's alignment is known here (chunk count
     // limits, head size, table budget, forced variants), and a caller sizing its own workspace should not pay 1.25-1.5 x the input for nothing
-    const bool passes = algo != DENSITY_HIP_CHAMELEON && p.n_chunks <= 0xffffffffull && stage_encode_eligible(algo, nullptr, n, chunk, (uint32_t)p.n_chunks);
+    const bool passes = algo != DENSITY_HIP_CHAMELEON && p.n_chunks <= 0xffffffffull && serial_slots(algo, p.n_chunks) == p.n_chunks &&   // (the passes keep a table slot per CHUNK)
+                        stage_encode_eligible(algo, nullptr, n, chunk, (uint32_t)p.n_chunks);
     p.total = p.off_stage + (passes ? align_up(stage_scratch_bytes(algo, n, (uint32_t)p.n_chunks), kAlign) : 0);
     return p;
 }
@@ -98,7 +99,7 @@ DecodePlan plan_decode(int algo, size_t n_chunks, size_t out_stride) {
 hipError_t codec_encode(int algo, const uint8_t* d_in, uint64_t total, uint64_t chunk_bytes, uint32_t n_chunks, uint8_t* d_out,
                         uint64_t out_stride, uint64_t* d_sizes, uint8_t* d_index, uint8_t* d_tables, uint32_t* d_zmap, uint8_t* d_stage, uint32_t* d_err, hipStream_t s) {
     if (algo == DENSITY_HIP_CHAMELEON) return launch_chameleon_encode(d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_index, d_zmap, d_err, s);
-    if (d_stage && stage_encode_eligible(algo, d_in, total, chunk_bytes, n_chunks))   // Cheetah / Lion: passes of ordered LDS exchanges, the one-wave kernels for what they hand back
+    if (d_stage && serial_slots(algo, n_chunks) == n_chunks && stage_encode_eligible(algo, d_in, total, chunk_bytes, n_chunks))   // Cheetah / Lion: passes of ordered LDS exchanges, the one-wave kernels for what they hand back
         return launch_stage_encode(algo, d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, (uint32_t)serial_slots(algo, n_chunks), d_stage, d_err, s);
     return launch_serial_encode(algo, d_in, total, chunk_bytes, n_chunks, d_out, out_stride, d_sizes, d_tables, (uint32_t)serial_slots(algo, n_chunks), s);
 }
